@@ -1,0 +1,144 @@
+/*
+ * litegs_hip.h -- C ABI of liblitegs_hip.so, the MI355X (gfx950) implementation of the LiteGS
+ * `litegs.render` hot path.
+ *
+ * This is the drop-in boundary.  The reference's boundary is the pybind11/ATen module `litegs_fused`
+ * (GR/ext_cuda.cpp:9-35, GR = litegs/submodules/gaussian_raster); each entry point below is the
+ * raw-pointer form of one of its 26 exports (or of one of the torch ops the reference's wrapper glues
+ * between them), so kernels are testable without torch and bindable from any host language.
+ * litegs_amd/fused.py is the ATen-shaped binding (same names / argument order / returned tensors as
+ * GR/ext_cuda.cpp); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; tensors are C-contiguous float32 / int32 /
+ *     int64 exactly as the reference lays them out (SoA, Gaussian index innermost: [C,N] or [V,C,N]);
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); launches are async;
+ *   - `valid_length` (nullable) is the reference's GPU-driven bound: int32[1] on the device, work with
+ *     index >= *valid_length is skipped inside the kernel (no host sync);
+ *   - return value: 0 on success, otherwise the hipError_t of the failed launch / argument check.
+ *   - V = views, N = Gaussians after compaction, C/chunks = number of 128-wide chunks, S = chunk size,
+ *     A = allocated (predicted) visible chunks, L = tile-instance table length, H/W image, TH/TW tile.
+ */
+#ifndef LITEGS_HIP_H
+#define LITEGS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- compact.hip : GR/compact.h ------------------------------------------------------------- */
+
+/* frustum_culling_aabb (GR/compact.cu:419-551, compact.h:28).  visibility bool[M]; *visible_num = count;
+ * visible_chunk_id int64[M] = visible ids ASCENDING then arange() tail.  Feedback copy: lg_feedback_d2h. */
+int lg_frustum_culling_aabb(const float* aabb_origin, const float* aabb_ext, const float* frustumplane, int V, int M,
+                            uint8_t* visibility, int* visible_num, int64_t* visible_chunk_id, void* stream);
+
+/* cull_compact_activate (GR/compact.cu:826-893,983-1085, compact.h:3-8) */
+int lg_cull_compact_activate(int sh_degree, const int64_t* visible_chunk_id, const int* visible_chunks_num, int A,
+                             const float* view_matrix, int V,
+                             const float* position, const float* scale, const float* rotation,
+                             const float* sh_base, const float* sh_rest, const float* opacity, int chunks, int S,
+                             float* out_position /*[4,A,S]*/, float* out_scale /*[3,A,S]*/, float* out_rotation /*[4,A,S]*/,
+                             float* out_color /*[V,3,A,S]*/, float* out_opacity /*[1,A,S]*/, void* stream);
+
+/* activate_backward (GR/compact.cu:896-980,1087-1212, compact.h:10-16); R = sh_rest.shape[0] */
+int lg_activate_backward(int sh_degree, const int64_t* visible_chunk_id, const int* visible_chunks_num, int A,
+                         const float* view_matrix, int V,
+                         const float* position, const float* scale, const float* rotation, const float* opacity,
+                         int chunks, int S, int R,
+                         const float* g_position /*[4,A,S]*/, const float* g_scale, const float* g_rotation,
+                         const float* g_color /*[V,3,A,S]*/, const float* g_opacity,
+                         float* d_position /*[3,A,S]*/, float* d_scale, float* d_rotation,
+                         float* d_sh_base /*[1,3,A,S]*/, float* d_sh_rest /*[R,3,A,S]*/, float* d_opacity, void* stream);
+
+/* adamUpdate (GR/compact.cu:320-417, compact.h:18-23): chunk form ([E,chunks,S] params, [E,A,S] compact grads)
+ * and primitive form ([E,N], int64 mask[N]).  No bias correction, as in the reference. */
+int lg_adam_update_chunk(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* visible_chunk_id,
+                         const int* valid_length, int E, int chunks, int A, int S,
+                         float lr, float b1, float b2, float eps, void* stream);
+int lg_adam_update_primitive(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* mask,
+                             int E, int N, float lr, float b1, float b2, float eps, void* stream);
+
+/* gpu_driven_pipeline_sparse_op (GR/compact.cu:1222-1336, compact.h:30-36).
+ * dtype: 0 f32, 1 i32, 2 i64, 3 f64, 4 i16, 5 i8;  op: 0 add, 1 min, 2 max */
+int lg_sparse_scatter(void* A_, const void* B, const int64_t* chunk_ids, const int* valid_count,
+                      int E, int chunks, int alloc, int S, int dtype, int op, void* stream);
+
+/* the 4-byte async device->pinned-host feedback copy of GR/compact.cu:538 and GR/binning.cu:148 */
+int lg_feedback_d2h(int* host_dst, const int* device_src, void* stream);
+
+/* ---- transform.hip : GR/transform.h --------------------------------------------------------- */
+int lg_mvp_transform_forward(const float* world /*[4,N]*/, const float* view, const float* proj, const int* valid_length,
+                             int V, int N, float* view_pos /*[V,4,N]*/, float* ndc_pos /*[V,4,N]*/, void* stream); /* transform.cu:378-470 */
+int lg_mvp_transform_backward(const float* g_ndc, const float* g_view, const float* view, const float* proj,
+                              const float* view_pos, const int* valid_length, int V, int N, float* g_world /*[4,N]*/, void* stream); /* :472-598 */
+int lg_create_transform_matrix_forward(const float* quat /*[4,N]*/, const float* scale /*[3,N]*/, const int* valid_length,
+                                       int N, float* T /*[3,3,N]*/, void* stream);                                /* :92-149 */
+int lg_create_transform_matrix_backward(const float* gT, const float* quat, const float* scale, const int* valid_length,
+                                        int N, float* g_quat, float* g_scale, void* stream);                        /* :151-256 */
+int lg_jacobian_rayspace(const float* view_pos, const float* proj, const int* valid_length, int V, int N, int H, int W,
+                         float* J /*[V,3,3,N], fully written*/, void* stream);                                      /* :23-90 */
+int lg_create_cov2d_forward(const float* J, const float* view, const float* T, const int* valid_length, int V, int N,
+                            float* cov2d /*[V,2,2,N]*/, void* stream);                                              /* :737-821 */
+int lg_create_cov2d_backward(const float* g_cov2d, const float* J, const float* view, const float* T, const int* valid_length,
+                             int V, int N, float* gT /*[3,3,N]*/, void* stream);                                    /* :824-927 */
+int lg_eigh_inv_2x2_forward(const float* cov2d, const int* valid_length, int V, int N,
+                            float* eig_val /*[V,2,N] or NULL*/, float* eig_vec /*[V,2,2,N] or NULL*/, float* inv /*[V,2,2,N]*/,
+                            void* stream);                                                                          /* :1365-1487 */
+int lg_inv_2x2_backward(const float* inv, const float* g_inv, const int* valid_length, int V, int N, int zero_nonfinite,
+                        float* g_cov2d, void* stream);                                                              /* :1425-1518 (+wrapper.py:591) */
+int lg_sh2rgb_forward(int degree, const float* sh_base, const float* sh_rest, const float* dirs, int V, int N,
+                      float* rgb /*[V,3,N]*/, void* stream);                                                        /* :952-1089 */
+int lg_sh2rgb_backward(int degree, const float* g_rgb, const float* dirs, int V, int N, int rest_dim,
+                       float* d_sh_base, float* d_sh_rest, float* d_dirs, void* stream);                            /* :1091-1363 */
+int lg_world2ndc_forward(const float* world, const float* viewproj, int V, int N, float* ndc, float* recp_w, void* stream);   /* :602-669 */
+int lg_world2ndc_backward(const float* viewproj, const float* ndc, const float* recp_w, const float* g_ndc, int V, int N,
+                          float* g_pos, void* stream);                                                              /* :671-731 */
+
+/* ---- binning.hip : GR/binning.h ------------------------------------------------------------- */
+int lg_get_allocate_size(const float* ndc, const float* view_z, const float* inv_cov2d, const float* opacity,
+                         const int* valid_length, int V, int N, int H, int W, int TH, int TW,
+                         int32_t* left_up /*[V,2,N] or NULL*/, int32_t* right_down, int32_t* allocate_size /*[V,N]*/,
+                         void* stream);                                                                             /* binning.cu:290-440 */
+/* create_table, first half (binning.cu:34-110): keys must be zero-filled; sorted_id int64 (torch.sort) or int32 */
+int lg_duplicate_with_keys(const float* ndc, const float* inv_cov2d, const float* opacity, const int32_t* prefix_sum,
+                           const void* depth_sorted_id, int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW,
+                           long long table_len, int32_t* keys, int32_t* values, void* stream);
+/* create_table, second half: stable LSD radix sort replacing cub::DeviceRadixSort::SortPairs (binning.cu:204-221).
+ * Ping-pongs a->b->a...; result is in the b pair when lg_radix_sort_num_passes() is odd, else in the a pair. */
+long long lg_radix_sort_temp_bytes(long long n);
+int lg_radix_sort_num_passes(int begin_bit, int end_bit);
+int lg_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n,
+                        int begin_bit, int end_bit, void* temp, long long temp_bytes, void* stream);
+/* depth sort keys + gathered inclusive scan: the torch.sort / gather / cumsum glue of wrapper.py:739-745 */
+int lg_depth_sort_keys(const float* depth, long long n, uint32_t* keys, uint32_t* vals, void* stream);
+long long lg_scan_temp_bytes(long long n);
+int lg_gather_inclusive_scan(const int32_t* src, const void* idx, int idx_is_int64, long long n, int32_t* out,
+                             void* temp, long long temp_bytes, void* stream);
+int lg_tile_range(const int32_t* sorted_keys, int V, long long L, int max_tile, int32_t* out /*[V,max_tile+2]*/, void* stream); /* binning.cu:228-287 */
+int lg_memset_async(void* ptr, int value, long long bytes, void* stream);
+
+/* ---- raster.hip : GR/raster.h --------------------------------------------------------------- */
+int lg_packed_record_floats(void);   /* floats per packed splat record (16) */
+int lg_packed_grad_floats(void);     /* floats per packed gradient record (16) */
+int lg_pack_forward_params(const float* ndc, const float* inv_cov2d, const float* color, const float* opacity,
+                           const int* valid_length, int V, int N, int H, int W, float* packed /*[V,N,16]*/, void* stream); /* raster.cu:334-356 */
+/* rasterize_forward / rasterize_forward_packed (raster.cu:162-332,386-586); tiles = specific_tiles int32[V,K] or NULL */
+int lg_raster_forward(const int* sorted_points /*[V,L]*/, const int* start_index /*[V,T+2]*/, const float* packed,
+                      const int* tiles, int K, int V, long long L, int N, int H, int W, int TH, int TW, int enable_statistic,
+                      float* img /*[V,3,Hp,Wp]*/, float* transmitance /*[V,1,Hp,Wp]*/, short* last_contributor /*[V,1,Hp,Wp]*/,
+                      int* fragment_count /*[V,1,N] zeroed*/, float* fragment_weight_sum /*[V,1,N] zeroed*/, void* stream);
+/* rasterize_backward (raster.cu:600-853,917-1037): accumulates into packed_grad [V,N,16] (zeroed by the caller) */
+int lg_raster_backward(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
+                       const float* final_transmitance, const short* last_contributor, const float* d_img,
+                       const float* d_trans /*or NULL*/, int V, long long L, int N, int H, int W, int TH, int TW,
+                       int enable_statistic, float* packed_grad, float* err_square_sum /*[V,1,N] zeroed*/, void* stream);
+int lg_unpack_gradient(const float* packed_grad, const float* grad_inv_scaler /*[1] or NULL*/, const int* valid_length,
+                       int V, int N, int H, int W, float* d_ndc /*[V,4,N]*/, float* d_cov2d_inv /*[V,2,2,N]*/,
+                       float* d_color /*[V,3,N]*/, float* d_opacity /*[1,N]*/, void* stream);                        /* raster.cu:855-886 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LITEGS_HIP_H */

@@ -1,0 +1,545 @@
+// Per-Gaussian projection chain, forward and backward.
+// All tensors are SoA with the Gaussian index innermost ([C,N] / [V,C,N]), so one thread per Gaussian
+// gives fully coalesced 256-byte wave accesses on every component; each kernel is a pure HBM stream
+// (16-72 B in, 16-64 B out per Gaussian) -- no LDS, no MFMA (a 3x3.3x3.3x2 product per Gaussian is
+// ~100 flops on ~100 B: bandwidth bound by >10x, see DESIGN.md "MFMA").
+// Compiled with -ffp-contract=off so results are bit-comparable with the CPU oracle's op order.
+#include "lg_common.h"
+
+#define TPB 256
+
+// ---------------------------------------------------------------------------------------------
+// a3 mvp_transform_forward (reference: GR/transform.cu:378-470): view = p.V, ndc = (view.P)/w
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) mvp_forward_kernel(const float* __restrict__ world, const float* __restrict__ view,
+                                                          const float* __restrict__ proj, const int* __restrict__ valid_length,
+                                                          int N, float* __restrict__ view_pos, float* __restrict__ ndc_pos)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    int b = blockIdx.y;
+    if (i >= lg_valid_len(valid_length, N)) return;
+    const float* V = view + b * 16;
+    const float* P = proj + b * 16;
+    float w0 = world[i], w1 = world[(size_t)N + i], w2 = world[2 * (size_t)N + i], w3 = world[3 * (size_t)N + i];
+    float v[4], h[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = w0 * V[k] + w1 * V[4 + k] + w2 * V[8 + k] + w3 * V[12 + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = v[0] * P[k] + v[1] * P[4 + k] + v[2] * P[8 + k] + v[3] * P[12 + k];
+    float iw = (fabsf(h[3]) > 1e-12f) ? (1.0f / h[3]) : 0.0f;
+    size_t o = (size_t)b * 4 * N + i;
+#pragma unroll
+    for (int k = 0; k < 4; k++) view_pos[o + (size_t)k * N] = v[k];
+    ndc_pos[o] = h[0] * iw;
+    ndc_pos[o + (size_t)N] = h[1] * iw;
+    ndc_pos[o + 2 * (size_t)N] = h[2] * iw;
+    ndc_pos[o + 3 * (size_t)N] = 1.0f;
+}
+
+LG_API int lg_mvp_transform_forward(const float* world, const float* view, const float* proj, const int* valid_length,
+                                    int V, int N, float* view_pos, float* ndc_pos, void* stream)
+{
+    if (N <= 0) return 0;
+    dim3 grid(lg_cdiv(N, TPB), V);
+    hipLaunchKernelGGL(mvp_forward_kernel, grid, dim3(TPB), 0, (hipStream_t)stream, world, view, proj, valid_length, N, view_pos, ndc_pos);
+    LG_RETURN_LAST();
+}
+
+// a18 mvp_transform_backward (GR/transform.cu:472-598); no gradient to the matrices (reference TODO)
+__global__ void __launch_bounds__(TPB) mvp_backward_kernel(const float* __restrict__ g_ndc, const float* __restrict__ g_view,
+                                                           const float* __restrict__ view, const float* __restrict__ proj,
+                                                           const float* __restrict__ view_pos, const int* __restrict__ valid_length,
+                                                           int V, int N, float* __restrict__ g_world)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= lg_valid_len(valid_length, N)) return;
+    float acc[4] = { 0.f, 0.f, 0.f, 0.f };
+    for (int b = 0; b < V; b++) {
+        const float* Vm = view + b * 16;
+        const float* P = proj + b * 16;
+        size_t o = (size_t)b * 4 * N + i;
+        float v[4], h[4], gn[4], dh[4], dv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = view_pos[o + (size_t)k * N];
+#pragma unroll
+        for (int k = 0; k < 4; k++) h[k] = v[0] * P[k] + v[1] * P[4 + k] + v[2] * P[8 + k] + v[3] * P[12 + k];
+        float iw = (fabsf(h[3]) > 1e-12f) ? (1.0f / h[3]) : 0.0f;
+        float n0 = h[0] * iw, n1 = h[1] * iw, n2 = h[2] * iw;
+#pragma unroll
+        for (int k = 0; k < 4; k++) gn[k] = g_ndc[o + (size_t)k * N];
+        dh[0] = gn[0] * iw; dh[1] = gn[1] * iw; dh[2] = gn[2] * iw;
+        dh[3] = -(gn[0] * n0 + gn[1] * n1 + gn[2] * n2) * iw;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            dv[k] = g_view[o + (size_t)k * N] + (dh[0] * P[k * 4] + dh[1] * P[k * 4 + 1] + dh[2] * P[k * 4 + 2] + dh[3] * P[k * 4 + 3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            acc[k] += dv[0] * Vm[k * 4] + dv[1] * Vm[k * 4 + 1] + dv[2] * Vm[k * 4 + 2] + dv[3] * Vm[k * 4 + 3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) g_world[(size_t)k * N + i] = acc[k];
+}
+
+LG_API int lg_mvp_transform_backward(const float* g_ndc, const float* g_view, const float* view, const float* proj,
+                                     const float* view_pos, const int* valid_length, int V, int N, float* g_world, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(mvp_backward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream,
+                       g_ndc, g_view, view, proj, view_pos, valid_length, V, N, g_world);
+    LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4 createTransformMatrix_forward (GR/transform.cu:92-149): T[r][:] = R(q)[r][:] * s_r
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quat_rows(float r, float x, float y, float z, float* R)
+{
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y + r * z);     R[2] = 2 * (x * z - r * y);
+    R[3] = 2 * (x * y - r * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z + r * x);
+    R[6] = 2 * (x * z + r * y);     R[7] = 2 * (y * z - r * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+__global__ void __launch_bounds__(TPB) transform_matrix_forward_kernel(const float* __restrict__ quat, const float* __restrict__ scale,
+                                                                       const int* __restrict__ valid_length, int N, float* __restrict__ T)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= lg_valid_len(valid_length, N)) return;
+    float R[9];
+    quat_rows(quat[i], quat[(size_t)N + i], quat[2 * (size_t)N + i], quat[3 * (size_t)N + i], R);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float s = scale[(size_t)r * N + i];
+#pragma unroll
+        for (int c = 0; c < 3; c++) T[((size_t)r * 3 + c) * N + i] = R[r * 3 + c] * s;
+    }
+}
+
+LG_API int lg_create_transform_matrix_forward(const float* quat, const float* scale, const int* valid_length, int N, float* T, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(transform_matrix_forward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, quat, scale, valid_length, N, T);
+    LG_RETURN_LAST();
+}
+
+// a17 createTransformMatrix_backward (GR/transform.cu:151-256)
+__global__ void __launch_bounds__(TPB) transform_matrix_backward_kernel(const float* __restrict__ gT, const float* __restrict__ quat,
+                                                                        const float* __restrict__ scale, const int* __restrict__ valid_length,
+                                                                        int N, float* __restrict__ g_quat, float* __restrict__ g_scale)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= lg_valid_len(valid_length, N)) return;
+    float r = quat[i], x = quat[(size_t)N + i], y = quat[2 * (size_t)N + i], z = quat[3 * (size_t)N + i];
+    float R[9], dt[9];
+    quat_rows(r, x, y, z, R);
+#pragma unroll
+    for (int k = 0; k < 9; k++) dt[k] = gT[(size_t)k * N + i];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++)
+        g_scale[(size_t)rr * N + i] = R[rr * 3] * dt[rr * 3] + R[rr * 3 + 1] * dt[rr * 3 + 1] + R[rr * 3 + 2] * dt[rr * 3 + 2];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+        float s = scale[(size_t)rr * N + i];
+        dt[rr * 3] *= s; dt[rr * 3 + 1] *= s; dt[rr * 3 + 2] *= s;
+    }
+    g_quat[i] = 2 * z * (dt[1] - dt[3]) + 2 * y * (dt[6] - dt[2]) + 2 * x * (dt[5] - dt[7]);
+    g_quat[(size_t)N + i] = 2 * y * (dt[3] + dt[1]) + 2 * z * (dt[6] + dt[2]) + 2 * r * (dt[5] - dt[7]) - 4 * x * (dt[8] + dt[4]);
+    g_quat[2 * (size_t)N + i] = 2 * x * (dt[3] + dt[1]) + 2 * r * (dt[6] - dt[2]) + 2 * z * (dt[5] + dt[7]) - 4 * y * (dt[8] + dt[0]);
+    g_quat[3 * (size_t)N + i] = 2 * r * (dt[1] - dt[3]) + 2 * x * (dt[6] + dt[2]) + 2 * y * (dt[5] + dt[7]) - 4 * z * (dt[4] + dt[0]);
+}
+
+LG_API int lg_create_transform_matrix_backward(const float* gT, const float* quat, const float* scale, const int* valid_length,
+                                               int N, float* g_quat, float* g_scale, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(transform_matrix_backward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream,
+                       gT, quat, scale, valid_length, N, g_quat, g_scale);
+    LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5 jacobianRayspace (GR/transform.cu:23-90).  Writes all 9 entries (5 of them zero) so the caller
+// needs no separate memset pass -- the reference does torch::zeros + a 4-entry kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) jacobian_rayspace_kernel(const float* __restrict__ view_pos, const float* __restrict__ proj,
+                                                                const int* __restrict__ valid_length, int N, int H, int W,
+                                                                float* __restrict__ J)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    int b = blockIdx.y;
+    if (i >= N) return;
+    size_t jo = (size_t)b * 9 * N + i;
+    if (i >= lg_valid_len(valid_length, N)) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) J[jo + (size_t)k * N] = 0.0f;
+        return;
+    }
+    const float* P = proj + b * 16;
+    float fx = P[0] * W * 0.5f, fy = P[5] * H * 0.5f;
+    size_t o = (size_t)b * 4 * N + i;
+    float tx = view_pos[o], ty = view_pos[o + (size_t)N], tz = view_pos[o + 2 * (size_t)N];
+    float lx = tz / P[0] * 1.3f, ly = tz / P[5] * 1.3f;
+    tx = fmaxf(fminf(tx, lx), -lx);
+    ty = fmaxf(fminf(ty, ly), -ly);
+    float rz = 1.0f / fmaxf(tz, 1e-2f);
+    float rz2 = rz * rz;
+    J[jo] = fx * rz;
+    J[jo + (size_t)N] = 0.0f;
+    J[jo + 2 * (size_t)N] = 0.0f;
+    J[jo + 3 * (size_t)N] = 0.0f;
+    J[jo + 4 * (size_t)N] = fy * rz;
+    J[jo + 5 * (size_t)N] = 0.0f;
+    J[jo + 6 * (size_t)N] = -fx * tx * rz2;
+    J[jo + 7 * (size_t)N] = -fy * ty * rz2;
+    J[jo + 8 * (size_t)N] = 0.0f;
+}
+
+LG_API int lg_jacobian_rayspace(const float* view_pos, const float* proj, const int* valid_length, int V, int N, int H, int W,
+                                float* J, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(jacobian_rayspace_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream,
+                       view_pos, proj, valid_length, N, H, W, J);
+    LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6 createCov2dDirectly_forward (GR/transform.cu:737-821): M=(T.V33).J[:, :2]; cov=M^T M + 0.3 I
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) cov2d_forward_kernel(const float* __restrict__ J, const float* __restrict__ view,
+                                                            const float* __restrict__ T, const int* __restrict__ valid_length,
+                                                            int N, float* __restrict__ cov)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    int b = blockIdx.y;
+    if (i >= lg_valid_len(valid_length, N)) return;
+    const float* Vm = view + b * 16;
+    float T9[9], J6[6], tv[9], M[6];
+#pragma unroll
+    for (int k = 0; k < 9; k++) T9[k] = T[(size_t)k * N + i];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        J6[r * 2] = J[((size_t)b * 9 + r * 3) * N + i];
+        J6[r * 2 + 1] = J[((size_t)b * 9 + r * 3 + 1) * N + i];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += T9[r * 3 + k] * Vm[k * 4 + c];
+            tv[r * 3 + c] = s;
+        }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            float s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += tv[r * 3 + k] * J6[k * 2 + c];
+            M[r * 2 + c] = s;
+        }
+    float c00 = 0, c01 = 0, c11 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { c00 += M[k * 2] * M[k * 2]; c01 += M[k * 2] * M[k * 2 + 1]; c11 += M[k * 2 + 1] * M[k * 2 + 1]; }
+    size_t o = (size_t)b * 4 * N + i;
+    cov[o] = c00 + 0.3f;
+    cov[o + (size_t)N] = c01;
+    cov[o + 2 * (size_t)N] = c01;
+    cov[o + 3 * (size_t)N] = c11 + 0.3f;
+}
+
+LG_API int lg_create_cov2d_forward(const float* J, const float* view, const float* T, const int* valid_length, int V, int N,
+                                   float* cov, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(cov2d_forward_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream, J, view, T, valid_length, N, cov);
+    LG_RETURN_LAST();
+}
+
+// a16 createCov2dDirectly_backward (GR/transform.cu:824-927): dT = 2.M.dcov.(V33.J)^T summed over views;
+// entries >= valid_length are written as 0 like the reference (:884-887).
+__global__ void __launch_bounds__(TPB) cov2d_backward_kernel(const float* __restrict__ g_cov, const float* __restrict__ J,
+                                                             const float* __restrict__ view, const float* __restrict__ T,
+                                                             const int* __restrict__ valid_length, int V, int N, float* __restrict__ gT)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= N) return;
+    float sum[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) sum[k] = 0.0f;
+    if (i < lg_valid_len(valid_length, N)) {
+        float T9[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) T9[k] = T[(size_t)k * N + i];
+        for (int b = 0; b < V; b++) {
+            const float* Vm = view + b * 16;
+            float J6[6], vj[6], M[6], g[4], dM[6];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                J6[r * 2] = J[((size_t)b * 9 + r * 3) * N + i];
+                J6[r * 2 + 1] = J[((size_t)b * 9 + r * 3 + 1) * N + i];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    float s = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) s += Vm[r * 4 + k] * J6[k * 2 + c];
+                    vj[r * 2 + c] = s;
+                }
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    float s = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) s += T9[r * 3 + k] * vj[k * 2 + c];
+                    M[r * 2 + c] = s;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; k++) g[k] = g_cov[((size_t)b * 4 + k) * N + i];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                dM[r * 2] = 2 * (M[r * 2] * g[0] + M[r * 2 + 1] * g[2]);
+                dM[r * 2 + 1] = 2 * (M[r * 2] * g[1] + M[r * 2 + 1] * g[3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) sum[r * 3 + c] += dM[r * 2] * vj[c * 2] + dM[r * 2 + 1] * vj[c * 2 + 1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) gT[(size_t)k * N + i] = sum[k];
+}
+
+LG_API int lg_create_cov2d_backward(const float* g_cov, const float* J, const float* view, const float* T, const int* valid_length,
+                                    int V, int N, float* gT, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(cov2d_backward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, g_cov, J, view, T, valid_length, V, N, gT);
+    LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+// a7 eigh_and_inv_2x2matrix_forward (GR/transform.cu:1365-1487)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) eigh_inv_forward_kernel(const float* __restrict__ in, const int* __restrict__ valid_length, int N,
+                                                               float* __restrict__ val, float* __restrict__ vec, float* __restrict__ inv)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    int b = blockIdx.y;
+    if (i >= lg_valid_len(valid_length, N)) return;
+    size_t o = (size_t)b * 4 * N + i;
+    float m00 = in[o], m01 = in[o + (size_t)N], m10 = in[o + 2 * (size_t)N], m11 = in[o + 3 * (size_t)N];
+    float det = m00 * m11 - m01 * m10;
+    float det1 = (m00 - m01) * (m11 - m01) + m01 * (m00 + m11 - 2 * m01);
+    det = (fabsf(det) < fabsf(1e-5f * m01 * m10)) ? det1 : det;
+    float t0 = m00 + m11;
+    float t1 = sqrtf((m00 - m11) * (m00 - m11) + 4 * m01 * m01);
+    t1 = fmaxf(t1, 1e-9f);
+    float e0 = 0.5f * (t0 - t1), e1 = 0.5f * (t0 + t1);
+    if (val != nullptr) {
+        val[((size_t)b * 2) * N + i] = e0;
+        val[((size_t)b * 2 + 1) * N + i] = e1;
+    }
+    if (vec != nullptr) {
+        float v00, v01, v10, v11;
+        if (fabsf(e0 - m00) > fabsf(e0 - m11)) { v00 = -m01; v01 = m00 - e0; v10 = e1 - m11; v11 = m01; }
+        else { v00 = m11 - e0; v01 = -m01; v10 = m01; v11 = e1 - m00; }
+        float l0 = 1.0f / sqrtf(v00 * v00 + v01 * v01);
+        float l1 = 1.0f / sqrtf(v10 * v10 + v11 * v11);
+        vec[o] = v00 * l0; vec[o + (size_t)N] = v10 * l1; vec[o + 2 * (size_t)N] = v01 * l0; vec[o + 3 * (size_t)N] = v11 * l1;
+    }
+    det = (fabsf(det) < 1e-9f) ? 1e-9f : det;
+    float dr = 1.0f / det;
+    inv[o] = m11 * dr; inv[o + (size_t)N] = -m01 * dr; inv[o + 2 * (size_t)N] = -m10 * dr; inv[o + 3 * (size_t)N] = m00 * dr;
+}
+
+LG_API int lg_eigh_inv_2x2_forward(const float* in, const int* valid_length, int V, int N, float* val, float* vec, float* inv, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(eigh_inv_forward_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream, in, valid_length, N, val, vec, inv);
+    LG_RETURN_LAST();
+}
+
+// a15 inv_2x2matrix_backward (GR/transform.cu:1425-1454, 1489-1518) with the caller's nan_to_num_(0)
+// (litegs/utils/wrapper.py:591) optionally folded in (zero_nonfinite).
+__global__ void __launch_bounds__(TPB) inv2x2_backward_kernel(const float* __restrict__ inv, const float* __restrict__ g_inv,
+                                                              const int* __restrict__ valid_length, int N, int zero_nonfinite,
+                                                              float* __restrict__ g_in)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    int b = blockIdx.y;
+    if (i >= lg_valid_len(valid_length, N)) return;
+    size_t o = (size_t)b * 4 * N + i;
+    float a[4], g[4], t[4], r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[k] = inv[o + (size_t)k * N]; g[k] = g_inv[o + (size_t)k * N]; }
+    t[0] = a[0] * g[0] + a[1] * g[2]; t[1] = a[0] * g[1] + a[1] * g[3];
+    t[2] = a[2] * g[0] + a[3] * g[2]; t[3] = a[2] * g[1] + a[3] * g[3];
+    r[0] = t[0] * a[0] + t[1] * a[2]; r[1] = t[0] * a[1] + t[1] * a[3];
+    r[2] = t[2] * a[0] + t[3] * a[2]; r[3] = t[2] * a[1] + t[3] * a[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float v = -r[k];
+        if (zero_nonfinite && !(fabsf(v) <= 3.402823466e+38f)) v = 0.0f;
+        g_in[o + (size_t)k * N] = v;
+    }
+}
+
+LG_API int lg_inv_2x2_backward(const float* inv, const float* g_inv, const int* valid_length, int V, int N, int zero_nonfinite,
+                               float* g_in, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(inv2x2_backward_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream, inv, g_inv, valid_length, N, zero_nonfinite, g_in);
+    LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+// SH basis (shared with the activation kernels through lg_sh.h)
+// ---------------------------------------------------------------------------------------------
+#include "lg_sh.h"
+
+// a22 sh2rgb_forward / sh2rgb_backward (GR/transform.cu:952-1363) -- the cluster_size==0 path
+template <int DEG>
+__global__ void __launch_bounds__(TPB) sh2rgb_forward_kernel(const float* __restrict__ sh0, const float* __restrict__ shr,
+                                                             const float* __restrict__ dirs, int N, float* __restrict__ rgb)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    int v = blockIdx.y;
+    if (i >= N) return;
+    float b[16];
+    lg_sh_basis<DEG>(dirs[((size_t)v * 3) * N + i], dirs[((size_t)v * 3 + 1) * N + i], dirs[((size_t)v * 3 + 2) * N + i], b);
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        float r = b[0] * sh0[(size_t)ch * N + i];
+#pragma unroll
+        for (int k = 1; k < NB; k++) r += b[k] * shr[((size_t)(k - 1) * 3 + ch) * N + i];
+        rgb[((size_t)v * 3 + ch) * N + i] = r + 0.5f;
+    }
+}
+
+LG_API int lg_sh2rgb_forward(int degree, const float* sh0, const float* shr, const float* dirs, int V, int N, float* rgb, void* stream)
+{
+    if (N <= 0) return 0;
+    dim3 grid(lg_cdiv(N, TPB), V);
+    hipStream_t s = (hipStream_t)stream;
+    switch (degree) {
+    case 0: hipLaunchKernelGGL(sh2rgb_forward_kernel<0>, grid, dim3(TPB), 0, s, sh0, shr, dirs, N, rgb); break;
+    case 1: hipLaunchKernelGGL(sh2rgb_forward_kernel<1>, grid, dim3(TPB), 0, s, sh0, shr, dirs, N, rgb); break;
+    case 2: hipLaunchKernelGGL(sh2rgb_forward_kernel<2>, grid, dim3(TPB), 0, s, sh0, shr, dirs, N, rgb); break;
+    case 3: hipLaunchKernelGGL(sh2rgb_forward_kernel<3>, grid, dim3(TPB), 0, s, sh0, shr, dirs, N, rgb); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    LG_RETURN_LAST();
+}
+
+// rest_dim rows of d_shr beyond the active degree are written as zero; d_dirs is zero (reference drops it)
+template <int DEG>
+__global__ void __launch_bounds__(TPB) sh2rgb_backward_kernel(const float* __restrict__ g_rgb, const float* __restrict__ dirs,
+                                                              int V, int N, int rest_dim, float* __restrict__ d_sh0,
+                                                              float* __restrict__ d_shr, float* __restrict__ d_dirs)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= N) return;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    float acc[NB * 3];
+#pragma unroll
+    for (int k = 0; k < NB * 3; k++) acc[k] = 0.0f;
+    for (int v = 0; v < V; v++) {
+        float b[16];
+        lg_sh_basis<DEG>(dirs[((size_t)v * 3) * N + i], dirs[((size_t)v * 3 + 1) * N + i], dirs[((size_t)v * 3 + 2) * N + i], b);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float g = g_rgb[((size_t)v * 3 + ch) * N + i];
+#pragma unroll
+            for (int k = 0; k < NB; k++) acc[k * 3 + ch] += b[k] * g;
+            d_dirs[((size_t)v * 3 + ch) * N + i] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) d_sh0[(size_t)ch * N + i] = acc[ch];
+#pragma unroll
+    for (int k = 1; k < NB; k++)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) d_shr[((size_t)(k - 1) * 3 + ch) * N + i] = acc[k * 3 + ch];
+    for (int k = NB; k <= rest_dim; k++)
+        for (int ch = 0; ch < 3; ch++) d_shr[((size_t)(k - 1) * 3 + ch) * N + i] = 0.0f;
+}
+
+LG_API int lg_sh2rgb_backward(int degree, const float* g_rgb, const float* dirs, int V, int N, int rest_dim,
+                              float* d_sh0, float* d_shr, float* d_dirs, void* stream)
+{
+    if (N <= 0) return 0;
+    dim3 grid(lg_cdiv(N, TPB));
+    hipStream_t s = (hipStream_t)stream;
+    switch (degree) {
+    case 0: hipLaunchKernelGGL(sh2rgb_backward_kernel<0>, grid, dim3(TPB), 0, s, g_rgb, dirs, V, N, rest_dim, d_sh0, d_shr, d_dirs); break;
+    case 1: hipLaunchKernelGGL(sh2rgb_backward_kernel<1>, grid, dim3(TPB), 0, s, g_rgb, dirs, V, N, rest_dim, d_sh0, d_shr, d_dirs); break;
+    case 2: hipLaunchKernelGGL(sh2rgb_backward_kernel<2>, grid, dim3(TPB), 0, s, g_rgb, dirs, V, N, rest_dim, d_sh0, d_shr, d_dirs); break;
+    case 3: hipLaunchKernelGGL(sh2rgb_backward_kernel<3>, grid, dim3(TPB), 0, s, g_rgb, dirs, V, N, rest_dim, d_sh0, d_shr, d_dirs); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+// world2ndc forward/backward (GR/transform.cu:602-731) -- legacy projection, no caller on the render
+// path; provided so the 26-symbol surface is complete.  Backward sums over views (the reference
+// overwrites per view, i.e. keeps the last one: a bug for V>1, identical for V==1).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) world2ndc_forward_kernel(const float* __restrict__ world, const float* __restrict__ vp, int N,
+                                                                float* __restrict__ ndc, float* __restrict__ rw)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    int b = blockIdx.y;
+    if (i >= N) return;
+    const float* M = vp + b * 16;
+    float w0 = world[i], w1 = world[(size_t)N + i], w2 = world[2 * (size_t)N + i], w3 = world[3 * (size_t)N + i];
+    float h[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = w0 * M[k] + w1 * M[4 + k] + w2 * M[8 + k] + w3 * M[12 + k];
+    float r = 1.0f / (h[3] + 1e-7f);
+    rw[(size_t)b * N + i] = r;
+    size_t o = (size_t)b * 4 * N + i;
+    ndc[o] = h[0] * r; ndc[o + (size_t)N] = h[1] * r; ndc[o + 2 * (size_t)N] = h[2] * r; ndc[o + 3 * (size_t)N] = 1.0f;
+}
+
+LG_API int lg_world2ndc_forward(const float* world, const float* viewproj, int V, int N, float* ndc, float* recp_w, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(world2ndc_forward_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream, world, viewproj, N, ndc, recp_w);
+    LG_RETURN_LAST();
+}
+
+__global__ void __launch_bounds__(TPB) world2ndc_backward_kernel(const float* __restrict__ vp, const float* __restrict__ ndc,
+                                                                 const float* __restrict__ rw, const float* __restrict__ g_ndc,
+                                                                 int V, int N, float* __restrict__ g_pos)
+{
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= N) return;
+    float gx = 0, gy = 0, gz = 0;
+    for (int b = 0; b < V; b++) {
+        const float* M = vp + b * 16;
+        size_t o = (size_t)b * 4 * N + i;
+        float r = rw[(size_t)b * N + i];
+        float m1 = ndc[o] * r, m2 = ndc[o + (size_t)N] * r, m3 = ndc[o + 2 * (size_t)N] * r;
+        float g0 = g_ndc[o], g1 = g_ndc[o + (size_t)N], g2 = g_ndc[o + 2 * (size_t)N];
+        gx += (M[0] * r - M[3] * m1) * g0 + (M[1] * r - M[3] * m2) * g1 + (M[2] * r - M[3] * m3) * g2;
+        gy += (M[4] * r - M[7] * m1) * g0 + (M[5] * r - M[7] * m2) * g1 + (M[6] * r - M[7] * m3) * g2;
+        gz += (M[8] * r - M[11] * m1) * g0 + (M[9] * r - M[11] * m2) * g1 + (M[10] * r - M[11] * m3) * g2;
+    }
+    g_pos[i] = gx; g_pos[(size_t)N + i] = gy; g_pos[2 * (size_t)N + i] = gz; g_pos[3 * (size_t)N + i] = 0.0f;
+}
+
+LG_API int lg_world2ndc_backward(const float* viewproj, const float* ndc, const float* recp_w, const float* g_ndc, int V, int N,
+                                 float* g_pos, void* stream)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(world2ndc_backward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, viewproj, ndc, recp_w, g_ndc, V, N, g_pos);
+    LG_RETURN_LAST();
+}

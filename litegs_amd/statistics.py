@@ -1,0 +1,133 @@
+"""Per-Gaussian statistics side channel (densification inputs) -- host-side mirror of
+``litegs/utils/statistic_helper.py`` (StatisticsHelper :14-245, StatisticGuard :247-260).
+
+The object is algorithmic state, not logging: while ``active`` the raster kernels run in statistic mode
+(fragment counts / weights / error moments) and the per-frame "heavy tiles first" schedule is refreshed.
+All accumulation into the full [*, chunks, S] tensors goes through the GPU-driven sparse scatter
+(``gpu_driven_pipeline_sparse_op``), because the tail of every compacted tensor is dirty by design.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import fused
+
+
+class _Moments:
+    def __init__(self, lead_shape, chunks, S, device):
+        self.sum = torch.zeros((*lead_shape, chunks, S), device=device)
+        self.square_sum = torch.zeros((*lead_shape, chunks, S), device=device)
+        self.count = torch.zeros((chunks, S), device=device, dtype=torch.int32)
+
+
+class Statistics:
+    def __init__(self):
+        self.active = False
+        self.enabled_for_epoch: Callable[[int], bool] = lambda epoch: False
+        self.chunks = 0
+        self.S = 0
+        self.device = None
+        self.moments: Dict[str, _Moments] = {}
+        self.visible_count: Optional[torch.Tensor] = None
+        self.compact_ids: Optional[torch.Tensor] = None
+        self.compact_count: Optional[torch.Tensor] = None
+        self.tile_schedule: Dict[object, torch.Tensor] = {}     # frame key -> int32[tiles] (1-based ids, heavy first)
+        self.tile_blend_count: Dict[object, torch.Tensor] = {}
+        self.current_frame = None
+
+    # -- lifecycle ---------------------------------------------------------------------------------
+    def reset(self, chunks: int, S: int, enabled_for_epoch: Optional[Callable[[int], bool]] = None, device="cuda"):
+        self.active = False
+        if enabled_for_epoch is not None:
+            self.enabled_for_epoch = enabled_for_epoch
+        self.chunks, self.S, self.device = chunks, S, device
+        self.moments = {}
+        self.visible_count = torch.zeros((chunks, S), dtype=torch.int32, device=device)
+        self.compact_ids = None
+        self.compact_count = None
+
+    def epoch(self, epoch: int) -> "_Guard":
+        return _Guard(self if self.enabled_for_epoch(epoch) else None)
+
+    # -- hooks called from render ------------------------------------------------------------------
+    def set_compaction(self, visible_chunkid: torch.Tensor, visible_chunks_num: torch.Tensor):
+        self.compact_ids, self.compact_count = visible_chunkid, visible_chunks_num
+
+    @torch.no_grad()
+    def add_visible(self, visible_mask: torch.Tensor):
+        """visible_mask bool[V, A*S] over the compacted Gaussians."""
+        add = visible_mask.sum(0, dtype=torch.int32).reshape(1, -1, self.S)
+        fused.gpu_driven_pipeline_sparse_op(self.visible_count.view(1, self.chunks, self.S), add, self.compact_ids, self.compact_count, "add")
+
+    @torch.no_grad()
+    def add_moments(self, key: str, value_sum: torch.Tensor, square_sum: torch.Tensor, count: torch.Tensor):
+        """value_sum / square_sum [..., A*S] float32, count int32[..., A*S] (compacted)."""
+        value_sum = value_sum.reshape(*value_sum.shape[:-1], -1, self.S)
+        square_sum = square_sum.reshape(*square_sum.shape[:-1], -1, self.S)
+        mom = self.moments.get(key)
+        if mom is None:
+            mom = _Moments(value_sum.shape[:-2], self.chunks, self.S, value_sum.device)
+            self.moments[key] = mom
+        A = value_sum.shape[-2]
+        fused.gpu_driven_pipeline_sparse_op(mom.sum.view(-1, self.chunks, self.S), value_sum.reshape(-1, A, self.S).contiguous(),
+                                            self.compact_ids, self.compact_count, "add")
+        fused.gpu_driven_pipeline_sparse_op(mom.square_sum.view(-1, self.chunks, self.S), square_sum.reshape(-1, A, self.S).contiguous(),
+                                            self.compact_ids, self.compact_count, "add")
+        fused.gpu_driven_pipeline_sparse_op(mom.count.view(-1, self.chunks, self.S), count.reshape(-1, A, self.S).contiguous(),
+                                            self.compact_ids, self.compact_count, "add")
+
+    @torch.no_grad()
+    def update_tile_schedule(self, last_contributor: torch.Tensor, th: int, tw: int):
+        """Per-tile max blend depth -> heavy-first tile order for the next time this frame is rendered
+        (statistic_helper.py:68-79)."""
+        if self.current_frame is None:
+            return
+        N, _, Hp, Wp = last_contributor.shape
+        ty, tx = Hp // th, Wp // tw
+        per_tile = last_contributor.reshape(N, ty, th, tx, tw).permute(1, 3, 0, 2, 4).reshape(ty * tx, -1).max(dim=1).values
+        self.tile_blend_count[self.current_frame] = per_tile
+        self.tile_schedule[self.current_frame] = (per_tile.sort(descending=True)[1].int() + 1)
+
+    def schedule_for_current_frame(self) -> Optional[torch.Tensor]:
+        t = self.tile_schedule.get(self.current_frame)
+        return None if t is None else t.unsqueeze(0)
+
+    # -- queries used by the density controller --------------------------------------------------------
+    @torch.no_grad()
+    def mean(self, key: str):
+        mom = self.moments.get(key)
+        if mom is None:
+            return None
+        m = mom.sum / (mom.count + 1e-9)
+        return m.reshape(*m.shape[:-2], -1), mom.count.reshape(-1)
+
+    @torch.no_grad()
+    def var(self, key: str):
+        mom = self.moments.get(key)
+        if mom is None:
+            return None
+        mean = mom.sum / (mom.count + 1)
+        sq = mom.square_sum / (mom.count + 1)
+        v = (sq - mean ** 2).clamp_min(0)
+        return v.reshape(*v.shape[:-2], -1), mom.count.reshape(-1)
+
+    def never_visible(self) -> torch.Tensor:
+        return (self.visible_count == 0).reshape(-1)
+
+
+class _Guard:
+    def __init__(self, stats: Optional[Statistics]):
+        self.stats = stats
+
+    def __enter__(self):
+        if self.stats is not None:
+            self.stats.active = True
+
+    def __exit__(self, *exc):
+        if self.stats is not None:
+            self.stats.active = False
+
+
+STATS = Statistics()

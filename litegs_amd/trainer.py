@@ -1,0 +1,91 @@
+"""One training iteration of the LiteGS hot loop on synthetic data (litegs/training/trainer.py:111-163):
+render_preprocess -> render -> L1+SSIM loss -> backward -> sparse Adam -> zero_grad -> lr schedule.
+
+``SyntheticTrainer`` owns a seeded Gaussian cloud, a set of camera frames with per-frame targets and the
+pinned feedback buffers of the GPU-driven protocol (litegs/data.py:236-241), so steady-state iterations run
+without any host<->device synchronisation.  Used by bench.py, the smoke test and the DP tests.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import loss as loss_mod
+from . import optimizer as opt_mod
+from . import render as R
+from . import synthetic as S
+from .statistics import STATS
+
+
+class Frame:
+    def __init__(self, view, proj, planes, gt, idx):
+        self.view, self.proj, self.planes, self.gt = view, proj, planes, gt
+        self.idx_tensor = torch.tensor([idx], dtype=torch.int64)       # CPU, as the reference's DataLoader yields it
+
+
+class SyntheticTrainer:
+    def __init__(self, n_gaussians: int, width: int, height: int, focal: float, n_frames: int = 8, seed: int = 0, sh_degree: int = 3,
+                 device: Optional[torch.device] = None, radius: float = 4.0, cam_radius_frac: float = 0.5, use_torch_loss: bool = False,
+                 scene=None):
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.H, self.W, self.degree = height, width, sh_degree
+        self.pp = R.PipelineParams()
+        if scene is None:
+            scene = S.make_scene(n_gaussians, seed=seed, sh_degree=sh_degree, radius=radius)
+        self.params = [torch.nn.Parameter(torch.from_numpy(p).to(self.device)) for p in scene]
+        self.n_chunks, self.S = self.params[0].shape[-2], self.params[0].shape[-1]
+        cams = S.orbit_cameras(n_frames, width, height, focal, focal, cam_radius_frac * radius)
+        rng = np.random.default_rng(seed + 1)
+        self.frames: List[Frame] = []
+        for k, (view, proj, planes) in enumerate(cams):
+            gt = torch.from_numpy(rng.random((1, 3, height, width), dtype=np.float32)).to(self.device)
+            self.frames.append(Frame(*[torch.from_numpy(x).to(self.device) for x in (view, proj, planes)], gt, k))
+        # Implicit synchronisation buffers: written in epoch N, read in epoch N+1 (litegs/data.py:238)
+        self.feedback_visible_chunks_num = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
+        self.feedback_binning_allocate_size = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
+        self.opt, self.sched = opt_mod.get_optimizer(*self.params, 1.0, opt_mod.OptimizationParams())
+        with torch.no_grad():
+            xyz, scale, rot = self.params[0], self.params[1], self.params[2]
+            self.cluster_origin, self.cluster_extend = R.get_cluster_AABB(xyz, scale.exp(), torch.nn.functional.normalize(rot, dim=0))
+        self.loss_fn = loss_mod.l1_ssim_loss_torch if use_torch_loss else loss_mod.fused_l1_ssim_loss
+        self.last = {}
+
+    # -------------------------------------------------------------------------------------------
+    def forward(self, frame: Frame):
+        xyz, scale, rot, sh_0, sh_rest, opacity = self.params
+        STATS.current_frame = int(frame.idx_tensor[0])
+        vis_id, vis_num, cx, cs, cr, cc, co = R.render_preprocess(
+            self.cluster_origin, self.cluster_extend, frame.planes, frame.view, xyz, scale, rot, sh_0, sh_rest, opacity,
+            self.feedback_visible_chunks_num, frame.idx_tensor, self.pp, self.degree)
+        valid_length = vis_num * self.pp.cluster_size
+        img, trans, depth, normal, prim_vis = R.render(frame.view, frame.proj, cx, cs, cr, cc, co, valid_length,
+                                                       self.feedback_binning_allocate_size, frame.idx_tensor, self.degree,
+                                                       (self.H, self.W), self.pp)
+        return img, vis_id, vis_num, prim_vis
+
+    def step(self, frame_index: int, grad_hook=None):
+        frame = self.frames[frame_index % len(self.frames)]
+        img, vis_id, vis_num, prim_vis = self.forward(frame)
+        loss = self.loss_fn(img, frame.gt)
+        loss.backward()
+        if grad_hook is not None:            # data-parallel gradient exchange (litegs_amd/dp.py)
+            vis_id, vis_num = grad_hook(self.params, vis_id, vis_num)
+        self.opt.step(vis_id, vis_num, prim_vis)
+        self.opt.zero_grad(set_to_none=True)
+        self.sched.step()
+        self.last = dict(loss=loss.detach(), vis_num=vis_num)
+        return loss
+
+    @torch.no_grad()
+    def forward_only(self, frame_index: int):
+        frame = self.frames[frame_index % len(self.frames)]
+        return self.forward(frame)[0]
+
+    def workload_stats(self, frame_index: int = 0):
+        """N_vis (Gaussians after chunk culling), I (tile instances) for one frame -- host sync, call outside timed regions."""
+        frame = self.frames[frame_index % len(self.frames)]
+        torch.cuda.synchronize()
+        k = int(frame.idx_tensor[0])
+        return dict(n_vis=int(self.feedback_visible_chunks_num[k]) * self.S, instances=int(self.feedback_binning_allocate_size[k]))

@@ -1,0 +1,241 @@
+"""Autograd bindings of the HIP operators -- host-side mirror of ``litegs/utils/wrapper.py``.
+
+Same class names and call conventions as the reference (``X.apply`` / ``X.call_fused``), so code written
+against ``litegs.utils.wrapper`` reads the same here.  What each Function saves and which inputs get
+``None`` gradients follows wrapper.py:180-196 (CreateTransformMatrix), :270-285 (MVPTransform), :396-410
+(CreateCov2dDirectly), :444-524 (GaussiansRasterFunc), :579-593 (EighAndInverse2x2Matrix), :793-845
+(CullCompactActivateWithSparseGrad).  No gradient flows through the ray-space Jacobian or the SH view
+direction (wrapper.py:243,257; GR/compact.cu:656ff) -- neither here.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import binning as _binning
+from . import fused
+from .statistics import STATS
+
+
+# ------------------------------------------------------------------------------------------------
+# Sparse gradient container: a tensor that *claims* the full parameter shape (so autograd accepts it as
+# `.grad`) while holding only the rows of the visible chunks (litegs/utils/CompactedTensor.py:3-45).
+# ------------------------------------------------------------------------------------------------
+class CompactedTensor(torch.Tensor):
+    @staticmethod
+    def __new__(cls, full_shape, chunk_ids: torch.Tensor, compacted_values: torch.Tensor):
+        return torch.Tensor._make_wrapper_subclass(cls, tuple(full_shape), dtype=compacted_values.dtype, device=compacted_values.device,
+                                                   layout=torch.strided, requires_grad=False)
+
+    def __init__(self, full_shape, chunk_ids: torch.Tensor, compacted_values: torch.Tensor):
+        self.chunk_ids = chunk_ids
+        self.compacted_values = compacted_values
+
+    def __repr__(self):
+        return f"CompactedTensor(shape={tuple(self.shape)}, compacted={tuple(self.compacted_values.shape)})"
+
+    def to_dense(self, valid_chunks: Optional[int] = None) -> torch.Tensor:
+        """Materialise the full gradient (zeros for invisible chunks).  `valid_chunks` bounds the rows that hold data."""
+        vals = self.compacted_values
+        n = vals.shape[-2] if valid_chunks is None else int(valid_chunks)
+        lead = self.shape[:-2]
+        dense = torch.zeros((int(torch.tensor(lead).prod()) if len(lead) else 1, self.shape[-2], self.shape[-1]), dtype=vals.dtype, device=vals.device)
+        dense[:, self.chunk_ids[:n], :] = vals.reshape(dense.shape[0], -1, self.shape[-1])[:, :n, :]
+        return dense.reshape(self.shape)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        packet = getattr(func, "overloadpacket", None)
+        if packet is torch.ops.aten.detach or packet is torch.ops.aten.alias:
+            src = args[0]
+            return cls(src.shape, src.chunk_ids, src.compacted_values)
+        if packet is torch.ops.aten.clone:
+            src = args[0]
+            return cls(src.shape, src.chunk_ids.clone(), src.compacted_values.clone())
+        raise NotImplementedError(f"CompactedTensor does not support {func}; use .compacted_values / .to_dense()")
+
+
+# ------------------------------------------------------------------------------------------------
+class MVPTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, position, view_matrix, proj_matrix, valid_length=None):
+        view_pos, ndc_pos = fused.mvp_transform_forward(position, view_matrix, proj_matrix, valid_length)
+        ctx.save_for_backward(view_pos, view_matrix, proj_matrix, valid_length)
+        return view_pos, ndc_pos
+
+    @staticmethod
+    def backward(ctx, grad_view_pos, grad_ndc_pos):
+        view_pos, view_matrix, proj_matrix, valid_length = ctx.saved_tensors
+        g = fused.mvp_transform_backward(grad_ndc_pos, grad_view_pos, view_matrix, proj_matrix, view_pos, valid_length)
+        return g, None, None, None
+
+
+class _TransformMatrixFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, quaternion, scale, valid_length):
+        ctx.save_for_backward(quaternion, scale, valid_length)
+        return fused.createTransformMatrix_forward(quaternion, scale, valid_length)
+
+    @staticmethod
+    def backward(ctx, grad_T):
+        quaternion, scale, valid_length = ctx.saved_tensors
+        gq, gs = fused.createTransformMatrix_backward(grad_T, quaternion, scale, valid_length)
+        return gq, gs, None
+
+
+class CreateTransformMatrix:
+    @staticmethod
+    def call_fused(scaling_vec, rotator_vec, valid_length=None):
+        return _TransformMatrixFn.apply(rotator_vec, scaling_vec, valid_length)
+
+    call = call_fused
+
+
+class CreateRaySpaceTransformMatrix:
+    @staticmethod
+    @torch.no_grad()
+    def call_fused(view_pos, proj_matrix, output_shape, valid_length=None):
+        return fused.jacobianRayspace(view_pos, proj_matrix, output_shape[0], output_shape[1], valid_length)
+
+    call = call_fused
+
+
+class _Cov2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, J, view_matrix, transform_matrix, valid_length):
+        ctx.save_for_backward(J, view_matrix, transform_matrix, valid_length)
+        return fused.createCov2dDirectly_forward(J, view_matrix, transform_matrix, valid_length)
+
+    @staticmethod
+    def backward(ctx, grad_cov2d):
+        J, view_matrix, transform_matrix, valid_length = ctx.saved_tensors
+        return None, None, fused.createCov2dDirectly_backward(grad_cov2d, J, view_matrix, transform_matrix, valid_length), None
+
+
+class CreateCov2dDirectly:
+    @staticmethod
+    def call_fused(J, view_matrix, transform_matrix, valid_length=None):
+        return _Cov2dFn.apply(J, view_matrix, transform_matrix, valid_length)
+
+    call = call_fused
+
+
+class _EighInvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cov2d, valid_length):
+        val, vec, inv = fused.eigh_and_inv_2x2matrix_forward(cov2d, valid_length)
+        ctx.save_for_backward(inv, valid_length)
+        ctx.mark_non_differentiable(val, vec)
+        return val, vec, inv
+
+    @staticmethod
+    def backward(ctx, _gval, _gvec, grad_inv):
+        inv, valid_length = ctx.saved_tensors
+        g = fused.inv_2x2matrix_backward(inv, grad_inv, valid_length)
+        g.nan_to_num_(0)                         # wrapper.py:591
+        return g, None
+
+
+class EighAndInverse2x2Matrix:
+    @staticmethod
+    def call_fused(cov2d, valid_length=None):
+        return _EighInvFn.apply(cov2d, valid_length)
+
+    call = call_fused
+
+
+class _SHFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, deg, sh_base, sh_rest, dirs):
+        ctx.save_for_backward(dirs, sh_base, sh_rest)
+        ctx.deg = deg
+        return fused.sh2rgb_forward(deg, sh_base, sh_rest, dirs)
+
+    @staticmethod
+    def backward(ctx, grad_rgb):
+        dirs, sh_base, sh_rest = ctx.saved_tensors
+        d0, dr, dd = fused.sh2rgb_backward(ctx.deg, grad_rgb, sh_rest.shape[0], dirs, sh_base, sh_rest)
+        return None, d0, dr, dd
+
+
+class SphericalHarmonicToRGB:
+    @staticmethod
+    def call_fused(deg, sh_base, sh_rest, dirs):
+        return _SHFn.apply(deg, sh_base, sh_rest, dirs).clamp_min(0)     # wrapper.py:558
+
+    call = call_fused
+
+
+class Binning:
+    @staticmethod
+    @torch.no_grad()
+    def call_fused(ndc, view_depth, inv_cov2d, opacity, valid_length, feedback_binning_allocate_size, idx_tensor, img_pixel_shape, tile_size):
+        hook = STATS.add_visible if STATS.active else None
+        return _binning.binning(ndc, view_depth, inv_cov2d, opacity, valid_length, feedback_binning_allocate_size, idx_tensor,
+                                img_pixel_shape, tile_size, on_visible=hook)
+
+    call = call_fused
+
+
+class GaussiansRasterFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sorted_pointId, tile_start_index, ndc, cov2d_inv, color, opacities, tiles, img_h, img_w, tile_h, tile_w,
+                enable_transmitance=False, enable_depth=False):
+        stat = STATS.active
+        img, trans, depth, last, packed, frag_count, frag_weight = fused.rasterize_forward(
+            sorted_pointId, tile_start_index, ndc, cov2d_inv, color, opacities, tiles, img_h, img_w, tile_h, tile_w,
+            stat, enable_transmitance, enable_depth)
+        ctx.save_for_backward(sorted_pointId, tile_start_index, trans, last, packed, tiles, frag_count, frag_weight)
+        ctx.geom = (img_h, img_w, tile_h, tile_w)
+        ctx.stat = stat
+        ctx.mark_non_differentiable(last)
+        return img, (trans if enable_transmitance else None), (depth if enable_depth else None), None, last
+
+    @staticmethod
+    def backward(ctx, grad_img, grad_trans, grad_depth, _grad_normal, _):
+        sorted_pointId, tile_start_index, trans, last, packed, tiles, frag_count, frag_weight = ctx.saved_tensors
+        img_h, img_w, tile_h, tile_w = ctx.geom
+        # fp32 blend: the reference's max-normalisation of grad_img (wrapper.py:490-491) is an fp16 range hack and
+        # an exact identity here, so it is skipped (saves a full-image reduction and a host-visible dependency).
+        d_ndc, d_cov2d_inv, d_color, d_opacity, _, err_sq = fused.rasterize_backward(
+            sorted_pointId, tile_start_index, packed, tiles, trans, last, grad_img.contiguous(), grad_trans, grad_depth, None,
+            img_h, img_w, tile_h, tile_w, ctx.stat)
+        if ctx.stat:
+            STATS.add_moments("fragment_weight", frag_weight, frag_weight * frag_weight, frag_count)
+            STATS.add_moments("fragment_err", d_opacity.unsqueeze(0), err_sq, frag_count)
+        return None, None, d_ndc, d_cov2d_inv, d_color, d_opacity, None, None, None, None, None, None, None
+
+
+class CullCompactActivateWithSparseGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b_sparse_grad, sh_degree, visible_chunkid, visible_chunk_num, view_matrix, xyz, scale, rot, sh_0, sh_rest, opacity):
+        ctx.meta = (b_sparse_grad, sh_degree, xyz.shape[-2], xyz.shape[-1])
+        out = fused.cull_compact_activate(sh_degree, visible_chunkid, visible_chunk_num, view_matrix, xyz, scale, rot, sh_0, sh_rest, opacity)
+        ctx.save_for_backward(visible_chunkid, visible_chunk_num, view_matrix, xyz, scale, rot, sh_0, sh_rest, opacity)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, g_pos, g_scale, g_rot, g_color, g_opacity):
+        b_sparse_grad, sh_degree, chunk_num, chunk_size = ctx.meta
+        visible_chunkid, visible_chunk_num, view_matrix, xyz, scale, rot, sh_0, sh_rest, opacity = ctx.saved_tensors
+        compact = fused.activate_backward(sh_degree, visible_chunkid, visible_chunk_num, view_matrix, xyz, scale, rot, sh_0, sh_rest, opacity,
+                                          g_pos, g_scale, g_rot, g_color, g_opacity)
+        A = visible_chunkid.shape[0]
+        grads = []
+        for g in compact:
+            full = (*g.shape[:-2], chunk_num, chunk_size)
+            if b_sparse_grad:
+                grads.append(CompactedTensor(full, visible_chunkid, g.reshape(-1, A, chunk_size)))
+            else:
+                dense = torch.zeros(full, device=g.device, dtype=g.dtype)
+                fused.gpu_driven_pipeline_sparse_op(dense.view(-1, chunk_num, chunk_size), g.reshape(-1, A, chunk_size), visible_chunkid,
+                                                    visible_chunk_num, "add")
+                grads.append(dense)
+        return (None, None, None, None, None, *grads)
+
+
+def sparse_adam_update(param, grad, exp_avg, exp_avg_sq, visible_index, valid_length, lr, b1, b2, eps):
+    """wrapper.py:847-856."""
+    if param.shape[0] != 0:
+        fused.adamUpdate(param, grad, exp_avg, exp_avg_sq, visible_index, valid_length, lr, b1, b2, eps)

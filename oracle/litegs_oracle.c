@@ -1,0 +1,1062 @@
+/*
+ * litegs_oracle.c -- CPU restatement (fp32) of the LiteGS `litegs.render` hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under litegs_amd/ (the product) may include,
+ * link or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it -- as the checker / the timed CPU baseline, never as
+ * the thing shipped.
+ *
+ * Every function restates one reference kernel.  File:line citations are relative
+ * to /root/reference/litegs/submodules/gaussian_raster/ (abbreviated GR/).
+ * Deliberate deviations from the reference binary (all documented in DESIGN.md):
+ *   - the blend runs in fp32, not half2 (GR/raster.cu:72-78,203-283 are fp16 range hacks:
+ *     the x128 transmittance scale and the grad_inv_scaler normalisation are identities here);
+ *   - colour/opacity are NOT rounded to fp16 when packed (GR/raster.cu:353-354);
+ *   - reference bugs listed in SURVEY.md 8a ("do not reproduce") are not reproduced:
+ *     empty-tile backward (raster.cu:688-696), shared_img_grad[3] OOB (raster.cu:683),
+ *     multi-view sort (binning.cu:213-221), depth output uninitialised (raster.cu:443).
+ *   - log() in the tile-extent computation is a fixed polynomial (orc_logf) so that the
+ *     HIP binning kernels (compiled -ffp-contract=off) are BIT-EXACT against this file.
+ *
+ * Build: gcc -O2 -fopenmp -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* helpers                                                                    */
+/* ------------------------------------------------------------------------- */
+static inline float fminf_(float a, float b) { return a < b ? a : b; }
+static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* float -> int with the saturating / NaN->0 semantics of the GPU's v_cvt_i32_f32,
+ * so `(int)(x / Tile)` in GR/speedy_splat.cuh:120-125 has one defined meaning. */
+static inline int f2i(float v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 2147483648.0f) return INT_MAX;
+    if (v <= -2147483648.0f) return INT_MIN;
+    return (int)v;
+}
+
+/* Natural log for normal positive floats; fixed operation order (no libm), so the HIP
+ * twin in litegs_amd/csrc/binning.hip produces the same bits.  |rel err| < 3e-7. */
+static inline float orc_logf(float x)
+{
+    uint32_t ux;
+    memcpy(&ux, &x, 4);
+    int e = (int)((ux >> 23) & 0xff) - 127;
+    ux = (ux & 0x007fffffu) | 0x3f800000u; /* m in [1,2) */
+    float m;
+    memcpy(&m, &ux, 4);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * (0.40000972152f + w * 0.24279078841f);
+    float t2 = z * (0.66666662693f + w * 0.28498786688f);
+    float R = t2 + t1;
+    float hfsq = 0.5f * f * f;
+    float dk = (float)e;
+    return dk * 0.69313812256f + ((dk * 9.0580006145e-6f + (s * (hfsq + R) - hfsq)) + f);
+}
+
+static const float SH_C0 = 0.28209479177387814f;
+static const float SH_C1 = 0.4886025119029199f;
+static const float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                -1.0925484305920792f, 0.5462742152960396f };
+static const float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                -0.5900435899266435f };
+
+/* SH basis values b[0..15] for unit direction (x,y,z): rgb = sum_k b[k]*sh[k] (+0.5).
+ * GR/compact.cu:574-653 (identical maths in GR/transform.cu:952-1037). */
+static inline void sh_basis(int degree, float x, float y, float z, float* b)
+{
+    b[0] = SH_C0;
+    if (degree > 0) {
+        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+        if (degree > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = SH_C2[0] * xy; b[5] = SH_C2[1] * yz; b[6] = SH_C2[2] * (2.0f * zz - xx - yy);
+            b[7] = SH_C2[3] * xz; b[8] = SH_C2[4] * (xx - yy);
+            if (degree > 2) {
+                b[9]  = SH_C3[0] * y * (3.0f * xx - yy);
+                b[10] = SH_C3[1] * xy * z;
+                b[11] = SH_C3[2] * y * (4.0f * zz - xx - yy);
+                b[12] = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                b[13] = SH_C3[4] * x * (4.0f * zz - xx - yy);
+                b[14] = SH_C3[5] * z * (xx - yy);
+                b[15] = SH_C3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+/* camera centre = -t . R^T for a row-vector view matrix; GR/compact.cu:875-879 */
+static inline void camera_center(const float* V, float* cc)
+{
+    float ix = -V[3 * 4 + 0], iy = -V[3 * 4 + 1], iz = -V[3 * 4 + 2];
+    cc[0] = ix * V[0 * 4 + 0] + iy * V[0 * 4 + 1] + iz * V[0 * 4 + 2];
+    cc[1] = ix * V[1 * 4 + 0] + iy * V[1 * 4 + 1] + iz * V[1 * 4 + 2];
+    cc[2] = ix * V[2 * 4 + 0] + iy * V[2 * 4 + 1] + iz * V[2 * 4 + 2];
+}
+
+/* ------------------------------------------------------------------------- */
+/* a1  frustum_culling_aabb     GR/compact.cu:437-473                          */
+/* visibility[m] = OR_views AND_planes ( n.o + d + |n|.e >= 0 )                */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_frustum_culling_aabb(const float* origin, const float* ext, const float* planes,
+                                      int V, int M, uint8_t* visibility)
+{
+#pragma omp parallel for
+    for (int m = 0; m < M; m++) {
+        int gv = 0;
+        for (int v = 0; v < V; v++) {
+            int vis = 1;
+            for (int p = 0; p < 6; p++) {
+                const float* pl = planes + (v * 6 + p) * 4;
+                float d_o = pl[0] * origin[0 * M + m] + pl[1] * origin[1 * M + m] + pl[2] * origin[2 * M + m] + pl[3];
+                float d_e = fabsf(pl[0]) * ext[0 * M + m] + fabsf(pl[1]) * ext[1 * M + m] + fabsf(pl[2]) * ext[2 * M + m];
+                vis &= ((d_o + d_e) >= 0.0f);
+            }
+            gv |= vis;
+        }
+        visibility[m] = (uint8_t)gv;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a2  cull_compact_activate    GR/compact.cu:826-893                          */
+/* params: pos[3,C,S] scale[3,C,S] rot[4,C,S] sh0[1,3,C,S] shr[R,3,C,S] opa[1,C,S] */
+/* outputs sized for A allocated chunks: pos[4,A,S] scale[3,A,S] rot[4,A,S]     */
+/* color[V,3,A,S] opacity[1,A,S].  Chunks >= nvis only get opacity = 0.         */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_activate_forward(int degree, const int64_t* chunk_id, int nvis, int A,
+                                  const float* view, int V,
+                                  const float* pos, const float* scale, const float* rot,
+                                  const float* sh0, const float* shr, const float* opa,
+                                  int C, int S,
+                                  float* o_pos, float* o_scale, float* o_rot, float* o_color, float* o_opa)
+{
+    const size_t CS = (size_t)C * S, AS = (size_t)A * S;
+#pragma omp parallel for
+    for (int a = 0; a < A; a++) {
+        for (int i = 0; i < S; i++) {
+            size_t od = (size_t)a * S + i;
+            if (a >= nvis) { o_opa[od] = 0.0f; continue; }
+            size_t sd = (size_t)chunk_id[a] * S + i;
+            float px = pos[0 * CS + sd], py = pos[1 * CS + sd], pz = pos[2 * CS + sd];
+            o_pos[0 * AS + od] = px; o_pos[1 * AS + od] = py; o_pos[2 * AS + od] = pz; o_pos[3 * AS + od] = 1.0f;
+            for (int k = 0; k < 3; k++) o_scale[k * AS + od] = expf(scale[k * CS + sd]);
+            float w = rot[0 * CS + sd], x = rot[1 * CS + sd], y = rot[2 * CS + sd], z = rot[3 * CS + sd];
+            float rn = 1.0f / sqrtf(w * w + x * x + y * y + z * z + 1e-12f);
+            o_rot[0 * AS + od] = w * rn; o_rot[1 * AS + od] = x * rn; o_rot[2 * AS + od] = y * rn; o_rot[3 * AS + od] = z * rn;
+            o_opa[od] = 1.0f / (1.0f + expf(-opa[sd]));
+            for (int v = 0; v < V; v++) {
+                float cc[3];
+                camera_center(view + v * 16, cc);
+                float dx = px - cc[0], dy = py - cc[1], dz = pz - cc[2];
+                float nr = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz + 1e-12f);
+                dx *= nr; dy *= nr; dz *= nr;
+                float b[16];
+                sh_basis(degree, dx, dy, dz, b);
+                int nb = (degree + 1) * (degree + 1);
+                for (int ch = 0; ch < 3; ch++) {
+                    float r = b[0] * sh0[ch * CS + sd];
+                    for (int k = 1; k < nb; k++) r += b[k] * shr[((size_t)(k - 1) * 3 + ch) * CS + sd];
+                    o_color[((size_t)v * 3 + ch) * AS + od] = r + 0.5f;
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a19 activate_backward        GR/compact.cu:896-980                          */
+/* NOTE opacity grad = g * sigmoid(x) (sic, compact.cu:952) -- reproduced.     */
+/* Direction gradient is dropped (compact.cu:656ff commented out).             */
+/* sh_rest grads for inactive degrees stay 0 (buffer pre-zeroed, :1107).       */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_activate_backward(int degree, const int64_t* chunk_id, int nvis, int A,
+                                   const float* view, int V,
+                                   const float* pos, const float* scale, const float* rot,
+                                   const float* sh0, const float* shr, const float* opa,
+                                   int C, int S, int R,
+                                   const float* g_pos /*[4,A,S]*/, const float* g_scale, const float* g_rot,
+                                   const float* g_color /*[V,3,A,S]*/, const float* g_opa,
+                                   float* d_pos /*[3,A,S]*/, float* d_scale, float* d_rot,
+                                   float* d_sh0 /*[1,3,A,S]*/, float* d_shr /*[R,3,A,S] pre-zeroed*/, float* d_opa)
+{
+    (void)sh0; (void)shr;
+    const size_t CS = (size_t)C * S, AS = (size_t)A * S;
+    memset(d_shr, 0, sizeof(float) * (size_t)R * 3 * AS);
+#pragma omp parallel for
+    for (int a = 0; a < nvis; a++) {
+        for (int i = 0; i < S; i++) {
+            size_t od = (size_t)a * S + i;
+            size_t sd = (size_t)chunk_id[a] * S + i;
+            for (int k = 0; k < 3; k++) d_pos[k * AS + od] = g_pos[k * AS + od];
+            for (int k = 0; k < 3; k++) d_scale[k * AS + od] = expf(scale[k * CS + sd]) * g_scale[k * AS + od];
+            float w = rot[0 * CS + sd], x = rot[1 * CS + sd], y = rot[2 * CS + sd], z = rot[3 * CS + sd];
+            float rn = 1.0f / sqrtf(w * w + x * x + y * y + z * z + 1e-12f);
+            float ow = w * rn, ox = x * rn, oy = y * rn, oz = z * rn;
+            float g0 = g_rot[0 * AS + od], g1 = g_rot[1 * AS + od], g2 = g_rot[2 * AS + od], g3 = g_rot[3 * AS + od];
+            float dot = g0 * ow + g1 * ox + g2 * oy + g3 * oz;
+            d_rot[0 * AS + od] = rn * (g0 - dot * ow);
+            d_rot[1 * AS + od] = rn * (g1 - dot * ox);
+            d_rot[2 * AS + od] = rn * (g2 - dot * oy);
+            d_rot[3 * AS + od] = rn * (g3 - dot * oz);
+            d_opa[od] = g_opa[od] * (1.0f - 1.0f / (1.0f + expf(opa[sd])));
+            float px = pos[0 * CS + sd], py = pos[1 * CS + sd], pz = pos[2 * CS + sd];
+            int nb = (degree + 1) * (degree + 1);
+            for (int v = 0; v < V; v++) {
+                float cc[3];
+                camera_center(view + v * 16, cc);
+                float dx = px - cc[0], dy = py - cc[1], dz = pz - cc[2];
+                float nr = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz + 1e-12f);
+                dx *= nr; dy *= nr; dz *= nr;
+                float b[16];
+                sh_basis(degree, dx, dy, dz, b);
+                for (int ch = 0; ch < 3; ch++) {
+                    float g = g_color[((size_t)v * 3 + ch) * AS + od];
+                    if (v == 0) d_sh0[ch * AS + od] = b[0] * g; else d_sh0[ch * AS + od] += b[0] * g;
+                    for (int k = 1; k < nb; k++) {
+                        size_t o = ((size_t)(k - 1) * 3 + ch) * AS + od;
+                        if (v == 0) d_shr[o] = b[k] * g; else d_shr[o] += b[k] * g;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a22 sh2rgb forward/backward (non-cluster path)  GR/transform.cu:952-1296    */
+/* sh0[1,3,N] shr[R,3,N] dirs[V,3,N] -> rgb[V,3,N]; backward sums over views,  */
+/* direction gradient returned as zeros (transform.cu:1288-1290 commented out) */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_sh2rgb_forward(int degree, const float* sh0, const float* shr, const float* dirs,
+                                int V, int N, float* rgb)
+{
+    int nb = (degree + 1) * (degree + 1);
+#pragma omp parallel for
+    for (int i = 0; i < N; i++)
+        for (int v = 0; v < V; v++) {
+            float b[16];
+            sh_basis(degree, dirs[((size_t)v * 3 + 0) * N + i], dirs[((size_t)v * 3 + 1) * N + i], dirs[((size_t)v * 3 + 2) * N + i], b);
+            for (int ch = 0; ch < 3; ch++) {
+                float r = b[0] * sh0[(size_t)ch * N + i];
+                for (int k = 1; k < nb; k++) r += b[k] * shr[((size_t)(k - 1) * 3 + ch) * N + i];
+                rgb[((size_t)v * 3 + ch) * N + i] = r + 0.5f;
+            }
+        }
+}
+
+ORC_API void orc_sh2rgb_backward(int degree, const float* g_rgb, const float* dirs, int V, int N, int R,
+                                 float* d_sh0, float* d_shr, float* d_dirs)
+{
+    int nb = (degree + 1) * (degree + 1);
+    memset(d_shr, 0, sizeof(float) * (size_t)R * 3 * N);
+    memset(d_dirs, 0, sizeof(float) * (size_t)V * 3 * N);
+#pragma omp parallel for
+    for (int i = 0; i < N; i++) {
+        for (int ch = 0; ch < 3; ch++) d_sh0[(size_t)ch * N + i] = 0.0f;
+        for (int v = 0; v < V; v++) {
+            float b[16];
+            sh_basis(degree, dirs[((size_t)v * 3 + 0) * N + i], dirs[((size_t)v * 3 + 1) * N + i], dirs[((size_t)v * 3 + 2) * N + i], b);
+            for (int ch = 0; ch < 3; ch++) {
+                float g = g_rgb[((size_t)v * 3 + ch) * N + i];
+                d_sh0[(size_t)ch * N + i] += b[0] * g;
+                for (int k = 1; k < nb; k++) d_shr[((size_t)(k - 1) * 3 + ch) * N + i] += b[k] * g;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a3  mvp_transform_forward    GR/transform.cu:398-436                        */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_mvp_forward(const float* world /*[4,N]*/, const float* view, const float* proj,
+                             int V, int N, int valid, float* view_pos /*[V,4,N]*/, float* ndc_pos)
+{
+#pragma omp parallel for
+    for (int i = 0; i < valid; i++)
+        for (int b = 0; b < V; b++) {
+            const float* Vm = view + b * 16; const float* P = proj + b * 16;
+            float w4[4], v4[4], h4[4];
+            for (int k = 0; k < 4; k++) w4[k] = world[(size_t)k * N + i];
+            for (int k = 0; k < 4; k++) v4[k] = w4[0] * Vm[0 * 4 + k] + w4[1] * Vm[1 * 4 + k] + w4[2] * Vm[2 * 4 + k] + w4[3] * Vm[3 * 4 + k];
+            for (int k = 0; k < 4; k++) h4[k] = v4[0] * P[0 * 4 + k] + v4[1] * P[1 * 4 + k] + v4[2] * P[2 * 4 + k] + v4[3] * P[3 * 4 + k];
+            float iw = (fabsf(h4[3]) > 1e-12f) ? (1.0f / h4[3]) : 0.0f;
+            size_t o = (size_t)b * 4 * N + i;
+            for (int k = 0; k < 4; k++) view_pos[o + (size_t)k * N] = v4[k];
+            ndc_pos[o + 0 * (size_t)N] = h4[0] * iw; ndc_pos[o + 1 * (size_t)N] = h4[1] * iw;
+            ndc_pos[o + 2 * (size_t)N] = h4[2] * iw; ndc_pos[o + 3 * (size_t)N] = 1.0f;
+        }
+}
+
+/* a18 mvp_transform_backward   GR/transform.cu:496-558 */
+ORC_API void orc_mvp_backward(const float* g_ndc, const float* g_view, const float* view, const float* proj,
+                              const float* view_pos, int V, int N, int valid, float* g_world /*[4,N]*/)
+{
+#pragma omp parallel for
+    for (int i = 0; i < valid; i++) {
+        float acc[4] = { 0, 0, 0, 0 };
+        for (int b = 0; b < V; b++) {
+            const float* Vm = view + b * 16; const float* P = proj + b * 16;
+            size_t o = (size_t)b * 4 * N + i;
+            float v4[4], h4[4], gn[4], dh[4], dv[4];
+            for (int k = 0; k < 4; k++) v4[k] = view_pos[o + (size_t)k * N];
+            for (int k = 0; k < 4; k++) h4[k] = v4[0] * P[0 * 4 + k] + v4[1] * P[1 * 4 + k] + v4[2] * P[2 * 4 + k] + v4[3] * P[3 * 4 + k];
+            float iw = (fabsf(h4[3]) > 1e-12f) ? (1.0f / h4[3]) : 0.0f;
+            float n0 = h4[0] * iw, n1 = h4[1] * iw, n2 = h4[2] * iw;
+            for (int k = 0; k < 4; k++) gn[k] = g_ndc[o + (size_t)k * N];
+            dh[0] = gn[0] * iw; dh[1] = gn[1] * iw; dh[2] = gn[2] * iw;
+            dh[3] = -(gn[0] * n0 + gn[1] * n1 + gn[2] * n2) * iw;
+            for (int k = 0; k < 4; k++)
+                dv[k] = g_view[o + (size_t)k * N] + (dh[0] * P[k * 4 + 0] + dh[1] * P[k * 4 + 1] + dh[2] * P[k * 4 + 2] + dh[3] * P[k * 4 + 3]);
+            for (int k = 0; k < 4; k++)
+                acc[k] += dv[0] * Vm[k * 4 + 0] + dv[1] * Vm[k * 4 + 1] + dv[2] * Vm[k * 4 + 2] + dv[3] * Vm[k * 4 + 3];
+        }
+        for (int k = 0; k < 4; k++) g_world[(size_t)k * N + i] = acc[k];
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a4  createTransformMatrix_forward  GR/transform.cu:106-125                  */
+/* T[r][:] = R(q)[r][:] * s_r, q = (r,x,y,z)                                   */
+/* ------------------------------------------------------------------------- */
+static inline void quat_rows(float r, float x, float y, float z, float* R)
+{
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y + r * z);     R[2] = 2 * (x * z - r * y);
+    R[3] = 2 * (x * y - r * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z + r * x);
+    R[6] = 2 * (x * z + r * y);     R[7] = 2 * (y * z - r * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+ORC_API void orc_transform_matrix_forward(const float* quat /*[4,N]*/, const float* scale /*[3,N]*/,
+                                          int N, int valid, float* T /*[3,3,N]*/)
+{
+#pragma omp parallel for
+    for (int i = 0; i < valid; i++) {
+        float R[9];
+        quat_rows(quat[0 * (size_t)N + i], quat[1 * (size_t)N + i], quat[2 * (size_t)N + i], quat[3 * (size_t)N + i], R);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) T[((size_t)r * 3 + c) * N + i] = R[r * 3 + c] * scale[(size_t)r * N + i];
+    }
+}
+
+/* a17 createTransformMatrix_backward GR/transform.cu:185-225 */
+ORC_API void orc_transform_matrix_backward(const float* gT, const float* quat, const float* scale,
+                                           int N, int valid, float* g_quat /*[4,N]*/, float* g_scale /*[3,N]*/)
+{
+#pragma omp parallel for
+    for (int i = 0; i < valid; i++) {
+        float r = quat[0 * (size_t)N + i], x = quat[1 * (size_t)N + i], y = quat[2 * (size_t)N + i], z = quat[3 * (size_t)N + i];
+        float R[9], dt[9];
+        quat_rows(r, x, y, z, R);
+        for (int k = 0; k < 9; k++) dt[k] = gT[(size_t)k * N + i];
+        for (int rr = 0; rr < 3; rr++)
+            g_scale[(size_t)rr * N + i] = R[rr * 3 + 0] * dt[rr * 3 + 0] + R[rr * 3 + 1] * dt[rr * 3 + 1] + R[rr * 3 + 2] * dt[rr * 3 + 2];
+        for (int rr = 0; rr < 3; rr++)
+            for (int c = 0; c < 3; c++) dt[rr * 3 + c] *= scale[(size_t)rr * N + i];
+        g_quat[0 * (size_t)N + i] = 2 * z * (dt[1] - dt[3]) + 2 * y * (dt[6] - dt[2]) + 2 * x * (dt[5] - dt[7]);
+        g_quat[1 * (size_t)N + i] = 2 * y * (dt[3] + dt[1]) + 2 * z * (dt[6] + dt[2]) + 2 * r * (dt[5] - dt[7]) - 4 * x * (dt[8] + dt[4]);
+        g_quat[2 * (size_t)N + i] = 2 * x * (dt[3] + dt[1]) + 2 * r * (dt[6] - dt[2]) + 2 * z * (dt[5] + dt[7]) - 4 * y * (dt[8] + dt[0]);
+        g_quat[3 * (size_t)N + i] = 2 * r * (dt[1] - dt[3]) + 2 * x * (dt[6] + dt[2]) + 2 * y * (dt[5] + dt[7]) - 4 * z * (dt[4] + dt[0]);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a5  jacobianRayspace         GR/transform.cu:36-50  (output pre-zeroed)     */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_jacobian_rayspace(const float* view_pos /*[V,4,N]*/, const float* proj, int V, int N, int valid,
+                                   int H, int W, float* J /*[V,3,3,N] zeroed by caller*/)
+{
+#pragma omp parallel for
+    for (int i = 0; i < valid; i++)
+        for (int b = 0; b < V; b++) {
+            const float* P = proj + b * 16;
+            float fx = P[0] * W * 0.5f, fy = P[5] * H * 0.5f;
+            size_t o = (size_t)b * 4 * N + i;
+            float tx = view_pos[o], ty = view_pos[o + (size_t)N], tz = view_pos[o + 2 * (size_t)N];
+            float lx = tz / P[0] * 1.3f, ly = tz / P[5] * 1.3f;
+            tx = fmaxf_(fminf_(tx, lx), -lx);
+            ty = fmaxf_(fminf_(ty, ly), -ly);
+            float rz = 1.0f / fmaxf_(tz, 1e-2f);
+            float rz2 = rz * rz;
+            size_t jo = (size_t)b * 9 * N + i;
+            J[jo + 0 * (size_t)N] = fx * rz;
+            J[jo + 4 * (size_t)N] = fy * rz;
+            J[jo + 6 * (size_t)N] = -fx * tx * rz2;
+            J[jo + 7 * (size_t)N] = -fy * ty * rz2;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a6  createCov2dDirectly_forward   GR/transform.cu:760-778                   */
+/* M = (T . V33) . J[:, :2];  cov = M^T M + 0.3 I                               */
+/* ------------------------------------------------------------------------- */
+static inline void cov2d_M(const float* T9, const float* Vm, const float* J6, float* tvj /*3x2*/, float* vj /*3x2*/)
+{
+    /* vj = V33 . J(3x2) ; tvj = T . vj   (associativity differs from the reference's (T.V).J by rounding only) */
+    (void)vj;
+    float tv[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            float s = 0;
+            for (int k = 0; k < 3; k++) s += T9[r * 3 + k] * Vm[k * 4 + c];
+            tv[r * 3 + c] = s;
+        }
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 2; c++) {
+            float s = 0;
+            for (int k = 0; k < 3; k++) s += tv[r * 3 + k] * J6[k * 2 + c];
+            tvj[r * 2 + c] = s;
+        }
+}
+
+ORC_API void orc_cov2d_forward(const float* J /*[V,3,3,N]*/, const float* view, const float* T /*[3,3,N]*/,
+                               int V, int N, int valid, float* cov /*[V,2,2,N]*/)
+{
+#pragma omp parallel for
+    for (int i = 0; i < valid; i++)
+        for (int b = 0; b < V; b++) {
+            float T9[9], J6[6], M[6];
+            for (int k = 0; k < 9; k++) T9[k] = T[(size_t)k * N + i];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 2; c++) J6[r * 2 + c] = J[((size_t)b * 9 + r * 3 + c) * N + i];
+            cov2d_M(T9, view + b * 16, J6, M, NULL);
+            float c00 = 0, c01 = 0, c11 = 0;
+            for (int k = 0; k < 3; k++) { c00 += M[k * 2] * M[k * 2]; c01 += M[k * 2] * M[k * 2 + 1]; c11 += M[k * 2 + 1] * M[k * 2 + 1]; }
+            size_t o = (size_t)b * 4 * N + i;
+            cov[o] = c00 + 0.3f; cov[o + (size_t)N] = c01; cov[o + 2 * (size_t)N] = c01; cov[o + 3 * (size_t)N] = c11 + 0.3f;
+        }
+}
+
+/* a16 createCov2dDirectly_backward  GR/transform.cu:849-881 : dT = 2 . M . dcov . (V33 . J)^T, summed over views.
+ * Entries >= valid are written as 0 (the reference saves the zero-initialised sum, :884-887). */
+ORC_API void orc_cov2d_backward(const float* g_cov, const float* J, const float* view, const float* T,
+                                int V, int N, int valid, float* gT /*[3,3,N]*/)
+{
+#pragma omp parallel for
+    for (int i = 0; i < N; i++) {
+        float sum[9] = { 0 };
+        if (i < valid)
+            for (int b = 0; b < V; b++) {
+                const float* Vm = view + b * 16;
+                float T9[9], J6[6], vj[6], M[6], g[4], dM[6];
+                for (int k = 0; k < 9; k++) T9[k] = T[(size_t)k * N + i];
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 2; c++) J6[r * 2 + c] = J[((size_t)b * 9 + r * 3 + c) * N + i];
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 2; c++) {
+                        float s = 0;
+                        for (int k = 0; k < 3; k++) s += Vm[r * 4 + k] * J6[k * 2 + c];
+                        vj[r * 2 + c] = s;
+                    }
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 2; c++) {
+                        float s = 0;
+                        for (int k = 0; k < 3; k++) s += T9[r * 3 + k] * vj[k * 2 + c];
+                        M[r * 2 + c] = s;
+                    }
+                for (int k = 0; k < 4; k++) g[k] = g_cov[((size_t)b * 4 + k) * N + i];
+                for (int r = 0; r < 3; r++) {
+                    dM[r * 2 + 0] = 2 * (M[r * 2] * g[0] + M[r * 2 + 1] * g[2]);
+                    dM[r * 2 + 1] = 2 * (M[r * 2] * g[1] + M[r * 2 + 1] * g[3]);
+                }
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) sum[r * 3 + c] += dM[r * 2] * vj[c * 2] + dM[r * 2 + 1] * vj[c * 2 + 1];
+            }
+        for (int k = 0; k < 9; k++) gT[(size_t)k * N + i] = sum[k];
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a7  eigh_and_inv_2x2matrix_forward  GR/transform.cu:1379-1420               */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_eigh_inv_forward(const float* in /*[V,2,2,N]*/, int V, int N, int valid,
+                                  float* val /*[V,2,N]*/, float* vec /*[V,2,2,N]*/, float* inv /*[V,2,2,N]*/)
+{
+#pragma omp parallel for
+    for (int i = 0; i < valid; i++)
+        for (int b = 0; b < V; b++) {
+            size_t o = (size_t)b * 4 * N + i;
+            float m00 = in[o], m01 = in[o + (size_t)N], m10 = in[o + 2 * (size_t)N], m11 = in[o + 3 * (size_t)N];
+            float det = m00 * m11 - m01 * m10;
+            float det1 = (m00 - m01) * (m11 - m01) + m01 * (m00 + m11 - 2 * m01);
+            det = (fabsf(det) < fabsf(1e-5f * m01 * m10)) ? det1 : det;
+            float t0 = m00 + m11;
+            float t1 = sqrtf((m00 - m11) * (m00 - m11) + 4 * m01 * m01);
+            t1 = fmaxf_(t1, 1e-9f);
+            float e0 = 0.5f * (t0 - t1), e1 = 0.5f * (t0 + t1);
+            val[((size_t)b * 2 + 0) * N + i] = e0; val[((size_t)b * 2 + 1) * N + i] = e1;
+            float v0[2], v1[2];
+            if (fabsf(e0 - m00) > fabsf(e0 - m11)) { v0[0] = -m01; v0[1] = m00 - e0; v1[0] = e1 - m11; v1[1] = m01; }
+            else { v0[0] = m11 - e0; v0[1] = -m01; v1[0] = m01; v1[1] = e1 - m00; }
+            float l0 = 1.0f / sqrtf(v0[0] * v0[0] + v0[1] * v0[1]);
+            float l1 = 1.0f / sqrtf(v1[0] * v1[0] + v1[1] * v1[1]);
+            vec[o] = v0[0] * l0; vec[o + (size_t)N] = v1[0] * l1; vec[o + 2 * (size_t)N] = v0[1] * l0; vec[o + 3 * (size_t)N] = v1[1] * l1;
+            det = (fabsf(det) < 1e-9f) ? 1e-9f : det;
+            float dr = 1.0f / det;
+            inv[o] = m11 * dr; inv[o + (size_t)N] = -m01 * dr; inv[o + 2 * (size_t)N] = -m10 * dr; inv[o + 3 * (size_t)N] = m00 * dr;
+        }
+}
+
+/* a15 inv_2x2matrix_backward   GR/transform.cu:1440-1451 : dA = -(A^-1 . dA^-1 . A^-1) */
+ORC_API void orc_inv2x2_backward(const float* inv, const float* g_inv, int V, int N, int valid, float* g_in)
+{
+#pragma omp parallel for
+    for (int i = 0; i < valid; i++)
+        for (int b = 0; b < V; b++) {
+            size_t o = (size_t)b * 4 * N + i;
+            float a[4], g[4], t[4], r[4];
+            for (int k = 0; k < 4; k++) { a[k] = inv[o + (size_t)k * N]; g[k] = g_inv[o + (size_t)k * N]; }
+            t[0] = a[0] * g[0] + a[1] * g[2]; t[1] = a[0] * g[1] + a[1] * g[3];
+            t[2] = a[2] * g[0] + a[3] * g[2]; t[3] = a[2] * g[1] + a[3] * g[3];
+            r[0] = t[0] * a[0] + t[1] * a[2]; r[1] = t[0] * a[1] + t[1] * a[3];
+            r[2] = t[2] * a[0] + t[3] * a[2]; r[3] = t[2] * a[1] + t[3] * a[3];
+            for (int k = 0; k < 4; k++) g_in[o + (size_t)k * N] = -r[k];
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a8/a10  tile extent + AccuTile walk                                         */
+/* GR/binning.cu:310-373 (get_allocate_size), :34-110 (duplicate_with_keys),   */
+/* GR/speedy_splat.cuh:16-149.  Followed literally, including the float->int   */
+/* truncations and the isY axis choice.                                        */
+/* ------------------------------------------------------------------------- */
+typedef struct { float x, y; } f2;
+
+static inline f2 ellipse_intersection(float a, float b, float c, float disc, float t, f2 p, int isY, float coord)
+{
+    float p_u = isY ? p.y : p.x;
+    float p_v = isY ? p.x : p.y;
+    float coeff = isY ? a : c;
+    float h = coord - p_u;
+    float sq = sqrtf(disc * h * h + t * coeff);
+    f2 r;
+    r.x = (-b * h - sq) / coeff + p_v;
+    r.y = (-b * h + sq) / coeff + p_v;
+    return r;
+}
+
+/* returns tiles touched; if keys!=NULL emits (tile_id+1, idx) pairs starting at off */
+static uint32_t process_tiles(int TH, int TW, float a, float b, float c, float disc, float t, f2 p,
+                              f2 bbox_min, f2 bbox_max, f2 bbox_argmin, f2 bbox_argmax,
+                              int rminx, int rminy, int rmaxx, int rmaxy,
+                              int grid_x, int isY, int32_t idx, int64_t off, int32_t* keys, int32_t* values)
+{
+    float BLOCK_U = isY ? (float)TH : (float)TW;
+    float BLOCK_V = isY ? (float)TW : (float)TH;
+    int rect_min_x = rminx, rect_min_y = rminy, rect_max_x = rmaxx, rect_max_y = rmaxy;
+    if (isY) {
+        rect_min_x = rminy; rect_min_y = rminx; rect_max_x = rmaxy; rect_max_y = rmaxx;
+        f2 s;
+        s.x = bbox_min.y; s.y = bbox_min.x; bbox_min = s;
+        s.x = bbox_max.y; s.y = bbox_max.x; bbox_max = s;
+        s.x = bbox_argmin.y; s.y = bbox_argmin.x; bbox_argmin = s;
+        s.x = bbox_argmax.y; s.y = bbox_argmax.x; bbox_argmax = s;
+    }
+    uint32_t tiles_count = 0;
+    f2 imin_line, imax_line;
+    float ellipse_min, ellipse_max, min_line, max_line;
+    imax_line.x = bbox_max.y; imax_line.y = bbox_min.y;
+    min_line = rect_min_x * BLOCK_U;
+    if (bbox_min.x <= min_line) imin_line = ellipse_intersection(a, b, c, disc, t, p, isY, rect_min_x * BLOCK_U);
+    else imin_line = imax_line;
+
+    for (int u = rect_min_x; u < rect_max_x; ++u) {
+        max_line = min_line + BLOCK_U;
+        if (max_line <= bbox_max.x) imax_line = ellipse_intersection(a, b, c, disc, t, p, isY, max_line);
+        if (min_line <= bbox_argmin.y && bbox_argmin.y < max_line) ellipse_min = bbox_min.y;
+        else ellipse_min = fminf_(imin_line.x, imax_line.x);
+        if (min_line <= bbox_argmax.y && bbox_argmax.y < max_line) ellipse_max = bbox_max.y;
+        else ellipse_max = fmaxf_(imin_line.y, imax_line.y);
+        int min_tile_v = imax(rect_min_y, imin(rect_max_y, f2i(ellipse_min / BLOCK_V)));
+        int max_tile_v = imin(rect_max_y, imax(rect_min_y, f2i(ellipse_max / BLOCK_V + 1)));
+        /* NB the reference adds (max-min) as unsigned even when negative; with valid ellipses max>=min. */
+        tiles_count += (uint32_t)(max_tile_v - min_tile_v);
+        if (keys != NULL)
+            for (int v = min_tile_v; v < max_tile_v; v++) {
+                uint32_t key = isY ? (uint32_t)(u * grid_x + v) : (uint32_t)(v * grid_x + u);
+                keys[off] = (int32_t)(key + 1);
+                values[off] = idx;
+                off++;
+            }
+        imin_line = imax_line;
+        min_line = max_line;
+    }
+    return tiles_count;
+}
+
+typedef struct {
+    int visible;
+    float a, b, c, disc, t;
+    f2 p, bbox_min, bbox_max, bbox_argmin, bbox_argmax;
+    int rminx, rminy, rmaxx, rmaxy;
+} splat_extent;
+
+static inline void compute_extent(float ndcx, float ndcy, float ic00, float ic01, float ic11, float opacity,
+                                  int H, int W, int TH, int TW, int grid_x, int grid_y, splat_extent* e)
+{
+    e->a = ic00; e->b = ic01; e->c = ic11;
+    e->disc = ic01 * ic01 - ic00 * ic11;
+    float u = ndcx * 0.5f + 0.5f, v = ndcy * 0.5f + 0.5f;
+    e->p.x = u * W - 0.5f; e->p.y = v * H - 0.5f;
+    float t = 2.0f * orc_logf(opacity * 255.0f);
+    e->t = t;
+    float x_term = sqrtf(-(ic01 * ic01 * t) / (e->disc * ic00));
+    x_term = (ic01 < 0) ? x_term : -x_term;
+    float y_term = sqrtf(-(ic01 * ic01 * t) / (e->disc * ic11));
+    y_term = (ic01 < 0) ? y_term : -y_term;
+    e->bbox_argmin.x = e->p.y - y_term; e->bbox_argmin.y = e->p.x - x_term;
+    e->bbox_argmax.x = e->p.y + y_term; e->bbox_argmax.y = e->p.x + x_term;
+    e->bbox_min.x = ellipse_intersection(e->a, e->b, e->c, e->disc, t, e->p, 1, e->bbox_argmin.x).x;
+    e->bbox_min.y = ellipse_intersection(e->a, e->b, e->c, e->disc, t, e->p, 0, e->bbox_argmin.y).x;
+    e->bbox_max.x = ellipse_intersection(e->a, e->b, e->c, e->disc, t, e->p, 1, e->bbox_argmax.x).y;
+    e->bbox_max.y = ellipse_intersection(e->a, e->b, e->c, e->disc, t, e->p, 0, e->bbox_argmax.y).y;
+    e->rminx = imax(0, imin(grid_x, f2i(e->bbox_min.x / TW)));
+    e->rminy = imax(0, imin(grid_y, f2i(e->bbox_min.y / TH)));
+    e->rmaxx = imax(0, imin(grid_x, f2i((e->bbox_max.x + TW - 1) / TW)));
+    e->rmaxy = imax(0, imin(grid_y, f2i((e->bbox_max.y + TH - 1) / TH)));
+}
+
+/* a8 get_allocate_size.  ndc[V,4,N], view_z[V,N], inv_cov[V,2,2,N], opacity[1,N].
+ * Entries >= valid: allocate_size = 0 (zeros), left_up/right_down untouched (reference: torch::empty). */
+ORC_API void orc_get_allocate_size(const float* ndc, const float* view_z, const float* inv_cov, const float* opacity,
+                                   int V, int N, int valid, int H, int W, int TH, int TW,
+                                   int32_t* left_up /*[V,2,N]*/, int32_t* right_down, int32_t* alloc /*[V,N]*/)
+{
+    int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
+#pragma omp parallel for
+    for (int i = 0; i < N; i++)
+        for (int b = 0; b < V; b++) {
+            size_t ao = (size_t)b * N + i;
+            if (i >= valid) { alloc[ao] = 0; continue; }
+            float nx = ndc[((size_t)b * 4 + 0) * N + i], ny = ndc[((size_t)b * 4 + 1) * N + i];
+            float a = inv_cov[((size_t)b * 4 + 0) * N + i], bb = inv_cov[((size_t)b * 4 + 1) * N + i], c = inv_cov[((size_t)b * 4 + 3) * N + i];
+            float o = opacity[i];
+            float disc = bb * bb - a * c;
+            int vis = !((nx < -1.3f) || (nx > 1.3f) || (ny < -1.3f) || (ny > 1.3f) || (view_z[ao] <= 0.2f) || (o < 1.0f / 255));
+            vis &= ((a > 0) & (c > 0) & (disc < 0));
+            size_t l0 = ((size_t)b * 2 + 0) * N + i, l1 = ((size_t)b * 2 + 1) * N + i;
+            if (!vis) { left_up[l0] = -1; left_up[l1] = -1; right_down[l0] = -1; right_down[l1] = -1; alloc[ao] = 0; continue; }
+            splat_extent e;
+            compute_extent(nx, ny, a, bb, c, o, H, W, TH, TW, gx, gy, &e);
+            left_up[l0] = f2i(ceilf(e.bbox_min.x)); left_up[l1] = f2i(ceilf(e.bbox_min.y));
+            right_down[l0] = f2i(floorf(e.bbox_max.x)); right_down[l1] = f2i(floorf(e.bbox_max.y));
+            int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx, n = 0;
+            if (ys * xs > 0)
+                n = (int)process_tiles(TH, TW, e.a, e.b, e.c, e.disc, e.t, e.p, e.bbox_min, e.bbox_max, e.bbox_argmin, e.bbox_argmax,
+                                       e.rminx, e.rminy, e.rmaxx, e.rmaxy, gx, ys < xs, i, 0, NULL, NULL);
+            alloc[ao] = n;
+        }
+}
+
+/* a10 (first half) duplicate_with_keys: for slot j in depth order, point = sorted_id[j], emits its pairs at
+ * prefix[j-1].. ; silently drops a splat whose range overflows the table (binning.cu:63). keys must be zeroed. */
+ORC_API void orc_duplicate_with_keys(const float* ndc, const float* inv_cov, const float* opacity,
+                                     const int32_t* prefix /*[V,N] inclusive*/, const int64_t* sorted_id /*[V,N]*/,
+                                     int V, int N, int H, int W, int TH, int TW, int64_t table_len,
+                                     int32_t* keys /*[V,table_len]*/, int32_t* values)
+{
+    int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
+    for (int b = 0; b < V; b++) {
+#pragma omp parallel for
+        for (int j = 0; j < N; j++) {
+            int64_t off = (j == 0) ? 0 : prefix[(size_t)b * N + j - 1];
+            int64_t cnt = prefix[(size_t)b * N + j] - off;
+            if (!(cnt > 0 && off + cnt <= table_len)) continue;
+            int i = (int)sorted_id[(size_t)b * N + j];
+            float nx = ndc[((size_t)b * 4 + 0) * N + i], ny = ndc[((size_t)b * 4 + 1) * N + i];
+            float a = inv_cov[((size_t)b * 4 + 0) * N + i], bb = inv_cov[((size_t)b * 4 + 1) * N + i], c = inv_cov[((size_t)b * 4 + 3) * N + i];
+            splat_extent e;
+            compute_extent(nx, ny, a, bb, c, opacity[i], H, W, TH, TW, gx, gy, &e);
+            int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
+            if (ys * xs > 0)
+                process_tiles(TH, TW, e.a, e.b, e.c, e.disc, e.t, e.p, e.bbox_min, e.bbox_max, e.bbox_argmin, e.bbox_argmax,
+                              e.rminx, e.rminy, e.rmaxx, e.rmaxy, gx, ys < xs, i, off, keys + (size_t)b * table_len, values + (size_t)b * table_len);
+        }
+    }
+}
+
+/* a10 (second half) stable sort of (key,value) pairs on key bits [0,bits): the semantics of
+ * cub::DeviceRadixSort::SortPairs at GR/binning.cu:204-221 (applied per view -- the reference's
+ * view-0-only loop is a bug).  Counting sort = stable by construction. */
+ORC_API void orc_stable_sort_pairs(const int32_t* keys, const int32_t* values, int64_t n, int bits,
+                                   int32_t* keys_out, int32_t* values_out)
+{
+    size_t nb = (size_t)1 << bits;
+    uint32_t mask = (uint32_t)(nb - 1);
+    int64_t* cnt = (int64_t*)calloc(nb + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) cnt[((uint32_t)keys[i] & mask) + 1]++;
+    for (size_t k = 0; k < nb; k++) cnt[k + 1] += cnt[k];
+    for (int64_t i = 0; i < n; i++) {
+        int64_t d = cnt[(uint32_t)keys[i] & mask]++;
+        keys_out[d] = keys[i]; values_out[d] = values[i];
+    }
+    free(cnt);
+}
+
+/* a11 tileRange  GR/binning.cu:239-264.  out[V, max_tile+2], pre-filled with -1 here. */
+ORC_API void orc_tile_range(const int32_t* sorted_keys /*[V,L]*/, int V, int64_t L, int max_tile, int32_t* out)
+{
+    for (int b = 0; b < V; b++) {
+        const int32_t* k = sorted_keys + (size_t)b * L;
+        int32_t* o = out + (size_t)b * (max_tile + 2);
+        for (int t = 0; t < max_tile + 2; t++) o[t] = -1;
+        if (L <= 0) continue;
+        o[k[0]] = 0;
+        o[max_tile + 1] = (int32_t)L;
+        for (int64_t i = 0; i + 1 < L; i++) {
+            int cur = k[i], nxt = k[i + 1];
+            if (cur != nxt) {
+                if (cur + 1 < nxt) o[cur + 1] = (int32_t)(i + 1);
+                o[nxt] = (int32_t)(i + 1);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a12 pack_forward_params      GR/raster.cu:346-354 (fp32, no half rounding)  */
+/* record = 16 floats: px py ic00 ic01 | ic11 r g b | opacity depth 0 0 | 0 0 0 0 */
+/* (layout is private to the oracle; the HIP path has its own packed layout)    */
+/* ------------------------------------------------------------------------- */
+#define ORC_REC 16
+ORC_API void orc_pack_params(const float* ndc /*[V,4,N]*/, const float* inv_cov, const float* color /*[V,3,N]*/,
+                             const float* opacity, int V, int N, int H, int W, float* packed /*[V,N,16]*/)
+{
+#pragma omp parallel for
+    for (int i = 0; i < N; i++)
+        for (int b = 0; b < V; b++) {
+            float* r = packed + ((size_t)b * N + i) * ORC_REC;
+            r[0] = (ndc[((size_t)b * 4 + 0) * N + i] + 1.0f) * 0.5f * W - 0.5f;
+            r[1] = (ndc[((size_t)b * 4 + 1) * N + i] + 1.0f) * 0.5f * H - 0.5f;
+            r[2] = inv_cov[((size_t)b * 4 + 0) * N + i];
+            r[3] = inv_cov[((size_t)b * 4 + 1) * N + i];
+            r[4] = inv_cov[((size_t)b * 4 + 3) * N + i];
+            r[5] = color[((size_t)b * 3 + 0) * N + i];
+            r[6] = color[((size_t)b * 3 + 1) * N + i];
+            r[7] = color[((size_t)b * 3 + 2) * N + i];
+            r[8] = opacity[i];
+            r[9] = ndc[((size_t)b * 4 + 2) * N + i];
+            for (int k = 10; k < ORC_REC; k++) r[k] = 0.0f;
+        }
+}
+
+static inline float splat_power(const float* r, float pixel_x, float pixel_y, float* dx, float* dy)
+{
+    /* GR/raster.cu:237-240 */
+    float ddx = r[0] - pixel_x, ddy = r[1] - pixel_y;
+    float bxcy = r[4] * ddy + r[3] * ddx;
+    float axby = r[2] * ddx + r[3] * ddy;
+    *dx = ddx; *dy = ddy;
+    return -0.5f * (ddx * axby + ddy * bxcy);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a13 rasterize_forward        GR/raster.cu:226-329                           */
+/* Per tile, front to back; pixel active iff T > 1/8192 (tested BEFORE the     */
+/* splat); alpha = o*exp(power); contributes iff active && alpha >= 1/256;     */
+/* alpha = min(255/256, alpha); last_contributor counts splats seen while      */
+/* active; out = min(C,1); no background term.                                 */
+/* tiles: optional list (specific_tiles) of 1-based tile ids, 0 = skip.        */
+/* Pixels of tiles not rendered are left untouched (reference: torch::empty).  */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_raster_forward(const int32_t* sorted_points /*[V,L]*/, const int32_t* start_index /*[V,T+2]*/,
+                                const float* packed /*[V,N,16]*/, const int32_t* tiles /*[V,K] or NULL*/, int K,
+                                int V, int64_t L, int N, int H, int W, int TH, int TW, int enable_stat,
+                                float* img /*[V,3,Hp,Wp]*/, float* trans /*[V,1,Hp,Wp]*/, int16_t* last /*[V,1,Hp,Wp]*/,
+                                int32_t* frag_count /*[V,1,N] zeroed*/, float* frag_weight /*[V,1,N] zeroed*/)
+{
+    int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
+    int Wp = gx * TW, Hp = gy * TH, ntiles = gx * gy;
+    int nrender = tiles ? K : ntiles;
+    int P = TH * TW;
+    for (int b = 0; b < V; b++) {
+        const int32_t* sp = sorted_points + (size_t)b * L;
+        const int32_t* si = start_index + (size_t)b * (ntiles + 2);
+        const float* pk = packed + (size_t)b * N * ORC_REC;
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int s = 0; s < nrender; s++) {
+            int tile = tiles ? tiles[(size_t)b * K + s] : s + 1;
+            if (tile == 0 || tile > ntiles) continue;
+            int start = si[tile], end = si[tile + 1];
+            int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
+            float T[256], Cr[256], Cg[256], Cb[256];
+            int lc[256];
+            for (int q = 0; q < P; q++) { T[q] = 1.0f; Cr[q] = Cg[q] = Cb[q] = 0.0f; lc[q] = 0; }
+            if (start != -1) {
+                for (int idx = start; idx < end; idx++) {
+                    int any_active = 0;
+                    for (int q = 0; q < P; q++) any_active |= (T[q] > 1.0f / 8192);
+                    if (!any_active) break;
+                    int pid = sp[idx];
+                    const float* r = pk + (size_t)pid * ORC_REC;
+                    int fc = 0; double ws = 0.0;
+                    for (int q = 0; q < P; q++) {
+                        int active = T[q] > 1.0f / 8192;
+                        float dx, dy;
+                        float power = splat_power(r, (float)(tx * TW + q % TW), (float)(ty * TH + q / TW), &dx, &dy);
+                        float alpha = r[8] * expf(power);
+                        int valid = active && (alpha >= 1.0f / 256);
+                        alpha = fminf_(255.0f / 256, alpha);
+                        lc[q] += active;
+                        if (!valid) alpha = 0.0f;
+                        float w = T[q] * alpha;
+                        if (valid) { fc++; ws += w; }
+                        Cr[q] += r[5] * w; Cg[q] += r[6] * w; Cb[q] += r[7] * w;
+                        T[q] = T[q] * (1.0f - alpha);
+                    }
+                    if (enable_stat && fc) {
+#pragma omp atomic
+                        frag_count[(size_t)b * N + pid] += fc;
+#pragma omp atomic
+                        frag_weight[(size_t)b * N + pid] += (float)ws;
+                    }
+                }
+            }
+            for (int q = 0; q < P; q++) {
+                int x = tx * TW + q % TW, y = ty * TH + q / TW;
+                size_t o = (size_t)y * Wp + x;
+                size_t plane = (size_t)Hp * Wp;
+                img[((size_t)b * 3 + 0) * plane + o] = fminf_(Cr[q], 1.0f);
+                img[((size_t)b * 3 + 1) * plane + o] = fminf_(Cg[q], 1.0f);
+                img[((size_t)b * 3 + 2) * plane + o] = fminf_(Cb[q], 1.0f);
+                trans[(size_t)b * plane + o] = T[q];
+                last[(size_t)b * plane + o] = (int16_t)lc[q];
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a14 rasterize_backward       GR/raster.cu:651-849 (+ unpack :866-884)       */
+/* Reverse order from max(last)-1; pixel valid iff alpha>=1/256 && idx<last;    */
+/* T_i = min(1, T_{i+1}/(1-alpha)); dC/dc = alpha*T; dalpha = sum_ch (c-Cbehind)*T*dL/dC */
+/* (- dL/dT * T_final/(1-alpha) if trans); do = dalpha*G; dpower = G*o*dalpha.  */
+/* Gradients are accumulated in double per Gaussian, then scaled:               */
+/*   d_ndc.xy = g_xy * 0.5*(W,H) * inv_scaler; d_inv_cov[0][1]=[1][0]=-0.5*sum(dP*dx*dy)*inv_scaler */
+/* err_square_sum (statistic mode) reproduces the reference's running-sum quirk: */
+/*   each reference (thread, half2-lane) owns pixels {rows strip*2*PPT + 2i + p}, */
+/*   cur_err = running sum over i of dalpha*G, and err_square += cur_err^2 for    */
+/*   every i whose row-group has ANY valid pixel in the tile (raster.cu:753,781-783). */
+/* grad accumulators pg[V,N,9]: dx dy a00 a01 a11 r g b o                        */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_raster_backward(const int32_t* sorted_points, const int32_t* start_index, const float* packed,
+                                 const int32_t* tiles, int K,
+                                 const float* final_T /*[V,1,Hp,Wp]*/, const int16_t* last /*[V,1,Hp,Wp]*/,
+                                 const float* d_img /*[V,3,Hp,Wp]*/, const float* d_trans /*[V,1,Hp,Wp] or NULL*/,
+                                 float inv_scaler,
+                                 int V, int64_t L, int N, int H, int W, int TH, int TW, int enable_stat,
+                                 float* d_ndc /*[V,4,N]*/, float* d_inv_cov /*[V,2,2,N]*/, float* d_color /*[V,3,N]*/,
+                                 float* d_opacity /*[1,N]*/, float* err_square_sum /*[V,1,N]*/)
+{
+    int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
+    int Wp = gx * TW, Hp = gy * TH, ntiles = gx * gy;
+    int nrender = tiles ? K : ntiles;
+    int P = TH * TW;
+    size_t plane = (size_t)Hp * Wp;
+    int PPT = P / 64;                 /* half2 pairs per reference thread */
+    double* pg = (double*)calloc((size_t)V * N * 9, sizeof(double));
+    double* esq = (double*)calloc((size_t)V * N, sizeof(double));
+    for (int b = 0; b < V; b++) {
+        const int32_t* sp = sorted_points + (size_t)b * L;
+        const int32_t* si = start_index + (size_t)b * (ntiles + 2);
+        const float* pk = packed + (size_t)b * N * ORC_REC;
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int s = 0; s < nrender; s++) {
+            int tile = tiles ? tiles[(size_t)b * K + s] : s + 1;
+            if (tile == 0 || tile > ntiles) continue;
+            int start = si[tile], end = si[tile + 1];
+            if (start == -1 || start >= end) continue;
+            int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
+            float T[256], Tf[256], Br[256], Bg[256], Bb[256], gr[256], gg[256], gb[256], gt[256];
+            int lc[256];
+            int maxlast = 0;
+            for (int q = 0; q < P; q++) {
+                int x = tx * TW + q % TW, y = ty * TH + q / TW;
+                size_t o = (size_t)y * Wp + x;
+                T[q] = Tf[q] = final_T[(size_t)b * plane + o];
+                lc[q] = last[(size_t)b * plane + o];
+                gr[q] = d_img[((size_t)b * 3 + 0) * plane + o];
+                gg[q] = d_img[((size_t)b * 3 + 1) * plane + o];
+                gb[q] = d_img[((size_t)b * 3 + 2) * plane + o];
+                gt[q] = d_trans ? d_trans[(size_t)b * plane + o] : 0.0f;
+                Br[q] = Bg[q] = Bb[q] = 0.0f;
+                if (lc[q] > maxlast) maxlast = lc[q];
+            }
+            if (maxlast > end - start) maxlast = end - start;
+            for (int idx = maxlast - 1; idx >= 0; idx--) {
+                int pid = sp[start + idx];
+                const float* r = pk + (size_t)pid * ORC_REC;
+                double a_dx = 0, a_dy = 0, a_00 = 0, a_01 = 0, a_11 = 0, a_r = 0, a_g = 0, a_b = 0, a_o = 0;
+                float ga_pix[256];
+                int valid_pix[256];
+                int anyvalid = 0;
+                for (int q = 0; q < P; q++) {
+                    float dx, dy;
+                    float power = splat_power(r, (float)(tx * TW + q % TW), (float)(ty * TH + q / TW), &dx, &dy);
+                    float G = expf(power);
+                    float alpha = fminf_(255.0f / 256, r[8] * G);
+                    int valid = (alpha >= 1.0f / 256) && (idx < lc[q]);
+                    valid_pix[q] = valid; ga_pix[q] = 0.0f;
+                    if (!valid) continue;
+                    anyvalid = 1;
+                    T[q] = fminf_(1.0f, T[q] / (1.0f - alpha));
+                    a_r += alpha * T[q] * gr[q]; a_g += alpha * T[q] * gg[q]; a_b += alpha * T[q] * gb[q];
+                    float d_alpha = (r[5] - Br[q]) * T[q] * gr[q] + (r[6] - Bg[q]) * T[q] * gg[q] + (r[7] - Bb[q]) * T[q] * gb[q];
+                    Br[q] += alpha * (r[5] - Br[q]); Bg[q] += alpha * (r[6] - Bg[q]); Bb[q] += alpha * (r[7] - Bb[q]);
+                    if (d_trans) d_alpha -= (Tf[q] * gt[q]) / (1.0f - alpha);
+                    float gaq = d_alpha * G;
+                    ga_pix[q] = gaq;
+                    a_o += gaq;
+                    float dP = G * (r[8] * d_alpha);
+                    a_00 += -0.5f * dx * dx * dP;
+                    a_01 += -0.5f * dx * dy * dP;
+                    a_11 += -0.5f * dy * dy * dP;
+                    a_dx += (-r[2] * dx - r[3] * dy) * dP;
+                    a_dy += (-r[4] * dy - r[3] * dx) * dP;
+                }
+                if (!anyvalid) continue;
+                double* g = pg + ((size_t)b * N + pid) * 9;
+#pragma omp atomic
+                g[0] += a_dx;
+#pragma omp atomic
+                g[1] += a_dy;
+#pragma omp atomic
+                g[2] += a_00;
+#pragma omp atomic
+                g[3] += a_01;
+#pragma omp atomic
+                g[4] += a_11;
+#pragma omp atomic
+                g[5] += a_r;
+#pragma omp atomic
+                g[6] += a_g;
+#pragma omp atomic
+                g[7] += a_b;
+#pragma omp atomic
+                g[8] += a_o;
+                if (enable_stat) {
+                    /* reference lane ownership: x = q%TW, row = strip*(2*PPT) + 2*i + p */
+                    double e = 0.0;
+                    int nstrip = TH / (2 * PPT);
+                    int group_any[8] = { 0 };
+                    for (int i = 0; i < PPT; i++)
+                        for (int st = 0; st < nstrip; st++)
+                            for (int p = 0; p < 2; p++)
+                                for (int x = 0; x < TW; x++) group_any[i] |= valid_pix[(st * 2 * PPT + 2 * i + p) * TW + x];
+                    for (int st = 0; st < nstrip; st++)
+                        for (int p = 0; p < 2; p++)
+                            for (int x = 0; x < TW; x++) {
+                                float run = 0.0f;
+                                for (int i = 0; i < PPT; i++) {
+                                    if (!group_any[i]) continue;
+                                    run += ga_pix[(st * 2 * PPT + 2 * i + p) * TW + x];
+                                    e += (double)run * run;
+                                }
+                            }
+#pragma omp atomic
+                    esq[(size_t)b * N + pid] += e;
+                }
+            }
+        }
+    }
+    /* unpack  GR/raster.cu:866-884; d_opacity summed over views (reference writes view 0 only: "todo fix") */
+    for (int i = 0; i < N; i++) d_opacity[i] = 0.0f;
+    for (int b = 0; b < V; b++)
+        for (int i = 0; i < N; i++) {
+            const double* g = pg + ((size_t)b * N + i) * 9;
+            d_ndc[((size_t)b * 4 + 0) * N + i] = (float)(g[0] * 0.5 * W * inv_scaler);
+            d_ndc[((size_t)b * 4 + 1) * N + i] = (float)(g[1] * 0.5 * H * inv_scaler);
+            d_ndc[((size_t)b * 4 + 2) * N + i] = 0.0f;
+            d_ndc[((size_t)b * 4 + 3) * N + i] = 0.0f;
+            d_inv_cov[((size_t)b * 4 + 0) * N + i] = (float)(g[2] * inv_scaler);
+            d_inv_cov[((size_t)b * 4 + 1) * N + i] = (float)(g[3] * inv_scaler);
+            d_inv_cov[((size_t)b * 4 + 2) * N + i] = (float)(g[3] * inv_scaler);
+            d_inv_cov[((size_t)b * 4 + 3) * N + i] = (float)(g[4] * inv_scaler);
+            d_color[((size_t)b * 3 + 0) * N + i] = (float)(g[5] * inv_scaler);
+            d_color[((size_t)b * 3 + 1) * N + i] = (float)(g[6] * inv_scaler);
+            d_color[((size_t)b * 3 + 2) * N + i] = (float)(g[7] * inv_scaler);
+            d_opacity[i] += (float)(g[8] * inv_scaler);
+            err_square_sum[(size_t)b * N + i] = (float)esq[(size_t)b * N + i];
+        }
+    free(pg); free(esq);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a20 adamUpdate (chunk form)  GR/compact.cu:333-342 -- no bias correction    */
+/* param/m/v [C, chunks, S]; grad [C, A, S]; visible chunks a < nvis            */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_adam_chunk(float* param, const float* grad, float* m, float* v, const int64_t* chunk_id,
+                            int nvis, int C, int chunks, int A, int S, float lr, float b1, float b2, float eps)
+{
+#pragma omp parallel for
+    for (int a = 0; a < nvis; a++)
+        for (int c = 0; c < C; c++)
+            for (int i = 0; i < S; i++) {
+                size_t go = ((size_t)c * A + a) * S + i;
+                size_t po = ((size_t)c * chunks + chunk_id[a]) * S + i;
+                float g = grad[go];
+                float mm = b1 * m[po] + (1.0f - b1) * g;
+                float vv = b2 * v[po] + (1.0f - b2) * g * g;
+                float step = -lr * mm / (sqrtf(vv) + eps);
+                param[po] += step; m[po] = mm; v[po] = vv;
+            }
+}
+
+/* a20 adamUpdate (primitive form) GR/compact.cu:348-375: param/grad/m/v [C,N], mask[N] != 0 */
+ORC_API void orc_adam_primitive(float* param, const float* grad, float* m, float* v, const int64_t* mask,
+                                int C, int N, float lr, float b1, float b2, float eps)
+{
+#pragma omp parallel for
+    for (int i = 0; i < N; i++) {
+        if (!mask[i]) continue;
+        for (int c = 0; c < C; c++) {
+            size_t o = (size_t)c * N + i;
+            float g = grad[o];
+            float mm = b1 * m[o] + (1.0f - b1) * g;
+            float vv = b2 * v[o] + (1.0f - b2) * g * g;
+            param[o] += -lr * mm / (sqrtf(vv) + eps); m[o] = mm; v[o] = vv;
+        }
+    }
+}
+
+/* a21 gpu_driven_pipeline_sparse_op  GR/compact.cu:1222-1255 (float and int32 variants) */
+ORC_API void orc_sparse_scatter_f32(float* A, const float* B, const int64_t* chunk_id, int nvis,
+                                    int E, int chunks, int alloc, int S, int op)
+{
+    for (int a = 0; a < nvis; a++)
+        for (int e = 0; e < E; e++)
+            for (int i = 0; i < S; i++) {
+                float bv = B[((size_t)e * alloc + a) * S + i];
+                float* p = A + ((size_t)e * chunks + chunk_id[a]) * S + i;
+                if (op == 0) *p += bv; else if (op == 1) *p = fminf_(*p, bv); else *p = fmaxf_(*p, bv);
+            }
+}
+ORC_API void orc_sparse_scatter_i32(int32_t* A, const int32_t* B, const int64_t* chunk_id, int nvis,
+                                    int E, int chunks, int alloc, int S, int op)
+{
+    for (int a = 0; a < nvis; a++)
+        for (int e = 0; e < E; e++)
+            for (int i = 0; i < S; i++) {
+                int32_t bv = B[((size_t)e * alloc + a) * S + i];
+                int32_t* p = A + ((size_t)e * chunks + chunk_id[a]) * S + i;
+                if (op == 0) *p += bv; else if (op == 1) *p = imin(*p, bv); else *p = imax(*p, bv);
+            }
+}
+
+/* exported so tests can check the HIP twin bit-for-bit */
+ORC_API float orc_logf_export(float x) { return orc_logf(x); }
