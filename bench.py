@@ -1,0 +1,288 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the LiteGS render hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched through
+``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).  W untimed warm-up steps,
+then exactly K timed steps bracketed by barrier + synchronize on both sides, MAX over ranks; rank 0 prints
+ONE JSON line.
+
+Workload = BASELINE.json configs[2]: 3M synthetic Gaussians (SURVEY.md 8d distribution, seed 0), SH degree 3,
+1920x1080, one camera frame per GPU per step, full training iteration (render_preprocess + render + L1/SSIM loss +
+backward + sparse Adam + lr schedule), steady state (feedback buffers warm: no host sync in the timed region).
+``value`` = camera frames trained per second over the whole job (== train iters/s at 1 GPU; weak scaling).
+Extra keys: fwd Msplats/s, the roofline object of the dominant kernel (measured live with events on the launch
+stream) and, on rank 0 at N=1, the CPU baseline (the oracle restatement timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--config", default="3m_1080p", help="key of litegs_amd.synthetic.CONFIGS")
+    ap.add_argument("--frames", type=int, default=8, help="camera frames per rank (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tile-stride", type=int, default=24, help="CPU baseline rasterises every n-th tile")
+    return ap.parse_args()
+
+
+def time_kernel(fn, iters=10):
+    """Average duration (ms) of `fn` measured with events on the current stream (the stream fn launches on)."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def roofline_probe(tr, frame_index=0):
+    """Re-runs the blend kernels of one frame in isolation and prices them against the roofline.
+
+    Algorithmic bytes: forward blend  = I*36 [id 4 + packed 32] + P*18 [img 12 + T 4 + last 2];
+    backward blend = P*18 + I*36 + I_c*36 [9-float atomic RMW per contributing instance].
+    Algorithmic flops: forward 2 px * ... counted as 26 flop per (pixel, splat) visited, backward 60."""
+    from litegs_amd import fused, wrapper, render as R
+    from litegs_amd._lib import lib, check
+    frame = tr.frames[frame_index]
+    pp = tr.pp
+    H, W = tr.H, tr.W
+    th, tw = pp.tile_size
+    with torch.no_grad():
+        xyz, scale, rot, sh_0, sh_rest, opacity = tr.params
+        vis_id, vis_num, cx, cs, cr, cc, co = R.render_preprocess(tr.cluster_origin, tr.cluster_extend, frame.planes, frame.view, xyz, scale, rot,
+                                                                  sh_0, sh_rest, opacity, None, None, pp, tr.degree)
+        vl = vis_num * pp.cluster_size
+        view_pos, ndc = fused.mvp_transform_forward(cx, frame.view, frame.proj, vl)
+        T = fused.createTransformMatrix_forward(cr, cs, vl)
+        J = fused.jacobianRayspace(view_pos, frame.proj, H, W, vl)
+        cov = fused.createCov2dDirectly_forward(J, frame.view, T, vl)
+        _, _, inv = fused.eigh_and_inv_2x2matrix_forward(cov, vl)
+        tile_start, sorted_pt, _ = wrapper.Binning.call_fused(ndc, view_pos[:, 2, :], inv, co, vl, None, None, (H, W), pp.tile_size)
+        out = fused.rasterize_forward(sorted_pt, tile_start, ndc, inv, cc, co, None, H, W, th, tw, False, False, False)
+        img, trans, _, last, packed, _, _ = out
+        d_img = torch.rand_like(img) - 0.5
+        n_inst = int((tile_start[0, -1] - tile_start[0, 1]).item()) if tile_start[0, 1] >= 0 else int(sorted_pt.shape[1])
+        n_inst = int(sorted_pt.shape[1])
+        visited = int(last.to(torch.int64).sum().item())            # (pixel, splat) pairs visited by the forward
+        P = img.shape[2] * img.shape[3]
+        N = packed.shape[1]
+        L = lib()
+        pg = torch.zeros((1, N, L.lg_packed_grad_floats()), device=img.device)
+        esq = torch.zeros((1, 1, N), device=img.device)
+        s = torch.cuda.current_stream().cuda_stream
+        fc = torch.zeros((1, 1, N), dtype=torch.int32, device=img.device)
+        fw = torch.zeros((1, 1, N), device=img.device)
+
+        def fwd():
+            check(L.lg_raster_forward(sorted_pt.data_ptr(), tile_start.data_ptr(), packed.data_ptr(), None, 0, 1, n_inst, N, H, W, th, tw, 0,
+                                      img.data_ptr(), trans.data_ptr(), last.data_ptr(), fc.data_ptr(), fw.data_ptr(), s), "fwd")
+
+        def bwd():
+            check(L.lg_raster_backward(sorted_pt.data_ptr(), tile_start.data_ptr(), packed.data_ptr(), None, 0, trans.data_ptr(), last.data_ptr(),
+                                       d_img.data_ptr(), None, 1, n_inst, N, H, W, th, tw, 0, pg.data_ptr(), esq.data_ptr(), s), "bwd")
+
+        t_fwd = time_kernel(fwd)
+        t_bwd = time_kernel(bwd)
+        # contributing instances: count gradient records touched by one backward pass (lower bound on I_c per Gaussian
+        # is not what we need; use visited-pair statistics instead): I_c is bounded by I; report the bound used.
+        bytes_fwd = n_inst * 36 + P * 18
+        bytes_bwd = P * 18 + n_inst * 36 + n_inst * 36
+        dom = "raster_backward_kernel" if t_bwd >= t_fwd else "raster_forward_kernel"
+        t_dom = max(t_bwd, t_fwd)
+        b_dom = bytes_bwd if t_bwd >= t_fwd else bytes_fwd
+        flop_dom = visited * (60.0 if t_bwd >= t_fwd else 26.0)
+        achieved = b_dom / (t_dom * 1e-3) / 1e9
+        return {
+            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "avg_launch_ms": round(t_dom, 4), "algorithmic_bytes_per_launch": int(b_dom),
+            "note": "blend kernels are VALU-bound, not HBM-bound (SURVEY 8d): see valu_frac",
+            "valu_achieved_tflops": round(flop_dom / (t_dom * 1e-3) / 1e12, 3), "valu_peak_tflops": VALU_PEAK_TFLOPS,
+            "valu_frac": round(flop_dom / (t_dom * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
+            "forward_ms": round(t_fwd, 4), "backward_ms": round(t_bwd, 4), "instances": n_inst, "pixel_splat_pairs": visited,
+        }
+
+
+def cpu_baseline(scene, cam, H, W, degree, tile_stride):
+    """The oracle (CPU restatement of the reference algorithm -- the reference ships no CPU path) on the host cores:
+    whole per-Gaussian chain + binning + sort for the full frame, blend forward+backward on every `tile_stride`-th tile
+    (extrapolated x tile_stride), Adam on the visible chunks.  kind = "port"."""
+    from oracle import oracle as O
+    view, proj, planes = cam
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    xyz, scale, rot, sh0, shr, opa = scene
+    origin, extend = O.cluster_AABB(xyz, scale, rot)
+    _, chunk_id = O.frustum_culling_aabb(origin, extend, planes)
+    nvis = len(chunk_id)
+    a_pos, a_scale, a_rot, a_color, a_opa = O.activate_forward(degree, chunk_id, nvis, view, xyz, scale, rot, sh0, shr, opa)
+    S = xyz.shape[-1]
+    N = nvis * S
+    pos, sc, rt = a_pos.reshape(4, N), a_scale.reshape(3, N), a_rot.reshape(4, N)
+    col, op = a_color.reshape(1, 3, N), a_opa.reshape(1, N)
+    view_pos, ndc = O.mvp_forward(pos, view, proj)
+    T = O.transform_matrix_forward(rt, sc)
+    J = O.jacobian_rayspace(view_pos, proj, H, W)
+    cov = O.cov2d_forward(J, view, T)
+    _, _, inv = O.eigh_inv_forward(cov)
+    vd = np.ascontiguousarray(view_pos[:, 2, :])
+    _, _, alloc = O.get_allocate_size(ndc, vd, inv, op, H, W, 8, 16)
+    dsi = np.argsort(vd, axis=-1, kind="stable").astype(np.int64)
+    prefix = np.cumsum(np.take_along_axis(alloc, dsi, axis=-1), axis=-1, dtype=np.int64).astype(np.int32)
+    st, spt, _, _ = O.create_table(ndc, inv, op, prefix, dsi, H, W, 8, 16)
+    ntiles = ((H + 7) // 8) * ((W + 15) // 16)
+    ts = O.tile_range(st, ntiles)
+    packed = O.pack_params(ndc, inv, col, op, H, W)
+    t_chain = time.time() - t0
+    tiles = np.arange(1, ntiles + 1, tile_stride, dtype=np.int32)[None]
+    t0 = time.time()
+    img, trans, last, _, _ = O.raster_forward(spt, ts, packed, H, W, 8, 16, tiles=tiles)
+    t_rf = time.time() - t0
+    d_img = np.random.default_rng(0).standard_normal(img.shape).astype(np.float32)
+    t0 = time.time()
+    d_ndc, d_ic, d_color, d_opa, _ = O.raster_backward(spt, ts, packed, trans, last, d_img, H, W, 8, 16, tiles=tiles)
+    t_rb = time.time() - t0
+    t0 = time.time()
+    g_cov = np.nan_to_num(O.inv2x2_backward(inv, d_ic))
+    gT = O.cov2d_backward(g_cov, J, view, T)
+    g_rot, g_scale = O.transform_matrix_backward(gT, rt, sc)
+    g_pos = O.mvp_backward(d_ndc, np.zeros_like(view_pos), view, proj, view_pos)
+    grads = O.activate_backward(degree, chunk_id, nvis, view, xyz, scale, rot, sh0, shr, opa, g_pos.reshape(4, nvis, S), g_scale.reshape(3, nvis, S),
+                                g_rot.reshape(4, nvis, S), d_color.reshape(1, 3, nvis, S), d_opa.reshape(1, nvis, S))
+    for p, g in zip(scene, grads):
+        p3 = p.reshape(-1, p.shape[-2], p.shape[-1]).copy()
+        O.adam_chunk(p3, g.reshape(-1, nvis, S), np.zeros_like(p3), np.zeros_like(p3), chunk_id, nvis, 1e-3)
+    t_bchain = time.time() - t0
+    t_iter = t_chain + t_bchain + tile_stride * (t_rf + t_rb)
+    t_fwd = t_chain + tile_stride * t_rf
+    n_total = xyz.shape[-2] * xyz.shape[-1]
+    return {
+        "value": round(1.0 / t_iter, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+        "fwd_msplats_per_s": round(n_total / t_fwd / 1e6, 4),
+        "sample": f"full per-Gaussian chain+binning+sort+Adam of one frame, blend fwd+bwd on every {tile_stride}th tile "
+                  f"(x{tile_stride} extrapolated); measured {t_chain + t_bchain + t_rf + t_rb:.1f}s of CPU work, OpenMP {cores} threads",
+        "cpu_model": _cpu_model(), "n_vis": int(N), "instances": int(prefix[0, -1]),
+    }
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (litegs_amd has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from litegs_amd import synthetic as S
+    from litegs_amd.trainer import SyntheticTrainer
+    n, W, H, focal = S.CONFIGS[args.config]
+    scene = S.make_scene(n, seed=0)                   # identical replica on every rank
+    tr = SyntheticTrainer(n, W, H, focal, n_frames=args.frames * world, scene=scene)
+    hook = None
+    if world > 1:
+        from litegs_amd import dp
+        hook = dp.GradientExchange(tr.params, world).hook
+
+    def frame_of(step):                               # rank r trains frame (step*world + r): disjoint frames per step
+        return (step * world + rank) % len(tr.frames)
+
+    # every frame must be seen once (blocking sizing path) before steady state
+    warm = max(args.warmup, args.frames + 2)
+    for i in range(warm):
+        tr.step(frame_of(i), hook)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warm, warm + args.steps):
+        tr.step(frame_of(i), hook)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # forward-only throughput (render_preprocess + render), same frames
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tr.forward_only(frame_of(i))
+    torch.cuda.synchronize()
+    fwd_s = (time.perf_counter() - t0) / args.steps
+
+    if rank == 0:
+        stats = tr.workload_stats(frame_of(0))
+        result = {
+            "metric": "train iters/s (camera frames trained per second, whole job) + fwd Msplats/s, 3M Gaussians @1080p",
+            "value": round(world * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n} Gaussians SH3, {W}x{H}, 1 camera frame per GPU per step, full training iteration "
+                                   "(render_preprocess+render+L1/SSIM loss+backward+sparse Adam), seed 0 (SURVEY 8d)",
+                       "frames_per_rank": args.frames, "tile": [8, 16], "parallelism": f"dp{world} (one frame per GPU, RCCL gradient all-reduce)" if world > 1 else "single GPU"},
+            "fwd_msplats_per_s": round(n / fwd_s / 1e6, 2), "fwd_ms": round(fwd_s * 1e3, 4),
+            "n_vis": stats["n_vis"], "instances": stats["instances"],
+            "reference_derived_rtx3090_iters_per_s": 103.0,
+        }
+        if world == 1:
+            result["roofline"] = roofline_probe(tr, frame_of(0))
+            traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(traffic_file):
+                try:
+                    tj = json.load(open(traffic_file))
+                    result["roofline"]["traffic"] = tj.get(result["roofline"]["kernel"])
+                except Exception:
+                    pass
+            if not args.no_cpu_baseline:
+                fr = tr.frames[frame_of(0)]
+                cam = (fr.view.cpu().numpy(), fr.proj.cpu().numpy(), fr.planes.cpu().numpy())
+                result["cpu_baseline"] = cpu_baseline(scene, cam, H, W, 3, args.cpu_tile_stride)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

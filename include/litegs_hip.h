@@ -55,7 +55,7 @@ int lg_activate_backward(int sh_degree, const int64_t* visible_chunk_id, const i
 /* adamUpdate (GR/compact.cu:320-417, compact.h:18-23): chunk form ([E,chunks,S] params, [E,A,S] compact grads)
  * and primitive form ([E,N], int64 mask[N]).  No bias correction, as in the reference. */
 int lg_adam_update_chunk(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* visible_chunk_id,
-                         const int* valid_length, int E, int chunks, int A, int S,
+                         const int* valid_length, int E, int chunks, int A, int S, int grad_dense /*grad is [E,chunks,S]*/,
                          float lr, float b1, float b2, float eps, void* stream);
 int lg_adam_update_primitive(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* mask,
                              int E, int N, float lr, float b1, float b2, float eps, void* stream);
@@ -64,6 +64,11 @@ int lg_adam_update_primitive(float* param, const float* grad, float* exp_avg, fl
  * dtype: 0 f32, 1 i32, 2 i64, 3 f64, 4 i16, 5 i8;  op: 0 add, 1 min, 2 max */
 int lg_sparse_scatter(void* A_, const void* B, const int64_t* chunk_ids, const int* valid_count,
                       int E, int chunks, int alloc, int S, int dtype, int op, void* stream);
+
+/* data-parallel helpers (new: the reference has no multi-GPU path): mask[ids[i]]=1 for i<*count; ordered compaction of an
+ * int32 mask into (count, ids) with the output contract of lg_frustum_culling_aabb */
+int lg_mark_chunks(const int64_t* ids, const int* count, int A, int* mask, void* stream);
+int lg_compact_mask(const int* mask, int M, int* count, int64_t* ids, void* stream);
 
 /* the 4-byte async device->pinned-host feedback copy of GR/compact.cu:538 and GR/binning.cu:148 */
 int lg_feedback_d2h(int* host_dst, const int* device_src, void* stream);
@@ -137,6 +142,15 @@ int lg_raster_backward(const int* sorted_points, const int* start_index, const f
 int lg_unpack_gradient(const float* packed_grad, const float* grad_inv_scaler /*[1] or NULL*/, const int* valid_length,
                        int V, int N, int H, int W, float* d_ndc /*[V,4,N]*/, float* d_cov2d_inv /*[V,2,2,N]*/,
                        float* d_color /*[V,3,N]*/, float* d_opacity /*[1,N]*/, void* stream);                        /* raster.cu:855-886 */
+
+/* ---- loss.hip : fused_ssim.fused_l1_ssim_loss (litegs/training/trainer.py:145; un-vendored submodule, formula in
+ * litegs_amd/loss.py).  planes = B*C image planes of H x W.  dmaps [3,planes,H,W] carries dS/dmu1, dS/dE[x^2], dS/dE[xy]
+ * from forward to backward; partial holds lg_l1_ssim_partial_floats() floats; loss is a device scalar. */
+long long lg_l1_ssim_partial_floats(int planes, int H, int W);
+int lg_l1_ssim_forward(const float* img, const float* gt, int planes, int H, int W, float lam,
+                       float* dmaps, float* partial, float* loss, void* stream);
+int lg_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, const float* grad_out /*[1] or NULL*/,
+                        int planes, int H, int W, float lam, float* d_img, void* stream);
 
 #ifdef __cplusplus
 }

@@ -167,26 +167,112 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
     LG_RETURN_LAST();
 }
 
-// a10 (first half) duplicate_with_keys: slot j (depth order) -> point sorted_id[j]; emits at prefix[j-1]
+// a10 (first half) duplicate_with_keys: slot j (depth order) -> point sorted_id[j]; emits at prefix[j-1].
+// A 256-thread workgroup owns 256 consecutive depth slots, whose output ranges are CONTIGUOUS in the table
+// (prefix order).  Each thread runs the serial AccuTile walk, but instead of scattering 4-byte stores (64 cache
+// lines per wave instruction) it writes into an LDS window of DUP_WIN entries that the workgroup then streams
+// out with coalesced stores; the walk is suspended / resumed at window boundaries.  Arithmetic is the walk of
+// walk_tiles<> verbatim (same cuts, same order) so the emitted keys stay bit-identical to the oracle.
+#define DUP_WIN 4096
 template <int TH, int TW, typename IdxT>
 __global__ void __launch_bounds__(TPB) duplicate_with_keys_kernel(const float* __restrict__ ndc, const float* __restrict__ inv_cov,
                                                                   const float* __restrict__ opacity, const int32_t* __restrict__ prefix,
                                                                   const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                                   long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values)
 {
-    int j = blockIdx.x * TPB + threadIdx.x;
-    int b = blockIdx.y;
-    if (j >= N) return;
-    long long off = (j == 0) ? 0 : prefix[(size_t)b * N + j - 1];
-    long long cnt = prefix[(size_t)b * N + j] - off;
-    if (!(cnt > 0 && off + cnt <= table_len)) return;
-    int i = (int)sorted_id[(size_t)b * N + j];
-    float nx = ndc[((size_t)b * 4) * N + i], ny = ndc[((size_t)b * 4 + 1) * N + i];
-    float a = inv_cov[((size_t)b * 4) * N + i], bb = inv_cov[((size_t)b * 4 + 1) * N + i], c = inv_cov[((size_t)b * 4 + 3) * N + i];
+    __shared__ int2 buf[DUP_WIN];
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * TPB;
+    const int j = j0 + tid;
+    const int b = blockIdx.y;
+    const int32_t* pf = prefix + (size_t)b * N;
+    int32_t* kout = keys + (size_t)b * table_len;
+    int32_t* vout = values + (size_t)b * table_len;
+    const int jl = min(j0 + TPB, N) - 1;
+    long long block_start = (j0 == 0) ? 0 : pf[j0 - 1];
+    long long block_end = pf[jl];
+    if (block_end > table_len) block_end = table_len;
+    if (block_start >= block_end) return;
+
+    // ---- per-thread walk state ----
+    bool done = true;
+    long long cur = 0;
+    int idx = 0;
     SplatExtent e;
-    splat_extent<TH, TW>(nx, ny, a, bb, c, opacity[i], H, W, gx, gy, e);
-    if ((e.rmaxy - e.rminy) * (e.rmaxx - e.rminx) > 0)
-        walk_tiles<TH, TW, true>(e, gx, i, off, keys + (size_t)b * table_len, values + (size_t)b * table_len);
+    bool isY = false;
+    float BLOCK_U = 0.f, BLOCK_V = 0.f, bmax_u = 0.f, bmin_v = 0.f, bmax_v = 0.f, argmin_v = 0.f, argmax_v = 0.f;
+    int u = 0, u_end = 0, rect_min_v = 0, rect_max_v = 0, v = 0, v_end = 0, cur_u = 0;
+    float min_line = 0.f, imin_lo = 0.f, imin_hi = 0.f, imax_lo = 0.f, imax_hi = 0.f;
+    if (j < N) {
+        long long off = (j == 0) ? 0 : pf[j - 1];
+        long long cnt = pf[j] - off;
+        if (cnt > 0 && off + cnt <= table_len) {
+            idx = (int)sorted_id[(size_t)b * N + j];
+            float nx = ndc[((size_t)b * 4) * N + idx], ny = ndc[((size_t)b * 4 + 1) * N + idx];
+            float a = inv_cov[((size_t)b * 4) * N + idx], bb = inv_cov[((size_t)b * 4 + 1) * N + idx], c = inv_cov[((size_t)b * 4 + 3) * N + idx];
+            splat_extent<TH, TW>(nx, ny, a, bb, c, opacity[idx], H, W, gx, gy, e);
+            const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
+            if (ys * xs > 0) {
+                done = false;
+                cur = off;
+                isY = ys < xs;
+                BLOCK_U = isY ? (float)TH : (float)TW;
+                BLOCK_V = isY ? (float)TW : (float)TH;
+                u = isY ? e.rminy : e.rminx; u_end = isY ? e.rmaxy : e.rmaxx;
+                rect_min_v = isY ? e.rminx : e.rminy; rect_max_v = isY ? e.rmaxx : e.rmaxy;
+                const float bmin_u = isY ? e.bbox_min_y : e.bbox_min_x;
+                bmin_v = isY ? e.bbox_min_x : e.bbox_min_y;
+                bmax_u = isY ? e.bbox_max_y : e.bbox_max_x; bmax_v = isY ? e.bbox_max_x : e.bbox_max_y;
+                argmin_v = isY ? e.argmin_x : e.argmin_y;
+                argmax_v = isY ? e.argmax_x : e.argmax_y;
+                imax_lo = bmax_v; imax_hi = bmin_v;
+                min_line = u * BLOCK_U;
+                if (bmin_u <= min_line) ellipse_cut(e, isY, u * BLOCK_U, imin_lo, imin_hi);
+                else { imin_lo = imax_lo; imin_hi = imax_hi; }
+            }
+        }
+    }
+    // advance to the next non-empty slice (or finish)
+    auto advance = [&]() {
+        while (true) {
+            if (u >= u_end) { done = true; return; }
+            float max_line = min_line + BLOCK_U;
+            if (max_line <= bmax_u) ellipse_cut(e, isY, max_line, imax_lo, imax_hi);
+            float ellipse_min, ellipse_max;
+            if (min_line <= argmin_v && argmin_v < max_line) ellipse_min = bmin_v;
+            else ellipse_min = fminf(imin_lo, imax_lo);
+            if (min_line <= argmax_v && argmax_v < max_line) ellipse_max = bmax_v;
+            else ellipse_max = fmaxf(imin_hi, imax_hi);
+            v = max(rect_min_v, min(rect_max_v, lg_f2i(ellipse_min / BLOCK_V)));
+            v_end = min(rect_max_v, max(rect_min_v, lg_f2i(ellipse_max / BLOCK_V + 1)));
+            cur_u = u;
+            imin_lo = imax_lo; imin_hi = imax_hi;
+            min_line = max_line;
+            u++;
+            if (v < v_end) return;
+        }
+    };
+    if (!done) advance();
+
+    for (long long w0 = block_start; w0 < block_end; w0 += DUP_WIN) {
+        const long long w1 = (w0 + DUP_WIN < block_end) ? (w0 + DUP_WIN) : block_end;
+        for (int k = tid; k < (int)(w1 - w0); k += TPB) buf[k] = make_int2(0, 0);      // holes of dropped splats stay padding
+        __syncthreads();
+        while (!done && cur < w1) {
+            uint32_t key = isY ? (uint32_t)(cur_u * gx + v) : (uint32_t)(v * gx + cur_u);
+            buf[cur - w0] = make_int2((int)(key + 1), idx);
+            cur++;
+            v++;
+            if (v >= v_end) advance();
+        }
+        __syncthreads();
+        for (int k = tid; k < (int)(w1 - w0); k += TPB) {
+            int2 kv = buf[k];
+            kout[w0 + k] = kv.x;
+            vout[w0 + k] = kv.y;
+        }
+        __syncthreads();
+    }
 }
 
 LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const float* opacity, const int32_t* prefix,

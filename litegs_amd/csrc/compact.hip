@@ -36,8 +36,9 @@ __device__ __forceinline__ bool aabb_visible(const float* __restrict__ planes_ld
     return gv;
 }
 
+template <bool FROM_MASK>
 __global__ void __launch_bounds__(CULL_TPB) frustum_culling_kernel(const float* __restrict__ origin, const float* __restrict__ ext,
-                                                                   const float* __restrict__ planes, int V, int M,
+                                                                   const float* __restrict__ planes, const int* __restrict__ mask, int V, int M,
                                                                    uint8_t* __restrict__ visibility, int* __restrict__ visible_num,
                                                                    int64_t* __restrict__ visible_chunk_id)
 {
@@ -56,9 +57,12 @@ __global__ void __launch_bounds__(CULL_TPB) frustum_culling_kernel(const float* 
         int m = p * CULL_TPB + tid;
         bool vis = false;
         if (m < M) {
-            vis = aabb_visible(planes_lds, V, origin[m], origin[(size_t)M + m], origin[2 * (size_t)M + m],
-                               ext[m], ext[(size_t)M + m], ext[2 * (size_t)M + m]);
-            visibility[m] = vis ? 1 : 0;
+            if (FROM_MASK) vis = mask[m] != 0;
+            else {
+                vis = aabb_visible(planes_lds, V, origin[m], origin[(size_t)M + m], origin[2 * (size_t)M + m],
+                                   ext[m], ext[(size_t)M + m], ext[2 * (size_t)M + m]);
+                visibility[m] = vis ? 1 : 0;
+            }
         }
         unsigned long long mask = __ballot(vis);
         if (lane == 0) {
@@ -108,8 +112,35 @@ LG_API int lg_frustum_culling_aabb(const float* origin, const float* ext, const 
     int passes = (M + CULL_TPB - 1) / CULL_TPB;
     size_t lds = ((V * 24 * 4 + 15) & ~15) + (size_t)passes * CULL_WAVES * (8 + 4) + 16;
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(frustum_culling_kernel, dim3(1), dim3(CULL_TPB), lds, (hipStream_t)stream,
-                       origin, ext, planes, V, M, visibility, visible_num, visible_chunk_id);
+    hipLaunchKernelGGL(frustum_culling_kernel<false>, dim3(1), dim3(CULL_TPB), lds, (hipStream_t)stream,
+                       origin, ext, planes, (const int*)nullptr, V, M, visibility, visible_num, visible_chunk_id);
+    LG_RETURN_LAST();
+}
+
+// Ordered compaction of an int32 mask (non-zero = keep) with the same output contract as frustum_culling_aabb:
+// used by the data-parallel path to turn the all-reduced visibility mask into the union chunk list.
+LG_API int lg_compact_mask(const int* mask, int M, int* count, int64_t* ids, void* stream)
+{
+    if (M <= 0) return 0;
+    int passes = (M + CULL_TPB - 1) / CULL_TPB;
+    size_t lds = 16 + (size_t)passes * CULL_WAVES * (8 + 4) + 16;
+    if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(frustum_culling_kernel<true>, dim3(1), dim3(CULL_TPB), lds, (hipStream_t)stream,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, mask, 0, M, (uint8_t*)nullptr, count, ids);
+    LG_RETURN_LAST();
+}
+
+// mask[ids[i]] = 1 for i < *count  (mask pre-zeroed)
+__global__ void __launch_bounds__(256) mark_chunks_kernel(const int64_t* __restrict__ ids, const int* __restrict__ count, int A, int* __restrict__ mask)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < A && i < count[0]) mask[ids[i]] = 1;
+}
+
+LG_API int lg_mark_chunks(const int64_t* ids, const int* count, int A, int* mask, void* stream)
+{
+    if (A <= 0) return 0;
+    hipLaunchKernelGGL(mark_chunks_kernel, dim3(lg_cdiv(A, 256)), dim3(256), 0, (hipStream_t)stream, ids, count, A, mask);
     LG_RETURN_LAST();
 }
 
@@ -321,7 +352,7 @@ LG_API int lg_activate_backward(int degree, const int64_t* visible_chunk_id, con
 __global__ void __launch_bounds__(ADAM_TPB) adam_chunk_kernel_v4(float* __restrict__ param, const float* __restrict__ grad,
                                                                  float* __restrict__ m, float* __restrict__ v,
                                                                  const int64_t* __restrict__ visible_chunk_id, const int* __restrict__ valid_length,
-                                                                 int E, int chunks, int A, int S,
+                                                                 int E, int chunks, int A, int S, int grad_dense,
                                                                  float lr, float b1, float b2, float eps)
 {
     const int a = blockIdx.x;
@@ -332,8 +363,8 @@ __global__ void __launch_bounds__(ADAM_TPB) adam_chunk_kernel_v4(float* __restri
     const int q = threadIdx.x % quads;
     if (e >= E || (int)threadIdx.x >= rows_per_block * quads) return;
     const size_t chunk = (size_t)visible_chunk_id[a];
-    const size_t go = (((size_t)e * A + a) * S) / 4 + q;
     const size_t po = (((size_t)e * chunks + chunk) * S) / 4 + q;
+    const size_t go = grad_dense ? po : (((size_t)e * A + a) * S) / 4 + q;
     float4 g = reinterpret_cast<const float4*>(grad)[go];
     float4 mm = reinterpret_cast<float4*>(m)[po];
     float4 vv = reinterpret_cast<float4*>(v)[po];
@@ -351,13 +382,13 @@ __global__ void __launch_bounds__(ADAM_TPB) adam_chunk_kernel_v4(float* __restri
 
 __global__ void adam_chunk_kernel_generic(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
                                           float* __restrict__ v, const int64_t* __restrict__ visible_chunk_id,
-                                          const int* __restrict__ valid_length, int E, int chunks, int A, int S,
+                                          const int* __restrict__ valid_length, int E, int chunks, int A, int S, int grad_dense,
                                           float lr, float b1, float b2, float eps)
 {
     const int a = blockIdx.x, e = blockIdx.y, i = threadIdx.x;
     if (valid_length != nullptr && a >= valid_length[0]) return;
-    const size_t go = ((size_t)e * A + a) * S + i;
     const size_t po = ((size_t)e * chunks + (size_t)visible_chunk_id[a]) * S + i;
+    const size_t go = grad_dense ? po : ((size_t)e * A + a) * S + i;
     float g = grad[go];
     float mm = b1 * m[po] + (1.0f - b1) * g;
     float vv = b2 * v[po] + (1.0f - b2) * g * g;
@@ -366,7 +397,7 @@ __global__ void adam_chunk_kernel_generic(float* __restrict__ param, const float
 }
 
 LG_API int lg_adam_update_chunk(float* param, const float* grad, float* m, float* v, const int64_t* visible_chunk_id,
-                                const int* valid_length, int E, int chunks, int A, int S,
+                                const int* valid_length, int E, int chunks, int A, int S, int grad_dense,
                                 float lr, float b1, float b2, float eps, void* stream)
 {
     if (A <= 0 || E <= 0) return 0;
@@ -374,11 +405,11 @@ LG_API int lg_adam_update_chunk(float* param, const float* grad, float* m, float
     if (S % 4 == 0 && (S / 4) <= ADAM_TPB && ADAM_TPB % (S / 4) == 0) {
         int rows = ADAM_TPB / (S / 4);
         hipLaunchKernelGGL(adam_chunk_kernel_v4, dim3(A, lg_cdiv(E, rows)), dim3(ADAM_TPB), 0, s, param, grad, m, v, visible_chunk_id,
-                           valid_length, E, chunks, A, S, lr, b1, b2, eps);
+                           valid_length, E, chunks, A, S, grad_dense, lr, b1, b2, eps);
     } else {
         if (S > 1024) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(adam_chunk_kernel_generic, dim3(A, E), dim3(S), 0, s, param, grad, m, v, visible_chunk_id, valid_length,
-                           E, chunks, A, S, lr, b1, b2, eps);
+                           E, chunks, A, S, grad_dense, lr, b1, b2, eps);
     }
     LG_RETURN_LAST();
 }

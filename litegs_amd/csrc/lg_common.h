@@ -20,7 +20,7 @@ __device__ __forceinline__ int lg_f2i(float v)
     return (int)v;
 }
 
-// Natural log with a fixed operation order: bit-identical to oracle/litegs_oracle.c:orc_logf when this
+// Natural log with a fixed operation order: bit-identical to the CPU checker's twin (orc_logf) when this
 // translation unit is compiled with -ffp-contract=off (binning.hip is).  Input: positive normal float.
 __device__ __forceinline__ float lg_logf(float x)
 {

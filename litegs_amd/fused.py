@@ -125,8 +125,8 @@ def activate_backward(sh_degree, visible_chunk_id, visible_chunks_num, view_matr
     return [d_pos, d_scale, d_rot, d_sh0, d_shr, d_opa]
 
 
-def adamUpdate(param, param_grad, exp_avg, exp_avg_sq, visible_index, valid_length, lr, b1, b2, eps):
-    """GR/compact.cu:377-417 (in place)."""
+def adamUpdate(param, param_grad, exp_avg, exp_avg_sq, visible_index, valid_length, lr, b1, b2, eps, grad_dense=False):
+    """GR/compact.cu:377-417 (in place).  grad_dense (extension for the DP path): param_grad is [E,chunks,S], indexed by chunk id."""
     for t, n in ((param, "param"), (param_grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
             raise RuntimeError(f"adamUpdate: '{n}' must be a contiguous float32 device tensor")
@@ -134,7 +134,7 @@ def adamUpdate(param, param_grad, exp_avg, exp_avg_sq, visible_index, valid_leng
         E, chunks, S = param.shape
         A = visible_index.shape[0]
         check(lib().lg_adam_update_chunk(_p(param), _p(param_grad), _p(exp_avg), _p(exp_avg_sq), _p(_dev(visible_index, "visible_index")),
-                                         _vl(valid_length), E, chunks, A, S, float(lr), float(b1), float(b2), float(eps), _s()), "adamUpdate")
+                                         _vl(valid_length), E, chunks, A, S, 1 if grad_dense else 0, float(lr), float(b1), float(b2), float(eps), _s()), "adamUpdate")
     elif param.dim() == 2:
         E, N = param.shape
         check(lib().lg_adam_update_primitive(_p(param), _p(param_grad), _p(exp_avg), _p(exp_avg_sq), _p(_dev(visible_index, "visible_index")),

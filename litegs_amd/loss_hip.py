@@ -1,0 +1,41 @@
+"""autograd binding of csrc/loss.hip (fused L1 + SSIM loss, forward and backward on the GPU, no host sync)."""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib
+from .loss import LAMBDA_DSSIM
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class FusedL1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img: torch.Tensor, gt: torch.Tensor):
+        if not (img.is_cuda and gt.is_cuda):
+            raise RuntimeError("fused_l1_ssim_loss: GPU tensors required (no CPU path)")
+        img = img.contiguous()
+        gt = gt.contiguous()
+        if img.shape != gt.shape or img.dtype != torch.float32 or gt.dtype != torch.float32:
+            raise RuntimeError("fused_l1_ssim_loss: img and gt must be float32 tensors of the same shape [B,C,H,W]")
+        B, C, H, W = img.shape
+        L = lib()
+        dmaps = torch.empty((3, B * C, H, W), dtype=torch.float32, device=img.device)
+        partial = torch.empty((L.lg_l1_ssim_partial_floats(B * C, H, W),), dtype=torch.float32, device=img.device)
+        loss = torch.empty((), dtype=torch.float32, device=img.device)
+        check(L.lg_l1_ssim_forward(img.data_ptr(), gt.data_ptr(), B * C, H, W, LAMBDA_DSSIM, dmaps.data_ptr(), partial.data_ptr(),
+                                   loss.data_ptr(), _s()), "l1_ssim_forward")
+        ctx.save_for_backward(img, gt, dmaps)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        img, gt, dmaps = ctx.saved_tensors
+        B, C, H, W = img.shape
+        d_img = torch.empty_like(img)
+        g = grad_out.contiguous()
+        check(lib().lg_l1_ssim_backward(img.data_ptr(), gt.data_ptr(), dmaps.data_ptr(), g.data_ptr(), B * C, H, W, LAMBDA_DSSIM,
+                                        d_img.data_ptr(), _s()), "l1_ssim_backward")
+        return d_img, None

@@ -12,6 +12,7 @@ from dataclasses import dataclass
 
 import torch
 
+from . import fused
 from .wrapper import CompactedTensor, sparse_adam_update
 
 
@@ -51,13 +52,17 @@ class SparseGaussianAdam(torch.optim.Adam):
                 chunks, S = param.shape[-2], param.shape[-1]
                 grad = param.grad
                 if isinstance(grad, CompactedTensor):
-                    values, ids = grad.compacted_values, (visible_chunk if visible_chunk is not None else grad.chunk_ids)
-                else:   # dense gradient (e.g. after a dense all-reduce): every chunk is "visible"
-                    values = grad.reshape(-1, chunks, S)
-                    ids = torch.arange(chunks, device=param.device)
-                    visible_chunks_num = None
-                sparse_adam_update(param.data.view(-1, chunks, S), values, state["exp_avg"].view(-1, chunks, S),
-                                   state["exp_avg_sq"].view(-1, chunks, S), ids, visible_chunks_num, lr, 0.9, 0.999, eps)
+                    ids = visible_chunk if visible_chunk is not None else grad.chunk_ids
+                    sparse_adam_update(param.data.view(-1, chunks, S), grad.compacted_values, state["exp_avg"].view(-1, chunks, S),
+                                       state["exp_avg_sq"].view(-1, chunks, S), ids, visible_chunks_num, lr, 0.9, 0.999, eps)
+                else:
+                    # dense gradient [*, chunks, S] (data-parallel exchange): update exactly the chunks of `visible_chunk`
+                    # (the union of all ranks' visibility); without a list, every chunk.
+                    ids, cnt = visible_chunk, visible_chunks_num
+                    if ids is None:
+                        ids, cnt = torch.arange(chunks, device=param.device), None
+                    fused.adamUpdate(param.data.view(-1, chunks, S), grad.reshape(-1, chunks, S), state["exp_avg"].view(-1, chunks, S),
+                                     state["exp_avg_sq"].view(-1, chunks, S), ids, cnt, lr, 0.9, 0.999, eps, grad_dense=True)
             else:
                 N = param.shape[-1]
                 sparse_adam_update(param.data.view(-1, N), param.grad.reshape(-1, N), state["exp_avg"].view(-1, N),

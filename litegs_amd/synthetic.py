@@ -76,6 +76,28 @@ def look_at(cam_pos, target, up=(0.0, -1.0, 0.0)):
     return R, t
 
 
+def frustum_planes(view: np.ndarray, proj: np.ndarray) -> np.ndarray:
+    """Six frustum planes [6,4] (left, right, bottom, top, near, far) from the columns of view@proj (litegs/data.py:139-176)."""
+    vp = view @ proj
+    pl = np.zeros((6, 4), np.float32)
+    pl[0] = vp[:, 3] + vp[:, 0]
+    pl[1] = vp[:, 3] - vp[:, 0]
+    pl[2] = vp[:, 3] + vp[:, 1]
+    pl[3] = vp[:, 3] - vp[:, 1]
+    pl[4] = vp[:, 2]
+    pl[5] = vp[:, 3] - vp[:, 2]
+    return pl
+
+
+def pinhole_proj(width: int, height: int, fx: float, fy: float, z_near: float = 0.01, z_far: float = 5000.0) -> np.ndarray:
+    """Row-vector projection matrix of litegs/data.py:36-46."""
+    a = fx / (width * 0.5)
+    b = fy / (height * 0.5)
+    return np.array([[a, 0, 0, 0], [0, b, 0, 0],
+                     [0, 0, z_far / (z_far - z_near), -z_far * z_near / (z_far - z_near)],
+                     [0, 0, 1, 0]], dtype=np.float32).T
+
+
 def make_camera(width: int, height: int, fx: float, fy: float, cam_pos, target=(0, 0, 0),
                 z_near: float = 0.01, z_far: float = 5000.0):
     """-> view_matrix[1,4,4], proj_matrix[1,4,4], frustumplane[1,6,4] (float32)."""
@@ -85,20 +107,8 @@ def make_camera(width: int, height: int, fx: float, fy: float, cam_pos, target=(
     Rt[:3, 3] = t
     Rt[3, 3] = 1.0
     view = Rt.T.astype(np.float32)                       # litegs/utils/__init__.py:38-43 + data.py:77
-    a = fx / (width * 0.5)
-    b = fy / (height * 0.5)
-    proj = np.array([[a, 0, 0, 0], [0, b, 0, 0],
-                     [0, 0, z_far / (z_far - z_near), -z_far * z_near / (z_far - z_near)],
-                     [0, 0, 1, 0]], dtype=np.float32).T   # litegs/data.py:42-46
-    vp = view @ proj
-    pl = np.zeros((6, 4), np.float32)                    # litegs/data.py:139-176
-    pl[0] = vp[:, 3] + vp[:, 0]
-    pl[1] = vp[:, 3] - vp[:, 0]
-    pl[2] = vp[:, 3] + vp[:, 1]
-    pl[3] = vp[:, 3] - vp[:, 1]
-    pl[4] = vp[:, 2]
-    pl[5] = vp[:, 3] - vp[:, 2]
-    return view[None].copy(), proj[None].copy(), pl[None].copy()
+    proj = pinhole_proj(width, height, fx, fy, z_near, z_far)
+    return view[None].copy(), proj[None].copy(), frustum_planes(view, proj)[None].copy()
 
 
 def orbit_cameras(count: int, width: int, height: int, fx: float, fy: float, radius: float,

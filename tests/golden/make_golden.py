@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""Generates tests/golden/reference_chain.npz by RUNNING THE REFERENCE's own Python twins on the CPU.
+
+Runs only in the build container (needs /root/reference; never at test time on the GPU box -- the fixture is
+committed).  The reference's rasteriser, binning, sort, cull/activate and Adam have no executable twin
+(SURVEY.md 4), so the golden vectors pin exactly the pieces the reference can evaluate without CUDA:
+
+  * litegs/utils/spherical_harmonics.py:38-93           sh_to_rgb             (degrees 0..3)
+  * litegs/utils/__init__.py:63-136                     viewproj_to_frustumplane, frustum_culling_aabb
+  * litegs/utils/wrapper.py:198-220  (_script)          CreateTransformMatrix
+  * litegs/utils/wrapper.py:243-255  (_script)          CreateRaySpaceTransformMatrix (no +-1.3 clamp: inputs kept inside it)
+  * litegs/utils/wrapper.py:419-442  (call_script)      CreateCov2dDirectly, forward and autograd backward
+  * litegs/utils/wrapper.py:569-577  (_script)          EighAndInverse2x2Matrix (torch.linalg eigh / inv), fwd + inverse backward
+  * litegs/data.py:35-57, 139-176                       PinHoleCameraInfo projection matrix, frustum planes
+
+The reference package cannot be imported as a whole here (litegs/__init__.py pulls in CUDA-only extensions and
+StatisticsHelper allocates on 'cuda' at import), so the needed modules are loaded with stub modules for
+`litegs_fused`, `simple_knn`, `cv2` and the statistics singleton.  Nothing of the reference is copied: its
+functions are CALLED and only their numeric outputs are stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_chain.npz")
+
+
+def load_reference():
+    pkg = types.ModuleType("litegs")
+    pkg.__path__ = [os.path.join(REF, "litegs")]
+    sys.modules["litegs"] = pkg
+    sys.modules["litegs_fused"] = types.ModuleType("litegs_fused")
+    stat = types.ModuleType("litegs.utils.statistic_helper")
+
+    class _S:
+        bStart = False
+    stat.StatisticsHelperInst = _S()
+    stat.StatisticsHelper = _S
+    sys.modules["litegs.utils.statistic_helper"] = stat
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    import importlib
+    utils = importlib.import_module("litegs.utils")
+    wrapper = importlib.import_module("litegs.utils.wrapper")
+    sh = importlib.import_module("litegs.utils.spherical_harmonics")
+    data = importlib.import_module("litegs.data")
+    return utils, wrapper, sh, data
+
+
+def main():
+    utils, wrapper, sh, data = load_reference()
+    g = torch.Generator().manual_seed(1234)
+    N = 257
+    out = {}
+
+    # --- camera conventions (litegs/data.py) -------------------------------------------------
+    cam = data.PinHoleCameraInfo(0, 640, 360, np.array([500.0, 480.0, 320.0, 180.0]))
+    proj = cam.get_project_matrix()                                             # [4,4] row-vector convention
+    qvec = np.array([0.9, 0.1, -0.3, 0.2]); qvec /= np.linalg.norm(qvec)
+    tvec = np.array([0.3, -0.2, 2.5])
+    frame = data.ImageFrame(0, qvec, tvec, 0, "f", "", np.zeros((0, 2)))
+    view = frame.get_viewmatrix()
+    vp = torch.tensor(view @ proj)[None]
+    planes = utils.viewproj_to_frustumplane(vp)
+    out.update(cam_proj=proj.astype(np.float32), cam_view=view.astype(np.float32), cam_qvec=qvec, cam_tvec=tvec, cam_planes=planes.numpy())
+
+    # --- frustum culling of AABBs (litegs/utils/__init__.py:109-136) --------------------------
+    M = 300
+    origin = (torch.rand((3, M), generator=g) * 2 - 1) * 6
+    ext = torch.rand((3, M), generator=g) * 0.5
+    vis = utils.frustum_culling_aabb(planes, origin, ext)                        # [1, M]
+    out.update(cull_origin=origin.numpy(), cull_ext=ext.numpy(), cull_visible=vis.numpy())
+
+    # --- SH (litegs/utils/spherical_harmonics.py) ---------------------------------------------
+    sh_all = torch.randn((16, 3, N), generator=g)
+    dirs = torch.nn.functional.normalize(torch.randn((2, 3, N), generator=g), dim=1)
+    out.update(sh_coeffs=sh_all.numpy(), sh_dirs=dirs.numpy())
+    for deg in range(4):
+        out[f"sh_rgb_deg{deg}"] = sh.sh_to_rgb(deg, sh_all, dirs).numpy()
+
+    # --- transform matrix (wrapper.py:198-220; the script hard-codes device='cuda' in torch.zeros) ----
+    scale = torch.rand((3, N), generator=g) + 0.1
+    quat = torch.nn.functional.normalize(torch.randn((4, N), generator=g), dim=0)
+    real_zeros = torch.zeros
+    torch.zeros = lambda *a, **k: real_zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    try:
+        T = wrapper.CreateTransformMatrix.call_script(scale, quat)
+    finally:
+        torch.zeros = real_zeros
+    out.update(tm_scale=scale.numpy(), tm_quat=quat.numpy(), tm_T=T.numpy())
+
+    # --- ray-space Jacobian (wrapper.py:243-255) -----------------------------------------------
+    view_pos = torch.randn((1, 4, N), generator=g)
+    view_pos[:, 2] = view_pos[:, 2].abs() * 3 + 0.5
+    view_pos[:, 0] *= 0.15 * view_pos[:, 2]          # inside the +-1.3 z/P clamp so both definitions agree
+    view_pos[:, 1] *= 0.1 * view_pos[:, 2]
+    view_pos[:, 3] = 1
+    projm = torch.tensor(proj)[None]
+    J = wrapper.CreateRaySpaceTransformMatrix.call_script(view_pos.clone(), projm, (360, 640))
+    out.update(j_view_pos=view_pos.numpy(), j_proj=projm.numpy(), j_J=J.numpy())
+
+    # --- cov2d forward + backward (wrapper.py:419-442 with :312-371 autograd functions) -----------
+    Tm = T.clone().requires_grad_(True)
+    viewm = torch.tensor(view)[None]
+    cov = wrapper.CreateCov2dDirectly.call_script(J, viewm, Tm)
+    gcov = torch.randn(cov.shape, generator=g)
+    gcov[:, 0, 1] = gcov[:, 1, 0]
+    (cov * gcov).sum().backward()
+    out.update(cov_view=viewm.numpy(), cov_cov2d=cov.detach().numpy(), cov_gcov=gcov.numpy(), cov_gT=Tm.grad.numpy())
+
+    # --- eigh + inverse (wrapper.py:569-577) --------------------------------------------------------
+    c2 = cov.detach().clone().requires_grad_(True)
+    val, vec, inv = wrapper.EighAndInverse2x2Matrix.call_script(c2)
+    ginv = torch.randn(inv.shape, generator=g)
+    ginv[:, 0, 1] = ginv[:, 1, 0]
+    (inv * ginv).sum().backward()
+    out.update(eig_val=val.numpy(), eig_vec=vec.numpy(), eig_inv=inv.detach().numpy(), eig_ginv=ginv.numpy(), eig_gcov=c2.grad.numpy())
+
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

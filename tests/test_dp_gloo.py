@@ -1,0 +1,80 @@
+"""world_size=2 data-parallel exchange on CPU (gloo): union visibility, one dense averaged buffer, replicas stay identical.
+The device primitives are injected as plain-torch ops (the product's HipOps need a GPU)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class TorchOps:
+    @staticmethod
+    def mark(mask, ids, count):
+        mask[ids[: int(count)]] = 1
+
+    @staticmethod
+    def compact(mask):
+        ids = torch.nonzero(mask)[:, 0]
+        full = torch.arange(mask.shape[0], dtype=torch.int64)
+        full[: len(ids)] = ids
+        return full, torch.tensor([len(ids)], dtype=torch.int32)
+
+    @staticmethod
+    def scatter_add(dense, compact, ids, count):
+        n = int(count)
+        dense[:, ids[:n], :] += compact[:, :n, :]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from litegs_amd import dp
+    from litegs_amd.wrapper import CompactedTensor
+    chunks, S = 12, 4
+    g = torch.Generator().manual_seed(0)
+    shapes = [(3, chunks, S), (3, chunks, S), (4, chunks, S), (1, 3, chunks, S), (15, 3, chunks, S), (1, chunks, S)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]            # identical replicas
+    ex = dp.GradientExchange(params, world, ops=TorchOps)
+    # rank-specific visibility (over-allocated id list, as with the 1.2x prediction) and compact gradients
+    vis = [torch.tensor([1, 4, 5, 9, 0, 0]), torch.tensor([4, 5, 6, 11, 2, 0])][rank]
+    cnt = torch.tensor([4], dtype=torch.int32)
+    gr = torch.Generator().manual_seed(100 + rank)
+    dense_local = []
+    for p in params:
+        rows = p.numel() // (chunks * S)
+        vals = torch.randn((rows, len(vis), S), generator=gr)
+        p.grad = CompactedTensor(p.shape, vis, vals)
+        d = torch.zeros(rows, chunks, S)
+        d[:, vis[:4]] = vals[:, :4]
+        dense_local.append(d)
+    union_ids, union_count = ex.hook(params, vis, cnt)
+    gathered = [torch.zeros(sum(ex.rows), chunks, S) for _ in range(world)]
+    dist.all_gather(gathered, torch.cat(dense_local))
+    expect = sum(gathered) / world
+    got = torch.cat([p.grad.reshape(-1, chunks, S) for p in params])
+    ok = torch.allclose(got, expect, atol=1e-6)
+    ok &= int(union_count) == 6
+    ok &= union_ids[: int(union_count)].tolist() == [1, 4, 5, 6, 9, 11]
+    ok &= all(p.grad.shape == p.shape for p in params)
+    ok &= dp.frame_for(3, rank, world, 8) == (3 * world + rank) % 8
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)

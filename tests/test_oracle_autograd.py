@@ -1,0 +1,152 @@
+"""Pins the parts of the oracle the reference cannot execute on a CPU (blend forward/backward, chain backward ops,
+activation) against an INDEPENDENT formulation: plain torch float64 + autograd on tiny cases."""
+import numpy as np
+import pytest
+import torch
+
+from litegs_amd import synthetic as S
+
+
+def tiny_case():
+    n, W, H, f = 700, 96, 64, 90.0
+    params = S.make_scene(n, seed=3, scale_mult=1.2)
+    view, proj, planes = S.make_camera(W, H, f, f, (1.8, -0.3, 0.8))
+    return params, view, proj, planes, H, W
+
+
+def torch_blend(packed, sorted_point, tile_start, H, W, TH, TW):
+    """Dense per-tile front-to-back blend in float64 with autograd; decision masks are constants (as in the kernels)."""
+    gx, gy = (W + TW - 1) // TW, (H + TH - 1) // TH
+    Hp, Wp = gy * TH, gx * TW
+    img = torch.zeros((3, Hp, Wp), dtype=torch.float64)
+    trans = torch.ones((Hp, Wp), dtype=torch.float64)
+    last = torch.zeros((Hp, Wp), dtype=torch.int64)
+    for tile in range(1, gx * gy + 1):
+        start, end = int(tile_start[tile]), int(tile_start[tile + 1])
+        if start < 0 or start >= end:
+            continue
+        tx, ty = (tile - 1) % gx, (tile - 1) // gx
+        ys, xs = torch.meshgrid(torch.arange(ty * TH, ty * TH + TH, dtype=torch.float64), torch.arange(tx * TW, tx * TW + TW, dtype=torch.float64), indexing="ij")
+        T = torch.ones((TH, TW), dtype=torch.float64)
+        C = torch.zeros((3, TH, TW), dtype=torch.float64)
+        lc = torch.zeros((TH, TW), dtype=torch.int64)
+        for i in range(start, end):
+            r = packed[int(sorted_point[i])]
+            active = (T > 1.0 / 8192).detach()
+            if not active.any():
+                break
+            dx, dy = r[0] - xs, r[1] - ys
+            power = -0.5 * (r[2] * dx * dx + (r[3] + r[10]) * dx * dy + r[4] * dy * dy)     # r[10] = ic10 (second off-diagonal)
+            alpha = r[8] * torch.exp(power)
+            valid = (active & (alpha >= 1.0 / 256)).detach()
+            alpha = torch.where(alpha > 255.0 / 256, alpha * 0 + 255.0 / 256 + (alpha - alpha.detach()), alpha)   # clamp keeps the gradient (reference)
+            alpha = alpha * valid
+            lc = lc + active.long()
+            w = T * alpha
+            C = C + torch.stack([r[5], r[6], r[7]])[:, None, None] * w
+            T = T * (1 - alpha)
+        img[:, ty * TH:(ty + 1) * TH, tx * TW:(tx + 1) * TW] = C
+        trans[ty * TH:(ty + 1) * TH, tx * TW:(tx + 1) * TW] = T
+        last[ty * TH:(ty + 1) * TH, tx * TW:(tx + 1) * TW] = lc
+    return img, trans, last
+
+
+def test_raster_forward_backward_vs_torch_autograd(oracle):
+    params, view, proj, planes, H, W = tiny_case()
+    res = oracle.render_forward(params, view, proj, planes, H, W, 3)
+    assert res.n_instances > 2000 and res.last.max() > 20
+    N = res.packed.shape[1]
+    pk = torch.tensor(res.packed[0].astype(np.float64))
+    cols = [pk[:, k].clone().requires_grad_(True) for k in range(9)]
+    b10 = pk[:, 3].clone().requires_grad_(True)
+    half_b = [c for c in cols]
+    rec = [torch.stack([cols[0][i], cols[1][i], cols[2][i], cols[3][i], cols[4][i], cols[5][i], cols[6][i], cols[7][i], cols[8][i],
+                        torch.zeros((), dtype=torch.float64), b10[i]]) for i in range(N)]
+    img, trans, last = torch_blend(rec, res.sorted_point[0], res.tile_start[0], H, W, 8, 16)
+    np.testing.assert_allclose(np.minimum(img.detach().numpy(), 1.0), res.img[0], atol=2e-5)
+    np.testing.assert_allclose(trans.detach().numpy(), res.trans[0, 0], atol=2e-5)
+    assert np.array_equal(last.numpy(), res.last[0, 0].astype(np.int64))
+
+    rng = np.random.default_rng(0)
+    d_img = rng.standard_normal(res.img.shape).astype(np.float32)
+    (img * torch.tensor(d_img[0].astype(np.float64))).sum().backward()
+    d_ndc, d_ic, d_color, d_opa, _ = oracle.raster_backward(res.sorted_point, res.tile_start, res.packed, res.trans, res.last, d_img, H, W, 8, 16)
+
+    def rel(a, b):
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    # pixel -> ndc: px = (ndc+1)*0.5*W - 0.5
+    assert rel(d_ndc[0, 0], cols[0].grad.numpy() * 0.5 * W) < 2e-4
+    assert rel(d_ndc[0, 1], cols[1].grad.numpy() * 0.5 * H) < 2e-4
+    assert rel(d_ic[0, 0, 0], cols[2].grad.numpy()) < 2e-4
+    assert rel(d_ic[0, 0, 1], cols[3].grad.numpy()) < 2e-4          # each off-diagonal carries half of d/db
+    assert rel(d_ic[0, 1, 0], b10.grad.numpy()) < 2e-4
+    assert rel(d_ic[0, 1, 1], cols[4].grad.numpy()) < 2e-4
+    for ch in range(3):
+        assert rel(d_color[0, ch], cols[5 + ch].grad.numpy()) < 2e-4
+    assert rel(d_opa[0], cols[8].grad.numpy()) < 2e-4
+
+
+def test_chain_backward_ops_vs_autograd(oracle):
+    rng = np.random.default_rng(1)
+    N = 500
+    f64 = lambda a: torch.tensor(a.astype(np.float64), requires_grad=True)
+    # --- transform matrix
+    quat = rng.standard_normal((4, N)).astype(np.float32)
+    quat /= np.linalg.norm(quat, axis=0, keepdims=True)
+    scale = (rng.random((3, N)) + 0.2).astype(np.float32)
+    gT = rng.standard_normal((3, 3, N)).astype(np.float32)
+    q, s = f64(quat), f64(scale)
+    r, x, y, z = q[0], q[1], q[2], q[3]
+    R = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y + r * z), 2 * (x * z - r * y)]),
+                     torch.stack([2 * (x * y - r * z), 1 - 2 * (x * x + z * z), 2 * (y * z + r * x)]),
+                     torch.stack([2 * (x * z + r * y), 2 * (y * z - r * x), 1 - 2 * (x * x + y * y)])])
+    T = R * s[:, None, :]
+    np.testing.assert_allclose(oracle.transform_matrix_forward(quat, scale), T.detach().numpy(), atol=1e-6)
+    (T * torch.tensor(gT.astype(np.float64))).sum().backward()
+    gq, gs = oracle.transform_matrix_backward(gT, quat, scale)
+    np.testing.assert_allclose(gq, q.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gs, s.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+    # --- mvp
+    view, proj, _ = S.make_camera(640, 360, 500.0, 480.0, (1.0, -0.4, 3.0))
+    world = np.concatenate([rng.standard_normal((3, N)), np.ones((1, N))]).astype(np.float32)
+    w = f64(world)
+    vp = (w.T @ torch.tensor(view[0].astype(np.float64))).T
+    hom = (vp.T @ torch.tensor(proj[0].astype(np.float64))).T
+    ndc = hom[:3] / hom[3:4]
+    vp_o, ndc_o = oracle.mvp_forward(world, view, proj)
+    np.testing.assert_allclose(vp_o[0], vp.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ndc_o[0, :3], ndc.detach().numpy(), rtol=1e-4, atol=1e-4)
+    g_ndc = rng.standard_normal((1, 4, N)).astype(np.float32)
+    g_view = rng.standard_normal((1, 4, N)).astype(np.float32)
+    ((ndc * torch.tensor(g_ndc[0, :3].astype(np.float64))).sum() + (vp * torch.tensor(g_view[0].astype(np.float64))).sum()).backward()
+    gw = oracle.mvp_backward(g_ndc, g_view, view, proj, vp_o)
+    np.testing.assert_allclose(gw, w.grad.numpy(), rtol=2e-3, atol=2e-3)
+
+
+def test_activation_vs_torch(oracle):
+    rng = np.random.default_rng(2)
+    params = S.make_scene(1000, seed=5)
+    view, _, _ = S.make_camera(320, 200, 300.0, 300.0, (1.8, -0.3, 0.8))
+    C, Sz = params[0].shape[-2:]
+    ids = np.array([5, 2, 7], dtype=np.int64)
+    pos, sc, rt, col, op = oracle.activate_forward(3, ids, 3, view, *params)
+    xyz, scale, rot, sh0, shr, opa = [torch.tensor(p[..., ids, :].astype(np.float64), requires_grad=True) for p in params]
+    np.testing.assert_allclose(sc, torch.exp(scale).detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(rt, torch.nn.functional.normalize(rot, dim=0).detach().numpy(), atol=1e-6)
+    np.testing.assert_allclose(op, torch.sigmoid(opa).detach().numpy(), atol=1e-6)
+    cam = -view[0, 3, :3] @ view[0, :3, :3].T
+    d = torch.nn.functional.normalize(xyz.detach() - torch.tensor(cam.astype(np.float64))[:, None, None], dim=0)
+    # independent SH evaluation: the reference's own sh_to_rgb pins orc_sh2rgb in test_oracle_golden; reuse it here
+    rgb = oracle.sh2rgb_forward(3, sh0.detach().numpy().reshape(1, 3, -1).astype(np.float32), shr.detach().numpy().reshape(15, 3, -1).astype(np.float32),
+                                d.numpy().reshape(1, 3, -1).astype(np.float32))
+    np.testing.assert_allclose(col.reshape(1, 3, -1), rgb, atol=2e-5)
+    # backward: scale / rot chain rule vs autograd; opacity quirk g*sigmoid(x) (GR/compact.cu:952) checked explicitly
+    g = [rng.standard_normal(a.shape).astype(np.float32) for a in (pos, sc, rt, col, op)]
+    d_pos, d_scale, d_rot, d_sh0, d_shr, d_opa = oracle.activate_backward(3, ids, 3, view, *params, *g)
+    (torch.exp(scale) * torch.tensor(g[1].astype(np.float64))).sum().backward()
+    (rot / torch.sqrt((rot * rot).sum(0, keepdim=True) + 1e-12) * torch.tensor(g[2].astype(np.float64))).sum().backward()
+    np.testing.assert_allclose(d_scale, scale.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(d_rot, rot.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(d_pos, g[0][:3], atol=0)
+    np.testing.assert_allclose(d_opa, g[4] * torch.sigmoid(opa).detach().numpy(), rtol=1e-5, atol=1e-6)
