@@ -152,6 +152,32 @@ int lg_l1_ssim_forward(const float* img, const float* gt, int planes, int H, int
 int lg_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, const float* grad_out /*[1] or NULL*/,
                         int planes, int H, int W, float lam, float* d_img, void* stream);
 
+/* ---- fused.hip : native executor of the whole path (one C call enqueues a stage; same arithmetic as the operators above).
+ * There is no counterpart in the reference (its executor is the Python in litegs/render/__init__.py:11-94 + wrapper.py); these
+ * entry points are what litegs_amd/fast.py binds.  view_host/proj_host are HOST float[16] (row-vector 4x4, passed to kernels by value).
+ * Workspace 1 holds per-Gaussian buffers for N = A*S, workspace 2 the tile-instance table of length L. */
+long long lg_fused_workspace1_bytes(long long N);
+long long lg_fused_workspace2_bytes(long long L, int H, int W, int TH, int TW);
+long long lg_fused_total_offset(long long N);
+int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
+                    const float* view_host, const float* proj_host, int H, int W, int TH, int TW, int degree,
+                    const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,
+                    int do_cull, uint8_t* visibility, int* vis_num, int64_t* vis_ids, int A,
+                    void* ws1, long long ws1_bytes, int* host_feedback_vis, int* host_feedback_total, void* stream);
+int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
+                    void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
+                    float* img, float* trans, short* last, int* frag_count, float* frag_weight, void* stream);
+int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
+                      const void* ws2, long long ws2_bytes, const float* view_host, const float* proj_host, int degree, int chunks, int R,
+                      const int64_t* vis_ids, const int* vis_num,
+                      const float* pos, const float* scale, const float* rot, const float* opa,
+                      const int* tiles, int K, const float* final_T, const short* last, const float* d_img, const float* d_trans,
+                      const float* grad_inv_scaler, int enable_stat, float* packed_grad, float* err_square_sum,
+                      float* d_pos, float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa, void* stream);
+int lg_adam_update_multi(int ngroups, void* const* param, const void* const* grad, void* const* exp_avg, void* const* exp_avg_sq,
+                         const int* rows, const float* lr, const int64_t* visible_chunk_id, const int* valid_length,
+                         int chunks, int A, int S, int grad_dense, float b1, float b2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

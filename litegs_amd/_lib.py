@@ -51,6 +51,9 @@ class _Lib:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m litegs_amd.build` (hipcc, gfx950). "
                 "litegs_amd has no CPU fallback.")
+        # torch first: its wheel bundles the HIP runtime (libamdhip64) it was built against; loading this library before
+        # torch would bind the system copy and leave two runtimes in one process ("no ROCm-capable device" at first launch).
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         for name, (ret, argtypes) in self.protos.items():

@@ -1,0 +1,439 @@
+// Fused hot path: the native executor of one render forward / backward / optimizer step.
+//
+// The drop-in surface (GR/ext_cuda.cpp's 26 functions) forces one launch per operator and ~60 host-side
+// calls per training iteration; on MI355X the blend kernels are fast enough that this host work (>2 ms)
+// was the bottleneck.  This file provides what a CDNA-first design wants instead:
+//   * project_fused_kernel   : gather + activate + SH->RGB + MVP + cov2d + inverse + tile count + record pack in
+//                              ONE pass over the visible Gaussians (reads 236 B, writes ~100 B per Gaussian;
+//                              replaces 8 launches and ~300 B/Gaussian of intermediate traffic);
+//   * project_fused_backward : packed gradient -> six compact parameter gradients in ONE pass (recomputes the
+//                              cheap forward chain from the raw parameters instead of saving intermediates);
+//   * adam_multi_kernel      : all six parameter groups (59 rows) in one launch;
+//   * lg_fused_stage1/2, lg_fused_backward : C entry points that enqueue the whole forward / backward
+//                              sequence on the caller's stream using one workspace arena (no allocation, no
+//                              host sync; GPU-driven sizes exactly as the reference's feedback protocol).
+// All arithmetic goes through lg_chain.h / the binning walk, i.e. it is the same arithmetic as the
+// op-by-op kernels.  Compiled with -ffp-contract=off.
+#include "lg_common.h"
+#include "lg_chain.h"
+#include "litegs_hip.h"
+
+#define REC 16
+#define GREC 16
+#define LOG2E 1.4426950408889634f
+
+struct Camera {
+    float V[16];
+    float P[16];
+    int H, W;
+};
+
+// ---------------------------------------------------------------------------------------------
+// forward: one workgroup per allocated visible chunk, one thread per Gaussian (S <= 1024)
+// outputs are SoA over N = A*S:  ndc[4,N] (rows 0,1,2 written), view_z[N], inv_cov[4,N], opacity[N],
+// alloc[N] is produced by a second tiny kernel (tile walk lives in binning.hip), packed[N,16]
+// ---------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_id, const int* __restrict__ visible_chunks_num,
+                                     Camera cam,
+                                     const float* __restrict__ pos, const float* __restrict__ scale, const float* __restrict__ rot,
+                                     const float* __restrict__ sh0, const float* __restrict__ shr, const float* __restrict__ opa,
+                                     int C, int S, int A,
+                                     float* __restrict__ ndc, float* __restrict__ view_z, float* __restrict__ inv_cov,
+                                     float* __restrict__ opacity, float4* __restrict__ packed)
+{
+    const int a = blockIdx.x, t = threadIdx.x;
+    const size_t N = (size_t)A * S;
+    const size_t i = (size_t)a * S + t;
+    if (a >= visible_chunks_num[0]) {
+        opacity[i] = 0.0f;
+        view_z[i] = 3.0e38f;            // sorts last; allocate_size is 0 for it (valid_length bound)
+        return;
+    }
+    const size_t CS = (size_t)C * S;
+    const size_t sd = (size_t)visible_chunk_id[a] * S + t;
+    // ---- activation
+    const float px = pos[sd], py = pos[CS + sd], pz = pos[2 * CS + sd];
+    float s3[3], q[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) s3[k] = lg_act_scale(scale[k * CS + sd]);
+    lg_act_quat(rot[sd], rot[CS + sd], rot[2 * CS + sd], rot[3 * CS + sd], q);
+    const float o = lg_act_opacity(opa[sd]);
+    // ---- SH -> RGB (+0.5, no clamp)
+    float cx, cy, cz, dx, dy, dz;
+    lg_camera_center(cam.V, cx, cy, cz);
+    lg_view_dir(px, py, pz, cx, cy, cz, dx, dy, dz);
+    float b[16];
+    lg_sh_basis<DEG>(dx, dy, dz, b);
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    float r0 = b[0] * sh0[sd], r1 = b[0] * sh0[CS + sd], r2 = b[0] * sh0[2 * CS + sd];
+#pragma unroll
+    for (int k = 1; k < NB; k++) {
+        const float* s = shr + ((size_t)(k - 1) * 3) * CS + sd;
+        r0 += b[k] * s[0]; r1 += b[k] * s[CS]; r2 += b[k] * s[2 * CS];
+    }
+    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+    // ---- projection chain
+    float v[4], n[4], T9[9], j4[4], J6[6], c4[4], i4[4];
+    lg_mvp(cam.V, cam.P, px, py, pz, 1.0f, v, n);
+    lg_transform_matrix(q, s3, T9);
+    lg_jacobian(cam.P, cam.H, cam.W, v[0], v[1], v[2], j4);
+    J6[0] = j4[0]; J6[1] = 0.0f; J6[2] = 0.0f; J6[3] = j4[1]; J6[4] = j4[2]; J6[5] = j4[3];
+    lg_cov2d(T9, cam.V, J6, c4);
+    lg_inv2x2(c4[0], c4[1], c4[2], c4[3], i4);
+    // ---- outputs
+    ndc[i] = n[0]; ndc[N + i] = n[1]; ndc[2 * N + i] = n[2];
+    view_z[i] = v[2];
+    inv_cov[i] = i4[0]; inv_cov[N + i] = i4[1]; inv_cov[2 * N + i] = i4[2]; inv_cov[3 * N + i] = i4[3];
+    opacity[i] = o;
+    const float ppx = (n[0] + 1.0f) * 0.5f * cam.W - 0.5f;
+    const float ppy = (n[1] + 1.0f) * 0.5f * cam.H - 0.5f;
+    float4* rec = packed + i * (REC / 4);
+    rec[0] = make_float4(ppx, ppy, i4[0], i4[1]);
+    rec[1] = make_float4(i4[3], r0, r1, r2);
+    rec[2] = make_float4(o, n[2], -0.5f * i4[0] * LOG2E, -i4[1] * LOG2E);
+    rec[3] = make_float4(-0.5f * i4[3] * LOG2E, 0.0f, 0.0f, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: packed_grad[N,16] -> compact grads d_pos[3,A,S] d_scale[3,A,S] d_rot[4,A,S] d_sh0[3,A,S]
+// d_shr[R*3,A,S] d_opa[1,A,S]   (rasterize_backward's unpack + wrapper.py's chain + activate_backward)
+// ---------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ void project_fused_backward_kernel(const int64_t* __restrict__ visible_chunk_id, const int* __restrict__ visible_chunks_num,
+                                              Camera cam,
+                                              const float* __restrict__ pos, const float* __restrict__ scale, const float* __restrict__ rot,
+                                              const float* __restrict__ opa, int C, int S, int A, int R,
+                                              const float4* __restrict__ packed_grad, const float* __restrict__ grad_inv_scaler,
+                                              float* __restrict__ d_pos, float* __restrict__ d_scale, float* __restrict__ d_rot,
+                                              float* __restrict__ d_sh0, float* __restrict__ d_shr, float* __restrict__ d_opa)
+{
+    const int a = blockIdx.x, t = threadIdx.x;
+    const size_t AS = (size_t)A * S;
+    const size_t od = (size_t)a * S + t;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    if (a >= visible_chunks_num[0]) {
+        for (int k = 0; k < R * 3; k++) d_shr[(size_t)k * AS + od] = 0.0f;
+        return;
+    }
+    const size_t CS = (size_t)C * S;
+    const size_t sd = (size_t)visible_chunk_id[a] * S + t;
+    const float sc = grad_inv_scaler ? grad_inv_scaler[0] : 1.0f;
+    // ---- unpack (GR/raster.cu:866-884)
+    const float4* rec = packed_grad + od * (GREC / 4);
+    const float4 g0 = rec[0], g1 = rec[1];
+    const float g8 = rec[2].x;
+    float gn[4] = { g0.x * 0.5f * cam.W * sc, g0.y * 0.5f * cam.H * sc, 0.0f, 0.0f };
+    float ginv[4] = { g0.z * sc, g0.w * sc, g0.w * sc, g1.x * sc };
+    const float gc0 = g1.y * sc, gc1 = g1.z * sc, gc2 = g1.w * sc;
+    const float gop = g8 * sc;
+    // ---- recompute the forward chain from the raw parameters
+    const float px = pos[sd], py = pos[CS + sd], pz = pos[2 * CS + sd];
+    float s3[3], q[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) s3[k] = lg_act_scale(scale[k * CS + sd]);
+    const float rn = lg_act_quat(rot[sd], rot[CS + sd], rot[2 * CS + sd], rot[3 * CS + sd], q);
+    float v[4], n[4], T9[9], j4[4], J6[6], c4[4], i4[4];
+    lg_mvp(cam.V, cam.P, px, py, pz, 1.0f, v, n);
+    lg_transform_matrix(q, s3, T9);
+    lg_jacobian(cam.P, cam.H, cam.W, v[0], v[1], v[2], j4);
+    J6[0] = j4[0]; J6[1] = 0.0f; J6[2] = 0.0f; J6[3] = j4[1]; J6[4] = j4[2]; J6[5] = j4[3];
+    lg_cov2d(T9, cam.V, J6, c4);
+    lg_inv2x2(c4[0], c4[1], c4[2], c4[3], i4);
+    // ---- chain backward
+    float gcov[4], gT[9], gq[4], gs[3];
+    lg_inv2x2_bwd(i4, ginv, true, gcov);
+#pragma unroll
+    for (int k = 0; k < 9; k++) gT[k] = 0.0f;
+    lg_cov2d_bwd(gcov, J6, cam.V, T9, gT);
+    lg_transform_matrix_bwd(gT, q, s3, gq, gs);
+    float gw[4] = { 0.f, 0.f, 0.f, 0.f }, gview[4] = { 0.f, 0.f, 0.f, 0.f };
+    lg_mvp_bwd(cam.V, cam.P, v, gn, gview, gw);
+    // ---- activation backward (GR/compact.cu:925-977)
+    d_pos[od] = gw[0]; d_pos[AS + od] = gw[1]; d_pos[2 * AS + od] = gw[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) d_scale[k * AS + od] = s3[k] * gs[k];
+    const float dot = gq[0] * q[0] + gq[1] * q[1] + gq[2] * q[2] + gq[3] * q[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) d_rot[k * AS + od] = rn * (gq[k] - dot * q[k]);
+    d_opa[od] = gop * (1.0f - 1.0f / (1.0f + __expf(opa[sd])));        // sic: g * sigmoid(x), compact.cu:952
+    float cx, cy, cz, dx, dy, dz;
+    lg_camera_center(cam.V, cx, cy, cz);
+    lg_view_dir(px, py, pz, cx, cy, cz, dx, dy, dz);
+    float b[16];
+    lg_sh_basis<DEG>(dx, dy, dz, b);
+    d_sh0[od] = b[0] * gc0; d_sh0[AS + od] = b[0] * gc1; d_sh0[2 * AS + od] = b[0] * gc2;
+#pragma unroll
+    for (int k = 1; k < NB; k++) {
+        float* d = d_shr + ((size_t)(k - 1) * 3) * AS + od;
+        d[0] = b[k] * gc0; d[AS] = b[k] * gc1; d[2 * AS] = b[k] * gc2;
+    }
+    for (int k = NB - 1; k < R; k++)
+        for (int ch = 0; ch < 3; ch++) d_shr[((size_t)k * 3 + ch) * AS + od] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace layout (bytes, 256-aligned), identical in stage1 / stage2 / backward
+// ---------------------------------------------------------------------------------------------
+struct Layout1 {      // sized by N = A*S (per-Gaussian buffers)
+    size_t ndc, view_z, inv_cov, opacity, alloc, packed, dk_a, dv_a, dk_b, dv_b, prefix, temp, total, temp_bytes;
+};
+struct Layout2 {      // sized by the tile-instance table length L
+    size_t tk_a, tv_a, tk_b, tv_b, temp, tile_start, total, temp_bytes;
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static Layout1 layout1(long long N)
+{
+    Layout1 f;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
+    f.ndc = take(sizeof(float) * 4 * N);
+    f.view_z = take(sizeof(float) * N);
+    f.inv_cov = take(sizeof(float) * 4 * N);
+    f.opacity = take(sizeof(float) * N);
+    f.alloc = take(sizeof(int) * N);
+    f.packed = take(sizeof(float) * REC * N);
+    f.dk_a = take(4 * N); f.dv_a = take(4 * N); f.dk_b = take(4 * N); f.dv_b = take(4 * N);
+    f.prefix = take(4 * N);
+    long long t1 = lg_radix_sort_temp_bytes(N), t2 = lg_scan_temp_bytes(N);
+    f.temp_bytes = (size_t)(t1 > t2 ? t1 : t2);
+    f.temp = take(f.temp_bytes);
+    f.total = o;
+    return f;
+}
+
+static Layout2 layout2(long long L, int ntiles)
+{
+    Layout2 f;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
+    f.tk_a = take(4 * (size_t)L); f.tv_a = take(4 * (size_t)L); f.tk_b = take(4 * (size_t)L); f.tv_b = take(4 * (size_t)L);
+    f.temp_bytes = (size_t)lg_radix_sort_temp_bytes(L);
+    f.temp = take(f.temp_bytes);
+    f.tile_start = take(sizeof(int) * ((size_t)ntiles + 2));
+    f.total = o;
+    return f;
+}
+
+LG_API long long lg_fused_workspace1_bytes(long long N) { return (long long)layout1(N > 0 ? N : 1).total; }
+
+LG_API long long lg_fused_workspace2_bytes(long long L, int H, int W, int TH, int TW)
+{
+    int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    return (long long)layout2(L > 0 ? L : 1, ntiles).total;
+}
+
+// byte offset in workspace 1 of the exact instance total (prefix[N-1]) -- for the blocking first-visit path
+LG_API long long lg_fused_total_offset(long long N) { return (long long)(layout1(N).prefix + 4 * (size_t)(N - 1)); }
+
+static Camera make_camera(const float* view_host, const float* proj_host, int H, int W)
+{
+    Camera c;
+    for (int k = 0; k < 16; k++) { c.V[k] = view_host[k]; c.P[k] = proj_host[k]; }
+    c.H = H; c.W = W;
+    return c;
+}
+
+// Stage 1: cull (unless vis_ids already computed) -> fused projection -> tile counts -> depth order -> prefix sums.
+// view_host / proj_host are HOST copies of the 4x4 matrices (passed by value to the kernels: no device reads of them).
+// Afterwards prefix[N-1] (device) is the exact table length; it is copied to host_feedback_total if given.
+LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
+                           const float* view_host, const float* proj_host, int H, int W, int TH, int TW, int degree,
+                           const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,
+                           int do_cull, uint8_t* visibility, int* vis_num, int64_t* vis_ids, int A,
+                           void* ws1, long long ws1_bytes,
+                           int* host_feedback_vis, int* host_feedback_total, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (do_cull) {
+        rc = lg_frustum_culling_aabb(aabb_origin, aabb_ext, planes_dev, 1, chunks, visibility, vis_num, vis_ids, stream);
+        if (rc) return rc;
+        if (host_feedback_vis) { rc = lg_feedback_d2h(host_feedback_vis, vis_num, stream); if (rc) return rc; }
+    }
+    if (A <= 0) return 0;
+    if (S > 1024 || S <= 0) return (int)hipErrorInvalidValue;
+    const long long N = (long long)A * S;
+    Layout1 f = layout1(N);
+    if ((long long)f.total > ws1_bytes) return (int)hipErrorInvalidValue;
+    char* w = (char*)ws1;
+    Camera cam = make_camera(view_host, proj_host, H, W);
+    float* ndc = (float*)(w + f.ndc); float* view_z = (float*)(w + f.view_z); float* inv_cov = (float*)(w + f.inv_cov);
+    float* opacity = (float*)(w + f.opacity); float4* packed = (float4*)(w + f.packed);
+#define LAUNCH_PF(D) hipLaunchKernelGGL(project_fused_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, pos, scale, rot, sh0, shr, opa, \
+                                        chunks, S, A, ndc, view_z, inv_cov, opacity, packed)
+    switch (degree) {
+    case 0: LAUNCH_PF(0); break;
+    case 1: LAUNCH_PF(1); break;
+    case 2: LAUNCH_PF(2); break;
+    case 3: LAUNCH_PF(3); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef LAUNCH_PF
+    rc = (int)hipGetLastError(); if (rc) return rc;
+    // tile counts: valid_length = vis_num * S, computed on the device by a 1-thread kernel into the temp area is avoided:
+    // get_allocate_size takes the bound as int32[1]; we keep N-bound blocks cheap by zero opacity in the tail (o < 1/255 => invisible).
+    rc = lg_get_allocate_size(ndc, view_z, inv_cov, opacity, nullptr, 1, (int)N, H, W, TH, TW, nullptr, nullptr, (int32_t*)(w + f.alloc), stream);
+    if (rc) return rc;
+    rc = lg_depth_sort_keys(view_z, N, (uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), stream); if (rc) return rc;
+    rc = lg_radix_sort_pairs((uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (uint32_t*)(w + f.dk_b), (uint32_t*)(w + f.dv_b), N, 0, 32,
+                             w + f.temp, (long long)f.temp_bytes, stream);
+    if (rc) return rc;
+    const bool odd = lg_radix_sort_num_passes(0, 32) % 2 == 1;
+    const void* order = odd ? (w + f.dv_b) : (w + f.dv_a);
+    rc = lg_gather_inclusive_scan((const int32_t*)(w + f.alloc), order, 0, N, (int32_t*)(w + f.prefix), w + f.temp, (long long)f.temp_bytes, stream);
+    if (rc) return rc;
+    if (host_feedback_total) { rc = lg_feedback_d2h(host_feedback_total, (const int*)(w + f.prefix) + (N - 1), stream); if (rc) return rc; }
+    return 0;
+}
+
+// Stage 2: key/value emission -> stable tile sort -> tile ranges -> blend forward.  L = table length of the layout.
+LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
+                           void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
+                           float* img, float* trans, short* last, int* frag_count, float* frag_weight, void* stream)
+{
+    if (A <= 0 || L <= 0) return (int)hipErrorInvalidValue;
+    const long long N = (long long)A * S;
+    const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    Layout1 f1 = layout1(N);
+    Layout2 f = layout2(L, ntiles);
+    if ((long long)f1.total > ws1_bytes || (long long)f.total > ws2_bytes) return (int)hipErrorInvalidValue;
+    const char* w1 = (const char*)ws1;
+    char* w = (char*)ws2;
+    int rc;
+    const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
+    const void* order = odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a);
+    rc = lg_memset_async(w + f.tk_a, 0, 4 * L, stream); if (rc) return rc;
+    rc = lg_duplicate_with_keys((const float*)(w1 + f1.ndc), (const float*)(w1 + f1.inv_cov), (const float*)(w1 + f1.opacity),
+                                (const int32_t*)(w1 + f1.prefix), order, 0, 1, (int)N, H, W, TH, TW, L,
+                                (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a), stream);
+    if (rc) return rc;
+    int bits = 0;
+    for (unsigned int mt = (unsigned int)ntiles; mt >>= 1;) bits++;
+    bits++;
+    rc = lg_radix_sort_pairs((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), L, 0, bits,
+                             w + f.temp, (long long)f.temp_bytes, stream);
+    if (rc) return rc;
+    const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
+    const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
+    const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
+    rc = lg_tile_range(sorted_keys, 1, L, ntiles, (int32_t*)(w + f.tile_start), stream); if (rc) return rc;
+    return lg_raster_forward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
+                             enable_stat, img, trans, last, frag_count, frag_weight, stream);
+}
+
+// Backward: blend backward (atomics into packed_grad) -> fused per-Gaussian backward -> six compact gradients.
+LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
+                             const void* ws2, long long ws2_bytes, const float* view_host, const float* proj_host, int degree, int chunks, int R,
+                             const int64_t* vis_ids, const int* vis_num,
+                             const float* pos, const float* scale, const float* rot, const float* opa,
+                             const int* tiles, int K, const float* final_T, const short* last, const float* d_img, const float* d_trans,
+                             const float* grad_inv_scaler, int enable_stat,
+                             float* packed_grad /*[N,16] scratch*/, float* err_square_sum,
+                             float* d_pos, float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa, void* stream)
+{
+    if (A <= 0 || L <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const long long N = (long long)A * S;
+    const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    Layout1 f1 = layout1(N);
+    Layout2 f = layout2(L, ntiles);
+    if ((long long)f1.total > ws1_bytes || (long long)f.total > ws2_bytes) return (int)hipErrorInvalidValue;
+    const char* w1 = (const char*)ws1;
+    const char* w = (const char*)ws2;
+    int bits = 0;
+    for (unsigned int mt = (unsigned int)ntiles; mt >>= 1;) bits++;
+    bits++;
+    const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
+    const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
+    int rc = lg_memset_async(packed_grad, 0, (long long)sizeof(float) * GREC * N, stream); if (rc) return rc;
+    rc = lg_raster_backward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, final_T, last, d_img, d_trans,
+                            1, L, (int)N, H, W, TH, TW, enable_stat, packed_grad, err_square_sum, stream);
+    if (rc) return rc;
+    Camera cam = make_camera(view_host, proj_host, H, W);
+#define LAUNCH_PB(D) hipLaunchKernelGGL(project_fused_backward_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, pos, scale, rot, opa, \
+                                        chunks, S, A, R, (const float4*)packed_grad, grad_inv_scaler, d_pos, d_scale, d_rot, d_sh0, d_shr, d_opa)
+    switch (degree) {
+    case 0: LAUNCH_PB(0); break;
+    case 1: LAUNCH_PB(1); break;
+    case 2: LAUNCH_PB(2); break;
+    case 3: LAUNCH_PB(3); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef LAUNCH_PB
+    LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam over several parameter groups in one launch (same update as adam_chunk_kernel_v4)
+// ---------------------------------------------------------------------------------------------
+#define ADAM_MAX_GROUPS 8
+struct AdamGroups {
+    float* param[ADAM_MAX_GROUPS];
+    const float* grad[ADAM_MAX_GROUPS];
+    float* m[ADAM_MAX_GROUPS];
+    float* v[ADAM_MAX_GROUPS];
+    float lr[ADAM_MAX_GROUPS];
+    int row_start[ADAM_MAX_GROUPS + 1];      // prefix of rows (E) per group
+    int ngroups;
+};
+
+__global__ void __launch_bounds__(256) adam_multi_kernel(AdamGroups G, const int64_t* __restrict__ visible_chunk_id,
+                                                         const int* __restrict__ valid_length, int chunks, int A, int S, int grad_dense,
+                                                         float b1, float b2, float eps)
+{
+    const int a = blockIdx.x;
+    if (valid_length != nullptr && a >= valid_length[0]) return;
+    const int quads = S >> 2;
+    const int rows_per_block = 256 / quads;
+    const int row = blockIdx.y * rows_per_block + threadIdx.x / quads;
+    const int q = threadIdx.x % quads;
+    if (row >= G.row_start[G.ngroups] || (int)threadIdx.x >= rows_per_block * quads) return;
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < ADAM_MAX_GROUPS; k++) g += (k < G.ngroups && row >= G.row_start[k]) ? 1 : 0;
+    const int e = row - G.row_start[g];
+    const size_t chunk = (size_t)visible_chunk_id[a];
+    const size_t po = (((size_t)e * chunks + chunk) * S) / 4 + q;
+    const size_t go = grad_dense ? po : (((size_t)e * A + a) * S) / 4 + q;
+    const float lr = G.lr[g];
+    float4 gr = reinterpret_cast<const float4*>(G.grad[g])[go];
+    float4 mm = reinterpret_cast<float4*>(G.m[g])[po];
+    float4 vv = reinterpret_cast<float4*>(G.v[g])[po];
+    float4 p = reinterpret_cast<float4*>(G.param[g])[po];
+#define ADAM1(c)                                  \
+    mm.c = b1 * mm.c + (1.0f - b1) * gr.c;        \
+    vv.c = b2 * vv.c + (1.0f - b2) * gr.c * gr.c; \
+    p.c += -lr * mm.c / (sqrtf(vv.c) + eps);
+    ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+    reinterpret_cast<float4*>(G.param[g])[po] = p;
+    reinterpret_cast<float4*>(G.m[g])[po] = mm;
+    reinterpret_cast<float4*>(G.v[g])[po] = vv;
+}
+
+LG_API int lg_adam_update_multi(int ngroups, void* const* param, const void* const* grad, void* const* exp_avg, void* const* exp_avg_sq,
+                                const int* rows, const float* lr, const int64_t* visible_chunk_id, const int* valid_length,
+                                int chunks, int A, int S, int grad_dense, float b1, float b2, float eps, void* stream)
+{
+    if (ngroups <= 0 || A <= 0) return 0;
+    if (ngroups > ADAM_MAX_GROUPS || S % 4 != 0 || (S / 4) > 256 || 256 % (S / 4) != 0) return (int)hipErrorInvalidValue;
+    AdamGroups G;
+    G.ngroups = ngroups;
+    G.row_start[0] = 0;
+    for (int k = 0; k < ADAM_MAX_GROUPS; k++) {
+        bool on = k < ngroups;
+        G.param[k] = on ? (float*)param[k] : nullptr;
+        G.grad[k] = on ? (const float*)grad[k] : nullptr;
+        G.m[k] = on ? (float*)exp_avg[k] : nullptr;
+        G.v[k] = on ? (float*)exp_avg_sq[k] : nullptr;
+        G.lr[k] = on ? lr[k] : 0.0f;
+        G.row_start[k + 1] = G.row_start[k] + (on ? rows[k] : 0);
+    }
+    const int rows_per_block = 256 / (S / 4);
+    dim3 grid(A, lg_cdiv(G.row_start[ngroups], rows_per_block));
+    hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, G, visible_chunk_id, valid_length, chunks, A, S, grad_dense, b1, b2, eps);
+    LG_RETURN_LAST();
+}

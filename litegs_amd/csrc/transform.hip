@@ -5,6 +5,7 @@
 // ~100 flops on ~100 B: bandwidth bound by >10x, see DESIGN.md "MFMA").
 // Compiled with -ffp-contract=off so results are bit-comparable with the CPU oracle's op order.
 #include "lg_common.h"
+#include "lg_chain.h"
 
 #define TPB 256
 
@@ -20,20 +21,11 @@ __global__ void __launch_bounds__(TPB) mvp_forward_kernel(const float* __restric
     if (i >= lg_valid_len(valid_length, N)) return;
     const float* V = view + b * 16;
     const float* P = proj + b * 16;
-    float w0 = world[i], w1 = world[(size_t)N + i], w2 = world[2 * (size_t)N + i], w3 = world[3 * (size_t)N + i];
-    float v[4], h[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = w0 * V[k] + w1 * V[4 + k] + w2 * V[8 + k] + w3 * V[12 + k];
-#pragma unroll
-    for (int k = 0; k < 4; k++) h[k] = v[0] * P[k] + v[1] * P[4 + k] + v[2] * P[8 + k] + v[3] * P[12 + k];
-    float iw = (fabsf(h[3]) > 1e-12f) ? (1.0f / h[3]) : 0.0f;
+    float v[4], n[4];
+    lg_mvp(V, P, world[i], world[(size_t)N + i], world[2 * (size_t)N + i], world[3 * (size_t)N + i], v, n);
     size_t o = (size_t)b * 4 * N + i;
 #pragma unroll
-    for (int k = 0; k < 4; k++) view_pos[o + (size_t)k * N] = v[k];
-    ndc_pos[o] = h[0] * iw;
-    ndc_pos[o + (size_t)N] = h[1] * iw;
-    ndc_pos[o + 2 * (size_t)N] = h[2] * iw;
-    ndc_pos[o + 3 * (size_t)N] = 1.0f;
+    for (int k = 0; k < 4; k++) { view_pos[o + (size_t)k * N] = v[k]; ndc_pos[o + (size_t)k * N] = n[k]; }
 }
 
 LG_API int lg_mvp_transform_forward(const float* world, const float* view, const float* proj, const int* valid_length,
@@ -55,26 +47,11 @@ __global__ void __launch_bounds__(TPB) mvp_backward_kernel(const float* __restri
     if (i >= lg_valid_len(valid_length, N)) return;
     float acc[4] = { 0.f, 0.f, 0.f, 0.f };
     for (int b = 0; b < V; b++) {
-        const float* Vm = view + b * 16;
-        const float* P = proj + b * 16;
         size_t o = (size_t)b * 4 * N + i;
-        float v[4], h[4], gn[4], dh[4], dv[4];
+        float v[4], gn[4], gv[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = view_pos[o + (size_t)k * N];
-#pragma unroll
-        for (int k = 0; k < 4; k++) h[k] = v[0] * P[k] + v[1] * P[4 + k] + v[2] * P[8 + k] + v[3] * P[12 + k];
-        float iw = (fabsf(h[3]) > 1e-12f) ? (1.0f / h[3]) : 0.0f;
-        float n0 = h[0] * iw, n1 = h[1] * iw, n2 = h[2] * iw;
-#pragma unroll
-        for (int k = 0; k < 4; k++) gn[k] = g_ndc[o + (size_t)k * N];
-        dh[0] = gn[0] * iw; dh[1] = gn[1] * iw; dh[2] = gn[2] * iw;
-        dh[3] = -(gn[0] * n0 + gn[1] * n1 + gn[2] * n2) * iw;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            dv[k] = g_view[o + (size_t)k * N] + (dh[0] * P[k * 4] + dh[1] * P[k * 4 + 1] + dh[2] * P[k * 4 + 2] + dh[3] * P[k * 4 + 3]);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            acc[k] += dv[0] * Vm[k * 4] + dv[1] * Vm[k * 4 + 1] + dv[2] * Vm[k * 4 + 2] + dv[3] * Vm[k * 4 + 3];
+        for (int k = 0; k < 4; k++) { v[k] = view_pos[o + (size_t)k * N]; gn[k] = g_ndc[o + (size_t)k * N]; gv[k] = g_view[o + (size_t)k * N]; }
+        lg_mvp_bwd(view + b * 16, proj + b * 16, v, gn, gv, acc);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) g_world[(size_t)k * N + i] = acc[k];
@@ -92,26 +69,17 @@ LG_API int lg_mvp_transform_backward(const float* g_ndc, const float* g_view, co
 // ---------------------------------------------------------------------------------------------
 // a4 createTransformMatrix_forward (GR/transform.cu:92-149): T[r][:] = R(q)[r][:] * s_r
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void quat_rows(float r, float x, float y, float z, float* R)
-{
-    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y + r * z);     R[2] = 2 * (x * z - r * y);
-    R[3] = 2 * (x * y - r * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z + r * x);
-    R[6] = 2 * (x * z + r * y);     R[7] = 2 * (y * z - r * x);     R[8] = 1 - 2 * (x * x + y * y);
-}
-
 __global__ void __launch_bounds__(TPB) transform_matrix_forward_kernel(const float* __restrict__ quat, const float* __restrict__ scale,
                                                                        const int* __restrict__ valid_length, int N, float* __restrict__ T)
 {
     int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= lg_valid_len(valid_length, N)) return;
-    float R[9];
-    quat_rows(quat[i], quat[(size_t)N + i], quat[2 * (size_t)N + i], quat[3 * (size_t)N + i], R);
+    float q[4] = { quat[i], quat[(size_t)N + i], quat[2 * (size_t)N + i], quat[3 * (size_t)N + i] };
+    float sc[3] = { scale[i], scale[(size_t)N + i], scale[2 * (size_t)N + i] };
+    float T9[9];
+    lg_transform_matrix(q, sc, T9);
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        float s = scale[(size_t)r * N + i];
-#pragma unroll
-        for (int c = 0; c < 3; c++) T[((size_t)r * 3 + c) * N + i] = R[r * 3 + c] * s;
-    }
+    for (int k = 0; k < 9; k++) T[(size_t)k * N + i] = T9[k];
 }
 
 LG_API int lg_create_transform_matrix_forward(const float* quat, const float* scale, const int* valid_length, int N, float* T, void* stream)
@@ -128,23 +96,16 @@ __global__ void __launch_bounds__(TPB) transform_matrix_backward_kernel(const fl
 {
     int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= lg_valid_len(valid_length, N)) return;
-    float r = quat[i], x = quat[(size_t)N + i], y = quat[2 * (size_t)N + i], z = quat[3 * (size_t)N + i];
-    float R[9], dt[9];
-    quat_rows(r, x, y, z, R);
+    float q[4] = { quat[i], quat[(size_t)N + i], quat[2 * (size_t)N + i], quat[3 * (size_t)N + i] };
+    float sc[3] = { scale[i], scale[(size_t)N + i], scale[2 * (size_t)N + i] };
+    float dt[9], gq[4], gs[3];
 #pragma unroll
     for (int k = 0; k < 9; k++) dt[k] = gT[(size_t)k * N + i];
+    lg_transform_matrix_bwd(dt, q, sc, gq, gs);
 #pragma unroll
-    for (int rr = 0; rr < 3; rr++)
-        g_scale[(size_t)rr * N + i] = R[rr * 3] * dt[rr * 3] + R[rr * 3 + 1] * dt[rr * 3 + 1] + R[rr * 3 + 2] * dt[rr * 3 + 2];
+    for (int k = 0; k < 3; k++) g_scale[(size_t)k * N + i] = gs[k];
 #pragma unroll
-    for (int rr = 0; rr < 3; rr++) {
-        float s = scale[(size_t)rr * N + i];
-        dt[rr * 3] *= s; dt[rr * 3 + 1] *= s; dt[rr * 3 + 2] *= s;
-    }
-    g_quat[i] = 2 * z * (dt[1] - dt[3]) + 2 * y * (dt[6] - dt[2]) + 2 * x * (dt[5] - dt[7]);
-    g_quat[(size_t)N + i] = 2 * y * (dt[3] + dt[1]) + 2 * z * (dt[6] + dt[2]) + 2 * r * (dt[5] - dt[7]) - 4 * x * (dt[8] + dt[4]);
-    g_quat[2 * (size_t)N + i] = 2 * x * (dt[3] + dt[1]) + 2 * r * (dt[6] - dt[2]) + 2 * z * (dt[5] + dt[7]) - 4 * y * (dt[8] + dt[0]);
-    g_quat[3 * (size_t)N + i] = 2 * r * (dt[1] - dt[3]) + 2 * x * (dt[6] + dt[2]) + 2 * y * (dt[5] + dt[7]) - 4 * z * (dt[4] + dt[0]);
+    for (int k = 0; k < 4; k++) g_quat[(size_t)k * N + i] = gq[k];
 }
 
 LG_API int lg_create_transform_matrix_backward(const float* gT, const float* quat, const float* scale, const int* valid_length,
@@ -173,23 +134,17 @@ __global__ void __launch_bounds__(TPB) jacobian_rayspace_kernel(const float* __r
         for (int k = 0; k < 9; k++) J[jo + (size_t)k * N] = 0.0f;
         return;
     }
-    const float* P = proj + b * 16;
-    float fx = P[0] * W * 0.5f, fy = P[5] * H * 0.5f;
     size_t o = (size_t)b * 4 * N + i;
-    float tx = view_pos[o], ty = view_pos[o + (size_t)N], tz = view_pos[o + 2 * (size_t)N];
-    float lx = tz / P[0] * 1.3f, ly = tz / P[5] * 1.3f;
-    tx = fmaxf(fminf(tx, lx), -lx);
-    ty = fmaxf(fminf(ty, ly), -ly);
-    float rz = 1.0f / fmaxf(tz, 1e-2f);
-    float rz2 = rz * rz;
-    J[jo] = fx * rz;
+    float j4[4];
+    lg_jacobian(proj + b * 16, H, W, view_pos[o], view_pos[o + (size_t)N], view_pos[o + 2 * (size_t)N], j4);
+    J[jo] = j4[0];
     J[jo + (size_t)N] = 0.0f;
     J[jo + 2 * (size_t)N] = 0.0f;
     J[jo + 3 * (size_t)N] = 0.0f;
-    J[jo + 4 * (size_t)N] = fy * rz;
+    J[jo + 4 * (size_t)N] = j4[1];
     J[jo + 5 * (size_t)N] = 0.0f;
-    J[jo + 6 * (size_t)N] = -fx * tx * rz2;
-    J[jo + 7 * (size_t)N] = -fy * ty * rz2;
+    J[jo + 6 * (size_t)N] = j4[2];
+    J[jo + 7 * (size_t)N] = j4[3];
     J[jo + 8 * (size_t)N] = 0.0f;
 }
 
@@ -212,8 +167,7 @@ __global__ void __launch_bounds__(TPB) cov2d_forward_kernel(const float* __restr
     int i = blockIdx.x * TPB + threadIdx.x;
     int b = blockIdx.y;
     if (i >= lg_valid_len(valid_length, N)) return;
-    const float* Vm = view + b * 16;
-    float T9[9], J6[6], tv[9], M[6];
+    float T9[9], J6[6], c4[4];
 #pragma unroll
     for (int k = 0; k < 9; k++) T9[k] = T[(size_t)k * N + i];
 #pragma unroll
@@ -221,32 +175,10 @@ __global__ void __launch_bounds__(TPB) cov2d_forward_kernel(const float* __restr
         J6[r * 2] = J[((size_t)b * 9 + r * 3) * N + i];
         J6[r * 2 + 1] = J[((size_t)b * 9 + r * 3 + 1) * N + i];
     }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float s = 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) s += T9[r * 3 + k] * Vm[k * 4 + c];
-            tv[r * 3 + c] = s;
-        }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            float s = 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) s += tv[r * 3 + k] * J6[k * 2 + c];
-            M[r * 2 + c] = s;
-        }
-    float c00 = 0, c01 = 0, c11 = 0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { c00 += M[k * 2] * M[k * 2]; c01 += M[k * 2] * M[k * 2 + 1]; c11 += M[k * 2 + 1] * M[k * 2 + 1]; }
+    lg_cov2d(T9, view + b * 16, J6, c4);
     size_t o = (size_t)b * 4 * N + i;
-    cov[o] = c00 + 0.3f;
-    cov[o + (size_t)N] = c01;
-    cov[o + 2 * (size_t)N] = c01;
-    cov[o + 3 * (size_t)N] = c11 + 0.3f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) cov[o + (size_t)k * N] = c4[k];
 }
 
 LG_API int lg_create_cov2d_forward(const float* J, const float* view, const float* T, const int* valid_length, int V, int N,
@@ -273,42 +205,15 @@ __global__ void __launch_bounds__(TPB) cov2d_backward_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 9; k++) T9[k] = T[(size_t)k * N + i];
         for (int b = 0; b < V; b++) {
-            const float* Vm = view + b * 16;
-            float J6[6], vj[6], M[6], g[4], dM[6];
+            float J6[6], g[4];
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 J6[r * 2] = J[((size_t)b * 9 + r * 3) * N + i];
                 J6[r * 2 + 1] = J[((size_t)b * 9 + r * 3 + 1) * N + i];
             }
 #pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    float s = 0;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) s += Vm[r * 4 + k] * J6[k * 2 + c];
-                    vj[r * 2 + c] = s;
-                }
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    float s = 0;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) s += T9[r * 3 + k] * vj[k * 2 + c];
-                    M[r * 2 + c] = s;
-                }
-#pragma unroll
             for (int k = 0; k < 4; k++) g[k] = g_cov[((size_t)b * 4 + k) * N + i];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                dM[r * 2] = 2 * (M[r * 2] * g[0] + M[r * 2 + 1] * g[2]);
-                dM[r * 2 + 1] = 2 * (M[r * 2] * g[1] + M[r * 2 + 1] * g[3]);
-            }
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) sum[r * 3 + c] += dM[r * 2] * vj[c * 2] + dM[r * 2 + 1] * vj[c * 2 + 1];
+            lg_cov2d_bwd(g, J6, view + b * 16, T9, sum);
         }
     }
 #pragma unroll
@@ -353,9 +258,10 @@ __global__ void __launch_bounds__(TPB) eigh_inv_forward_kernel(const float* __re
         float l1 = 1.0f / sqrtf(v10 * v10 + v11 * v11);
         vec[o] = v00 * l0; vec[o + (size_t)N] = v10 * l1; vec[o + 2 * (size_t)N] = v01 * l0; vec[o + 3 * (size_t)N] = v11 * l1;
     }
-    det = (fabsf(det) < 1e-9f) ? 1e-9f : det;
-    float dr = 1.0f / det;
-    inv[o] = m11 * dr; inv[o + (size_t)N] = -m01 * dr; inv[o + 2 * (size_t)N] = -m10 * dr; inv[o + 3 * (size_t)N] = m00 * dr;
+    float i4[4];
+    lg_inv2x2(m00, m01, m10, m11, i4);
+#pragma unroll
+    for (int k = 0; k < 4; k++) inv[o + (size_t)k * N] = i4[k];
 }
 
 LG_API int lg_eigh_inv_2x2_forward(const float* in, const int* valid_length, int V, int N, float* val, float* vec, float* inv, void* stream)
@@ -375,19 +281,12 @@ __global__ void __launch_bounds__(TPB) inv2x2_backward_kernel(const float* __res
     int b = blockIdx.y;
     if (i >= lg_valid_len(valid_length, N)) return;
     size_t o = (size_t)b * 4 * N + i;
-    float a[4], g[4], t[4], r[4];
+    float a[4], g[4], r[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { a[k] = inv[o + (size_t)k * N]; g[k] = g_inv[o + (size_t)k * N]; }
-    t[0] = a[0] * g[0] + a[1] * g[2]; t[1] = a[0] * g[1] + a[1] * g[3];
-    t[2] = a[2] * g[0] + a[3] * g[2]; t[3] = a[2] * g[1] + a[3] * g[3];
-    r[0] = t[0] * a[0] + t[1] * a[2]; r[1] = t[0] * a[1] + t[1] * a[3];
-    r[2] = t[2] * a[0] + t[3] * a[2]; r[3] = t[2] * a[1] + t[3] * a[3];
+    lg_inv2x2_bwd(a, g, zero_nonfinite != 0, r);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float v = -r[k];
-        if (zero_nonfinite && !(fabsf(v) <= 3.402823466e+38f)) v = 0.0f;
-        g_in[o + (size_t)k * N] = v;
-    }
+    for (int k = 0; k < 4; k++) g_in[o + (size_t)k * N] = r[k];
 }
 
 LG_API int lg_inv_2x2_backward(const float* inv, const float* g_inv, const int* valid_length, int V, int N, int zero_nonfinite,
@@ -399,9 +298,8 @@ LG_API int lg_inv_2x2_backward(const float* inv, const float* g_inv, const int* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// SH basis (shared with the activation kernels through lg_sh.h)
+// SH basis: lg_sh.h (shared with the activation kernels)
 // ---------------------------------------------------------------------------------------------
-#include "lg_sh.h"
 
 // a22 sh2rgb_forward / sh2rgb_backward (GR/transform.cu:952-1363) -- the cluster_size==0 path
 template <int DEG>

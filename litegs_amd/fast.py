@@ -1,0 +1,203 @@
+"""Fused fast path: ``render_preprocess`` + ``render`` (+ their backward) as three native calls.
+
+Same operator semantics as ``litegs_amd.render`` (which mirrors litegs/render/__init__.py:11-94 call by call) but
+executed by the native executor of csrc/fused.hip: one fused per-Gaussian kernel instead of eight operators, no
+intermediate tensors, all launches of a stage enqueued by ONE C call.  The GPU-driven sizing protocol is the
+reference's (litegs/data.py:236-241, GR/compact.cu:527-546, GR/binning.cu:139-163): per-frame pinned feedback buffers
+written by an async 4-byte copy in step k and read in step k+1 give the allocation sizes (1.2x visible chunks,
+1.5x tile instances); only the first visit of a frame takes a blocking read.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+from .statistics import STATS
+from .wrapper import CompactedTensor
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class CameraFrame:
+    """Device + host copies of one camera (the kernels take the 4x4 matrices by value)."""
+
+    def __init__(self, view: torch.Tensor, proj: torch.Tensor, planes: torch.Tensor, index: int):
+        self.view, self.proj, self.planes, self.index = view, proj, planes, index
+        self.view_host = np.ascontiguousarray(view.detach().cpu().numpy().reshape(-1)[:16], dtype=np.float32)
+        self.proj_host = np.ascontiguousarray(proj.detach().cpu().numpy().reshape(-1)[:16], dtype=np.float32)
+        self.view_ptr = self.view_host.ctypes.data
+        self.proj_ptr = self.proj_host.ctypes.data
+
+
+class FusedRenderer:
+    def __init__(self, n_frames: int, height: int, width: int, tile=(8, 16), cluster_size: int = 128):
+        self.H, self.W, self.TH, self.TW, self.S = height, width, tile[0], tile[1], cluster_size
+        self.fb_vis = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
+        self.fb_total = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
+        self.Hp = (height + tile[0] - 1) // tile[0] * tile[0]
+        self.Wp = (width + tile[1] - 1) // tile[1] * tile[1]
+        self.last_sizes = (0, 0)
+
+    def render(self, frame: CameraFrame, cluster_origin, cluster_extend, xyz, scale, rot, sh_0, sh_rest, opacity, degree: int):
+        """-> (img[1,3,H,W] clamped to [0,1], visible_chunkid, visible_chunks_num)."""
+        img, vis_ids, vis_num = _RenderFn.apply(self, frame, cluster_origin, cluster_extend, degree, xyz, scale, rot, sh_0, sh_rest, opacity)
+        img = img[..., : self.H, : self.W].clamp(0, 1)
+        return img, vis_ids, vis_num
+
+
+class _RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R: FusedRenderer, frame: CameraFrame, origin, extend, degree, xyz, scale, rot, sh_0, sh_rest, opacity):
+        L = lib()
+        dev = xyz.device
+        chunks, S = xyz.shape[-2], xyz.shape[-1]
+        k = frame.index
+        s = _s()
+        visibility = torch.empty((chunks,), dtype=torch.bool, device=dev)
+        vis_num = torch.empty((1,), dtype=torch.int32, device=dev)
+        vis_ids = torch.empty((chunks,), dtype=torch.int64, device=dev)
+        fb_vis_ptr = R.fb_vis.data_ptr() + 4 * k
+        fb_tot_ptr = R.fb_total.data_ptr() + 4 * k
+        common = (origin.data_ptr(), extend.data_ptr(), frame.planes.data_ptr(), chunks, frame.view_ptr, frame.proj_ptr, R.H, R.W, R.TH, R.TW,
+                  int(degree), xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), sh_0.data_ptr(), sh_rest.data_ptr(), opacity.data_ptr(), S)
+        pred_vis = int(R.fb_vis[k])
+        do_cull = 1
+        if pred_vis <= 0:                                    # first visit: blocking count (GR/compact.cu:543-546)
+            check(L.lg_fused_stage1(*common, 1, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), 0, None, 0, fb_vis_ptr, None, s),
+                  "fused cull")
+            A = int(vis_num.item())
+            do_cull = 0
+        else:
+            A = min(int(1.2 * pred_vis), chunks)
+        A = max(A, 1)
+        N = A * S
+        ws1_bytes = L.lg_fused_workspace1_bytes(N)
+        ws1 = torch.empty((ws1_bytes,), dtype=torch.uint8, device=dev)
+        check(L.lg_fused_stage1(*common, do_cull, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), A, ws1.data_ptr(), ws1_bytes,
+                                fb_vis_ptr if do_cull else None, fb_tot_ptr, s), "fused stage1")
+        pred_total = int(R.fb_total[k])
+        if pred_total <= 0:                                  # first visit: blocking table size (GR/binning.cu:152-163)
+            off = L.lg_fused_total_offset(N)
+            table_len = int(ws1[off:off + 4].view(torch.int32).item())
+        else:
+            table_len = int(1.5 * pred_total)
+        table_len = max(table_len, 1)
+        ws2_bytes = L.lg_fused_workspace2_bytes(table_len, R.H, R.W, R.TH, R.TW)
+        ws2 = torch.empty((ws2_bytes,), dtype=torch.uint8, device=dev)
+        img = torch.empty((1, 3, R.Hp, R.Wp), dtype=torch.float32, device=dev)
+        trans = torch.empty((1, 1, R.Hp, R.Wp), dtype=torch.float32, device=dev)
+        last = torch.empty((1, 1, R.Hp, R.Wp), dtype=torch.int16, device=dev)
+        stat = STATS.active
+        tiles = STATS.schedule_for_current_frame()
+        K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
+        fc = fw = None
+        if stat:
+            fc = torch.zeros((1, 1, N), dtype=torch.int32, device=dev)
+            fw = torch.zeros((1, 1, N), dtype=torch.float32, device=dev)
+            STATS.set_compaction(vis_ids[:A], vis_num)
+        if tiles is not None:
+            img.zero_(); trans.fill_(1.0); last.zero_()
+        check(L.lg_fused_stage2(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes, tp, K,
+                                1 if stat else 0, img.data_ptr(), trans.data_ptr(), last.data_ptr(),
+                                fc.data_ptr() if stat else None, fw.data_ptr() if stat else None, s), "fused stage2")
+        if stat:
+            STATS.update_tile_schedule(last, R.TH, R.TW)
+        ctx.R, ctx.frame, ctx.meta = R, frame, (A, S, table_len, int(degree), chunks, sh_rest.shape[0], ws1_bytes, ws2_bytes, stat)
+        ctx.tiles = tiles
+        ctx.stat_bufs = (fc, fw)
+        ctx.save_for_backward(ws1, ws2, vis_ids, vis_num, trans, last, xyz, scale, rot, sh_0, sh_rest, opacity)
+        ctx.mark_non_differentiable(vis_ids, vis_num)
+        R.last_sizes = (A, table_len)
+        return img, vis_ids[:A], vis_num
+
+    @staticmethod
+    def backward(ctx, g_img, _g_ids, _g_num):
+        ws1, ws2, vis_ids, vis_num, trans, last, xyz, scale, rot, sh_0, sh_rest, opacity = ctx.saved_tensors
+        R, frame = ctx.R, ctx.frame
+        A, S, table_len, degree, chunks, Rr, ws1_bytes, ws2_bytes, stat = ctx.meta
+        L = lib()
+        dev = xyz.device
+        N = A * S
+        g_img = g_img.contiguous()
+        pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev)
+        esq = torch.zeros((1, 1, N), dtype=torch.float32, device=dev) if stat else None
+        d_pos = torch.empty((3, A, S), dtype=torch.float32, device=dev)
+        d_scale = torch.empty((3, A, S), dtype=torch.float32, device=dev)
+        d_rot = torch.empty((4, A, S), dtype=torch.float32, device=dev)
+        d_sh0 = torch.empty((3, A, S), dtype=torch.float32, device=dev)
+        d_shr = torch.empty((Rr * 3, A, S), dtype=torch.float32, device=dev)
+        d_opa = torch.empty((1, A, S), dtype=torch.float32, device=dev)
+        tiles = ctx.tiles
+        K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
+        check(L.lg_fused_backward(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes,
+                                  frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
+                                  xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
+                                  trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
+                                  pg.data_ptr(), esq.data_ptr() if stat else None,
+                                  d_pos.data_ptr(), d_scale.data_ptr(), d_rot.data_ptr(), d_sh0.data_ptr(), d_shr.data_ptr(), d_opa.data_ptr(), _s()),
+              "fused backward")
+        if stat:
+            fc, fw = ctx.stat_bufs
+            # d_opacity of the activated opacity = packed_grad slot 8 (rasterize_backward's 4th output)
+            d_op_act = pg[:, 8].reshape(1, 1, N)
+            STATS.add_moments("fragment_weight", fw, fw * fw, fc)
+            STATS.add_moments("fragment_err", d_op_act, esq, fc)
+        ids = vis_ids[:A]
+        grads = (CompactedTensor(xyz.shape, ids, d_pos), CompactedTensor(scale.shape, ids, d_scale), CompactedTensor(rot.shape, ids, d_rot),
+                 CompactedTensor(sh_0.shape, ids, d_sh0), CompactedTensor(sh_rest.shape, ids, d_shr), CompactedTensor(opacity.shape, ids, d_opa))
+        return (None, None, None, None, None, *grads)
+
+
+class FusedAdam:
+    """All parameter groups in one launch (csrc/fused.hip: adam_multi_kernel); same update rule as adamUpdate."""
+
+    def __init__(self, optimizer):
+        self.opt = optimizer
+        self.groups = optimizer.param_groups
+        G = len(self.groups)
+        self._arr = ctypes.c_void_p * G
+        self._iarr = ctypes.c_int * G
+        self._farr = ctypes.c_float * G
+        self._ready = False
+
+    def _init_state(self):
+        for g in self.groups:
+            p = g["params"][0]
+            st = self.opt.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        ps = [g["params"][0] for g in self.groups]
+        self.chunks, self.S = ps[0].shape[-2], ps[0].shape[-1]
+        self._p = self._arr(*[p.data_ptr() for p in ps])
+        self._m = self._arr(*[self.opt.state[p]["exp_avg"].data_ptr() for p in ps])
+        self._v = self._arr(*[self.opt.state[p]["exp_avg_sq"].data_ptr() for p in ps])
+        self._rows = self._iarr(*[int(p.numel() // (self.chunks * self.S)) for p in ps])
+        self._ready = True
+
+    @torch.no_grad()
+    def step(self, visible_chunk: torch.Tensor, visible_chunks_num: Optional[torch.Tensor]):
+        if not self._ready:
+            self._init_state()
+        ps = [g["params"][0] for g in self.groups]
+        grads = [p.grad for p in ps]
+        if any(g is None for g in grads):
+            return self.opt.step(visible_chunk, visible_chunks_num, None)
+        dense = not isinstance(grads[0], CompactedTensor)
+        if dense:
+            gp = self._arr(*[g.data_ptr() for g in grads])
+        else:
+            gp = self._arr(*[g.compacted_values.data_ptr() for g in grads])
+        lr = self._farr(*[float(g["lr"]) for g in self.groups])
+        eps = float(self.groups[0]["eps"])
+        A = visible_chunk.shape[0]
+        check(lib().lg_adam_update_multi(len(ps), self._p, gp, self._m, self._v, self._rows, lr, visible_chunk.data_ptr(),
+                                         visible_chunks_num.data_ptr() if visible_chunks_num is not None else None,
+                                         self.chunks, A, self.S, 1 if dense else 0, 0.9, 0.999, eps, _s()), "adam_update_multi")

@@ -12,6 +12,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
+from . import fast
 from . import loss as loss_mod
 from . import optimizer as opt_mod
 from . import render as R
@@ -23,12 +24,14 @@ class Frame:
     def __init__(self, view, proj, planes, gt, idx):
         self.view, self.proj, self.planes, self.gt = view, proj, planes, gt
         self.idx_tensor = torch.tensor([idx], dtype=torch.int64)       # CPU, as the reference's DataLoader yields it
+        self.cam = fast.CameraFrame(view, proj, planes, idx)
 
 
 class SyntheticTrainer:
     def __init__(self, n_gaussians: int, width: int, height: int, focal: float, n_frames: int = 8, seed: int = 0, sh_degree: int = 3,
                  device: Optional[torch.device] = None, radius: float = 4.0, cam_radius_frac: float = 0.5, use_torch_loss: bool = False,
-                 scene=None):
+                 scene=None, fused: bool = True):
+        """fused=True: native executor (litegs_amd/fast.py); fused=False: operator-by-operator path through the litegs_fused surface."""
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.H, self.W, self.degree = height, width, sh_degree
         self.pp = R.PipelineParams()
@@ -50,12 +53,19 @@ class SyntheticTrainer:
             xyz, scale, rot = self.params[0], self.params[1], self.params[2]
             self.cluster_origin, self.cluster_extend = R.get_cluster_AABB(xyz, scale.exp(), torch.nn.functional.normalize(rot, dim=0))
         self.loss_fn = loss_mod.l1_ssim_loss_torch if use_torch_loss else loss_mod.fused_l1_ssim_loss
+        self.fused = fused
+        self.renderer = fast.FusedRenderer(n_frames, height, width, self.pp.tile_size, self.pp.cluster_size)
+        self.fadam = fast.FusedAdam(self.opt)
         self.last = {}
 
     # -------------------------------------------------------------------------------------------
     def forward(self, frame: Frame):
         xyz, scale, rot, sh_0, sh_rest, opacity = self.params
         STATS.current_frame = int(frame.idx_tensor[0])
+        if self.fused:
+            img, vis_id, vis_num = self.renderer.render(frame.cam, self.cluster_origin, self.cluster_extend, xyz, scale, rot, sh_0, sh_rest,
+                                                        opacity, self.degree)
+            return img, vis_id, vis_num, None
         vis_id, vis_num, cx, cs, cr, cc, co = R.render_preprocess(
             self.cluster_origin, self.cluster_extend, frame.planes, frame.view, xyz, scale, rot, sh_0, sh_rest, opacity,
             self.feedback_visible_chunks_num, frame.idx_tensor, self.pp, self.degree)
@@ -72,7 +82,10 @@ class SyntheticTrainer:
         loss.backward()
         if grad_hook is not None:            # data-parallel gradient exchange (litegs_amd/dp.py)
             vis_id, vis_num = grad_hook(self.params, vis_id, vis_num)
-        self.opt.step(vis_id, vis_num, prim_vis)
+        if self.fused:
+            self.fadam.step(vis_id, vis_num)
+        else:
+            self.opt.step(vis_id, vis_num, prim_vis)
         self.opt.zero_grad(set_to_none=True)
         self.sched.step()
         self.last = dict(loss=loss.detach(), vis_num=vis_num)
@@ -88,4 +101,6 @@ class SyntheticTrainer:
         frame = self.frames[frame_index % len(self.frames)]
         torch.cuda.synchronize()
         k = int(frame.idx_tensor[0])
+        if self.fused:
+            return dict(n_vis=int(self.renderer.fb_vis[k]) * self.S, instances=int(self.renderer.fb_total[k]))
         return dict(n_vis=int(self.feedback_visible_chunks_num[k]) * self.S, instances=int(self.feedback_binning_allocate_size[k]))
