@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(256) pack_params_kernel(const float* __restric
                                                           const int* __restrict__ valid_length, int N, int H, int W,
                                                           float4* __restrict__ packed)
 {
+#pragma clang fp contract(off)      // same record bits as the fused executor (fused.hip is built with -ffp-contract=off)
     int i = blockIdx.x * 256 + threadIdx.x;
     int b = blockIdx.y;
     if (i >= lg_valid_len(valid_length, N)) return;
