@@ -116,6 +116,11 @@ long long lg_radix_sort_temp_bytes(long long n);
 int lg_radix_sort_num_passes(int begin_bit, int end_bit);
 int lg_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n,
                         int begin_bit, int end_bit, void* temp, long long temp_bytes, void* stream);
+/* device-bounded variants for the GPU-driven pipeline: only the first min(n, *n_dev) elements are sorted / scanned for
+ * tile ranges, i.e. the actual instance count rather than the 1.5x over-allocated table (n_dev may be NULL) */
+int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
+                                int begin_bit, int end_bit, void* temp, long long temp_bytes, void* stream);
+int lg_tile_range_bounded(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream);
 /* depth sort keys + gathered inclusive scan: the torch.sort / gather / cumsum glue of wrapper.py:739-745 */
 int lg_depth_sort_keys(const float* depth, long long n, uint32_t* keys, uint32_t* vals, void* stream);
 long long lg_scan_temp_bytes(long long n);

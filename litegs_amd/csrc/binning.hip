@@ -422,10 +422,19 @@ LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const 
 #define SORT_TILE (TPB * SORT_ITEMS)
 #define SORT_MAX_PASSES 4
 
-__global__ void __launch_bounds__(TPB) radix_totals_kernel(const uint32_t* __restrict__ keys, long long n, int begin_bit, int passes,
+__device__ __forceinline__ long long bounded_n(long long n, const int* __restrict__ n_dev)
+{
+    if (n_dev == nullptr) return n;
+    long long m = n_dev[0];
+    return m < n ? (m < 0 ? 0 : m) : n;
+}
+
+__global__ void __launch_bounds__(TPB) radix_totals_kernel(const uint32_t* __restrict__ keys, long long n, const int* __restrict__ n_dev,
+                                                           int begin_bit, int passes,
                                                            uint32_t last_mask, int* __restrict__ totals /*[passes][RADIX]*/)
 {
     __shared__ int h[SORT_MAX_PASSES * RADIX];
+    n = bounded_n(n, n_dev);
     for (int k = threadIdx.x; k < passes * RADIX; k += TPB) h[k] = 0;
     __syncthreads();
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
@@ -440,13 +449,16 @@ __global__ void __launch_bounds__(TPB) radix_totals_kernel(const uint32_t* __res
         if (h[k]) atomicAdd(&totals[k], h[k]);
 }
 
-__global__ void __launch_bounds__(TPB) radix_hist_kernel(const uint32_t* __restrict__ keys, long long n, int shift, uint32_t mask,
+__global__ void __launch_bounds__(TPB) radix_hist_kernel(const uint32_t* __restrict__ keys, long long n, const int* __restrict__ n_dev,
+                                                         int shift, uint32_t mask,
                                                          int ntiles, int* __restrict__ hist /*[RADIX][ntiles]*/)
 {
     __shared__ int h[RADIX];
+    n = bounded_n(n, n_dev);
+    long long base = (long long)blockIdx.x * SORT_TILE;
+    if (base >= n) { hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = 0; return; }
     h[threadIdx.x] = 0;                              // TPB == RADIX
     __syncthreads();
-    long long base = (long long)blockIdx.x * SORT_TILE;
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
         long long i = base + j * TPB + threadIdx.x;
@@ -492,31 +504,45 @@ __global__ void __launch_bounds__(TPB) radix_scan_kernel(int* __restrict__ hist,
     }
 }
 
+// Scatter with an LDS-local reorder: (1) 16 rounds of 256 keys compute each key's stable rank inside the tile (wave
+// "match-any" ballots + per-wave digit counts, two barriers per round); (2) keys/values are placed in LDS in sorted order;
+// (3) the tile is streamed out: consecutive LDS slots with the same digit go to consecutive global addresses, so the
+// stores are coalesced runs instead of 4-byte scatters over 256 destinations (1.9 -> >3 TB/s effective on the tile sort).
 __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                             const int* __restrict__ offsets /*[RADIX][ntiles]*/, long long n,
-                                                            int shift, uint32_t mask, int ntiles)
+                                                            const int* __restrict__ n_dev, int shift, uint32_t mask, int ntiles)
 {
-    __shared__ int digit_base[RADIX];
-    __shared__ int wave_cnt[TPB / 64][RADIX];
+    __shared__ uint32_t lds_k[SORT_TILE];
+    __shared__ uint32_t lds_v[SORT_TILE];
+    __shared__ int wave_cnt[2][TPB / 64][RADIX];
+    __shared__ int digit_run[RADIX];          // running count per digit, then exclusive local base
+    __shared__ int global_base[RADIX];
+    __shared__ int wsum[TPB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    n = bounded_n(n, n_dev);
     const long long base = (long long)blockIdx.x * SORT_TILE;
-    digit_base[tid] = offsets[(size_t)tid * ntiles + blockIdx.x];
+    if (base >= n) return;
+    const int cnt_tile = (int)((n - base) < SORT_TILE ? (n - base) : SORT_TILE);
+    digit_run[tid] = 0;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; w++) { wave_cnt[0][w][tid] = 0; wave_cnt[1][w][tid] = 0; }
+    global_base[tid] = offsets[(size_t)tid * ntiles + blockIdx.x];
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
+    int lrank[SORT_ITEMS];
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
-        long long i = base + j * TPB + tid;
-        bool ok = i < n;
-        key[j] = ok ? keys_in[i] : 0u;
-        val[j] = ok ? vals_in[i] : 0u;
+        const int e = j * TPB + tid;
+        const bool ok = e < cnt_tile;
+        key[j] = ok ? keys_in[base + e] : 0u;
+        val[j] = ok ? vals_in[base + e] : 0u;
     }
+    __syncthreads();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
-#pragma unroll
-        for (int w = 0; w < TPB / 64; w++) wave_cnt[w][tid] = 0;
-        __syncthreads();
-        const bool ok = (base + j * TPB + tid) < n;
+        const int cur = j & 1;
+        const bool ok = (j * TPB + tid) < cnt_tile;
         const uint32_t d = (key[j] >> shift) & mask;
         unsigned long long peers = __ballot(ok);
 #pragma unroll
@@ -526,19 +552,61 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
             peers &= set ? bal : ~bal;
         }
         const int rank = __popcll(peers & lt_mask);
-        if (ok && rank == 0) wave_cnt[wave][d] = __popcll(peers);
+        if (ok && rank == 0) wave_cnt[cur][wave][d] = __popcll(peers);
         __syncthreads();
-        if (ok) {
-            int off = digit_base[d] + rank;
-            for (int w = 0; w < wave; w++) off += wave_cnt[w][d];
-            keys_out[off] = key[j];
-            vals_out[off] = val[j];
+        int off = digit_run[d] + rank;
+        for (int w = 0; w < wave; w++) off += wave_cnt[cur][w][d];
+        lrank[j] = off;
+        __syncthreads();
+        {
+            int add = 0;
+#pragma unroll
+            for (int w = 0; w < TPB / 64; w++) { add += wave_cnt[cur][w][tid]; wave_cnt[cur][w][tid] = 0; }
+            digit_run[tid] += add;
         }
-        __syncthreads();
-        digit_base[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
-        __syncthreads();
+    }
+    __syncthreads();
+    // exclusive scan of the per-digit tile counts -> local base (TPB == RADIX: one digit per thread)
+    const int dcount = digit_run[tid];
+    int incl = dcount;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int nb = __shfl_up(incl, o);
+        if (lane >= o) incl += nb;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wb = 0;
+    for (int w = 0; w < wave; w++) wb += wsum[w];
+    const int lbase = wb + incl - dcount;
+    __syncthreads();
+    digit_run[tid] = lbase;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        if ((j * TPB + tid) < cnt_tile) {
+            const uint32_t d = (key[j] >> shift) & mask;
+            const int pos = digit_run[d] + lrank[j];
+            lds_k[pos] = key[j];
+            lds_v[pos] = val[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        const int p = j * TPB + tid;
+        if (p < cnt_tile) {
+            const uint32_t k = lds_k[p];
+            const uint32_t d = (k >> shift) & mask;
+            const int g = global_base[d] + (p - digit_run[d]);
+            keys_out[g] = k;
+            vals_out[g] = lds_v[p];
+        }
     }
 }
+
+LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
+                                       int begin_bit, int end_bit, void* temp, long long temp_bytes, void* stream);
 
 LG_API long long lg_radix_sort_temp_bytes(long long n)
 {
@@ -558,6 +626,14 @@ LG_API int lg_radix_sort_num_passes(int begin_bit, int end_bit)
 LG_API int lg_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n,
                                int begin_bit, int end_bit, void* temp, long long temp_bytes, void* stream)
 {
+    return lg_radix_sort_pairs_bounded(keys_a, vals_a, keys_b, vals_b, n, nullptr, begin_bit, end_bit, temp, temp_bytes, stream);
+}
+
+// n_dev (nullable): device int32 holding the number of leading elements to sort (min(n, *n_dev)); the rest of the buffers is
+// left untouched.  Lets the GPU-driven pipeline sort the ACTUAL instance count instead of the 1.5x over-allocated table.
+LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
+                                       int begin_bit, int end_bit, void* temp, long long temp_bytes, void* stream)
+{
     int passes = lg_radix_sort_num_passes(begin_bit, end_bit);
     if (n <= 0 || passes == 0) return 0;
     if (passes > SORT_MAX_PASSES || n > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -571,14 +647,14 @@ LG_API int lg_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
     hipError_t err = hipMemsetAsync(totals, 0, sizeof(int) * SORT_MAX_PASSES * RADIX, s);
     if (err != hipSuccess) return (int)err;
     int tot_grid = ntiles < 512 ? ntiles : 512;
-    hipLaunchKernelGGL(radix_totals_kernel, dim3(tot_grid), dim3(TPB), 0, s, keys_a, n, begin_bit, passes, last_mask, totals);
+    hipLaunchKernelGGL(radix_totals_kernel, dim3(tot_grid), dim3(TPB), 0, s, keys_a, n, n_dev, begin_bit, passes, last_mask, totals);
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
     for (int p = 0; p < passes; p++) {
         int shift = begin_bit + p * RADIX_BITS;
         uint32_t mask = (p == passes - 1) ? last_mask : (uint32_t)(RADIX - 1);
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, n, shift, mask, ntiles, hist);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, n, n_dev, shift, mask, ntiles, hist);
         hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX), dim3(TPB), 0, s, hist, totals + p * RADIX, ntiles);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, hist, n, shift, mask, ntiles);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, hist, n, n_dev, shift, mask, ntiles);
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
@@ -718,12 +794,15 @@ LG_API int lg_gather_inclusive_scan(const int32_t* src, const void* idx, int idx
 // a11 tileRange (GR/binning.cu:228-287): out[V, max_tile+2]; start of each tile's run, -1 if empty,
 // out[cur+1] closes a run that is followed by a gap, out[max_tile+1] = table length.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TPB) tile_range_kernel(const int32_t* __restrict__ sorted_keys, long long L, int max_tile,
-                                                         int32_t* __restrict__ out)
+__global__ void __launch_bounds__(TPB) tile_range_kernel(const int32_t* __restrict__ sorted_keys, long long L, const int* __restrict__ n_dev,
+                                                         int max_tile, int32_t* __restrict__ out)
 {
     long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     const int b = blockIdx.y;
-    const int32_t* k = sorted_keys + (size_t)b * L;
+    const long long stride = L;
+    L = bounded_n(L, n_dev);
+    if (L <= 0) return;
+    const int32_t* k = sorted_keys + (size_t)b * stride;
     int32_t* o = out + (size_t)b * (max_tile + 2);
     if (i == 0) o[k[0]] = 0;
     if (i == L - 1) o[max_tile + 1] = (int32_t)L;
@@ -736,13 +815,21 @@ __global__ void __launch_bounds__(TPB) tile_range_kernel(const int32_t* __restri
     }
 }
 
+LG_API int lg_tile_range_bounded(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream);
+
 LG_API int lg_tile_range(const int32_t* sorted_keys, int V, long long L, int max_tile, int32_t* out, void* stream)
+{
+    return lg_tile_range_bounded(sorted_keys, V, L, nullptr, max_tile, out, stream);
+}
+
+// n_dev (nullable): only the first min(L, *n_dev) sorted entries are a valid table (see lg_radix_sort_pairs_bounded)
+LG_API int lg_tile_range_bounded(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     hipError_t err = hipMemsetAsync(out, 0xFF, sizeof(int32_t) * (size_t)V * (max_tile + 2), s);
     if (err != hipSuccess) return (int)err;
     if (L <= 0) return 0;
-    hipLaunchKernelGGL(tile_range_kernel, dim3(lg_cdiv(L, TPB), V), dim3(TPB), 0, s, sorted_keys, L, max_tile, out);
+    hipLaunchKernelGGL(tile_range_kernel, dim3(lg_cdiv(L, TPB), V), dim3(TPB), 0, s, sorted_keys, L, n_dev, max_tile, out);
     LG_RETURN_LAST();
 }
 

@@ -89,10 +89,10 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     const float ppx = (n[0] + 1.0f) * 0.5f * cam.W - 0.5f;
     const float ppy = (n[1] + 1.0f) * 0.5f * cam.H - 0.5f;
     float4* rec = packed + i * (REC / 4);
-    rec[0] = make_float4(ppx, ppy, i4[0], i4[1]);
-    rec[1] = make_float4(i4[3], r0, r1, r2);
-    rec[2] = make_float4(o, n[2], -0.5f * i4[0] * LOG2E, -i4[1] * LOG2E);
-    rec[3] = make_float4(-0.5f * i4[3] * LOG2E, 0.0f, 0.0f, 0.0f);
+    rec[0] = make_float4(ppx, ppy, -0.5f * i4[0] * LOG2E, -i4[1] * LOG2E);       // layout: raster.hip
+    rec[1] = make_float4(-0.5f * i4[3] * LOG2E, o, r0, r1);
+    rec[2] = make_float4(r2, i4[0], i4[1], i4[3]);
+    rec[3] = make_float4(n[2], 0.0f, 0.0f, 0.0f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -313,13 +313,15 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
     int bits = 0;
     for (unsigned int mt = (unsigned int)ntiles; mt >>= 1;) bits++;
     bits++;
-    rc = lg_radix_sort_pairs((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), L, 0, bits,
-                             w + f.temp, (long long)f.temp_bytes, stream);
+    // exact instance count on the device (prefix[N-1]): only that many entries are sorted and range-scanned
+    const int* total_dev = (const int*)(w1 + f1.prefix) + (N - 1);
+    rc = lg_radix_sort_pairs_bounded((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), L,
+                                     total_dev, 0, bits, w + f.temp, (long long)f.temp_bytes, stream);
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
     const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
-    rc = lg_tile_range(sorted_keys, 1, L, ntiles, (int32_t*)(w + f.tile_start), stream); if (rc) return rc;
+    rc = lg_tile_range_bounded(sorted_keys, 1, L, total_dev, ntiles, (int32_t*)(w + f.tile_start), stream); if (rc) return rc;
     return lg_raster_forward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
                              enable_stat, img, trans, last, frag_count, frag_weight, stream);
 }

@@ -26,8 +26,10 @@
 #define GREC 16                // floats per packed gradient record
 #define LOG2E 1.4426950408889634f
 
-// record layout: 0 px, 1 py, 2 a=ic00, 3 b=ic01, 4 c=ic11, 5 r, 6 g, 7 b, 8 opacity, 9 depth,
-//                10 A2=-0.5*a*log2e, 11 B2=-b*log2e, 12 C2=-0.5*c*log2e, 13..15 = 0
+// record layout (dwords): 0 px, 1 py, 2 A2=-0.5*a*log2e, 3 B2=-b*log2e, 4 C2=-0.5*c*log2e, 5 opacity, 6 r, 7 g | 8 b,
+//                          9 a=ic00, 10 b=ic01, 11 c=ic11 | 12 depth, 13..15 = 0
+// forward reads dwords 0-8 (one s_load_dwordx8 + one s_load_dword), backward 0-11 (x8 + x4): tuples land in adjacent SGPRs,
+// which is what lets the compiler feed v_pk_* ops straight from SGPR pairs.
 // power*log2e = A2*dx^2 + B2*dx*dy + C2*dy^2   (power as in GR/raster.cu:237-240)
 
 // ---------------------------------------------------------------------------------------------
@@ -49,10 +51,10 @@ __global__ void __launch_bounds__(256) pack_params_kernel(const float* __restric
     float r = color[((size_t)b * 3) * N + i], g = color[((size_t)b * 3 + 1) * N + i], bl = color[((size_t)b * 3 + 2) * N + i];
     float o = opacity[i];
     float4* rec = packed + ((size_t)b * N + i) * (REC / 4);
-    rec[0] = make_float4(px, py, a, bb);
-    rec[1] = make_float4(c, r, g, bl);
-    rec[2] = make_float4(o, depth, -0.5f * a * LOG2E, -bb * LOG2E);
-    rec[3] = make_float4(-0.5f * c * LOG2E, 0.0f, 0.0f, 0.0f);
+    rec[0] = make_float4(px, py, -0.5f * a * LOG2E, -bb * LOG2E);
+    rec[1] = make_float4(-0.5f * c * LOG2E, o, r, g);
+    rec[2] = make_float4(bl, a, bb, c);
+    rec[3] = make_float4(depth, 0.0f, 0.0f, 0.0f);
 }
 
 LG_API int lg_pack_forward_params(const float* ndc, const float* inv_cov, const float* color, const float* opacity,
@@ -67,6 +69,8 @@ LG_API int lg_pack_forward_params(const float* ndc, const float* inv_cov, const 
 // ---------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ float xor_dpp1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
@@ -147,8 +151,7 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
             if (!__any(any_act)) break;
             const int pid = rfl(sp[i]);
             const float* __restrict__ r = pk + (size_t)pid * REC;
-            const float spx = r[0], spy = r[1], cr = r[5], cg = r[6], cb = r[7], o = r[8];
-            const float A2 = r[10], B2 = r[11], C2 = r[12];
+            const float spx = r[0], spy = r[1], A2 = r[2], B2 = r[3], C2 = r[4], o = r[5], cr = r[6], cg = r[7], cb = r[8];
             const float dx = spx - X;
             const float t0 = A2 * dx * dx, t1 = B2 * dx;
             int fc = 0;
@@ -285,8 +288,8 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
     for (int idx = maxlast - 1; idx >= 0; idx--) {
         const int pid = rfl(sp[idx]);
         const float* __restrict__ r = pk + (size_t)pid * REC;
-        const float spx = r[0], spy = r[1], a = r[2], b = r[3], c = r[4], cr = r[5], cg = r[6], cb = r[7], o = r[8];
-        const float A2 = r[10], B2 = r[11], C2 = r[12];
+        const float spx = r[0], spy = r[1], A2 = r[2], B2 = r[3], C2 = r[4], o = r[5], cr = r[6], cg = r[7], cb = r[8];
+        const float a = r[9], b = r[10], c = r[11];
         const float dx = spx - X;
         const float t0 = A2 * dx * dx, t1 = B2 * dx;
         float G[PPL], alpha[PPL], dy[PPL];

@@ -312,3 +312,28 @@ def test_adam_and_sparse_scatter(F, oracle):
 def test_cpu_tensors_are_rejected(F):
     with pytest.raises(RuntimeError):
         F.createTransformMatrix_forward(torch.zeros(4, 8), torch.zeros(3, 8), None)
+
+
+def test_radix_sort_device_bounded_prefix(F):
+    """lg_radix_sort_pairs_bounded / lg_tile_range_bounded: only the first *n_dev entries form the table (GPU-driven sizing)."""
+    from litegs_amd._lib import lib, check
+    L = lib()
+    rng = np.random.default_rng(5)
+    n, live, bits, ntiles = 50_000, 33_333, 14, 16200
+    keys = rng.integers(1, ntiles + 1, size=n).astype(np.int32)
+    vals = np.arange(n, dtype=np.int32)
+    ka, va = dev(keys), dev(vals)
+    kb, vb = torch.empty_like(ka), torch.empty_like(va)
+    n_dev = torch.tensor([live], dtype=torch.int32).cuda()
+    tb = L.lg_radix_sort_temp_bytes(n)
+    temp = torch.empty((tb,), dtype=torch.uint8).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    check(L.lg_radix_sort_pairs_bounded(ka.data_ptr(), va.data_ptr(), kb.data_ptr(), vb.data_ptr(), n, n_dev.data_ptr(), 0, bits, temp.data_ptr(), tb, s), "sort")
+    out_k, out_v = (kb, vb) if L.lg_radix_sort_num_passes(0, bits) % 2 else (ka, va)
+    order = np.argsort(keys[:live], kind="stable")
+    assert np.array_equal(host(out_k)[:live], keys[:live][order])
+    assert np.array_equal(host(out_v)[:live], vals[:live][order])
+    tr = torch.empty((1, ntiles + 2), dtype=torch.int32).cuda()
+    check(L.lg_tile_range_bounded(out_k.data_ptr(), 1, n, n_dev.data_ptr(), ntiles, tr.data_ptr(), s), "range")
+    from oracle import oracle as O
+    assert np.array_equal(host(tr), O.tile_range(keys[:live][order][None], ntiles))
