@@ -7,110 +7,9 @@
 // 4 B (histogram read) + 8 B (scatter read) + 8 B (scatter write); 14 tile-id bits at 1080p = 2 passes
 // of 8 bits.  No MFMA: this is byte shuffling.
 #include "lg_common.h"
+#include "lg_tilewalk.h"
 
 #define TPB 256
-
-// ---------------------------------------------------------------------------------------------
-// Ellipse extent + AccuTile walk (reference: GR/binning.cu:310-373 and GR/speedy_splat.cuh:16-149).
-// ---------------------------------------------------------------------------------------------
-struct SplatExtent {
-    float a, b, c, disc, t;
-    float px, py;
-    float bbox_min_x, bbox_min_y, bbox_max_x, bbox_max_y;
-    float argmin_x, argmin_y, argmax_x, argmax_y;   // .x = along y, .y = along x (reference naming)
-    int rminx, rminy, rmaxx, rmaxy;
-};
-
-__device__ __forceinline__ void ellipse_cut(const SplatExtent& e, bool isY, float coord, float& lo, float& hi)
-{
-    float p_u = isY ? e.py : e.px;
-    float p_v = isY ? e.px : e.py;
-    float coeff = isY ? e.a : e.c;
-    float h = coord - p_u;
-    float sq = sqrtf(e.disc * h * h + e.t * coeff);
-    lo = (-e.b * h - sq) / coeff + p_v;
-    hi = (-e.b * h + sq) / coeff + p_v;
-}
-
-template <int TH, int TW>
-__device__ __forceinline__ void splat_extent(float ndcx, float ndcy, float ic00, float ic01, float ic11, float opacity,
-                                             int H, int W, int gx, int gy, SplatExtent& e)
-{
-    e.a = ic00; e.b = ic01; e.c = ic11;
-    e.disc = ic01 * ic01 - ic00 * ic11;
-    float u = ndcx * 0.5f + 0.5f, v = ndcy * 0.5f + 0.5f;
-    e.px = u * W - 0.5f;
-    e.py = v * H - 0.5f;
-    float t = 2.0f * lg_logf(opacity * 255.0f);
-    e.t = t;
-    float x_term = sqrtf(-(ic01 * ic01 * t) / (e.disc * ic00));
-    x_term = (ic01 < 0) ? x_term : -x_term;
-    float y_term = sqrtf(-(ic01 * ic01 * t) / (e.disc * ic11));
-    y_term = (ic01 < 0) ? y_term : -y_term;
-    e.argmin_x = e.py - y_term; e.argmin_y = e.px - x_term;
-    e.argmax_x = e.py + y_term; e.argmax_y = e.px + x_term;
-    float lo, hi;
-    ellipse_cut(e, true, e.argmin_x, lo, hi);  e.bbox_min_x = lo;
-    ellipse_cut(e, false, e.argmin_y, lo, hi); e.bbox_min_y = lo;
-    ellipse_cut(e, true, e.argmax_x, lo, hi);  e.bbox_max_x = hi;
-    ellipse_cut(e, false, e.argmax_y, lo, hi); e.bbox_max_y = hi;
-    e.rminx = max(0, min(gx, lg_f2i(e.bbox_min_x / TW)));
-    e.rminy = max(0, min(gy, lg_f2i(e.bbox_min_y / TH)));
-    e.rmaxx = max(0, min(gx, lg_f2i((e.bbox_max_x + TW - 1) / TW)));
-    e.rmaxy = max(0, min(gy, lg_f2i((e.bbox_max_y + TH - 1) / TH)));
-}
-
-// Walks tile slices along the shorter rect axis; returns tiles touched; EMIT writes (tile_id+1, idx).
-template <int TH, int TW, bool EMIT>
-__device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int32_t idx, long long off,
-                                               int32_t* __restrict__ keys, int32_t* __restrict__ values, int2* lds_pairs = nullptr)
-{
-    const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
-    const bool isY = ys < xs;
-    const float BLOCK_U = isY ? (float)TH : (float)TW;
-    const float BLOCK_V = isY ? (float)TW : (float)TH;
-    // (u,v) frame: u = slicing axis
-    const int rect_min_u = isY ? e.rminy : e.rminx, rect_max_u = isY ? e.rmaxy : e.rmaxx;
-    const int rect_min_v = isY ? e.rminx : e.rminy, rect_max_v = isY ? e.rmaxx : e.rmaxy;
-    const float bmin_u = isY ? e.bbox_min_y : e.bbox_min_x, bmin_v = isY ? e.bbox_min_x : e.bbox_min_y;
-    const float bmax_u = isY ? e.bbox_max_y : e.bbox_max_x, bmax_v = isY ? e.bbox_max_x : e.bbox_max_y;
-    const float argmin_v = isY ? e.argmin_x : e.argmin_y;   // coordinate along u where v is minimal
-    const float argmax_v = isY ? e.argmax_x : e.argmax_y;
-
-    uint32_t count = 0;
-    float imax_lo = bmax_v, imax_hi = bmin_v;              // "never selected" sentinels
-    float imin_lo, imin_hi;
-    float min_line = rect_min_u * BLOCK_U;
-    if (bmin_u <= min_line) ellipse_cut(e, isY, rect_min_u * BLOCK_U, imin_lo, imin_hi);
-    else { imin_lo = imax_lo; imin_hi = imax_hi; }
-
-    for (int u = rect_min_u; u < rect_max_u; ++u) {
-        float max_line = min_line + BLOCK_U;
-        if (max_line <= bmax_u) ellipse_cut(e, isY, max_line, imax_lo, imax_hi);
-        float ellipse_min, ellipse_max;
-        if (min_line <= argmin_v && argmin_v < max_line) ellipse_min = bmin_v;
-        else ellipse_min = fminf(imin_lo, imax_lo);
-        if (min_line <= argmax_v && argmax_v < max_line) ellipse_max = bmax_v;
-        else ellipse_max = fmaxf(imin_hi, imax_hi);
-        int min_tile_v = max(rect_min_v, min(rect_max_v, lg_f2i(ellipse_min / BLOCK_V)));
-        int max_tile_v = min(rect_max_v, max(rect_min_v, lg_f2i(ellipse_max / BLOCK_V + 1)));
-        count += (uint32_t)(max_tile_v - min_tile_v);
-        if (EMIT) {
-            for (int v = min_tile_v; v < max_tile_v; v++) {
-                uint32_t key = isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
-                if (lds_pairs) lds_pairs[off] = make_int2((int)(key + 1), idx);
-                else { keys[off] = (int32_t)(key + 1); values[off] = idx; }
-                off++;
-            }
-        }
-        imin_lo = imax_lo; imin_hi = imax_hi;
-        min_line = max_line;
-    }
-    return count;
-}
-
-// fminf/fmaxf above must behave like the oracle's (a<b?a:b): identical for non-NaN operands, and a NaN
-// intersection only arises for degenerate ellipses that the visibility test already rejects.
 
 // a8 get_allocate_size
 template <int TH, int TW>
@@ -508,6 +407,10 @@ __global__ void __launch_bounds__(TPB) radix_scan_kernel(int* __restrict__ hist,
 // "match-any" ballots + per-wave digit counts, two barriers per round); (2) keys/values are placed in LDS in sorted order;
 // (3) the tile is streamed out: consecutive LDS slots with the same digit go to consecutive global addresses, so the
 // stores are coalesced runs instead of 4-byte scatters over 256 destinations (1.9 -> >3 TB/s effective on the tile sort).
+// INLINE_SCAN (few tiles, e.g. the depth sort of ~1 M keys): `offsets` is the RAW histogram table and every workgroup derives
+// its own global offsets from it (digit d: sum of row d before this tile + exclusive scan over digits of the row totals), which
+// removes the totals and scan launches from each pass -- those small sorts are launch-latency bound.
+template <bool INLINE_SCAN>
 __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                             const int* __restrict__ offsets /*[RADIX][ntiles]*/, long long n,
@@ -527,7 +430,25 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
     digit_run[tid] = 0;
 #pragma unroll
     for (int w = 0; w < TPB / 64; w++) { wave_cnt[0][w][tid] = 0; wave_cnt[1][w][tid] = 0; }
-    global_base[tid] = offsets[(size_t)tid * ntiles + blockIdx.x];
+    if (INLINE_SCAN) {
+        const int* row = offsets + (size_t)tid * ntiles;
+        int before = 0, total = 0;
+        for (int t = 0; t < ntiles; t++) { int c = row[t]; total += c; before += (t < (int)blockIdx.x) ? c : 0; }
+        int inc = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int nb = __shfl_up(inc, o);
+            if (lane >= o) inc += nb;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int wb0 = 0;
+        for (int w = 0; w < wave; w++) wb0 += wsum[w];
+        global_base[tid] = wb0 + inc - total + before;
+        __syncthreads();
+    } else {
+        global_base[tid] = offsets[(size_t)tid * ntiles + blockIdx.x];
+    }
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
     int lrank[SORT_ITEMS];
 #pragma unroll
@@ -644,17 +565,24 @@ LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint3
     int* hist = totals + SORT_MAX_PASSES * RADIX;
     int last_bits = (end_bit - begin_bit) - (passes - 1) * RADIX_BITS;
     uint32_t last_mask = (1u << last_bits) - 1u;
-    hipError_t err = hipMemsetAsync(totals, 0, sizeof(int) * SORT_MAX_PASSES * RADIX, s);
-    if (err != hipSuccess) return (int)err;
-    int tot_grid = ntiles < 512 ? ntiles : 512;
-    hipLaunchKernelGGL(radix_totals_kernel, dim3(tot_grid), dim3(TPB), 0, s, keys_a, n, n_dev, begin_bit, passes, last_mask, totals);
+    const bool inline_scan = ntiles <= 8;      // measured: beyond a handful of tiles the per-workgroup row scan costs more than the two launches it saves
+    if (!inline_scan) {
+        hipError_t err = hipMemsetAsync(totals, 0, sizeof(int) * SORT_MAX_PASSES * RADIX, s);
+        if (err != hipSuccess) return (int)err;
+        int tot_grid = ntiles < 512 ? ntiles : 512;
+        hipLaunchKernelGGL(radix_totals_kernel, dim3(tot_grid), dim3(TPB), 0, s, keys_a, n, n_dev, begin_bit, passes, last_mask, totals);
+    }
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
     for (int p = 0; p < passes; p++) {
         int shift = begin_bit + p * RADIX_BITS;
         uint32_t mask = (p == passes - 1) ? last_mask : (uint32_t)(RADIX - 1);
         hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, n, n_dev, shift, mask, ntiles, hist);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX), dim3(TPB), 0, s, hist, totals + p * RADIX, ntiles);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, hist, n, n_dev, shift, mask, ntiles);
+        if (inline_scan) {
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, hist, n, n_dev, shift, mask, ntiles);
+        } else {
+            hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX), dim3(TPB), 0, s, hist, totals + p * RADIX, ntiles);
+            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, hist, n, n_dev, shift, mask, ntiles);
+        }
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;

@@ -16,6 +16,7 @@
 // op-by-op kernels.  Compiled with -ffp-contract=off.
 #include "lg_common.h"
 #include "lg_chain.h"
+#include "lg_tilewalk.h"
 #include "litegs_hip.h"
 
 #define REC 16
@@ -33,21 +34,22 @@ struct Camera {
 // outputs are SoA over N = A*S:  ndc[4,N] (rows 0,1,2 written), view_z[N], inv_cov[4,N], opacity[N],
 // alloc[N] is produced by a second tiny kernel (tile walk lives in binning.hip), packed[N,16]
 // ---------------------------------------------------------------------------------------------
-template <int DEG>
+template <int DEG, int TH, int TW>
 __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_id, const int* __restrict__ visible_chunks_num,
                                      Camera cam,
                                      const float* __restrict__ pos, const float* __restrict__ scale, const float* __restrict__ rot,
                                      const float* __restrict__ sh0, const float* __restrict__ shr, const float* __restrict__ opa,
                                      int C, int S, int A,
                                      float* __restrict__ ndc, float* __restrict__ view_z, float* __restrict__ inv_cov,
-                                     float* __restrict__ opacity, float4* __restrict__ packed)
+                                     float* __restrict__ opacity, int* __restrict__ alloc, float4* __restrict__ packed, int gx, int gy)
 {
     const int a = blockIdx.x, t = threadIdx.x;
     const size_t N = (size_t)A * S;
     const size_t i = (size_t)a * S + t;
     if (a >= visible_chunks_num[0]) {
         opacity[i] = 0.0f;
-        view_z[i] = 3.0e38f;            // sorts last; allocate_size is 0 for it (valid_length bound)
+        alloc[i] = 0;
+        view_z[i] = 3.0e38f;            // sorts last and emits nothing
         return;
     }
     const size_t CS = (size_t)C * S;
@@ -86,6 +88,7 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     view_z[i] = v[2];
     inv_cov[i] = i4[0]; inv_cov[N + i] = i4[1]; inv_cov[2 * N + i] = i4[2]; inv_cov[3 * N + i] = i4[3];
     opacity[i] = o;
+    alloc[i] = lg_tile_count<TH, TW>(n[0], n[1], v[2], i4[0], i4[1], i4[3], o, cam.H, cam.W, gx, gy);     // a8, fused
     const float ppx = (n[0] + 1.0f) * 0.5f * cam.W - 0.5f;
     const float ppy = (n[1] + 1.0f) * 0.5f * cam.H - 0.5f;
     float4* rec = packed + i * (REC / 4);
@@ -262,21 +265,26 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
     Camera cam = make_camera(view_host, proj_host, H, W);
     float* ndc = (float*)(w + f.ndc); float* view_z = (float*)(w + f.view_z); float* inv_cov = (float*)(w + f.inv_cov);
     float* opacity = (float*)(w + f.opacity); float4* packed = (float4*)(w + f.packed);
-#define LAUNCH_PF(D) hipLaunchKernelGGL(project_fused_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, pos, scale, rot, sh0, shr, opa, \
-                                        chunks, S, A, ndc, view_z, inv_cov, opacity, packed)
-    switch (degree) {
-    case 0: LAUNCH_PF(0); break;
-    case 1: LAUNCH_PF(1); break;
-    case 2: LAUNCH_PF(2); break;
-    case 3: LAUNCH_PF(3); break;
-    default: return (int)hipErrorInvalidValue;
+    const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
+    int* alloc = (int*)(w + f.alloc);
+#define LAUNCH_PF(D, A_, B_) hipLaunchKernelGGL((project_fused_kernel<D, A_, B_>), dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, pos, scale, rot, \
+                                                sh0, shr, opa, chunks, S, A, ndc, view_z, inv_cov, opacity, alloc, packed, gx, gy)
+#define DISPATCH_PF(A_, B_)                                                  \
+    switch (degree) {                                                        \
+    case 0: LAUNCH_PF(0, A_, B_); break;                                     \
+    case 1: LAUNCH_PF(1, A_, B_); break;                                     \
+    case 2: LAUNCH_PF(2, A_, B_); break;                                     \
+    case 3: LAUNCH_PF(3, A_, B_); break;                                     \
+    default: return (int)hipErrorInvalidValue;                               \
     }
+    if (TH == 8 && TW == 16) { DISPATCH_PF(8, 16) }
+    else if (TH == 16 && TW == 16) { DISPATCH_PF(16, 16) }
+    else if (TH == 12 && TW == 16) { DISPATCH_PF(12, 16) }
+    else if (TH == 8 && TW == 8) { DISPATCH_PF(8, 8) }
+    else return (int)hipErrorInvalidValue;
+#undef DISPATCH_PF
 #undef LAUNCH_PF
     rc = (int)hipGetLastError(); if (rc) return rc;
-    // tile counts: valid_length = vis_num * S, computed on the device by a 1-thread kernel into the temp area is avoided:
-    // get_allocate_size takes the bound as int32[1]; we keep N-bound blocks cheap by zero opacity in the tail (o < 1/255 => invisible).
-    rc = lg_get_allocate_size(ndc, view_z, inv_cov, opacity, nullptr, 1, (int)N, H, W, TH, TW, nullptr, nullptr, (int32_t*)(w + f.alloc), stream);
-    if (rc) return rc;
     rc = lg_depth_sort_keys(view_z, N, (uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), stream); if (rc) return rc;
     rc = lg_radix_sort_pairs((uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (uint32_t*)(w + f.dk_b), (uint32_t*)(w + f.dv_b), N, 0, 32,
                              w + f.temp, (long long)f.temp_bytes, stream);

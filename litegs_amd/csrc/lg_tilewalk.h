@@ -1,0 +1,122 @@
+// Ellipse extent and AccuTile tile walk shared by binning.hip (get_allocate_size / duplicate_with_keys) and fused.hip
+// (tile counting fused into the projection kernel).  Exact arithmetic: include only from translation units built with
+// -ffp-contract=off, so the results stay bit-identical to the CPU checker.
+#pragma once
+#include "lg_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Ellipse extent + AccuTile walk (reference: GR/binning.cu:310-373 and GR/speedy_splat.cuh:16-149).
+// ---------------------------------------------------------------------------------------------
+struct SplatExtent {
+    float a, b, c, disc, t;
+    float px, py;
+    float bbox_min_x, bbox_min_y, bbox_max_x, bbox_max_y;
+    float argmin_x, argmin_y, argmax_x, argmax_y;   // .x = along y, .y = along x (reference naming)
+    int rminx, rminy, rmaxx, rmaxy;
+};
+
+__device__ __forceinline__ void ellipse_cut(const SplatExtent& e, bool isY, float coord, float& lo, float& hi)
+{
+    float p_u = isY ? e.py : e.px;
+    float p_v = isY ? e.px : e.py;
+    float coeff = isY ? e.a : e.c;
+    float h = coord - p_u;
+    float sq = sqrtf(e.disc * h * h + e.t * coeff);
+    lo = (-e.b * h - sq) / coeff + p_v;
+    hi = (-e.b * h + sq) / coeff + p_v;
+}
+
+template <int TH, int TW>
+__device__ __forceinline__ void splat_extent(float ndcx, float ndcy, float ic00, float ic01, float ic11, float opacity,
+                                             int H, int W, int gx, int gy, SplatExtent& e)
+{
+    e.a = ic00; e.b = ic01; e.c = ic11;
+    e.disc = ic01 * ic01 - ic00 * ic11;
+    float u = ndcx * 0.5f + 0.5f, v = ndcy * 0.5f + 0.5f;
+    e.px = u * W - 0.5f;
+    e.py = v * H - 0.5f;
+    float t = 2.0f * lg_logf(opacity * 255.0f);
+    e.t = t;
+    float x_term = sqrtf(-(ic01 * ic01 * t) / (e.disc * ic00));
+    x_term = (ic01 < 0) ? x_term : -x_term;
+    float y_term = sqrtf(-(ic01 * ic01 * t) / (e.disc * ic11));
+    y_term = (ic01 < 0) ? y_term : -y_term;
+    e.argmin_x = e.py - y_term; e.argmin_y = e.px - x_term;
+    e.argmax_x = e.py + y_term; e.argmax_y = e.px + x_term;
+    float lo, hi;
+    ellipse_cut(e, true, e.argmin_x, lo, hi);  e.bbox_min_x = lo;
+    ellipse_cut(e, false, e.argmin_y, lo, hi); e.bbox_min_y = lo;
+    ellipse_cut(e, true, e.argmax_x, lo, hi);  e.bbox_max_x = hi;
+    ellipse_cut(e, false, e.argmax_y, lo, hi); e.bbox_max_y = hi;
+    e.rminx = max(0, min(gx, lg_f2i(e.bbox_min_x / TW)));
+    e.rminy = max(0, min(gy, lg_f2i(e.bbox_min_y / TH)));
+    e.rmaxx = max(0, min(gx, lg_f2i((e.bbox_max_x + TW - 1) / TW)));
+    e.rmaxy = max(0, min(gy, lg_f2i((e.bbox_max_y + TH - 1) / TH)));
+}
+
+// Walks tile slices along the shorter rect axis; returns tiles touched; EMIT writes (tile_id+1, idx).
+template <int TH, int TW, bool EMIT>
+__device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int32_t idx, long long off,
+                                               int32_t* __restrict__ keys, int32_t* __restrict__ values, int2* lds_pairs = nullptr)
+{
+    const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
+    const bool isY = ys < xs;
+    const float BLOCK_U = isY ? (float)TH : (float)TW;
+    const float BLOCK_V = isY ? (float)TW : (float)TH;
+    // (u,v) frame: u = slicing axis
+    const int rect_min_u = isY ? e.rminy : e.rminx, rect_max_u = isY ? e.rmaxy : e.rmaxx;
+    const int rect_min_v = isY ? e.rminx : e.rminy, rect_max_v = isY ? e.rmaxx : e.rmaxy;
+    const float bmin_u = isY ? e.bbox_min_y : e.bbox_min_x, bmin_v = isY ? e.bbox_min_x : e.bbox_min_y;
+    const float bmax_u = isY ? e.bbox_max_y : e.bbox_max_x, bmax_v = isY ? e.bbox_max_x : e.bbox_max_y;
+    const float argmin_v = isY ? e.argmin_x : e.argmin_y;   // coordinate along u where v is minimal
+    const float argmax_v = isY ? e.argmax_x : e.argmax_y;
+
+    uint32_t count = 0;
+    float imax_lo = bmax_v, imax_hi = bmin_v;              // "never selected" sentinels
+    float imin_lo, imin_hi;
+    float min_line = rect_min_u * BLOCK_U;
+    if (bmin_u <= min_line) ellipse_cut(e, isY, rect_min_u * BLOCK_U, imin_lo, imin_hi);
+    else { imin_lo = imax_lo; imin_hi = imax_hi; }
+
+    for (int u = rect_min_u; u < rect_max_u; ++u) {
+        float max_line = min_line + BLOCK_U;
+        if (max_line <= bmax_u) ellipse_cut(e, isY, max_line, imax_lo, imax_hi);
+        float ellipse_min, ellipse_max;
+        if (min_line <= argmin_v && argmin_v < max_line) ellipse_min = bmin_v;
+        else ellipse_min = fminf(imin_lo, imax_lo);
+        if (min_line <= argmax_v && argmax_v < max_line) ellipse_max = bmax_v;
+        else ellipse_max = fmaxf(imin_hi, imax_hi);
+        int min_tile_v = max(rect_min_v, min(rect_max_v, lg_f2i(ellipse_min / BLOCK_V)));
+        int max_tile_v = min(rect_max_v, max(rect_min_v, lg_f2i(ellipse_max / BLOCK_V + 1)));
+        count += (uint32_t)(max_tile_v - min_tile_v);
+        if (EMIT) {
+            for (int v = min_tile_v; v < max_tile_v; v++) {
+                uint32_t key = isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
+                if (lds_pairs) lds_pairs[off] = make_int2((int)(key + 1), idx);
+                else { keys[off] = (int32_t)(key + 1); values[off] = idx; }
+                off++;
+            }
+        }
+        imin_lo = imax_lo; imin_hi = imax_hi;
+        min_line = max_line;
+    }
+    return count;
+}
+
+// fminf/fmaxf above must behave like the oracle's (a<b?a:b): identical for non-NaN operands, and a NaN
+// intersection only arises for degenerate ellipses that the visibility test already rejects.
+
+
+// visibility test + exact tile count of one splat (reference: GR/binning.cu:310-373)
+template <int TH, int TW>
+__device__ __forceinline__ int lg_tile_count(float nx, float ny, float view_z, float a, float bb, float c, float o, int H, int W, int gx, int gy)
+{
+    float disc = bb * bb - a * c;
+    bool vis = !((nx < -1.3f) || (nx > 1.3f) || (ny < -1.3f) || (ny > 1.3f) || (view_z <= 0.2f) || (o < 1.0f / 255));
+    vis = vis && (a > 0) && (c > 0) && (disc < 0);
+    if (!vis) return 0;
+    SplatExtent e;
+    splat_extent<TH, TW>(nx, ny, a, bb, c, o, H, W, gx, gy, e);
+    if ((e.rmaxy - e.rminy) * (e.rmaxx - e.rminx) <= 0) return 0;
+    return (int)walk_tiles<TH, TW, false>(e, gx, 0, 0, nullptr, nullptr);
+}
