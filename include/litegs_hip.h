@@ -179,6 +179,12 @@ int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, c
                       const int* tiles, int K, const float* final_T, const short* last, const float* d_img, const float* d_trans,
                       const float* grad_inv_scaler, int enable_stat, float* packed_grad, float* err_square_sum,
                       float* d_pos, float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa, void* stream);
+int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_host, const float* proj_host, int degree, int chunks, int R,
+                           const int64_t* vis_ids, const int* vis_num, const float* packed_grad, const float* grad_inv_scaler,
+                           float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
+                           float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
+                           float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
+                           const float* lr6, float b1, float b2, float eps, void* stream);
 int lg_adam_update_multi(int ngroups, void* const* param, const void* const* grad, void* const* exp_avg, void* const* exp_avg_sq,
                          const int* rows, const float* lr, const int64_t* visible_chunk_id, const int* valid_length,
                          int chunks, int A, int S, int grad_dense, float b1, float b2, float eps, void* stream);

@@ -43,6 +43,11 @@ class FusedRenderer:
         self.Hp = (height + tile[0] - 1) // tile[0] * tile[0]
         self.Wp = (width + tile[1] - 1) // tile[1] * tile[1]
         self.last_sizes = (0, 0)
+        # fuse_optimizer: backward stops after the blend backward; FusedAdam.step() then runs the per-Gaussian backward fused
+        # with the Adam update (csrc/fused.hip: project_backward_adam_kernel) -- parameter gradients never go to HBM.
+        # Only valid when nothing needs the gradients between backward and the optimizer step (no DP exchange).
+        self.fuse_optimizer = False
+        self.pending = None
 
     def render(self, frame: CameraFrame, cluster_origin, cluster_extend, xyz, scale, rot, sh_0, sh_rest, opacity, degree: int):
         """-> (img[1,3,H,W] clamped to [0,1], visible_chunkid, visible_chunks_num)."""
@@ -127,14 +132,27 @@ class _RenderFn(torch.autograd.Function):
         g_img = g_img.contiguous()
         pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev)
         esq = torch.zeros((1, 1, N), dtype=torch.float32, device=dev) if stat else None
+        tiles = ctx.tiles
+        K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
+        if R.fuse_optimizer:
+            check(L.lg_fused_backward(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes,
+                                      frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
+                                      xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
+                                      trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
+                                      pg.data_ptr(), esq.data_ptr() if stat else None, None, None, None, None, None, None, _s()),
+                  "fused blend backward")
+            if stat:
+                fc, fw = ctx.stat_bufs
+                STATS.add_moments("fragment_weight", fw, fw * fw, fc)
+                STATS.add_moments("fragment_err", pg[:, 8].reshape(1, 1, N), esq, fc)
+            R.pending = dict(pg=pg, A=A, S=S, frame=frame, degree=degree, chunks=chunks, Rr=Rr, vis_ids=vis_ids, vis_num=vis_num)
+            return (None,) * 11
         d_pos = torch.empty((3, A, S), dtype=torch.float32, device=dev)
         d_scale = torch.empty((3, A, S), dtype=torch.float32, device=dev)
         d_rot = torch.empty((4, A, S), dtype=torch.float32, device=dev)
         d_sh0 = torch.empty((3, A, S), dtype=torch.float32, device=dev)
         d_shr = torch.empty((Rr * 3, A, S), dtype=torch.float32, device=dev)
         d_opa = torch.empty((1, A, S), dtype=torch.float32, device=dev)
-        tiles = ctx.tiles
-        K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
         check(L.lg_fused_backward(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes,
                                   frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
                                   xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
@@ -157,8 +175,9 @@ class _RenderFn(torch.autograd.Function):
 class FusedAdam:
     """All parameter groups in one launch (csrc/fused.hip: adam_multi_kernel); same update rule as adamUpdate."""
 
-    def __init__(self, optimizer):
+    def __init__(self, optimizer, renderer: Optional["FusedRenderer"] = None):
         self.opt = optimizer
+        self.renderer = renderer
         self.groups = optimizer.param_groups
         G = len(self.groups)
         self._arr = ctypes.c_void_p * G
@@ -180,12 +199,29 @@ class FusedAdam:
         self._m = self._arr(*[self.opt.state[p]["exp_avg"].data_ptr() for p in ps])
         self._v = self._arr(*[self.opt.state[p]["exp_avg_sq"].data_ptr() for p in ps])
         self._rows = self._iarr(*[int(p.numel() // (self.chunks * self.S)) for p in ps])
+        self._by_name = {g.get("name"): g for g in self.groups}
         self._ready = True
+
+    def _step_fused_backward(self, pend):
+        """per-Gaussian backward + Adam in one kernel, from the packed gradients left by the blend backward."""
+        order = ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]
+        ps = [self._by_name[n]["params"][0] for n in order]
+        ms = [self.opt.state[p]["exp_avg"] for p in ps]
+        vs = [self.opt.state[p]["exp_avg_sq"] for p in ps]
+        lr6 = (ctypes.c_float * 6)(*[float(self._by_name[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]])
+        R, fr = self.renderer, pend["frame"]
+        check(lib().lg_fused_backward_adam(pend["A"], pend["S"], R.H, R.W, fr.view_ptr, fr.proj_ptr, pend["degree"], pend["chunks"], pend["Rr"],
+                                           pend["vis_ids"].data_ptr(), pend["vis_num"].data_ptr(), pend["pg"].data_ptr(), None,
+                                           *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms], *[v.data_ptr() for v in vs],
+                                           lr6, 0.9, 0.999, float(self.groups[0]["eps"]), _s()), "fused backward+adam")
 
     @torch.no_grad()
     def step(self, visible_chunk: torch.Tensor, visible_chunks_num: Optional[torch.Tensor]):
         if not self._ready:
             self._init_state()
+        if self.renderer is not None and self.renderer.pending is not None:
+            pend, self.renderer.pending = self.renderer.pending, None
+            return self._step_fused_backward(pend)
         ps = [g["params"][0] for g in self.groups]
         grads = [p.grad for p in ps]
         if any(g is None for g in grads):

@@ -30,7 +30,7 @@ class Frame:
 class SyntheticTrainer:
     def __init__(self, n_gaussians: int, width: int, height: int, focal: float, n_frames: int = 8, seed: int = 0, sh_degree: int = 3,
                  device: Optional[torch.device] = None, radius: float = 4.0, cam_radius_frac: float = 0.5, use_torch_loss: bool = False,
-                 scene=None, fused: bool = True):
+                 scene=None, fused: bool = True, fuse_adam: bool = True):
         """fused=True: native executor (litegs_amd/fast.py); fused=False: operator-by-operator path through the litegs_fused surface."""
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.H, self.W, self.degree = height, width, sh_degree
@@ -55,7 +55,8 @@ class SyntheticTrainer:
         self.loss_fn = loss_mod.l1_ssim_loss_torch if use_torch_loss else loss_mod.fused_l1_ssim_loss
         self.fused = fused
         self.renderer = fast.FusedRenderer(n_frames, height, width, self.pp.tile_size, self.pp.cluster_size)
-        self.fadam = fast.FusedAdam(self.opt)
+        self.fadam = fast.FusedAdam(self.opt, self.renderer)
+        self.fuse_adam = fuse_adam
         self.last = {}
 
     # -------------------------------------------------------------------------------------------
@@ -77,6 +78,8 @@ class SyntheticTrainer:
 
     def step(self, frame_index: int, grad_hook=None):
         frame = self.frames[frame_index % len(self.frames)]
+        # gradients are only materialised when something consumes them between backward and the optimizer (DP exchange)
+        self.renderer.fuse_optimizer = self.fused and self.fuse_adam and grad_hook is None
         img, vis_id, vis_num, prim_vis = self.forward(frame)
         loss = self.loss_fn(img, frame.gt)
         loss.backward()

@@ -113,3 +113,23 @@ def test_fused_trainer_step_equals_operator_trainer_step():
         # Adam normalises the step to ~lr regardless of gradient magnitude: compare relative to that step size
         diff = (pa - pb).abs().max().item()
         assert diff < 5e-4, diff
+
+
+def test_backward_fused_with_adam_equals_separate_kernels():
+    """fuse_adam=True (gradients stay in registers) vs fuse_adam=False (gradients through HBM): same parameters after several steps."""
+    from litegs_amd import synthetic as S
+    from litegs_amd.trainer import SyntheticTrainer
+    scene = S.make_scene(5000, seed=7)
+    ta = SyntheticTrainer(5000, 320, 200, 300.0, n_frames=2, scene=scene, fuse_adam=True)
+    tb = SyntheticTrainer(5000, 320, 200, 300.0, n_frames=2, scene=scene, fuse_adam=False)
+    for i in range(5):
+        la, lb = ta.step(i), tb.step(i)
+        assert abs(la.item() - lb.item()) < 1e-5
+        assert all(p.grad is None for p in ta.params)
+    worst = 0.0
+    for pa, pb, p0 in zip(ta.params, tb.params, scene):
+        worst = max(worst, (pa - pb).abs().max().item())
+        assert (pa.detach().cpu() - torch.from_numpy(p0)).abs().max().item() > 0
+    assert worst < 5e-4, worst
+    for sa, sb in zip(ta.opt.state.values(), tb.opt.state.values()):
+        assert (sa["exp_avg"] - sb["exp_avg"]).abs().max().item() <= 1e-4 * max(sb["exp_avg"].abs().max().item(), 1e-12)
