@@ -270,8 +270,9 @@ def main():
             traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
             if os.path.exists(traffic_file):
                 try:
-                    tj = json.load(open(traffic_file))
-                    result["roofline"]["traffic"] = tj.get(result["roofline"]["kernel"])
+                    tj = json.load(open(traffic_file))     # rocprofv3 PMC pass (profiles/r01_pmc_summary.md): (2*FETCH_SIZE+WRITE_SIZE)*1024
+                    kname = result["roofline"]["kernel"]
+                    result["roofline"]["traffic"] = next((v for k, v in tj.items() if k.startswith(kname)), None)
                 except Exception:
                     pass
             if not args.no_cpu_baseline:
