@@ -101,6 +101,16 @@ int lg_world2ndc_forward(const float* world, const float* viewproj, int V, int N
 int lg_world2ndc_backward(const float* viewproj, const float* ndc, const float* recp_w, const float* g_ndc, int V, int N,
                           float* g_pos, void* stream);                                                              /* :671-731 */
 
+/* Learnable cameras (GR/compact.cu:17-316; wrapper.py:772-791).  view_params [V,7] = unit-less quaternion (r,x,y,z) + translation;
+ * outputs row-vector matrices [V,4,4] and frustum planes [V,6,4].  Backward keeps the reference's integer img_w/img_h ratio
+ * (compact.cu:268) and its quaternion-sphere projection (:271-277); grad_recp_tan_half_fov_x[1] is overwritten with the
+ * ordered sum over views (the reference's unsynchronised "+=" is a race for V>1). */
+int lg_create_viewproj_forward(const float* view_params, const float* recp_tan_half_fov_x, int V, int H, int W, float z_near, float z_far,
+                               float* view_matrix, float* proj_matrix, float* viewproj_matrix, float* frustumplane, void* stream); /* compact.cu:17-135 */
+int lg_create_viewproj_backward(const float* view_matrix_grad, const float* proj_matrix_grad, const float* viewproj_matrix_grad,
+                                const float* view_params, const float* recp_tan_half_fov_x, int V, int H, int W, float z_near,
+                                float z_far, float* grad_view_params, float* grad_recp_tan_half_fov_x, void* stream);          /* compact.cu:137-316 */
+
 /* ---- binning.hip : GR/binning.h ------------------------------------------------------------- */
 int lg_get_allocate_size(const float* ndc, const float* view_z, const float* inv_cov2d, const float* opacity,
                          const int* valid_length, int V, int N, int H, int W, int TH, int TW,

@@ -441,3 +441,138 @@ LG_API int lg_world2ndc_backward(const float* viewproj, const float* ndc, const 
     hipLaunchKernelGGL(world2ndc_backward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, viewproj, ndc, recp_w, g_ndc, V, N, g_pos);
     LG_RETURN_LAST();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Learnable cameras: create_viewproj forward/backward (GR/compact.cu:17-316).
+// view_params[v] = (qr,qx,qy,qz, tx,ty,tz); row-vector convention: view = [R^T rows | t], p_clip = p.view.proj.
+// One lane per view (a few hundred views at most: launch-latency bound, nothing to tile).
+// Reference behaviour kept:  d(proj_11)/d(fov) uses the INTEGER ratio img_w/img_h (compact.cu:268), and the
+// quaternion gradient is projected on the unit sphere without the 1/|q| factor (compact.cu:271-277).
+// Difference: the reference accumulates grad_fov[0] with a plain "+=" from every thread (a race for V>1);
+// here the per-view contributions are reduced in a fixed order.
+// ---------------------------------------------------------------------------------------------
+struct CamMats { float view[16]; float p00, p11, p22, p32; };
+
+__device__ __forceinline__ void lg_camera_matrices(const float* __restrict__ vp7, float fov_recp, int H, int W, float zn, float zf, CamMats& m,
+                                                   float q[4])
+{
+    float r = vp7[0], x = vp7[1], y = vp7[2], z = vp7[3];
+    float inv = 1.0f / sqrtf(r * r + x * x + y * y + z * z + 1e-12f);
+    r *= inv; x *= inv; y *= inv; z *= inv;
+    q[0] = r; q[1] = x; q[2] = y; q[3] = z;
+    float* V = m.view;
+    V[0] = 1 - 2 * (y * y + z * z); V[1] = 2 * (x * y + r * z);     V[2] = 2 * (x * z - r * y);      V[3] = 0;
+    V[4] = 2 * (x * y - r * z);     V[5] = 1 - 2 * (x * x + z * z); V[6] = 2 * (y * z + r * x);      V[7] = 0;
+    V[8] = 2 * (x * z + r * y);     V[9] = 2 * (y * z - r * x);     V[10] = 1 - 2 * (x * x + y * y); V[11] = 0;
+    V[12] = vp7[4]; V[13] = vp7[5]; V[14] = vp7[6]; V[15] = 1.0f;
+    m.p00 = fov_recp;
+    m.p11 = fov_recp * W / H;
+    m.p22 = zf / (zf - zn);
+    m.p32 = -zf * zn / (zf - zn);
+}
+
+__global__ void __launch_bounds__(64) create_viewproj_forward_kernel(const float* __restrict__ view_params, const float* __restrict__ fov_recp,
+                                                                     int V, int H, int W, float zn, float zf, float* __restrict__ view_m,
+                                                                     float* __restrict__ proj_m, float* __restrict__ vp_m,
+                                                                     float* __restrict__ planes)
+{
+    int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    CamMats m; float q[4];
+    lg_camera_matrices(view_params + 7 * v, fov_recp[0], H, W, zn, zf, m, q);
+    float P[16] = { m.p00, 0, 0, 0,  0, m.p11, 0, 0,  0, 0, m.p22, 1,  0, 0, m.p32, 0 };
+    float M[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) t += m.view[i * 4 + k] * P[k * 4 + j];
+            M[i * 4 + j] = t;
+        }
+#pragma unroll
+    for (int e = 0; e < 16; e++) { view_m[16 * v + e] = m.view[e]; proj_m[16 * v + e] = P[e]; vp_m[16 * v + e] = M[e]; }
+    // clip-space half spaces: w+x, w-x, w+y, w-y, z, w-z  (column c of viewproj = M[.][c])
+    float* pl = planes + 24 * v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float cx = M[r * 4 + 0], cy = M[r * 4 + 1], cz = M[r * 4 + 2], cw = M[r * 4 + 3];
+        pl[0 * 4 + r] = cw + cx; pl[1 * 4 + r] = cw - cx;
+        pl[2 * 4 + r] = cw + cy; pl[3 * 4 + r] = cw - cy;
+        pl[4 * 4 + r] = cz;      pl[5 * 4 + r] = cw - cz;
+    }
+}
+
+LG_API int lg_create_viewproj_forward(const float* view_params, const float* recp_tan_half_fov_x, int V, int H, int W, float z_near, float z_far,
+                                      float* view_matrix, float* proj_matrix, float* viewproj_matrix, float* frustumplane, void* stream)
+{
+    if (V <= 0) return 0;
+    hipLaunchKernelGGL(create_viewproj_forward_kernel, dim3(lg_cdiv(V, 64)), dim3(64), 0, (hipStream_t)stream, view_params, recp_tan_half_fov_x,
+                       V, H, W, z_near, z_far, view_matrix, proj_matrix, viewproj_matrix, frustumplane);
+    LG_RETURN_LAST();
+}
+
+// single workgroup: lanes stride over views, the fov gradient is reduced in lane order through LDS
+__global__ void __launch_bounds__(256) create_viewproj_backward_kernel(const float* __restrict__ g_view, const float* __restrict__ g_proj,
+                                                                       const float* __restrict__ g_vp, const float* __restrict__ view_params,
+                                                                       const float* __restrict__ fov_recp, int V, int H, int W, float zn,
+                                                                       float zf, float* __restrict__ g_params, float* __restrict__ g_fov)
+{
+    __shared__ float part[256];
+    float fov_acc = 0.0f;
+    const float int_aspect = (float)(W / H);                    // integer division, as compact.cu:268
+    for (int v = threadIdx.x; v < V; v += 256) {
+        CamMats m; float q[4];
+        lg_camera_matrices(view_params + 7 * v, fov_recp[0], H, W, zn, zf, m, q);
+        const float* Gm = g_vp + 16 * v;
+        float A[12];                                            // d/d(view[i][0..2]) for i = 0..3
+        float gp00 = 0.0f, gp11 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float g0 = Gm[i * 4 + 0], g1 = Gm[i * 4 + 1], g2 = Gm[i * 4 + 2], g3 = Gm[i * 4 + 3];
+            A[i * 3 + 0] = g_view[16 * v + i * 4 + 0] + g0 * m.p00;
+            A[i * 3 + 1] = g_view[16 * v + i * 4 + 1] + g1 * m.p11;
+            A[i * 3 + 2] = g_view[16 * v + i * 4 + 2] + (g2 * m.p22 + g3);
+            gp00 += g0 * m.view[i * 4 + 0];
+            gp11 += g1 * m.view[i * 4 + 1];
+        }
+        float r = q[0], x = q[1], y = q[2], z = q[3];
+        float gr = 0, gx = 0, gy = 0, gz = 0, g;
+        g = A[0]; gy += g * (-4 * y); gz += g * (-4 * z);
+        g = A[1]; gx += g * (2 * y); gy += g * (2 * x); gr += g * (2 * z); gz += g * (2 * r);
+        g = A[2]; gx += g * (2 * z); gz += g * (2 * x); gr += g * (-2 * y); gy += g * (-2 * r);
+        g = A[3]; gx += g * (2 * y); gy += g * (2 * x); gr += g * (-2 * z); gz += g * (-2 * r);
+        g = A[4]; gx += g * (-4 * x); gz += g * (-4 * z);
+        g = A[5]; gy += g * (2 * z); gz += g * (2 * y); gr += g * (2 * x); gx += g * (2 * r);
+        g = A[6]; gx += g * (2 * z); gz += g * (2 * x); gr += g * (2 * y); gy += g * (2 * r);
+        g = A[7]; gy += g * (2 * z); gz += g * (2 * y); gr += g * (-2 * x); gx += g * (-2 * r);
+        g = A[8]; gx += g * (-4 * x); gy += g * (-4 * y);
+        float norm = sqrtf(r * r + x * x + y * y + z * z);
+        float dot = (r * gr + x * gx + y * gy + z * gz) / (norm * norm);
+        float* o = g_params + 7 * v;
+        o[0] = gr / norm - r * dot; o[1] = gx / norm - x * dot; o[2] = gy / norm - y * dot; o[3] = gz / norm - z * dot;
+        o[4] = A[9]; o[5] = A[10]; o[6] = A[11];
+        fov_acc += (g_proj[16 * v + 0] + gp00);
+        fov_acc += (g_proj[16 * v + 5] + gp11) * int_aspect;
+    }
+    part[threadIdx.x] = fov_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+        int n = V < 256 ? V : 256;
+        for (int i = 0; i < n; i++) s += part[i];
+        g_fov[0] = s;
+    }
+}
+
+LG_API int lg_create_viewproj_backward(const float* view_matrix_grad, const float* proj_matrix_grad, const float* viewproj_matrix_grad,
+                                       const float* view_params, const float* recp_tan_half_fov_x, int V, int H, int W, float z_near,
+                                       float z_far, float* grad_view_params, float* grad_recp_tan_half_fov_x, void* stream)
+{
+    if (V <= 0) return 0;
+    hipLaunchKernelGGL(create_viewproj_backward_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, view_matrix_grad, proj_matrix_grad,
+                       viewproj_matrix_grad, view_params, recp_tan_half_fov_x, V, H, W, z_near, z_far, grad_view_params,
+                       grad_recp_tan_half_fov_x);
+    LG_RETURN_LAST();
+}

@@ -170,13 +170,31 @@ def gpu_driven_pipeline_sparse_op(A, B, visible_chunk_ids, visible_count, op_nam
 
 
 def create_viewproj_forward(view_params, recp_tan_half_fov_x, img_h, img_w, z_near, z_far):
-    from .viewproj import create_viewproj_forward as f
-    return f(view_params, recp_tan_half_fov_x, img_h, img_w, z_near, z_far)
+    """GR/compact.cu:119-135: [V,7] quaternion+translation and [1] 1/tan(fov_x/2) -> (view, proj, viewproj [V,4,4], frustumplane [V,6,4])."""
+    view_params, fov = _f32(view_params, "view_params").contiguous(), _f32(recp_tan_half_fov_x, "recp_tan_half_fov_x").contiguous()
+    if view_params.dim() != 2 or view_params.shape[1] != 7:
+        raise RuntimeError("create_viewproj_forward: view_params must be [views,7]")
+    V = view_params.shape[0]
+    view, proj, vp = (torch.empty((V, 4, 4), dtype=torch.float32, device=view_params.device) for _ in range(3))
+    planes = torch.empty((V, 6, 4), dtype=torch.float32, device=view_params.device)
+    check(lib().lg_create_viewproj_forward(_p(view_params), _p(fov), V, int(img_h), int(img_w), float(z_near), float(z_far),
+                                           _p(view), _p(proj), _p(vp), _p(planes), _s()), "create_viewproj_forward")
+    return [view, proj, vp, planes]
 
 
 def create_viewproj_backward(view_matrix_grad, proj_matrix_grad, viewproj_matrix_grad, view_params, recp_tan_half_fov_x, img_h, img_w, z_near, z_far):
-    from .viewproj import create_viewproj_backward as f
-    return f(view_matrix_grad, proj_matrix_grad, viewproj_matrix_grad, view_params, recp_tan_half_fov_x, img_h, img_w, z_near, z_far)
+    """GR/compact.cu:287-316 -> (grad_view_params [V,7], grad_recp_tan_half_fov_x [1])."""
+    view_params, fov = _f32(view_params, "view_params").contiguous(), _f32(recp_tan_half_fov_x, "recp_tan_half_fov_x").contiguous()
+    V = view_params.shape[0]
+    gs = [_f32(g, n).contiguous() for g, n in ((view_matrix_grad, "view_matrix_grad"), (proj_matrix_grad, "proj_matrix_grad"),
+                                               (viewproj_matrix_grad, "viewproj_matrix_grad"))]
+    for g in gs:
+        if tuple(g.shape) != (V, 4, 4):
+            raise RuntimeError("create_viewproj_backward: matrix gradients must be [views,4,4]")
+    g_params, g_fov = torch.zeros_like(view_params), torch.zeros_like(fov)
+    check(lib().lg_create_viewproj_backward(_p(gs[0]), _p(gs[1]), _p(gs[2]), _p(view_params), _p(fov), V, int(img_h), int(img_w),
+                                            float(z_near), float(z_far), _p(g_params), _p(g_fov), _s()), "create_viewproj_backward")
+    return [g_params, g_fov]
 
 
 # --------------------------------------------------------------------------------------------- transform.h

@@ -207,6 +207,26 @@ class GaussiansRasterFunc(torch.autograd.Function):
         return None, None, d_ndc, d_cov2d_inv, d_color, d_opacity, None, None, None, None, None, None, None
 
 
+class CreateViewProj(torch.autograd.Function):
+    """Learnable camera (wrapper.py:772-791): [V,7] pose + [1] 1/tan(fov_x/2) -> view, proj, viewproj, frustumplane."""
+
+    @staticmethod
+    def forward(ctx, view_params, proj_params, img_h, img_w, z_near, z_far):
+        view, proj, viewproj, planes = fused.create_viewproj_forward(view_params, proj_params, img_h, img_w, z_near, z_far)
+        ctx.save_for_backward(view_params, proj_params)
+        ctx.meta = (img_h, img_w, z_near, z_far)
+        ctx.mark_non_differentiable(planes)
+        return view, proj, viewproj, planes
+
+    @staticmethod
+    def backward(ctx, g_view, g_proj, g_viewproj, _g_planes):
+        view_params, proj_params = ctx.saved_tensors
+        V = view_params.shape[0]
+        zeros = lambda g: torch.zeros((V, 4, 4), device=view_params.device) if g is None else g
+        gp, gf = fused.create_viewproj_backward(zeros(g_view), zeros(g_proj), zeros(g_viewproj), view_params, proj_params, *ctx.meta)
+        return gp, gf, None, None, None, None
+
+
 class CullCompactActivateWithSparseGrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, b_sparse_grad, sh_degree, visible_chunkid, visible_chunk_num, view_matrix, xyz, scale, rot, sh_0, sh_rest, opacity):

@@ -1060,3 +1060,86 @@ ORC_API void orc_sparse_scatter_i32(int32_t* A, const int32_t* B, const int64_t*
 
 /* exported so tests can check the HIP twin bit-for-bit */
 ORC_API float orc_logf_export(float x) { return orc_logf(x); }
+
+/* ------------------------------------------------------------------------- */
+/* learnable cameras: create_viewproj forward/backward  GR/compact.cu:17-316   */
+/* ------------------------------------------------------------------------- */
+static void orc_cam_mats(const float* p7, float fov, int H, int W, float zn, float zf, float view[4][4], float proj[4][4], float q[4])
+{
+    float r = p7[0], x = p7[1], y = p7[2], z = p7[3];
+    float recp = 1.0f / sqrtf(r * r + x * x + y * y + z * z + 1e-12f);       /* compact.cu:35 (rsqrtf) */
+    r *= recp; x *= recp; y *= recp; z *= recp;
+    q[0] = r; q[1] = x; q[2] = y; q[3] = z;
+    float v[4][4] = { { 1 - 2 * (y * y + z * z), 2 * (x * y + r * z), 2 * (x * z - r * y), 0 },
+                      { 2 * (x * y - r * z), 1 - 2 * (x * x + z * z), 2 * (y * z + r * x), 0 },
+                      { 2 * (x * z + r * y), 2 * (y * z - r * x), 1 - 2 * (x * x + y * y), 0 },
+                      { p7[4], p7[5], p7[6], 1.0f } };                           /* compact.cu:40-45 */
+    float p00 = fov, p11 = p00 * W / H;                                         /* compact.cu:54-55 */
+    float p[4][4] = { { p00, 0, 0, 0 }, { 0, p11, 0, 0 }, { 0, 0, zf / (zf - zn), 1 }, { 0, 0, -zf * zn / (zf - zn), 0 } };
+    memcpy(view, v, sizeof(v)); memcpy(proj, p, sizeof(p));
+}
+
+ORC_API void orc_create_viewproj_forward(const float* view_params, const float* fov, int V, int H, int W, float zn, float zf,
+                                         float* view_m, float* proj_m, float* vp_m, float* planes)
+{
+    for (int b = 0; b < V; b++) {
+        float view[4][4], proj[4][4], vp[4][4], q[4];
+        orc_cam_mats(view_params + 7 * b, fov[0], H, W, zn, zf, view, proj, q);
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                float t = 0.0f;
+                for (int k = 0; k < 4; k++) t += view[i][k] * proj[k][j];       /* compact.cu:76-86 */
+                vp[i][j] = t;
+            }
+        memcpy(view_m + 16 * b, view, 64); memcpy(proj_m + 16 * b, proj, 64); memcpy(vp_m + 16 * b, vp, 64);
+        float* pl = planes + 24 * b;                                            /* compact.cu:89-117 */
+        for (int r = 0; r < 4; r++) {
+            pl[0 * 4 + r] = vp[r][3] + vp[r][0]; pl[1 * 4 + r] = vp[r][3] - vp[r][0];
+            pl[2 * 4 + r] = vp[r][3] + vp[r][1]; pl[3 * 4 + r] = vp[r][3] - vp[r][1];
+            pl[4 * 4 + r] = vp[r][2];            pl[5 * 4 + r] = vp[r][3] - vp[r][2];
+        }
+    }
+}
+
+ORC_API void orc_create_viewproj_backward(const float* g_view, const float* g_proj, const float* g_vp, const float* view_params,
+                                          const float* fov, int V, int H, int W, float zn, float zf, float* g_params, float* g_fov)
+{
+    /* fov gradient: the reference "+="s from every thread without atomics (compact.cu:267-268); restated as the
+       ordered sum, grouped the way the single-workgroup HIP kernel strides views over its 256 lanes. */
+    float lane_acc[256]; for (int i = 0; i < 256; i++) lane_acc[i] = 0.0f;
+    for (int b = 0; b < V; b++) {
+        float view[4][4], proj[4][4], q[4];
+        orc_cam_mats(view_params + 7 * b, fov[0], H, W, zn, zf, view, proj, q);
+        float lv[4][4] = { { 0 } }, lp[4][4] = { { 0 } };
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                float g = g_vp[16 * b + i * 4 + j];
+                for (int k = 0; k < 4; k++) { lv[i][k] += g * proj[k][j]; lp[k][j] += g * view[i][k]; }   /* :196-207 */
+            }
+        float av[4][4], ap[4][4];
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) { av[i][j] = g_view[16 * b + i * 4 + j] + lv[i][j]; ap[i][j] = g_proj[16 * b + i * 4 + j] + lp[i][j]; }
+        float r = q[0], x = q[1], y = q[2], z = q[3];
+        float gr = 0, gx = 0, gy = 0, gz = 0, g;                                 /* compact.cu:219-262 */
+        g = av[0][0]; gy += g * (-4 * y); gz += g * (-4 * z);
+        g = av[0][1]; gx += g * (2 * y); gy += g * (2 * x); gr += g * (2 * z); gz += g * (2 * r);
+        g = av[0][2]; gx += g * (2 * z); gz += g * (2 * x); gr += g * (-2 * y); gy += g * (-2 * r);
+        g = av[1][0]; gx += g * (2 * y); gy += g * (2 * x); gr += g * (-2 * z); gz += g * (-2 * r);
+        g = av[1][1]; gx += g * (-4 * x); gz += g * (-4 * z);
+        g = av[1][2]; gy += g * (2 * z); gz += g * (2 * y); gr += g * (2 * x); gx += g * (2 * r);
+        g = av[2][0]; gx += g * (2 * z); gz += g * (2 * x); gr += g * (2 * y); gy += g * (2 * r);
+        g = av[2][1]; gy += g * (2 * z); gz += g * (2 * y); gr += g * (-2 * x); gx += g * (-2 * r);
+        g = av[2][2]; gx += g * (-4 * x); gy += g * (-4 * y);
+        float* o = g_params + 7 * b;
+        o[4] = av[3][0]; o[5] = av[3][1]; o[6] = av[3][2];
+        int la = b % 256;
+        lane_acc[la] += ap[0][0];
+        lane_acc[la] += ap[1][1] * (float)(W / H);                               /* integer ratio, compact.cu:268 */
+        float norm = sqrtf(r * r + x * x + y * y + z * z);
+        float dot = (r * gr + x * gx + y * gy + z * gz) / (norm * norm);
+        o[0] = gr / norm - r * dot; o[1] = gx / norm - x * dot; o[2] = gy / norm - y * dot; o[3] = gz / norm - z * dot;
+    }
+    float s = 0.0f;
+    for (int i = 0; i < (V < 256 ? V : 256); i++) s += lane_acc[i];
+    g_fov[0] = s;
+}

@@ -450,3 +450,23 @@ def cluster_AABB(xyz, scale_raw, rot_raw):
     mx = (xyz + point_ext).max(axis=-1)
     mn = (xyz - point_ext).min(axis=-1)
     return ((mx + mn) / 2).astype(np.float32), ((mx - mn) / 2).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------- learnable cameras
+def create_viewproj_forward(view_params, fov, H, W, zn, zf):
+    """GR/compact.cu:17-135"""
+    vp7 = _f32(view_params); V = vp7.shape[0]
+    view, proj, vp = (np.zeros((V, 4, 4), np.float32) for _ in range(3))
+    planes = np.zeros((V, 6, 4), np.float32)
+    lib().orc_create_viewproj_forward(_p(vp7), _p(_f32(fov)), _i(V), _i(H), _i(W), ctypes.c_float(zn), ctypes.c_float(zf),
+                                      _p(view), _p(proj), _p(vp), _p(planes))
+    return view, proj, vp, planes
+
+
+def create_viewproj_backward(g_view, g_proj, g_vp, view_params, fov, H, W, zn, zf):
+    """GR/compact.cu:137-316"""
+    vp7 = _f32(view_params); V = vp7.shape[0]
+    gp, gf = np.zeros((V, 7), np.float32), np.zeros((1,), np.float32)
+    lib().orc_create_viewproj_backward(_p(_f32(g_view)), _p(_f32(g_proj)), _p(_f32(g_vp)), _p(vp7), _p(_f32(fov)), _i(V), _i(H), _i(W),
+                                       ctypes.c_float(zn), ctypes.c_float(zf), _p(gp), _p(gf))
+    return gp, gf

@@ -66,6 +66,13 @@ def main():
     vp = torch.tensor(view @ proj)[None]
     planes = utils.viewproj_to_frustumplane(vp)
     out.update(cam_proj=proj.astype(np.float32), cam_view=view.astype(np.float32), cam_qvec=qvec, cam_tvec=tvec, cam_planes=planes.numpy())
+    # square-pixel camera (fy == fx): the configuration create_viewproj (GR/compact.cu:54-55) can express from one fov parameter
+    cam_sq = data.PinHoleCameraInfo(1, 640, 360, np.array([500.0, 500.0, 320.0, 180.0]))
+    proj_sq = cam_sq.get_project_matrix()
+    planes_sq = utils.viewproj_to_frustumplane(torch.tensor(view @ proj_sq)[None])
+    out.update(camsq_proj=proj_sq.astype(np.float32), camsq_intr=np.asarray(cam_sq.intr_params, np.float32).reshape(1),
+               camsq_extr=frame.extr_params.astype(np.float32), camsq_viewproj=(view @ proj_sq).astype(np.float32),
+               camsq_planes=planes_sq.numpy())
 
     # --- frustum culling of AABBs (litegs/utils/__init__.py:109-136) --------------------------
     M = 300

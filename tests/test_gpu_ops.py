@@ -337,3 +337,37 @@ def test_radix_sort_device_bounded_prefix(F):
     check(L.lg_tile_range_bounded(out_k.data_ptr(), 1, n, n_dev.data_ptr(), ntiles, tr.data_ptr(), s), "range")
     from oracle import oracle as O
     assert np.array_equal(host(tr), O.tile_range(keys[:live][order][None], ntiles))
+
+
+@pytest.mark.parametrize("V,W,H", [(1, 64, 64), (7, 1920, 1080), (300, 128, 64)])
+def test_create_viewproj(F, oracle, V, W, H):
+    """Learnable-camera matrices and their backward (GR/compact.cu:17-316), incl. the ordered fov-gradient sum for V > 256 lanes."""
+    rng = np.random.default_rng(V)
+    p7 = rng.standard_normal((V, 7)).astype(np.float32)
+    p7[:, :4] *= rng.uniform(0.5, 2.0, (V, 1)).astype(np.float32)           # non-unit quaternions: same sphere projection as the reference
+    fov = np.array([1.7], np.float32)
+    outs = F.create_viewproj_forward(dev(p7), dev(fov), H, W, 0.01, 5000.0)
+    refs = oracle.create_viewproj_forward(p7, fov, H, W, 0.01, 5000.0)
+    for o, r in zip(outs, refs):
+        assert_close(host(o), r, 1e-6, normalize=True)
+    gv, gp, gvp = (rng.standard_normal((V, 4, 4)).astype(np.float32) for _ in range(3))
+    g7, gf = F.create_viewproj_backward(dev(gv), dev(gp), dev(gvp), dev(p7), dev(fov), H, W, 0.01, 5000.0)
+    r7, rf = oracle.create_viewproj_backward(gv, gp, gvp, p7, fov, H, W, 0.01, 5000.0)
+    assert_close(host(g7), r7, 1e-5, normalize=True)
+    assert_close(host(gf), rf, 1e-5, normalize=True)
+
+
+def test_create_viewproj_autograd_wrapper(oracle):
+    from litegs_amd.wrapper import CreateViewProj
+    rng = np.random.default_rng(0)
+    p7 = rng.standard_normal((3, 7)).astype(np.float32)
+    fov = np.array([1.2], np.float32)
+    tp, tf = dev(p7).requires_grad_(True), dev(fov).requires_grad_(True)
+    view, proj, vp, planes = CreateViewProj.apply(tp, tf, 48, 96, 0.01, 100.0)
+    assert not planes.requires_grad
+    gvp = rng.standard_normal((3, 4, 4)).astype(np.float32)
+    (vp * dev(gvp)).sum().backward()
+    z = np.zeros((3, 4, 4), np.float32)
+    r7, rf = oracle.create_viewproj_backward(z, z, gvp, p7, fov, 48, 96, 0.01, 100.0)
+    assert_close(host(tp.grad), r7, 1e-5, normalize=True)
+    assert_close(host(tf.grad), rf, 1e-5, normalize=True)

@@ -150,3 +150,56 @@ def test_activation_vs_torch(oracle):
     np.testing.assert_allclose(d_rot, rot.grad.numpy(), rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(d_pos, g[0][:3], atol=0)
     np.testing.assert_allclose(d_opa, g[4] * torch.sigmoid(opa).detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------- learnable cameras
+def _torch_viewproj(p7, fov, H, W, zn, zf):
+    q = p7[:, :4] / torch.sqrt((p7[:, :4] ** 2).sum(1, keepdim=True) + 1e-12)
+    r, x, y, z = q.unbind(1)
+    one, zero = torch.ones_like(r), torch.zeros_like(r)
+    view = torch.stack([
+        torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y + r * z), 2 * (x * z - r * y), zero], 1),
+        torch.stack([2 * (x * y - r * z), 1 - 2 * (x * x + z * z), 2 * (y * z + r * x), zero], 1),
+        torch.stack([2 * (x * z + r * y), 2 * (y * z - r * x), 1 - 2 * (x * x + y * y), zero], 1),
+        torch.stack([p7[:, 4], p7[:, 5], p7[:, 6], one], 1)], 1)
+    f = fov[0]
+    proj = torch.zeros((4, 4), dtype=p7.dtype)
+    proj = torch.stack([torch.stack([f, f * 0, f * 0, f * 0]), torch.stack([f * 0, f * W / H, f * 0, f * 0]),
+                        torch.tensor([0, 0, zf / (zf - zn), 1.0], dtype=p7.dtype), torch.tensor([0, 0, -zf * zn / (zf - zn), 0], dtype=p7.dtype)])
+    proj = proj[None].expand(p7.shape[0], 4, 4)
+    return view, proj, view @ proj
+
+
+@pytest.mark.parametrize("W,H", [(64, 64), (128, 64)])
+def test_create_viewproj_backward_matches_autograd(oracle, W, H):
+    """Integer aspect ratios only: for W/H non-integer the reference's fov gradient uses int division (compact.cu:268),
+    covered by test_create_viewproj_backward_integer_aspect_quirk."""
+    rng = np.random.default_rng(5)
+    V = 5
+    p7 = rng.standard_normal((V, 7)).astype(np.float32)
+    p7[:, :4] /= np.linalg.norm(p7[:, :4], axis=1, keepdims=True)          # unit quaternions: reference drops the 1/|q| factor
+    fov = np.array([1.3], np.float32)
+    gv, gp, gvp = (rng.standard_normal((V, 4, 4)).astype(np.float32) for _ in range(3))
+    view, proj, vp, planes = oracle.create_viewproj_forward(p7, fov, H, W, 0.01, 100.0)
+    tp7, tfov = torch.tensor(p7, dtype=torch.float64, requires_grad=True), torch.tensor(fov, dtype=torch.float64, requires_grad=True)
+    tview, tproj, tvp = _torch_viewproj(tp7, tfov, H, W, 0.01, 100.0)
+    np.testing.assert_allclose(view, tview.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(proj, tproj.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(vp, tvp.detach().numpy(), rtol=1e-5, atol=1e-5)
+    loss = (tview * torch.tensor(gv)).sum() + (tproj * torch.tensor(gp)).sum() + (tvp * torch.tensor(gvp)).sum()
+    loss.backward()
+    g7, gf = oracle.create_viewproj_backward(gv, gp, gvp, p7, fov, H, W, 0.01, 100.0)
+    np.testing.assert_allclose(g7, tp7.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gf, tfov.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_create_viewproj_backward_integer_aspect_quirk(oracle):
+    """1920x1080: forward uses 16/9 for proj[1][1], backward multiplies its gradient by int(1920/1080) == 1."""
+    p7 = np.array([[1, 0, 0, 0, 0, 0, 0]], np.float32)
+    fov = np.array([1.0], np.float32)
+    z = np.zeros((1, 4, 4), np.float32)
+    gp = z.copy(); gp[0, 1, 1] = 1.0
+    view, proj, vp, planes = oracle.create_viewproj_forward(p7, fov, 1080, 1920, 0.01, 100.0)
+    assert abs(proj[0, 1, 1] - 1920 / 1080) < 1e-6
+    _, gf = oracle.create_viewproj_backward(z, gp, z, p7, fov, 1080, 1920, 0.01, 100.0)
+    assert gf[0] == 1.0
