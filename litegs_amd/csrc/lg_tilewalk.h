@@ -103,8 +103,8 @@ __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int
     return count;
 }
 
-// fminf/fmaxf above must behave like the oracle's (a<b?a:b): identical for non-NaN operands, and a NaN
-// intersection only arises for degenerate ellipses that the visibility test already rejects.
+// fminf/fmaxf above drop a NaN operand (v_min_f32 / CUDA min()): a cut taken exactly on the ellipse's extreme line can have a
+// slightly negative discriminant (sqrt -> NaN) and the slice then uses the other line's intersection, as in the reference.
 
 
 // visibility test + exact tile count of one splat (reference: GR/binning.cu:310-373)

@@ -2,22 +2,27 @@
 // The reference takes this from the un-vendored submodule kemchenj/fused-ssim (.gitmodules:1-4): arithmetic
 // is not pinned by the reference tree; formula assumed (see litegs_amd/loss.py):
 //   loss = (1-lam) * mean|x-y| + lam * (1 - mean SSIM),  11x11 Gaussian window sigma 1.5, zero "same" padding.
-// Design: one 256-thread workgroup per 16x16 output tile per channel; the 26x26 halo of x and y is staged in
+// Design: one 256-thread workgroup per 32x32 output tile per channel; the 42x42 halo of x and y is staged in
 // LDS once (coalesced), the separable 11-tap blur of the five moments (x, y, x^2, y^2, xy) runs LDS->LDS
-// (horizontal) then LDS->registers (vertical).  The forward also emits the three partial-derivative maps
+// (horizontal, 8-output register sliding window) then LDS->registers (vertical, 4-output sliding window).  The forward also emits the three partial-derivative maps
 // (dS/dmu1, dS/dE[x^2], dS/dE[xy]) so the backward is a second separable blur of three maps.
 // HBM traffic: forward 8 B in + 12 B out, backward 20 B in + 4 B out per pixel-channel -- bandwidth bound.
 // Loss partial sums are written per workgroup and reduced in a fixed order (deterministic scalar).
 #include "lg_common.h"
 
-#define TS 16
+#define TS 32                   // output tile edge
 #define HALO 5
-#define TIN (TS + 2 * HALO)     // 26
+#define TIN (TS + 2 * HALO)     // 42
+#define HSEG 8                  // horizontal pass: outputs per work item (one row segment)
+#define VSEG 4                  // vertical pass: outputs per thread (one column strip); TS*TS/VSEG == 256 threads
 
 __constant__ float c_gauss[11] = { 0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f, 0.10936068743467331f,
                                    0.21300552785396576f, 0.26601171493530273f, 0.21300552785396576f, 0.10936068743467331f,
                                    0.036000773310661316f, 0.0075987582094967365f, 0.001028380123898387f };
 
+// Sliding-window separable blur: a work item that produces SEG consecutive outputs reads SEG+10 inputs once into registers and
+// feeds each into the (up to 11) accumulators it contributes to, so the LDS read count per output drops from 11 to (SEG+10)/SEG.
+// Tap order per output is t = 0..10, as in a plain 11-tap loop.
 __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W,
                                                               float* __restrict__ dmaps /*[3][B*C][H][W]*/, float* __restrict__ partial /*[blocks][2]*/)
 {
@@ -38,51 +43,79 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
         sy[r][c] = in ? y[(size_t)gy * W + gx] : 0.0f;
     }
     __syncthreads();
-    for (int k = tid; k < TIN * TS; k += 256) {
-        int r = k / TS, c = k % TS;
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    if (tid < TIN * (TS / HSEG)) {                       // 168 row segments
+        const int r = tid / (TS / HSEG), c0 = (tid % (TS / HSEG)) * HSEG;
+        float a[5][HSEG];
 #pragma unroll
-        for (int t = 0; t < 11; t++) {
-            float w = c_gauss[t], xv = sx[r][c + t], yv = sy[r][c + t];
-            a0 += w * xv; a1 += w * yv; a2 += w * xv * xv; a3 += w * yv * yv; a4 += w * xv * yv;
+        for (int j = 0; j < HSEG; j++) { a[0][j] = a[1][j] = a[2][j] = a[3][j] = a[4][j] = 0.0f; }
+#pragma unroll
+        for (int u = 0; u < HSEG + 10; u++) {
+            float xv = sx[r][c0 + u], yv = sy[r][c0 + u];
+            float xx = xv * xv, yy = yv * yv, xy = xv * yv;
+#pragma unroll
+            for (int j = 0; j < HSEG; j++) {
+                const int t = u - j;
+                if (t >= 0 && t <= 10) {
+                    float w = c_gauss[t];
+                    a[0][j] += w * xv; a[1][j] += w * yv; a[2][j] += w * xx; a[3][j] += w * yy; a[4][j] += w * xy;
+                }
+            }
         }
-        sh[0][r][c] = a0; sh[1][r][c] = a1; sh[2][r][c] = a2; sh[3][r][c] = a3; sh[4][r][c] = a4;
+#pragma unroll
+        for (int j = 0; j < HSEG; j++) {
+            sh[0][r][c0 + j] = a[0][j]; sh[1][r][c0 + j] = a[1][j]; sh[2][r][c0 + j] = a[2][j];
+            sh[3][r][c0 + j] = a[3][j]; sh[4][r][c0 + j] = a[4][j];
+        }
     }
     __syncthreads();
-    const int tx = tid % TS, ty = tid / TS;
-    float mu1 = 0, mu2 = 0, ex2 = 0, ey2 = 0, exy = 0;
+    const int tx = tid % TS, r0 = (tid / TS) * VSEG;
+    float m[5][VSEG];
 #pragma unroll
-    for (int t = 0; t < 11; t++) {
-        float w = c_gauss[t];
-        mu1 += w * sh[0][ty + t][tx]; mu2 += w * sh[1][ty + t][tx]; ex2 += w * sh[2][ty + t][tx];
-        ey2 += w * sh[3][ty + t][tx]; exy += w * sh[4][ty + t][tx];
+    for (int j = 0; j < VSEG; j++) { m[0][j] = m[1][j] = m[2][j] = m[3][j] = m[4][j] = 0.0f; }
+#pragma unroll
+    for (int u = 0; u < VSEG + 10; u++) {
+        float v0 = sh[0][r0 + u][tx], v1 = sh[1][r0 + u][tx], v2 = sh[2][r0 + u][tx], v3 = sh[3][r0 + u][tx], v4 = sh[4][r0 + u][tx];
+#pragma unroll
+        for (int j = 0; j < VSEG; j++) {
+            const int t = u - j;
+            if (t >= 0 && t <= 10) {
+                float w = c_gauss[t];
+                m[0][j] += w * v0; m[1][j] += w * v1; m[2][j] += w * v2; m[3][j] += w * v3; m[4][j] += w * v4;
+            }
+        }
     }
-    const int gx = bx + tx, gy = by + ty;
-    float s_val = 0.0f, l1 = 0.0f;
-    if (gx < W && gy < H) {
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        float s11 = ex2 - mu1 * mu1, s22 = ey2 - mu2 * mu2, s12 = exy - mu1 * mu2;
-        float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * s12 + C2;
-        float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
-        float inv = 1.0f / (B1 * B2);
-        s_val = A1 * A2 * inv;
-        // partial derivatives of S wrt the three blurred moments that depend on x
-        float dA = 2.0f * mu2 * A2 - 2.0f * mu2 * A1;                 // d(A1*A2)/dmu1
-        float dB = 2.0f * mu1 * B2 - 2.0f * mu1 * B1;                 // d(B1*B2)/dmu1
-        float dmu1 = (dA - s_val * dB) * inv;
-        float dex2 = -s_val / B2;                                      // d/dE[x^2] : only B2
-        float dexy = 2.0f * A1 * inv;                                  // d/dE[xy]  : only A2
-        size_t o = (size_t)gy * W + gx;
-        size_t stride = (size_t)gridDim.z * plane;
-        dmaps[plane_id * plane + o] = dmu1;
-        dmaps[stride + plane_id * plane + o] = dex2;
-        dmaps[2 * stride + plane_id * plane + o] = dexy;
-        l1 = fabsf(sx[ty + HALO][tx + HALO] - sy[ty + HALO][tx + HALO]);
+    const int gx = bx + tx;
+    float s_sum = 0.0f, l1_sum = 0.0f;
+    const size_t stride = (size_t)gridDim.z * plane;
+#pragma unroll
+    for (int j = 0; j < VSEG; j++) {
+        const int gy = by + r0 + j;
+        if (gx < W && gy < H) {
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            float mu1 = m[0][j], mu2 = m[1][j], ex2 = m[2][j], ey2 = m[3][j], exy = m[4][j];
+            float s11 = ex2 - mu1 * mu1, s22 = ey2 - mu2 * mu2, s12 = exy - mu1 * mu2;
+            float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * s12 + C2;
+            float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+            float inv = 1.0f / (B1 * B2);
+            float s_val = A1 * A2 * inv;
+            // partial derivatives of S wrt the three blurred moments that depend on x
+            float dA = 2.0f * mu2 * A2 - 2.0f * mu2 * A1;                 // d(A1*A2)/dmu1
+            float dB = 2.0f * mu1 * B2 - 2.0f * mu1 * B1;                 // d(B1*B2)/dmu1
+            float dmu1 = (dA - s_val * dB) * inv;
+            float dex2 = -s_val / B2;                                      // d/dE[x^2] : only B2
+            float dexy = 2.0f * A1 * inv;                                  // d/dE[xy]  : only A2
+            size_t o = plane_id * plane + (size_t)gy * W + gx;
+            dmaps[o] = dmu1;
+            dmaps[stride + o] = dex2;
+            dmaps[2 * stride + o] = dexy;
+            s_sum += s_val;
+            l1_sum += fabsf(sx[r0 + j + HALO][tx + HALO] - sy[r0 + j + HALO][tx + HALO]);
+        }
     }
     // block reduce (fixed order)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s_val += __shfl_down(s_val, off); l1 += __shfl_down(l1, off); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s_val; red[1][tid >> 6] = l1; }
+    for (int off = 32; off > 0; off >>= 1) { s_sum += __shfl_down(s_sum, off); l1_sum += __shfl_down(l1_sum, off); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s_sum; red[1][tid >> 6] = l1_sum; }
     __syncthreads();
     if (tid == 0) {
         size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -147,32 +180,50 @@ __global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __re
         sm[2][r][c] = in ? dmaps[2 * stride + o] : 0.0f;
     }
     __syncthreads();
-    for (int k = tid; k < TIN * TS; k += 256) {
-        int r = k / TS, c = k % TS;
-        float a0 = 0, a1 = 0, a2 = 0;
+    if (tid < TIN * (TS / HSEG)) {
+        const int r = tid / (TS / HSEG), c0 = (tid % (TS / HSEG)) * HSEG;
+        float a[3][HSEG];
 #pragma unroll
-        for (int t = 0; t < 11; t++) {
-            float w = c_gauss[t];
-            a0 += w * sm[0][r][c + t]; a1 += w * sm[1][r][c + t]; a2 += w * sm[2][r][c + t];
+        for (int j = 0; j < HSEG; j++) { a[0][j] = a[1][j] = a[2][j] = 0.0f; }
+#pragma unroll
+        for (int u = 0; u < HSEG + 10; u++) {
+            float v0 = sm[0][r][c0 + u], v1 = sm[1][r][c0 + u], v2 = sm[2][r][c0 + u];
+#pragma unroll
+            for (int j = 0; j < HSEG; j++) {
+                const int t = u - j;
+                if (t >= 0 && t <= 10) { float w = c_gauss[t]; a[0][j] += w * v0; a[1][j] += w * v1; a[2][j] += w * v2; }
+            }
         }
-        sh[0][r][c] = a0; sh[1][r][c] = a1; sh[2][r][c] = a2;
+#pragma unroll
+        for (int j = 0; j < HSEG; j++) { sh[0][r][c0 + j] = a[0][j]; sh[1][r][c0 + j] = a[1][j]; sh[2][r][c0 + j] = a[2][j]; }
     }
     __syncthreads();
-    const int tx = tid % TS, ty = tid / TS;
-    const int gx = bx + tx, gy = by + ty;
-    if (gx >= W || gy >= H) return;
-    float b0 = 0, b1 = 0, b2 = 0;
+    const int tx = tid % TS, r0 = (tid / TS) * VSEG;
+    float b[3][VSEG];
 #pragma unroll
-    for (int t = 0; t < 11; t++) {
-        float w = c_gauss[t];
-        b0 += w * sh[0][ty + t][tx]; b1 += w * sh[1][ty + t][tx]; b2 += w * sh[2][ty + t][tx];
+    for (int j = 0; j < VSEG; j++) { b[0][j] = b[1][j] = b[2][j] = 0.0f; }
+#pragma unroll
+    for (int u = 0; u < VSEG + 10; u++) {
+        float v0 = sh[0][r0 + u][tx], v1 = sh[1][r0 + u][tx], v2 = sh[2][r0 + u][tx];
+#pragma unroll
+        for (int j = 0; j < VSEG; j++) {
+            const int t = u - j;
+            if (t >= 0 && t <= 10) { float w = c_gauss[t]; b[0][j] += w * v0; b[1][j] += w * v1; b[2][j] += w * v2; }
+        }
     }
-    size_t o = plane_id * plane + (size_t)gy * W + gx;
-    float xv = img[o], yv = gt[o];
-    float g = grad_out ? grad_out[0] : 1.0f;
-    float d = xv - yv;
-    float sgn = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);
-    d_img[o] = g * (-lam * inv_n * (b0 + 2.0f * xv * b1 + yv * b2) + (1.0f - lam) * inv_n * sgn);
+    const int gx = bx + tx;
+    const float g = grad_out ? grad_out[0] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < VSEG; j++) {
+        const int gy = by + r0 + j;
+        if (gx < W && gy < H) {
+            size_t o = plane_id * plane + (size_t)gy * W + gx;
+            float xv = img[o], yv = gt[o];
+            float d = xv - yv;
+            float sgn = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);
+            d_img[o] = g * (-lam * inv_n * (b[0][j] + 2.0f * xv * b[1][j] + yv * b[2][j]) + (1.0f - lam) * inv_n * sgn);
+        }
+    }
 }
 
 LG_API int lg_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, const float* grad_out, int planes, int H, int W,

@@ -31,8 +31,12 @@
 /* ------------------------------------------------------------------------- */
 /* helpers                                                                    */
 /* ------------------------------------------------------------------------- */
-static inline float fminf_(float a, float b) { return a < b ? a : b; }
-static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
+/* min/max of floats with the device semantics the reference relies on (CUDA min()/fminf, v_min_f32): a NaN operand is
+ * dropped and the numeric one returned.  This matters in the tile walk (speedy_splat.cuh:105,115): an ellipse cut taken
+ * exactly at the ellipse's extreme line can have a discriminant of -1e-7 -> sqrt = NaN, and the slice must then fall back
+ * on the other line's intersection, as it does on the GPU. */
+static inline float fminf_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+static inline float fmaxf_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 

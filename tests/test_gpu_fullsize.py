@@ -1,0 +1,100 @@
+"""Parity at BASELINE.json's full sizes (configs[1] 500k @1080p, configs[2] 3M @1080p): the HIP path against the CPU oracle on
+the same seeded cloud and camera -- the C oracle renders 3M Gaussians @1080p in seconds on the host cores -- plus
+size-independent invariants of the binning stage (sorted keys, tile ranges partition the instance list, exact counts)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, case, oracle_forward
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name):
+    from litegs_amd import render as R
+    c = case(name)
+    params = [torch.nn.Parameter(torch.from_numpy(p).cuda()) for p in c["params"]]
+    view, proj, planes = [torch.from_numpy(x).cuda() for x in (c["view"], c["proj"], c["planes"])]
+    with torch.no_grad():
+        origin, extend = R.get_cluster_AABB(params[0], params[1].exp(), torch.nn.functional.normalize(params[2], dim=0))
+    return c, params, view, proj, planes, origin, extend
+
+
+@pytest.mark.parametrize("name", ["500k_1080p", "3m_1080p"])
+def test_fullsize_render_forward_backward_matches_oracle(oracle, name):
+    from litegs_amd import fast
+    c, params, view, proj, planes, origin, extend = _setup(name)
+    res = oracle_forward(name)
+    H, W = c["H"], c["W"]
+    rd = fast.FusedRenderer(1, H, W)
+    cam = fast.CameraFrame(view, proj, planes, 0)
+    rng = np.random.default_rng(4)
+    w_host = rng.standard_normal((1, 3, H, W)).astype(np.float32)
+    w = torch.from_numpy(w_host).cuda()
+    img, vis_id, vis_num = rd.render(cam, origin, extend, *params, c["degree"])
+    (img * w).sum().backward()
+    torch.cuda.synchronize()
+    # integer work: bit exact
+    assert int(vis_num.item()) == res.nvis
+    assert np.array_equal(vis_id.cpu().numpy()[:res.nvis], res.visible_chunkid)
+    # The tile count is an integer function of FLOAT inputs computed upstream (exp/normalize on the GPU vs libm on the host: <= 1 ulp
+    # apart), so a splat whose ellipse grazes a tile boundary may gain or lose one tile.  Given identical inputs the count is bit exact
+    # (test_fullsize_binning_bit_exact_3m below); end to end it is allowed to move by 2e-6 of the instances.
+    assert abs(int(rd.fb_total[0]) - res.n_instances) <= max(2, int(2e-6 * res.n_instances)), (int(rd.fb_total[0]), res.n_instances)
+    # image, 1e-4 (north_star), with the bounded allowance for threshold flips documented in tests/util.py
+    ref_img = np.clip(res.img[..., :H, :W], 0, 1)
+    assert_close(img.detach().cpu().numpy(), ref_img, flip_frac=5e-5, name="img")
+    d_img = np.zeros_like(res.img)
+    inside = (res.img[..., :H, :W] >= 0) & (res.img[..., :H, :W] <= 1)
+    d_img[..., :H, :W] = w_host * inside
+    (grads, _) = oracle.render_backward(res, c["params"], c["view"], c["proj"], d_img, H, W, c["degree"])
+    for p, g_ref, nm in zip(params, grads, ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]):
+        got = p.grad.compacted_values.cpu().numpy()
+        got = got.reshape(g_ref.shape[:-2] + (-1, g_ref.shape[-1]))[..., :res.nvis, :]
+        assert_close(got.reshape(g_ref.shape), g_ref, atol=1e-4, flip_frac=1e-3, flip_atol=5e-2, normalize=True, name=f"grad.{nm}")
+
+
+def test_fullsize_operator_path_500k(oracle):
+    """configs[1] through the litegs_fused operator surface (render_preprocess + render + autograd)."""
+    from litegs_amd import render as R
+    name = "500k_1080p"
+    c, params, view, proj, planes, origin, extend = _setup(name)
+    res = oracle_forward(name)
+    H, W = c["H"], c["W"]
+    pp = R.PipelineParams()
+    vis_id, vis_num, xyz, scale, rot, color, opacity = R.render_preprocess(origin, extend, planes, view, *params, None, None, pp, c["degree"])
+    img, trans, depth, normal, prim_vis = R.render(view, proj, xyz, scale, rot, color, opacity, vis_num * pp.cluster_size, None, None,
+                                                   c["degree"], (H, W), pp)
+    assert int(vis_num.item()) == res.nvis
+    assert int((prim_vis > 0).sum().item()) == int((res.alloc > 0).sum())
+    assert_close(img.detach().cpu().numpy(), np.clip(res.img[..., :H, :W], 0, 1), flip_frac=5e-5, name="img")
+    img.sum().backward()
+    assert all(torch.isfinite(p.grad.compacted_values).all() for p in params)
+
+
+def test_fullsize_binning_bit_exact_3m(oracle):
+    """Tile keys, the stable (tile, depth) order and the tile ranges at 3M @1080p: bit for bit against the oracle's tables, plus the
+    size-independent properties (sorted keys, ranges partition [0, L), every splat emitted exactly allocate_size times)."""
+    from litegs_amd import fused as F
+    name = "3m_1080p"
+    c = case(name)
+    res = oracle_forward(name)
+    H, W = c["H"], c["W"]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    op = res.act[4]
+    vd = np.ascontiguousarray(res.view_pos[:, 2, :])
+    lu, rd, al = F.get_allocate_size(dev(res.ndc), dev(vd), dev(res.inv_cov), dev(op), H, W, 8, 16, None)
+    assert np.array_equal(al.cpu().numpy(), res.alloc)
+    ks, vs = F.create_table(dev(res.ndc), dev(res.inv_cov), dev(op), dev(res.prefix), dev(res.depth_sorted_index), None, None, H, W, 8, 16)
+    ks_h, vs_h = ks.cpu().numpy(), vs.cpu().numpy()
+    assert np.array_equal(ks_h, res.sorted_tile)
+    assert np.array_equal(vs_h, res.sorted_point)
+    L = res.n_instances
+    assert ks_h.shape[1] == L and np.all(np.diff(ks_h[0].astype(np.int64)) >= 0)
+    assert np.array_equal(np.bincount(vs_h[0], minlength=res.alloc.shape[1]), res.alloc[0]), "each splat appears once per touched tile"
+    ntiles = ((H + 7) // 8) * ((W + 15) // 16)
+    tr = F.tileRange(ks, ntiles).cpu().numpy()
+    assert np.array_equal(tr, res.tile_start)
+    starts = tr[0][1:ntiles + 1]
+    occupied = starts >= 0
+    assert tr[0][ntiles + 1] == L and np.all(np.diff(starts[occupied]) > 0)

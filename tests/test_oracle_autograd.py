@@ -203,3 +203,16 @@ def test_create_viewproj_backward_integer_aspect_quirk(oracle):
     assert abs(proj[0, 1, 1] - 1920 / 1080) < 1e-6
     _, gf = oracle.create_viewproj_backward(z, gp, z, p7, fov, 1080, 1920, 0.01, 100.0)
     assert gf[0] == 1.0
+
+
+def test_tile_walk_drops_nan_cuts(oracle):
+    """Two splats from the 3M @1080p case whose ellipse cut on the extreme tile line has discriminant ~ -1e-7 (sqrt -> NaN).
+    The reference's device min()/max() drop the NaN operand (speedy_splat.cuh:105,115); a plain (a<b?a:b) would lose tiles."""
+    ndc = np.array([[[-0.2990493178367615, 0.30606648325920105], [0.1544468104839325, 0.017400385811924934],
+                     [0.9985971450805664, 0.9981240630149841], [1.0, 1.0]]], np.float32)
+    inv = np.array([[[[0.05738087370991707, 0.013648195192217827], [0.06315372884273529, 0.016611842438578606]],
+                     [[0.06315372884273529, 0.016611842438578606], [0.17696401476860046, 0.08646836876869202]]]], np.float32)
+    op = np.array([[0.27023929357528687, 0.23289351165294647]], np.float32)
+    vd = np.array([[7.118446350097656, 5.324782848358154]], np.float32)
+    lu, rd, al = oracle.get_allocate_size(ndc, vd, inv, op, 1080, 1920, 8, 16)
+    assert al.tolist() == [[5, 13]]

@@ -44,6 +44,8 @@ def case(name: str = "small", seed: int = 0):
         n, W, H, f = S.CONFIGS["10k_400"]
     elif name == "pad":          # image size not a multiple of the tile: exercises padded tiles
         n, W, H, f = 3000, 250, 141, 260.0
+    elif name in S.CONFIGS:      # BASELINE.json sizes (500k_1080p, 3m_1080p): full-size parity, GPU tests only
+        n, W, H, f = S.CONFIGS[name]
     else:
         raise KeyError(name)
     params = S.make_scene(n, seed=seed)
