@@ -526,14 +526,163 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-launch radix pass ("onesweep"): the per-workgroup digit counts are chained through a status table with
+// decoupled look-back instead of a histogram launch + a scan launch per pass.  Workgroups take a ticket (so a workgroup's
+// logical predecessors have all started), rank their 4096 keys exactly like radix_scatter_kernel, publish their 256 digit
+// counts (flag AGG), thread d then walks back over the predecessors' words for digit d until it meets an inclusive prefix
+// (flag INC), publishes its own inclusive prefix and the tile is streamed out.  One status word carries flag and value, so
+// no ordering between separate flag/value stores is needed.  status[] and ticket[] must be zero on entry.
+// ---------------------------------------------------------------------------------------------
+#define ST_AGG 0x40000000u
+#define ST_INC 0x80000000u
+#define ST_VAL 0x3fffffffu
+
+__global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                             const int* __restrict__ totals /*[RADIX] of this pass*/,
+                                                             uint32_t* __restrict__ status /*[ntiles][RADIX], zero*/, int* __restrict__ ticket,
+                                                             long long n, const int* __restrict__ n_dev, int shift, uint32_t mask)
+{
+    __shared__ uint32_t lds_k[SORT_TILE];
+    __shared__ uint32_t lds_v[SORT_TILE];
+    __shared__ int wave_cnt[2][TPB / 64][RADIX];
+    __shared__ int digit_run[RADIX];          // running count per digit, then exclusive local base
+    __shared__ int global_base[RADIX];
+    __shared__ int wsum[TPB / 64];
+    __shared__ int bid_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    n = bounded_n(n, n_dev);
+    if (tid == 0) bid_s = atomicAdd(ticket, 1);
+    digit_run[tid] = 0;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; w++) { wave_cnt[0][w][tid] = 0; wave_cnt[1][w][tid] = 0; }
+    __syncthreads();
+    const int bid = bid_s;
+    const long long base = (long long)bid * SORT_TILE;
+    if (base >= n) return;
+    const int cnt_tile = (int)((n - base) < SORT_TILE ? (n - base) : SORT_TILE);
+    // digit base = exclusive scan over digits of the global totals (TPB == RADIX)
+    {
+        const int total = totals[tid];
+        int inc = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int nb = __shfl_up(inc, o);
+            if (lane >= o) inc += nb;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int wb0 = 0;
+        for (int w = 0; w < wave; w++) wb0 += wsum[w];
+        global_base[tid] = wb0 + inc - total;
+        __syncthreads();
+    }
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
+    int lrank[SORT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        const int e = j * TPB + tid;
+        const bool ok = e < cnt_tile;
+        key[j] = ok ? keys_in[base + e] : 0u;
+        val[j] = ok ? vals_in[base + e] : 0u;
+    }
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        const int cur = j & 1;
+        const bool ok = (j * TPB + tid) < cnt_tile;
+        const uint32_t d = (key[j] >> shift) & mask;
+        unsigned long long peers = __ballot(ok);
+#pragma unroll
+        for (int bit = 0; bit < RADIX_BITS; bit++) {
+            const bool set = (d >> bit) & 1u;
+            unsigned long long bal = __ballot(set);
+            peers &= set ? bal : ~bal;
+        }
+        const int rank = __popcll(peers & lt_mask);
+        if (ok && rank == 0) wave_cnt[cur][wave][d] = __popcll(peers);
+        __syncthreads();
+        int off = digit_run[d] + rank;
+        for (int w = 0; w < wave; w++) off += wave_cnt[cur][w][d];
+        lrank[j] = off;
+        __syncthreads();
+        {
+            int add = 0;
+#pragma unroll
+            for (int w = 0; w < TPB / 64; w++) { add += wave_cnt[cur][w][tid]; wave_cnt[cur][w][tid] = 0; }
+            digit_run[tid] += add;
+        }
+    }
+    __syncthreads();
+    const int dcount = digit_run[tid];
+    // publish this workgroup's count of digit `tid`, then look back
+    uint32_t* my = status + (size_t)bid * RADIX + tid;
+    if (bid == 0) {
+        __hip_atomic_store(my, ST_INC | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(my, ST_AGG | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        for (int b = bid - 1; b >= 0; b--) {
+            const uint32_t* pw = status + (size_t)b * RADIX + tid;
+            uint32_t v;
+            while (((v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & (ST_AGG | ST_INC)) == 0u)
+                __builtin_amdgcn_s_sleep(1);
+            excl += v & ST_VAL;
+            if (v & ST_INC) break;
+        }
+        __hip_atomic_store(my, ST_INC | (excl + (uint32_t)dcount), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        global_base[tid] += (int)excl;
+    }
+    // exclusive scan of the per-digit tile counts -> local base
+    int incl = dcount;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int nb = __shfl_up(incl, o);
+        if (lane >= o) incl += nb;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wb = 0;
+    for (int w = 0; w < wave; w++) wb += wsum[w];
+    const int lbase = wb + incl - dcount;
+    __syncthreads();
+    digit_run[tid] = lbase;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        if ((j * TPB + tid) < cnt_tile) {
+            const uint32_t d = (key[j] >> shift) & mask;
+            const int pos = digit_run[d] + lrank[j];
+            lds_k[pos] = key[j];
+            lds_v[pos] = val[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        const int p = j * TPB + tid;
+        if (p < cnt_tile) {
+            const uint32_t k = lds_k[p];
+            const uint32_t d = (k >> shift) & mask;
+            const int g = global_base[d] + (p - digit_run[d]);
+            keys_out[g] = k;
+            vals_out[g] = lds_v[p];
+        }
+    }
+}
+
 LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                                        int begin_bit, int end_bit, void* temp, long long temp_bytes, void* stream);
 
+// temp layout: totals[SORT_MAX_PASSES][RADIX] | ticket[SORT_MAX_PASSES] (+pad to 64 ints) | table
+// table = per-pass histogram [RADIX][ntiles] (small sorts) or look-back status [SORT_MAX_PASSES][ntiles][RADIX] (onesweep)
+#define SORT_HEADER_INTS (SORT_MAX_PASSES * RADIX + 64)
 LG_API long long lg_radix_sort_temp_bytes(long long n)
 {
     long long ntiles = (n + SORT_TILE - 1) / SORT_TILE;
     if (ntiles < 1) ntiles = 1;
-    return (long long)sizeof(int) * (SORT_MAX_PASSES * RADIX + (long long)RADIX * ntiles);
+    return (long long)sizeof(int) * (SORT_HEADER_INTS + (long long)SORT_MAX_PASSES * RADIX * ntiles);
 }
 
 LG_API int lg_radix_sort_num_passes(int begin_bit, int end_bit)
@@ -557,17 +706,18 @@ LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint3
 {
     int passes = lg_radix_sort_num_passes(begin_bit, end_bit);
     if (n <= 0 || passes == 0) return 0;
-    if (passes > SORT_MAX_PASSES || n > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (passes > SORT_MAX_PASSES || n > 0x3fffffffLL) return (int)hipErrorInvalidValue;   // look-back status words carry 30-bit counts
     if (temp_bytes < lg_radix_sort_temp_bytes(n)) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
     int* totals = (int*)temp;
-    int* hist = totals + SORT_MAX_PASSES * RADIX;
+    int* ticket = totals + SORT_MAX_PASSES * RADIX;
+    int* table = totals + SORT_HEADER_INTS;
     int last_bits = (end_bit - begin_bit) - (passes - 1) * RADIX_BITS;
     uint32_t last_mask = (1u << last_bits) - 1u;
-    const bool inline_scan = ntiles <= 8;      // measured: beyond a handful of tiles the per-workgroup row scan costs more than the two launches it saves
+    const bool inline_scan = ntiles <= 8;      // tiny sorts: every workgroup scans the raw histogram rows itself (no look-back chain)
     if (!inline_scan) {
-        hipError_t err = hipMemsetAsync(totals, 0, sizeof(int) * SORT_MAX_PASSES * RADIX, s);
+        hipError_t err = hipMemsetAsync(totals, 0, sizeof(int) * (SORT_HEADER_INTS + (size_t)passes * RADIX * ntiles), s);
         if (err != hipSuccess) return (int)err;
         int tot_grid = ntiles < 512 ? ntiles : 512;
         hipLaunchKernelGGL(radix_totals_kernel, dim3(tot_grid), dim3(TPB), 0, s, keys_a, n, n_dev, begin_bit, passes, last_mask, totals);
@@ -576,12 +726,12 @@ LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint3
     for (int p = 0; p < passes; p++) {
         int shift = begin_bit + p * RADIX_BITS;
         uint32_t mask = (p == passes - 1) ? last_mask : (uint32_t)(RADIX - 1);
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, n, n_dev, shift, mask, ntiles, hist);
         if (inline_scan) {
-            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, hist, n, n_dev, shift, mask, ntiles);
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, n, n_dev, shift, mask, ntiles, table);
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, table, n, n_dev, shift, mask, ntiles);
         } else {
-            hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX), dim3(TPB), 0, s, hist, totals + p * RADIX, ntiles);
-            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, hist, n, n_dev, shift, mask, ntiles);
+            hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, totals + p * RADIX,
+                               (uint32_t*)table + (size_t)p * RADIX * ntiles, ticket + p, n, n_dev, shift, mask);
         }
         uint32_t* t;
         t = kin; kin = kout; kout = t;
