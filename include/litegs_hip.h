@@ -116,10 +116,12 @@ int lg_get_allocate_size(const float* ndc, const float* view_z, const float* inv
                          const int* valid_length, int V, int N, int H, int W, int TH, int TW,
                          int32_t* left_up /*[V,2,N] or NULL*/, int32_t* right_down, int32_t* allocate_size /*[V,N]*/,
                          void* stream);                                                                             /* binning.cu:290-440 */
-/* create_table, first half (binning.cu:34-110): keys must be zero-filled; sorted_id int64 (torch.sort) or int32 */
+/* create_table, first half (binning.cu:34-110): keys must be zero-filled; sorted_id int64 (torch.sort) or int32.
+ * temp (lg_duplicate_with_keys_temp_bytes): queue of the splats that touch many tiles, emitted by a second launch. */
+long long lg_duplicate_with_keys_temp_bytes(int V, int N);
 int lg_duplicate_with_keys(const float* ndc, const float* inv_cov2d, const float* opacity, const int32_t* prefix_sum,
                            const void* depth_sorted_id, int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW,
-                           long long table_len, int32_t* keys, int32_t* values, void* stream);
+                           long long table_len, int32_t* keys, int32_t* values, void* temp, long long temp_bytes, void* stream);
 /* create_table, second half: stable LSD radix sort replacing cub::DeviceRadixSort::SortPairs (binning.cu:204-221).
  * Ping-pongs a->b->a...; result is in the b pair when lg_radix_sort_num_passes() is odd, else in the a pair. */
 long long lg_radix_sort_temp_bytes(long long n);
@@ -179,7 +181,7 @@ int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float
                     const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,
                     int do_cull, uint8_t* visibility, int* vis_num, int64_t* vis_ids, int A,
                     void* ws1, long long ws1_bytes, int* host_feedback_vis, int* host_feedback_total, void* stream);
-int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
+int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                     void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
                     float* img, float* trans, short* last, int* frag_count, float* frag_weight, void* stream);
 int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,

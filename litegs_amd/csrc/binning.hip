@@ -8,6 +8,7 @@
 // of 8 bits.  No MFMA: this is byte shuffling.
 #include "lg_common.h"
 #include "lg_tilewalk.h"
+#include "lg_binning_internal.h"
 
 #define TPB 256
 
@@ -71,7 +72,8 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 //  * small splats (<= DUP_SMALL tiles): the owning thread runs the serial AccuTile walk into a compacted LDS
 //    buffer; the workgroup then streams the buffer out (entry -> owner by binary search over 256 offsets), so
 //    global stores are coalesced instead of 64 scattered 4-byte stores per wave instruction;
-//  * big splats (near-camera Gaussians can touch thousands of tiles): the owning WAVE emits them cooperatively:
+//  * big splats (near-camera Gaussians can touch thousands of tiles) are queued and emitted by a second launch whose
+//    persistent waves take one queued splat at a time (57 k of 590 k visible splats hold 39 % of the instances at 3 M):
 //    one lane per tile slice computes that slice's [min_tile_v, max_tile_v) independently (the serial walk's
 //    carried intersections are pure functions of the slice index, see slice_bounds), a wave scan turns the
 //    slice counts into offsets, and the 64 lanes then write the splat's contiguous output range in
@@ -80,6 +82,13 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 #define DUP_SMALL 32
 #define DUP_LDS_ENTRIES (TPB * DUP_SMALL)
 #define DUP_MAX_SLICES 256
+#define SORT_MAX_PASSES_DUP 4
+// Big splats are appended to DUP_NQ sub-queues (group g of 256 depth slots -> sub-queue g % DUP_NQ) with ONE returning atomic
+// per group: returning atomics on a single address serialise at ~8 ns each in L2, and one counter for the whole launch
+// (10 k wave-level appends at 3 M Gaussians) cost 85 us -- more than the rest of the kernel.
+#define DUP_NQ 64
+__host__ __device__ static inline long long dup_queue_cap(long long N) { return ((N + TPB - 1) / TPB + DUP_NQ - 1) / DUP_NQ * TPB; }     // entries per sub-queue
+__host__ __device__ static inline long long dup_queue_ints(long long N) { return DUP_NQ + DUP_NQ * dup_queue_cap(N); }                  // counters | entries
 
 struct WalkFrame {          // per-splat constants of the (u,v) walk, derivable from SplatExtent
     bool isY;
@@ -138,27 +147,96 @@ __device__ __forceinline__ void slice_bounds(const SplatExtent& e, const WalkFra
     max_tile_v = min(f.rect_max_v, max(f.rect_min_v, lg_f2i(ellipse_max / f.BLOCK_V + 1)));
 }
 
-__device__ __forceinline__ float bcast_f(float v, int src) { return __shfl(v, src); }
-__device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src); }
+// ---- helpers shared by the producers that feed the radix sort -------------------------------------------------
+// Radix digit counts of the keys a kernel emits, accumulated in an LDS table h[passes][RADIX] (flushed to the sort's `totals` at
+// the end of the workgroup).  Keys emitted by one wave instruction are often equal in their high digits (neighbouring tiles,
+// similar depths): when the whole wave agrees on a digit, one lane adds the wave's count instead of 64 same-address atomics.
+struct DigitSpec { int begin_bit, passes; uint32_t last_mask; };
 
-template <int TH, int TW, typename IdxT>
-__global__ void __launch_bounds__(TPB) duplicate_with_keys_kernel(const float* __restrict__ ndc, const float* __restrict__ inv_cov,
-                                                                  const float* __restrict__ opacity, const int32_t* __restrict__ prefix,
-                                                                  const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
-                                                                  long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values)
+__device__ __forceinline__ void digit_hist_add(int* __restrict__ h, uint32_t key, bool active, const DigitSpec& ds)
 {
-    __shared__ int2 buf[DUP_LDS_ENTRIES];                 // 64 KiB: compacted (key, idx) of the small splats
+    const unsigned long long m = __ballot(active);
+    if (m == 0ull) return;
+    const int leader = __ffsll((long long)m) - 1;
+    // low digits are effectively random across a wave: plain LDS atomics.  Only the top digit(s) get the wave-uniform shortcut.
+    const int first_uniform = ds.passes >= 3 ? ds.passes - 2 : ds.passes - 1;
+    for (int p = 0; p < ds.passes; p++) {
+        const uint32_t d = (key >> (ds.begin_bit + p * 8)) & ((p == ds.passes - 1) ? ds.last_mask : 255u);
+        if (p < first_uniform) {
+            if (active) atomicAdd(&h[p * 256 + d], 1);
+            continue;
+        }
+        const uint32_t d0 = (uint32_t)__shfl((int)d, leader);
+        if (__ballot(active && d != d0) == 0ull) {
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[p * 256 + d0], __popcll(m));
+        } else if (active) {
+            atomicAdd(&h[p * 256 + d], 1);
+        }
+    }
+}
+
+// "zero duty": a producer kernel clears a later kernel's scratch (look-back status words, counters) on the side, which
+// removes the separate fill launches (each costs ~5 us of dispatch latency on the critical path).
+__device__ __forceinline__ void zero_duty(uint32_t* __restrict__ p, long long words, long long gid, long long nthreads)
+{
+    for (long long i = gid; i < words; i += nthreads) p[i] = 0u;
+}
+
+// The six floats the tile walk needs.  SoA (operator path: separate ndc / inv_cov / opacity tensors, six 4-byte gathers = six
+// cache lines per splat) or the fused executor's 64-byte packed record (one line): at 3 M Gaussians the SoA gathers alone move
+// ~450 MB of cache lines for 14 MB of useful data.
+struct SplatSrc { const float* ndc; const float* inv_cov; const float* opacity; const float4* packed; };
+
+template <bool PACKED>
+__device__ __forceinline__ void load_splat(const SplatSrc& src, size_t b, int N, int idx, float& nx, float& ny, float& a, float& bb,
+                                           float& cc, float& o)
+{
+    if (PACKED) {       // record layout: raster.hip / fused.hip (slot 5 opacity, 9..11 inverse covariance, 13..14 ndc)
+        const float4* r = src.packed + ((size_t)b * N + idx) * 4;
+        const float4 r1 = r[1], r2 = r[2], r3 = r[3];
+        o = r1.y; a = r2.y; bb = r2.z; cc = r2.w; nx = r3.y; ny = r3.z;
+    } else {
+        nx = src.ndc[((size_t)b * 4) * N + idx]; ny = src.ndc[((size_t)b * 4 + 1) * N + idx];
+        a = src.inv_cov[((size_t)b * 4) * N + idx]; bb = src.inv_cov[((size_t)b * 4 + 1) * N + idx]; cc = src.inv_cov[((size_t)b * 4 + 3) * N + idx];
+        o = src.opacity[idx];
+    }
+}
+
+// Kernel 1 of duplicate_with_keys: one thread per depth slot.  Small splats are walked serially into a compacted LDS buffer of
+// keys and streamed out coalesced; big splats (> DUP_SMALL tiles) are only QUEUED for kernel 2.
+template <int TH, int TW, typename IdxT, bool PACKED>
+__global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
+                                                        const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
+                                                        long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
+                                                        int* __restrict__ queue /*[V][N+1]: count, entries*/,
+                                                        int* __restrict__ totals /*nullable [passes][256]*/, DigitSpec ds,
+                                                        uint32_t* __restrict__ zero_ptr, long long zero_words,
+                                                        uint32_t* __restrict__ ones_ptr, long long ones_words, int dbg)
+{
+    __shared__ int32_t buf[DUP_LDS_ENTRIES];              // 32 KiB: compacted keys of the small splats
     __shared__ int t_loff[TPB + 1];                       // per-thread start in buf
     __shared__ int t_goff[TPB];                           // per-thread start in the table
-    __shared__ int w_minv[TPB / 64][DUP_MAX_SLICES];      // per-wave slice scratch for the cooperative path
-    __shared__ int w_off[TPB / 64][DUP_MAX_SLICES + 1];
+    __shared__ int t_idx[TPB];                            // per-thread point id
+    __shared__ int hist[SORT_MAX_PASSES_DUP * 256];
     __shared__ int wsum[TPB / 64];
+    __shared__ int wbig[TPB / 64];
+    __shared__ int qbase_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = blockIdx.x * TPB + tid;
     const int b = blockIdx.y;
+    const long long qcap = dup_queue_cap(N), qints = dup_queue_ints(N);
     const int32_t* pf = prefix + (size_t)b * N;
     int32_t* kout = keys + (size_t)b * table_len;
     int32_t* vout = values + (size_t)b * table_len;
+    {
+        const long long gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, nthreads = (long long)gridDim.x * gridDim.y * TPB;
+        if (zero_ptr) zero_duty(zero_ptr, zero_words, gid, nthreads);
+        if (ones_ptr) for (long long i = gid; i < ones_words; i += nthreads) ones_ptr[i] = 0xffffffffu;      // tile range table: -1 = empty
+    }
+    if (totals) for (int k = tid; k < ds.passes * 256; k += TPB) hist[k] = 0;
+    // persistent workgroups (the digit table is flushed once per workgroup, not once per 256 splats)
+    const int ngroups = (N + TPB - 1) / TPB;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int j = grp * TPB + tid;
 
     long long off = 0;
     int cnt = 0, idx = 0;
@@ -169,14 +247,38 @@ __global__ void __launch_bounds__(TPB) duplicate_with_keys_kernel(const float* _
         long long c = pf[j] - off;
         if (c > 0 && off + c <= table_len) {
             idx = (int)sorted_id[(size_t)b * N + j];
-            float nx = ndc[((size_t)b * 4) * N + idx], ny = ndc[((size_t)b * 4 + 1) * N + idx];
-            float a = inv_cov[((size_t)b * 4) * N + idx], bb = inv_cov[((size_t)b * 4 + 1) * N + idx], cc = inv_cov[((size_t)b * 4 + 3) * N + idx];
-            splat_extent<TH, TW>(nx, ny, a, bb, cc, opacity[idx], H, W, gx, gy, e);
+            float nx, ny, a, bb, cc, o;
+            if (dbg & 16) { nx = 0.001f * (idx & 255); ny = 0.002f * (idx & 127); a = 0.05f; bb = 0.01f; cc = 0.07f; o = 0.5f; }
+            else load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
+            if (!(dbg & 8)) {
+            splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
             if ((e.rmaxy - e.rminy) * (e.rmaxx - e.rminx) > 0) { live = true; cnt = (int)c; }
+            } else { e.a = nx + ny + a + bb + cc + o; if (e.a == 123.0f) live = true; }
+        } else if (c > 0 && off < table_len) {
+            // first splat that does not fit (GR/binning.cu:63 drops it and, prefix being monotone, every later one): the rest of
+            // the table stays key 0 = "no tile"
+            for (long long q = off; q < table_len; q++) kout[q] = 0;
         }
     }
     const bool small = live && cnt <= DUP_SMALL;
     const bool big = live && cnt > DUP_SMALL;
+
+    // ---- big splats: append the slots to this group's sub-queue (one returning atomic per group) ----
+    {
+        const unsigned long long bm = __ballot(big);
+        if (lane == 0) wbig[wave] = __popcll(bm);
+        __syncthreads();
+        if (tid == 0) {
+            const int nbig = wbig[0] + wbig[1] + wbig[2] + wbig[3];
+            qbase_s = nbig ? atomicAdd(queue + (size_t)b * qints + (grp % DUP_NQ), nbig) : 0;
+        }
+        __syncthreads();
+        if (big) {
+            int pos = qbase_s + __popcll(bm & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; w++) pos += wbig[w];
+            queue[(size_t)b * qints + DUP_NQ + (size_t)(grp % DUP_NQ) * qcap + pos] = j;
+        }
+    }
 
     // ---- small splats: exclusive block scan of their counts -> compacted LDS layout ----
     const int scnt = small ? cnt : 0;
@@ -194,115 +296,245 @@ __global__ void __launch_bounds__(TPB) duplicate_with_keys_kernel(const float* _
     const int total_small = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     t_loff[tid] = loff;
     t_goff[tid] = (int)off;
+    t_idx[tid] = idx;
     if (tid == 0) t_loff[TPB] = total_small;
-    if (small) {
-        walk_tiles<TH, TW, true>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf);
-    }
+    if (small && !(dbg & 1)) walk_tiles<TH, TW, true>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf);
     __syncthreads();
-    for (int p = tid; p < total_small; p += TPB) {
-        // owner = last thread t with t_loff[t] <= p  (threads with no small entries have empty ranges)
-        int lo = 0, hi = TPB - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (t_loff[mid] <= p) lo = mid; else hi = mid - 1;
-        }
-        int2 kv = buf[p];
-        int g = t_goff[lo] + (p - t_loff[lo]);
-        kout[g] = kv.x;
-        vout[g] = kv.y;
-    }
-
-    // ---- big splats: wave-cooperative, one splat at a time ----
-    unsigned long long bigmask = __ballot(big);
-    while (bigmask) {
-        const int src = __ffsll((long long)bigmask) - 1;
-        bigmask &= bigmask - 1;
-        SplatExtent s;
-        s.a = bcast_f(e.a, src); s.b = bcast_f(e.b, src); s.c = bcast_f(e.c, src); s.disc = bcast_f(e.disc, src); s.t = bcast_f(e.t, src);
-        s.px = bcast_f(e.px, src); s.py = bcast_f(e.py, src);
-        s.bbox_min_x = bcast_f(e.bbox_min_x, src); s.bbox_min_y = bcast_f(e.bbox_min_y, src);
-        s.bbox_max_x = bcast_f(e.bbox_max_x, src); s.bbox_max_y = bcast_f(e.bbox_max_y, src);
-        s.argmin_x = bcast_f(e.argmin_x, src); s.argmin_y = bcast_f(e.argmin_y, src);
-        s.argmax_x = bcast_f(e.argmax_x, src); s.argmax_y = bcast_f(e.argmax_y, src);
-        s.rminx = bcast_i(e.rminx, src); s.rminy = bcast_i(e.rminy, src); s.rmaxx = bcast_i(e.rmaxx, src); s.rmaxy = bcast_i(e.rmaxy, src);
-        const int sidx = bcast_i(idx, src);
-        const int sgoff = bcast_i((int)off, src);
-        const WalkFrame f = walk_frame<TH, TW>(s);
-        const int nsl = f.rect_max_u - f.rect_min_u;                   // <= min(grid.x, grid.y) slices
-        if (nsl > DUP_MAX_SLICES) {                                    // > 4K-class images: owner lane walks serially
-            if (lane == src) walk_tiles<TH, TW, true>(e, gx, idx, off, kout, vout);
-            continue;
-        }
-        // K = number of leading slices whose upper line is <= bmax_u
-        int K = 0;
-        for (int i0 = 0; i0 < nsl; i0 += 64) {
-            int i = i0 + lane;
-            bool c = (i < nsl) && ((float)(f.rect_min_u + i) * f.BLOCK_U + f.BLOCK_U <= f.bmax_u);
-            K += __popcll(__ballot(c));
-        }
-        int run = 0;
-        for (int i0 = 0; i0 < nsl; i0 += 64) {
-            int i = i0 + lane;
-            int mn = 0, n = 0;
-            if (i < nsl) {
-                int mx;
-                slice_bounds(s, f, i, K, mn, mx);
-                n = mx - mn;
-            }
-            int inc = n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int nb = __shfl_up(inc, o);
-                if (lane >= o) inc += nb;
-            }
-            if (i < nsl && i < DUP_MAX_SLICES) { w_minv[wave][i] = mn; w_off[wave][i] = run + inc - n; }
-            run += __shfl(inc, 63);
-        }
-        const int nsl_c = nsl < DUP_MAX_SLICES ? nsl : DUP_MAX_SLICES;
-        if (lane == 0) w_off[wave][nsl_c] = run;
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        for (int k = lane; k < run; k += 64) {
-            int lo = 0, hi = nsl_c - 1;
+    for (int p0 = 0; p0 < ((dbg & 2) ? 0 : total_small); p0 += TPB) {
+        const int p = p0 + tid;
+        const bool act = p < total_small;
+        int32_t key = 0;
+        if (act) {
+            // owner = last thread t with t_loff[t] <= p  (threads with no small entries have empty ranges)
+            int lo = 0, hi = TPB - 1;
             while (lo < hi) {
                 int mid = (lo + hi + 1) >> 1;
-                if (w_off[wave][mid] <= k) lo = mid; else hi = mid - 1;
+                if (t_loff[mid] <= p) lo = mid; else hi = mid - 1;
             }
-            const int u = f.rect_min_u + lo;
-            const int v = w_minv[wave][lo] + (k - w_off[wave][lo]);
-            const uint32_t key = f.isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
-            kout[sgoff + k] = (int32_t)(key + 1);
-            vout[sgoff + k] = sidx;
+            key = buf[p];
+            const int g = t_goff[lo] + (p - t_loff[lo]);
+            kout[g] = key;
+            vout[g] = t_idx[lo];
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
+    }
+    __syncthreads();                                      // buf / t_* are reused by the next group
+    }
+    if (totals) {
+        __syncthreads();
+        for (int k = tid; k < ds.passes * 256; k += TPB)
+            if (hist[k]) atomicAdd(&totals[k], hist[k]);
     }
 }
 
-LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const float* opacity, const int32_t* prefix,
-                                  const void* sorted_id, int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW,
-                                  long long table_len, int32_t* keys, int32_t* values, void* stream)
+__device__ __forceinline__ float bcast_f(float v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src); }
+
+// Kernel 2: persistent waves drain the queue of big splats, DUP_BATCH at a time: lanes 0..DUP_BATCH-1 each fetch one queued
+// splat and compute its extent (so the dependent loads slot -> point id -> record are paid once per batch, not once per splat),
+// then the wave emits the batch one splat at a time: one lane per tile slice computes that slice's [min_tile_v, max_tile_v)
+// independently (slice_bounds), a wave scan turns the slice counts into offsets and the 64 lanes write the splat's contiguous
+// output range in 256-byte coalesced stores.
+#define DUP_BATCH 16
+template <int TH, int TW, typename IdxT, bool PACKED>
+__global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
+                                                      const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
+                                                      long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
+                                                      const int* __restrict__ queue, int* __restrict__ totals, DigitSpec ds, int dbg)
+{
+    __shared__ int w_minv[TPB / 64][DUP_MAX_SLICES];      // per-wave slice scratch
+    __shared__ int w_off[TPB / 64][DUP_MAX_SLICES + 1];
+    __shared__ int hist[SORT_MAX_PASSES_DUP * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int32_t* pf = prefix + (size_t)b * N;
+    int32_t* kout = keys + (size_t)b * table_len;
+    int32_t* vout = values + (size_t)b * table_len;
+    const long long qcap = dup_queue_cap(N);
+    const int* q = queue + (size_t)b * dup_queue_ints(N);
+    __shared__ int qstart[DUP_NQ + 1];                     // exclusive prefix of the sub-queue lengths
+    if (tid < 64) {
+        const int c = q[tid];
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int nbv = __shfl_up(inc, o);
+            if (lane >= o) inc += nbv;
+        }
+        qstart[tid] = inc - c;
+        if (tid == 63) qstart[64] = inc;
+    }
+    if (totals) for (int k = tid; k < ds.passes * 256; k += TPB) hist[k] = 0;
+    __syncthreads();
+    const int nq = qstart[DUP_NQ];
+    const int nwaves = gridDim.x * (TPB / 64);
+    // entries are dealt round-robin (entry = slot * nwaves + wave): the queues are roughly in depth order and the giant
+    // near-camera splats sit together -- contiguous batches would hand all of them to a few waves
+    const int gw = blockIdx.x * (TPB / 64) + wave;
+    for (int r0 = 0; r0 * nwaves + gw < nq; r0 += DUP_BATCH) {
+        const int left = (nq - gw - r0 * nwaves + nwaves - 1) / nwaves;          // entries of this wave from slot r0 on
+        const int nb = left < DUP_BATCH ? left : DUP_BATCH;
+        SplatExtent e;
+        int my_off = 0, my_idx = 0;
+        if (lane < nb) {
+            const int t = (r0 + lane) * nwaves + gw;               // flat entry -> (sub-queue, position)
+            int lo = 0, hi = DUP_NQ - 1;
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (qstart[mid] <= t) lo = mid; else hi = mid - 1;
+            }
+            const int j = q[DUP_NQ + (size_t)lo * qcap + (t - qstart[lo])];
+            my_off = (j == 0) ? 0 : pf[j - 1];
+            my_idx = (int)sorted_id[(size_t)b * N + j];
+            float nx, ny, a, bb, cc, o;
+            load_splat<PACKED>(src, b, N, my_idx, nx, ny, a, bb, cc, o);
+            splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
+        }
+        for (int srcl = 0; srcl < nb; srcl++) {
+            SplatExtent s;
+            s.a = bcast_f(e.a, srcl); s.b = bcast_f(e.b, srcl); s.c = bcast_f(e.c, srcl); s.disc = bcast_f(e.disc, srcl); s.t = bcast_f(e.t, srcl);
+            s.px = bcast_f(e.px, srcl); s.py = bcast_f(e.py, srcl);
+            s.bbox_min_x = bcast_f(e.bbox_min_x, srcl); s.bbox_min_y = bcast_f(e.bbox_min_y, srcl);
+            s.bbox_max_x = bcast_f(e.bbox_max_x, srcl); s.bbox_max_y = bcast_f(e.bbox_max_y, srcl);
+            s.argmin_x = bcast_f(e.argmin_x, srcl); s.argmin_y = bcast_f(e.argmin_y, srcl);
+            s.argmax_x = bcast_f(e.argmax_x, srcl); s.argmax_y = bcast_f(e.argmax_y, srcl);
+            s.rminx = bcast_i(e.rminx, srcl); s.rminy = bcast_i(e.rminy, srcl); s.rmaxx = bcast_i(e.rmaxx, srcl); s.rmaxy = bcast_i(e.rmaxy, srcl);
+            const int sidx = bcast_i(my_idx, srcl);
+            const int sgoff = bcast_i(my_off, srcl);
+            const WalkFrame f = walk_frame<TH, TW>(s);
+            const int nsl = f.rect_max_u - f.rect_min_u;                   // <= min(grid.x, grid.y) slices
+            if (nsl > DUP_MAX_SLICES) {                                    // > 4K-class images: the owner lane walks serially
+                int c = 0;
+                if (lane == srcl) c = (int)walk_tiles<TH, TW, true>(e, gx, my_idx, my_off, kout, vout);
+                if (totals) {                                              // count what was just written
+                    c = __shfl(c, srcl);
+                    __threadfence();
+                    for (int k0 = 0; k0 < c; k0 += 64) {
+                        const bool act = k0 + lane < c;
+                        const int32_t key = act ? __hip_atomic_load(kout + sgoff + k0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                        digit_hist_add(hist, (uint32_t)key, act, ds);
+                    }
+                }
+                continue;
+            }
+            if (dbg & 64) { if (sidx == -12345) kout[0] = nsl; continue; }
+            // K = number of leading slices whose upper line is <= bmax_u
+            int K = 0;
+            for (int i0 = 0; i0 < nsl; i0 += 64) {
+                int i = i0 + lane;
+                bool c = (i < nsl) && ((float)(f.rect_min_u + i) * f.BLOCK_U + f.BLOCK_U <= f.bmax_u);
+                K += __popcll(__ballot(c));
+            }
+            int run = 0;
+            for (int i0 = 0; i0 < nsl; i0 += 64) {
+                int i = i0 + lane;
+                int mn = 0, n = 0;
+                if (i < nsl) {
+                    int mx;
+                    slice_bounds(s, f, i, K, mn, mx);
+                    n = mx - mn;
+                }
+                int inc = n;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    int nbv = __shfl_up(inc, o);
+                    if (lane >= o) inc += nbv;
+                }
+                if (i < nsl) { w_minv[wave][i] = mn; w_off[wave][i] = run + inc - n; }
+                run += __shfl(inc, 63);
+            }
+            if (lane == 0) w_off[wave][nsl] = run;
+            __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order: no fence (a fence would also wait for the global stores)
+            if (dbg & 32) run = 0;
+            for (int k0 = 0; k0 < run; k0 += 64) {
+                const int k = k0 + lane;
+                const bool act = k < run;
+                int32_t key = 0;
+                if (act) {
+                    int lo = 0, hi = nsl - 1;
+                    while (lo < hi) {
+                        int mid = (lo + hi + 1) >> 1;
+                        if (w_off[wave][mid] <= k) lo = mid; else hi = mid - 1;
+                    }
+                    const int u = f.rect_min_u + lo;
+                    const int v = w_minv[wave][lo] + (k - w_off[wave][lo]);
+                    const uint32_t tk = f.isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
+                    key = (int32_t)(tk + 1);
+                    kout[sgoff + k] = key;
+                    vout[sgoff + k] = sidx;
+                }
+                if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
+            }
+            __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order: no fence (a fence would also wait for the global stores)
+        }
+    }
+    if (totals) {
+        __syncthreads();
+        for (int k = tid; k < ds.passes * 256; k += TPB)
+            if (hist[k]) atomicAdd(&totals[k], hist[k]);
+    }
+}
+
+// queue: int32 [V][dup_queue_ints(N)], the DUP_NQ counters at the head of each view's block must be 0 on entry.  totals (nullable): the tile sort's digit counts, accumulated here.
+int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
+                int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
+                int* queue, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
+                uint32_t* ones_ptr, long long ones_words, void* stream)
 {
     if (N <= 0) return 0;
+    if (packed && sorted_id_is_int64) return (int)hipErrorInvalidValue;     // packed records: fused executor only (int32 order)
     int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
-    dim3 grid(lg_cdiv(N, TPB), V);
+    const int ngroups = lg_cdiv(N, TPB);
+    dim3 grid(ngroups < 1024 ? ngroups : 1024, V);        // persistent workgroups, 256 depth slots at a time
+    dim3 grid_big(1024, V);                               // persistent: 4096 waves drain the queue
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_DUP(A_, B_)                                                                                                              \
-    do {                                                                                                                                \
-        if (sorted_id_is_int64)                                                                                                         \
-            hipLaunchKernelGGL((duplicate_with_keys_kernel<A_, B_, int64_t>), grid, dim3(TPB), 0, s, ndc, inv_cov, opacity, prefix,     \
-                               (const int64_t*)sorted_id, N, H, W, gx, gy, table_len, keys, values);                                    \
-        else                                                                                                                            \
-            hipLaunchKernelGGL((duplicate_with_keys_kernel<A_, B_, int32_t>), grid, dim3(TPB), 0, s, ndc, inv_cov, opacity, prefix,     \
-                               (const int32_t*)sorted_id, N, H, W, gx, gy, table_len, keys, values);                                    \
+    DigitSpec ds = { begin_bit, 0, 0u };
+    if (totals) {
+        ds.passes = (end_bit - begin_bit + 7) / 8;
+        if (ds.passes < 1 || ds.passes > SORT_MAX_PASSES_DUP) return (int)hipErrorInvalidValue;
+        ds.last_mask = (1u << ((end_bit - begin_bit) - (ds.passes - 1) * 8)) - 1u;
+    }
+    SplatSrc src = { ndc, inv_cov, opacity, (const float4*)packed };
+    static int dbg = getenv("LG_DUP_DBG") ? atoi(getenv("LG_DUP_DBG")) : 0;
+#define LAUNCH_DUP(A_, B_, T_, P_)                                                                                                          \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,                \
+                           H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, dbg);                           \
+        if (!(dbg & 4)) hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
+                           N, H, W, gx, gy, table_len, keys, values, (const int*)queue, totals, ds, dbg);                                  \
     } while (0)
-    if (TH == 8 && TW == 16) LAUNCH_DUP(8, 16);
-    else if (TH == 16 && TW == 16) LAUNCH_DUP(16, 16);
-    else if (TH == 12 && TW == 16) LAUNCH_DUP(12, 16);
-    else if (TH == 8 && TW == 8) LAUNCH_DUP(8, 8);
+#define DISPATCH_DUP(A_, B_)                                              \
+    do {                                                                  \
+        if (packed) LAUNCH_DUP(A_, B_, int32_t, true);                    \
+        else if (sorted_id_is_int64) LAUNCH_DUP(A_, B_, int64_t, false);  \
+        else LAUNCH_DUP(A_, B_, int32_t, false);                          \
+    } while (0)
+    if (TH == 8 && TW == 16) DISPATCH_DUP(8, 16);
+    else if (TH == 16 && TW == 16) DISPATCH_DUP(16, 16);
+    else if (TH == 12 && TW == 16) DISPATCH_DUP(12, 16);
+    else if (TH == 8 && TW == 8) DISPATCH_DUP(8, 8);
     else return (int)hipErrorInvalidValue;
+#undef DISPATCH_DUP
 #undef LAUNCH_DUP
     LG_RETURN_LAST();
+}
+
+long long lg_dup_queue_ints(long long N) { return dup_queue_ints(N); }
+
+LG_API long long lg_duplicate_with_keys_temp_bytes(int V, int N) { return (long long)sizeof(int) * (long long)V * dup_queue_ints(N); }
+
+LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const float* opacity, const int32_t* prefix,
+                                  const void* sorted_id, int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW,
+                                  long long table_len, int32_t* keys, int32_t* values, void* temp, long long temp_bytes, void* stream)
+{
+    if (N <= 0) return 0;
+    if (temp == nullptr || temp_bytes < lg_duplicate_with_keys_temp_bytes(V, N)) return (int)hipErrorInvalidValue;
+    for (int v = 0; v < V; v++) {                                                                    // sub-queue counters
+        hipError_t err = hipMemsetAsync((int*)temp + (size_t)v * dup_queue_ints(N), 0, sizeof(int) * DUP_NQ, (hipStream_t)stream);
+        if (err != hipSuccess) return (int)err;
+    }
+    return lg_dup_emit(ndc, inv_cov, opacity, nullptr, prefix, sorted_id, sorted_id_is_int64, V, N, H, W, TH, TW, table_len, keys, values,
+                       (int*)temp, nullptr, 0, 0, nullptr, 0, nullptr, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -365,42 +597,6 @@ __global__ void __launch_bounds__(TPB) radix_hist_kernel(const uint32_t* __restr
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
-}
-
-// one workgroup per digit: base = sum of totals of smaller digits; exclusive scan of this digit's row
-__global__ void __launch_bounds__(TPB) radix_scan_kernel(int* __restrict__ hist, const int* __restrict__ totals, int ntiles)
-{
-    __shared__ int wsum[TPB / 64];
-    __shared__ int carry_s;
-    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // base
-    int t = (tid < d) ? totals[tid] : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
-    if (lane == 0) wsum[wave] = t;
-    __syncthreads();
-    int carry = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    int* row = hist + (size_t)d * ntiles;
-    for (int start = 0; start < ntiles; start += TPB) {
-        int k = start + tid;
-        int v = (k < ntiles) ? row[k] : 0;
-        int incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int nb = __shfl_up(incl, off);
-            if (lane >= off) incl += nb;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int wbase = 0;
-        for (int w = 0; w < wave; w++) wbase += wsum[w];
-        if (k < ntiles) row[k] = carry + wbase + incl - v;
-        if (tid == TPB - 1) carry_s = carry + wbase + incl;
-        __syncthreads();
-        carry = carry_s;
-        __syncthreads();
-    }
 }
 
 // Scatter with an LDS-local reorder: (1) 16 rounds of 256 keys compute each key's stable rank inside the tile (wave
@@ -544,54 +740,39 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
                                                              uint32_t* __restrict__ status /*[ntiles][RADIX], zero*/, int* __restrict__ ticket,
                                                              long long n, const int* __restrict__ n_dev, int shift, uint32_t mask)
 {
+    constexpr int NW = TPB / 64;
+    constexpr int WAVE_KEYS = SORT_ITEMS * 64;       // each wave ranks a contiguous run of 1024 keys on its own (no block barriers)
     __shared__ uint32_t lds_k[SORT_TILE];
     __shared__ uint32_t lds_v[SORT_TILE];
-    __shared__ int wave_cnt[2][TPB / 64][RADIX];
-    __shared__ int digit_run[RADIX];          // running count per digit, then exclusive local base
+    __shared__ int wave_cnt[NW][RADIX];              // running per-wave digit counts, then exclusive offset of the wave inside the digit
+    __shared__ int digit_base[RADIX];                // exclusive local base of the digit in the sorted tile
     __shared__ int global_base[RADIX];
-    __shared__ int wsum[TPB / 64];
+    __shared__ int wsum[NW];
     __shared__ int bid_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     n = bounded_n(n, n_dev);
     if (tid == 0) bid_s = atomicAdd(ticket, 1);
-    digit_run[tid] = 0;
 #pragma unroll
-    for (int w = 0; w < TPB / 64; w++) { wave_cnt[0][w][tid] = 0; wave_cnt[1][w][tid] = 0; }
+    for (int w = 0; w < NW; w++) wave_cnt[w][tid] = 0;
     __syncthreads();
     const int bid = bid_s;
     const long long base = (long long)bid * SORT_TILE;
     if (base >= n) return;
     const int cnt_tile = (int)((n - base) < SORT_TILE ? (n - base) : SORT_TILE);
-    // digit base = exclusive scan over digits of the global totals (TPB == RADIX)
-    {
-        const int total = totals[tid];
-        int inc = total;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int nb = __shfl_up(inc, o);
-            if (lane >= o) inc += nb;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int wb0 = 0;
-        for (int w = 0; w < wave; w++) wb0 += wsum[w];
-        global_base[tid] = wb0 + inc - total;
-        __syncthreads();
-    }
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
     int lrank[SORT_ITEMS];
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
-        const int e = j * TPB + tid;
+        const int e = wave * WAVE_KEYS + j * 64 + lane;
         const bool ok = e < cnt_tile;
         key[j] = ok ? keys_in[base + e] : 0u;
         val[j] = ok ? vals_in[base + e] : 0u;
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int* my_cnt = wave_cnt[wave];
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
-        const int cur = j & 1;
-        const bool ok = (j * TPB + tid) < cnt_tile;
+        const bool ok = (wave * WAVE_KEYS + j * 64 + lane) < cnt_tile;
         const uint32_t d = (key[j] >> shift) & mask;
         unsigned long long peers = __ballot(ok);
 #pragma unroll
@@ -601,63 +782,77 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
             peers &= set ? bal : ~bal;
         }
         const int rank = __popcll(peers & lt_mask);
-        if (ok && rank == 0) wave_cnt[cur][wave][d] = __popcll(peers);
-        __syncthreads();
-        int off = digit_run[d] + rank;
-        for (int w = 0; w < wave; w++) off += wave_cnt[cur][w][d];
-        lrank[j] = off;
-        __syncthreads();
-        {
-            int add = 0;
-#pragma unroll
-            for (int w = 0; w < TPB / 64; w++) { add += wave_cnt[cur][w][tid]; wave_cnt[cur][w][tid] = 0; }
-            digit_run[tid] += add;
-        }
+        const int prev = my_cnt[d];                      // wave-private counter: read by all peers, then bumped by the first one
+        __builtin_amdgcn_wave_barrier();
+        if (ok && rank == 0) my_cnt[d] = prev + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        lrank[j] = prev + rank;
     }
     __syncthreads();
-    const int dcount = digit_run[tid];
-    // publish this workgroup's count of digit `tid`, then look back
+    // thread d: counts of digit d per wave -> wave offsets inside the digit, tile count of the digit
+    int dcount = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { int c = wave_cnt[w][tid]; wave_cnt[w][tid] = dcount; dcount += c; }
     uint32_t* my = status + (size_t)bid * RADIX + tid;
-    if (bid == 0) {
-        __hip_atomic_store(my, ST_INC | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        __hip_atomic_store(my, ST_AGG | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        for (int b = bid - 1; b >= 0; b--) {
-            const uint32_t* pw = status + (size_t)b * RADIX + tid;
-            uint32_t v;
-            while (((v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & (ST_AGG | ST_INC)) == 0u)
-                __builtin_amdgcn_s_sleep(1);
-            excl += v & ST_VAL;
-            if (v & ST_INC) break;
-        }
-        __hip_atomic_store(my, ST_INC | (excl + (uint32_t)dcount), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        global_base[tid] += (int)excl;
-    }
-    // exclusive scan of the per-digit tile counts -> local base
-    int incl = dcount;
+    if (bid == 0) __hip_atomic_store(my, ST_INC | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(my, ST_AGG | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // digit base in the output = exclusive scan over digits of the global totals; local base = same scan of the tile counts
+    const int total = totals[tid];
+    int inc_g = total, inc_l = dcount;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        int nb = __shfl_up(incl, o);
-        if (lane >= o) incl += nb;
+        int ng = __shfl_up(inc_g, o), nl = __shfl_up(inc_l, o);
+        if (lane >= o) { inc_g += ng; inc_l += nl; }
     }
-    if (lane == 63) wsum[wave] = incl;
+    __shared__ int wsum_g[NW];
+    if (lane == 63) { wsum_g[wave] = inc_g; wsum[wave] = inc_l; }
     __syncthreads();
-    int wb = 0;
-    for (int w = 0; w < wave; w++) wb += wsum[w];
-    const int lbase = wb + incl - dcount;
+    int wbg = 0, wbl = 0;
+    for (int w = 0; w < wave; w++) { wbg += wsum_g[w]; wbl += wsum[w]; }
+    int gbase = wbg + inc_g - total;
+    digit_base[tid] = wbl + inc_l - dcount;
     __syncthreads();
-    digit_run[tid] = lbase;
-    __syncthreads();
+    // place the tile in LDS in sorted order while the predecessors' counts arrive
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
-        if ((j * TPB + tid) < cnt_tile) {
+        if ((wave * WAVE_KEYS + j * 64 + lane) < cnt_tile) {
             const uint32_t d = (key[j] >> shift) & mask;
-            const int pos = digit_run[d] + lrank[j];
+            const int pos = digit_base[d] + wave_cnt[wave][d] + lrank[j];
             lds_k[pos] = key[j];
             lds_v[pos] = val[j];
         }
     }
+    if (bid != 0) {
+        // look-back, LB predecessors per step: the loads of one step are independent, so the walk costs one L2 round trip per
+        // LB workgroups instead of one per workgroup (matters when ~1000 resident workgroups start together)
+        constexpr int LB = 8;
+        uint32_t excl = 0;
+        int b = bid - 1;
+        bool done = false;
+        while (!done) {
+            uint32_t v[LB];
+#pragma unroll
+            for (int k = 0; k < LB; k++)
+                v[k] = (b - k >= 0) ? __hip_atomic_load(status + (size_t)(b - k) * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : ST_INC;
+            int used = 0;
+#pragma unroll
+            for (int k = 0; k < LB; k++) {
+                if (!done && used == k) {
+                    if ((v[k] & (ST_AGG | ST_INC)) != 0u) {
+                        excl += v[k] & ST_VAL;
+                        used = k + 1;
+                        if (v[k] & ST_INC) done = true;
+                    }
+                }
+            }
+            b -= used;
+            if (!done && used < LB) __builtin_amdgcn_s_sleep(1);
+        }
+        __hip_atomic_store(my, ST_INC | (excl + (uint32_t)dcount), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gbase += (int)excl;
+    }
+    global_base[tid] = gbase;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
@@ -665,7 +860,7 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
         if (p < cnt_tile) {
             const uint32_t k = lds_k[p];
             const uint32_t d = (k >> shift) & mask;
-            const int g = global_base[d] + (p - digit_run[d]);
+            const int g = global_base[d] + (p - digit_base[d]);
             keys_out[g] = k;
             vals_out[g] = lds_v[p];
         }
@@ -677,7 +872,7 @@ LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint3
 
 // temp layout: totals[SORT_MAX_PASSES][RADIX] | ticket[SORT_MAX_PASSES] (+pad to 64 ints) | table
 // table = per-pass histogram [RADIX][ntiles] (small sorts) or look-back status [SORT_MAX_PASSES][ntiles][RADIX] (onesweep)
-#define SORT_HEADER_INTS (SORT_MAX_PASSES * RADIX + 64)
+#define SORT_HEADER_INTS LG_SORT_HEADER_INTS
 LG_API long long lg_radix_sort_temp_bytes(long long n)
 {
     long long ntiles = (n + SORT_TILE - 1) / SORT_TILE;
@@ -740,6 +935,38 @@ LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint3
     LG_RETURN_LAST();
 }
 
+long long lg_radix_table_words(long long n, int passes)
+{
+    long long ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+    if (ntiles < 1) ntiles = 1;
+    return (long long)passes * RADIX * ntiles;
+}
+
+int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
+                           int begin_bit, int end_bit, int* header, uint32_t* table, void* stream)
+{
+    int passes = lg_radix_sort_num_passes(begin_bit, end_bit);
+    if (n <= 0 || passes == 0) return 0;
+    if (passes > SORT_MAX_PASSES || n > 0x3fffffffLL) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
+    int* totals = header;
+    int* ticket = header + SORT_MAX_PASSES * RADIX;
+    int last_bits = (end_bit - begin_bit) - (passes - 1) * RADIX_BITS;
+    uint32_t last_mask = (1u << last_bits) - 1u;
+    uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
+    for (int p = 0; p < passes; p++) {
+        int shift = begin_bit + p * RADIX_BITS;
+        uint32_t mask = (p == passes - 1) ? last_mask : (uint32_t)(RADIX - 1);
+        hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, totals + p * RADIX,
+                           table + (size_t)p * RADIX * ntiles, ticket + p, n, n_dev, shift, mask);
+        uint32_t* t;
+        t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    LG_RETURN_LAST();
+}
+
 // depth keys: monotone float -> uint32 map (sign flip) + identity payload; replaces the key side of torch.sort
 __global__ void __launch_bounds__(TPB) depth_keys_kernel(const float* __restrict__ depth, long long n, uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ vals)
@@ -750,6 +977,41 @@ __global__ void __launch_bounds__(TPB) depth_keys_kernel(const float* __restrict
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     keys[i] = u;
     vals[i] = (uint32_t)i;
+}
+
+// same, plus the digit counts of the four 8-bit passes (saves the sort's own counting launch)
+__global__ void __launch_bounds__(TPB) depth_keys_hist_kernel(const float* __restrict__ depth, long long n, uint32_t* __restrict__ keys,
+                                                              uint32_t* __restrict__ vals, int* __restrict__ totals)
+{
+    __shared__ int hist[4 * 256];
+    for (int k = threadIdx.x; k < 4 * 256; k += TPB) hist[k] = 0;
+    __syncthreads();
+    const DigitSpec ds = { 0, 4, 255u };
+    const long long stride = (long long)gridDim.x * TPB;
+    for (long long i0 = (long long)blockIdx.x * TPB; i0 < n; i0 += stride) {
+        const long long i = i0 + threadIdx.x;
+        const bool act = i < n;
+        uint32_t u = 0;
+        if (act) {
+            u = __float_as_uint(depth[i]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            keys[i] = u;
+            vals[i] = (uint32_t)i;
+        }
+        digit_hist_add(hist, u, act, ds);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 4 * 256; k += TPB)
+        if (hist[k]) atomicAdd(&totals[k], hist[k]);
+}
+
+int lg_depth_keys_hist(const float* depth, long long n, uint32_t* keys, uint32_t* vals, int* header, void* stream)
+{
+    if (n <= 0) return 0;
+    long long blocks = lg_cdiv(n, (long long)TPB * 16);         // >= 16 keys per thread: amortises the flush of the 1024-entry LDS table
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(depth_keys_hist_kernel, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)stream, depth, n, keys, vals, header);
+    LG_RETURN_LAST();
 }
 
 LG_API int lg_depth_sort_keys(const float* depth, long long n, uint32_t* keys, uint32_t* vals, void* stream)
@@ -842,6 +1104,84 @@ __global__ void __launch_bounds__(TPB) scan_apply_kernel(const int32_t* __restri
     }
 }
 
+// Single-launch variant for the fused executor: tile sums are chained with decoupled look-back (status words as in the radix
+// sort; wave 0 inspects 64 predecessors per step), so the gathered values are read once and there is no spine launch.
+// status[ntiles] and ticket[1] must be zero on entry.  host_total (nullable): pinned host int that receives out[n-1]
+// (the GPU-driven sizing feedback, litegs/data.py:238) -- stored by the kernel itself instead of a copy launch.
+template <typename IdxT>
+__global__ void __launch_bounds__(TPB) scan_lookback_kernel(const int32_t* __restrict__ src, const IdxT* __restrict__ idx, long long n,
+                                                            int32_t* __restrict__ out, uint32_t* __restrict__ status,
+                                                            int* __restrict__ ticket, int* __restrict__ host_total)
+{
+    __shared__ int wsum[TPB / 64];
+    __shared__ int bid_s, excl_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) bid_s = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int bid = bid_s;
+    const long long base = (long long)bid * SORT_TILE + (long long)tid * SORT_ITEMS;
+    int v[SORT_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) { v[j] = scan_load(src, idx, base + j, n); s += v[j]; }
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int nb = __shfl_up(incl, off);
+        if (lane >= off) incl += nb;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    const int tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (wave == 0) {
+        uint32_t excl = 0;
+        if (bid == 0) {
+            if (lane == 0) __hip_atomic_store(status, ST_INC | (uint32_t)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(status + bid, ST_AGG | (uint32_t)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int b = bid - 1;
+            while (true) {
+                const uint32_t w = (b - lane >= 0) ? __hip_atomic_load(status + (b - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_INC;
+                const unsigned long long inc_m = __ballot((w & ST_INC) != 0u);
+                const unsigned long long nr_m = __ballot((w & (ST_AGG | ST_INC)) == 0u);
+                const int first_inc = inc_m ? __ffsll((long long)inc_m) - 1 : 64;
+                const int first_nr = nr_m ? __ffsll((long long)nr_m) - 1 : 64;
+                const int take = first_nr < first_inc ? first_nr : (first_inc < 64 ? first_inc + 1 : 64);   // lanes [0, take) are usable
+                uint32_t part = (lane < take) ? (w & ST_VAL) : 0u;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+                excl += __shfl(part, 0);
+                if (first_inc < first_nr) break;                   // reached an inclusive prefix
+                b -= take;
+                if (take < 64) __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) __hip_atomic_store(status + bid, ST_INC | (excl + (uint32_t)tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) excl_s = (int)excl;
+    }
+    __syncthreads();
+    int run = excl_s + incl - s;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        run += v[j];
+        if (base + j < n) out[base + j] = run;
+        if (host_total && base + j == n - 1) __hip_atomic_store(host_total, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// status: lg_scan_status_words(n) zero words followed by one zero ticket word
+long long lg_scan_status_words(long long n) { return (n + SORT_TILE - 1) / SORT_TILE + 1; }
+
+int lg_gather_scan_prepared(const int32_t* src, const int32_t* idx, long long n, int32_t* out, uint32_t* status, int* host_total, void* stream)
+{
+    if (n <= 0) return 0;
+    int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
+    hipLaunchKernelGGL(scan_lookback_kernel<int32_t>, dim3(ntiles), dim3(TPB), 0, (hipStream_t)stream, src, idx, n, out, status,
+                       (int*)(status + ntiles), host_total);
+    LG_RETURN_LAST();
+}
+
 LG_API long long lg_scan_temp_bytes(long long n)
 {
     long long ntiles = (n + SORT_TILE - 1) / SORT_TILE;
@@ -875,22 +1215,43 @@ LG_API int lg_gather_inclusive_scan(const int32_t* src, const void* idx, int idx
 __global__ void __launch_bounds__(TPB) tile_range_kernel(const int32_t* __restrict__ sorted_keys, long long L, const int* __restrict__ n_dev,
                                                          int max_tile, int32_t* __restrict__ out)
 {
-    long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    // 4 consecutive keys per thread (one 16-byte load) + the key after them
+    const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * 4;
     const int b = blockIdx.y;
     const long long stride = L;
     L = bounded_n(L, n_dev);
-    if (L <= 0) return;
+    if (L <= 0 || i0 >= L) return;
     const int32_t* k = sorted_keys + (size_t)b * stride;
     int32_t* o = out + (size_t)b * (max_tile + 2);
-    if (i == 0) o[k[0]] = 0;
-    if (i == L - 1) o[max_tile + 1] = (int32_t)L;
-    if (i < L - 1) {
-        int cur = k[i], nxt = k[i + 1];
-        if (cur != nxt) {
-            if (cur + 1 < nxt) o[cur + 1] = (int32_t)(i + 1);
-            o[nxt] = (int32_t)(i + 1);
+    int key[5];
+    if (i0 + 4 < L && ((stride & 3) == 0)) {
+        const int4 q = *reinterpret_cast<const int4*>(k + i0);
+        key[0] = q.x; key[1] = q.y; key[2] = q.z; key[3] = q.w; key[4] = k[i0 + 4];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; j++) key[j] = (i0 + j < L) ? k[i0 + j] : 0;
+    }
+    if (i0 == 0) o[key[0]] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const long long i = i0 + j;
+        if (i == L - 1) o[max_tile + 1] = (int32_t)L;
+        if (i < L - 1) {
+            const int cur = key[j], nxt = key[j + 1];
+            if (cur != nxt) {
+                if (cur + 1 < nxt) o[cur + 1] = (int32_t)(i + 1);
+                o[nxt] = (int32_t)(i + 1);
+            }
         }
     }
+}
+
+// `out` already filled with -1 (by a producer kernel's fill duty)
+int lg_tile_range_prefilled(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream)
+{
+    if (L <= 0) return 0;
+    hipLaunchKernelGGL(tile_range_kernel, dim3(lg_cdiv(L, TPB * 4), V), dim3(TPB), 0, (hipStream_t)stream, sorted_keys, L, n_dev, max_tile, out);
+    LG_RETURN_LAST();
 }
 
 LG_API int lg_tile_range_bounded(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream);
@@ -907,7 +1268,7 @@ LG_API int lg_tile_range_bounded(const int32_t* sorted_keys, int V, long long L,
     hipError_t err = hipMemsetAsync(out, 0xFF, sizeof(int32_t) * (size_t)V * (max_tile + 2), s);
     if (err != hipSuccess) return (int)err;
     if (L <= 0) return 0;
-    hipLaunchKernelGGL(tile_range_kernel, dim3(lg_cdiv(L, TPB), V), dim3(TPB), 0, s, sorted_keys, L, n_dev, max_tile, out);
+    hipLaunchKernelGGL(tile_range_kernel, dim3(lg_cdiv(L, TPB * 4), V), dim3(TPB), 0, s, sorted_keys, L, n_dev, max_tile, out);
     LG_RETURN_LAST();
 }
 

@@ -5,6 +5,7 @@
 // of the 59 channels.  These kernels are pure HBM streams (236 B/Gaussian gather, 1652 B/Gaussian Adam).
 // Compiled with -ffp-contract=off (bit-comparable visibility decisions vs the CPU oracle).
 #include "lg_common.h"
+#include "lg_binning_internal.h"
 #include "lg_sh.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -40,7 +41,7 @@ template <bool FROM_MASK>
 __global__ void __launch_bounds__(CULL_TPB) frustum_culling_kernel(const float* __restrict__ origin, const float* __restrict__ ext,
                                                                    const float* __restrict__ planes, const int* __restrict__ mask, int V, int M,
                                                                    uint8_t* __restrict__ visibility, int* __restrict__ visible_num,
-                                                                   int64_t* __restrict__ visible_chunk_id)
+                                                                   int64_t* __restrict__ visible_chunk_id, int* __restrict__ host_feedback)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int passes = (M + CULL_TPB - 1) / CULL_TPB;
@@ -92,7 +93,11 @@ __global__ void __launch_bounds__(CULL_TPB) frustum_culling_kernel(const float* 
     __syncthreads();
     int count = 0;
     for (int w = 0; w < CULL_WAVES; w++) count += wave_tot[w];
-    if (tid == 0) visible_num[0] = count;
+    if (tid == 0) {
+        visible_num[0] = count;
+        // GPU-driven sizing feedback (litegs/data.py:238): stored straight into the pinned host buffer, no copy launch
+        if (host_feedback) __hip_atomic_store(host_feedback, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 
     for (int p = 0; p < passes; p++) {
         int m = p * CULL_TPB + tid;
@@ -113,7 +118,19 @@ LG_API int lg_frustum_culling_aabb(const float* origin, const float* ext, const 
     size_t lds = ((V * 24 * 4 + 15) & ~15) + (size_t)passes * CULL_WAVES * (8 + 4) + 16;
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(frustum_culling_kernel<false>, dim3(1), dim3(CULL_TPB), lds, (hipStream_t)stream,
-                       origin, ext, planes, (const int*)nullptr, V, M, visibility, visible_num, visible_chunk_id);
+                       origin, ext, planes, (const int*)nullptr, V, M, visibility, visible_num, visible_chunk_id, (int*)nullptr);
+    LG_RETURN_LAST();
+}
+
+int lg_frustum_culling_fb(const float* origin, const float* ext, const float* planes, int V, int M, uint8_t* visibility, int* visible_num,
+                          int64_t* visible_chunk_id, int* host_feedback, void* stream)
+{
+    if (M <= 0) return 0;
+    int passes = (M + CULL_TPB - 1) / CULL_TPB;
+    size_t lds = ((V * 24 * 4 + 15) & ~15) + (size_t)passes * CULL_WAVES * (8 + 4) + 16;
+    if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(frustum_culling_kernel<false>, dim3(1), dim3(CULL_TPB), lds, (hipStream_t)stream,
+                       origin, ext, planes, (const int*)nullptr, V, M, visibility, visible_num, visible_chunk_id, host_feedback);
     LG_RETURN_LAST();
 }
 
@@ -126,7 +143,7 @@ LG_API int lg_compact_mask(const int* mask, int M, int* count, int64_t* ids, voi
     size_t lds = 16 + (size_t)passes * CULL_WAVES * (8 + 4) + 16;
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(frustum_culling_kernel<true>, dim3(1), dim3(CULL_TPB), lds, (hipStream_t)stream,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, mask, 0, M, (uint8_t*)nullptr, count, ids);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, mask, 0, M, (uint8_t*)nullptr, count, ids, (int*)nullptr);
     LG_RETURN_LAST();
 }
 

@@ -18,6 +18,7 @@
 #include "lg_chain.h"
 #include "lg_tilewalk.h"
 #include "litegs_hip.h"
+#include "lg_binning_internal.h"
 
 #define REC 16
 #define GREC 16
@@ -40,14 +41,15 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
                                      const float* __restrict__ pos, const float* __restrict__ scale, const float* __restrict__ rot,
                                      const float* __restrict__ sh0, const float* __restrict__ shr, const float* __restrict__ opa,
                                      int C, int S, int A,
-                                     float* __restrict__ ndc, float* __restrict__ view_z, float* __restrict__ inv_cov,
-                                     float* __restrict__ opacity, int* __restrict__ alloc, float4* __restrict__ packed, int gx, int gy)
+                                     float* __restrict__ view_z, int* __restrict__ alloc, float4* __restrict__ packed, int gx, int gy,
+                                     uint32_t* __restrict__ zero_ptr, long long zero_words)
 {
     const int a = blockIdx.x, t = threadIdx.x;
     const size_t N = (size_t)A * S;
     const size_t i = (size_t)a * S + t;
+    // zero duty: sort headers, look-back table and the big-splat counter of the kernels that follow (no fill launches)
+    for (long long z = (long long)i; z < zero_words; z += (long long)N) zero_ptr[z] = 0u;
     if (a >= visible_chunks_num[0]) {
-        opacity[i] = 0.0f;
         alloc[i] = 0;
         view_z[i] = 3.0e38f;            // sorts last and emits nothing
         return;
@@ -84,10 +86,7 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     lg_cov2d(T9, cam.V, J6, c4);
     lg_inv2x2(c4[0], c4[1], c4[2], c4[3], i4);
     // ---- outputs
-    ndc[i] = n[0]; ndc[N + i] = n[1]; ndc[2 * N + i] = n[2];
     view_z[i] = v[2];
-    inv_cov[i] = i4[0]; inv_cov[N + i] = i4[1]; inv_cov[2 * N + i] = i4[2]; inv_cov[3 * N + i] = i4[3];
-    opacity[i] = o;
     alloc[i] = lg_tile_count<TH, TW>(n[0], n[1], v[2], i4[0], i4[1], i4[3], o, cam.H, cam.W, gx, gy);     // a8, fused
     const float ppx = (n[0] + 1.0f) * 0.5f * cam.W - 0.5f;
     const float ppy = (n[1] + 1.0f) * 0.5f * cam.H - 0.5f;
@@ -95,7 +94,7 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     rec[0] = make_float4(ppx, ppy, -0.5f * i4[0] * LOG2E, -i4[1] * LOG2E);       // layout: raster.hip
     rec[1] = make_float4(-0.5f * i4[3] * LOG2E, o, r0, r1);
     rec[2] = make_float4(r2, i4[0], i4[1], i4[3]);
-    rec[3] = make_float4(n[2], 0.0f, 0.0f, 0.0f);
+    rec[3] = make_float4(n[2], n[0], n[1], 0.0f);                               // 13,14: ndc for the tile walk (binning.hip load_splat)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -249,10 +248,13 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
 // workspace layout (bytes, 256-aligned), identical in stage1 / stage2 / backward
 // ---------------------------------------------------------------------------------------------
 struct Layout1 {      // sized by N = A*S (per-Gaussian buffers)
-    size_t ndc, view_z, inv_cov, opacity, alloc, packed, dk_a, dv_a, dk_b, dv_b, prefix, temp, total, temp_bytes;
+    size_t view_z, alloc, packed, dk_a, dv_a, dk_b, dv_b, prefix, temp, total, temp_bytes;
+    // [zeroed, zeroed + zero_bytes) must be zero after the projection: depth-sort header | tile-sort header | depth-sort look-back
+    // table | scan look-back words | head of dup_queue (the big-splat sub-queue counters).  Cleared on the side by the culling kernel ("zero duty").
+    size_t zeroed, zero_bytes, dsort_hdr, tsort_hdr, dsort_table, scan_status, dup_queue;
 };
 struct Layout2 {      // sized by the tile-instance table length L
-    size_t tk_a, tv_a, tk_b, tv_b, temp, tile_start, total, temp_bytes;
+    size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, total;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -262,17 +264,18 @@ static Layout1 layout1(long long N)
     Layout1 f;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
-    f.ndc = take(sizeof(float) * 4 * N);
     f.view_z = take(sizeof(float) * N);
-    f.inv_cov = take(sizeof(float) * 4 * N);
-    f.opacity = take(sizeof(float) * N);
     f.alloc = take(sizeof(int) * N);
     f.packed = take(sizeof(float) * REC * N);
     f.dk_a = take(4 * N); f.dv_a = take(4 * N); f.dk_b = take(4 * N); f.dv_b = take(4 * N);
     f.prefix = take(4 * N);
-    long long t1 = lg_radix_sort_temp_bytes(N), t2 = lg_scan_temp_bytes(N);
-    f.temp_bytes = (size_t)(t1 > t2 ? t1 : t2);
-    f.temp = take(f.temp_bytes);
+    f.temp_bytes = 0; f.temp = o;
+    const size_t hdr = sizeof(int) * LG_SORT_HEADER_INTS;
+    f.zeroed = take(2 * hdr + 4 * (size_t)lg_radix_table_words(N, 4) + 4 * (size_t)lg_scan_status_words(N));
+    f.dsort_hdr = f.zeroed; f.tsort_hdr = f.zeroed + hdr; f.dsort_table = f.zeroed + 2 * hdr;
+    f.scan_status = f.dsort_table + 4 * (size_t)lg_radix_table_words(N, 4);
+    f.dup_queue = take(4 * (size_t)lg_dup_queue_ints(N));
+    f.zero_bytes = f.dup_queue + 4 * 64 - f.zeroed;            // ... + the 64 sub-queue counters
     f.total = o;
     return f;
 }
@@ -283,8 +286,8 @@ static Layout2 layout2(long long L, int ntiles)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
     f.tk_a = take(4 * (size_t)L); f.tv_a = take(4 * (size_t)L); f.tk_b = take(4 * (size_t)L); f.tv_b = take(4 * (size_t)L);
-    f.temp_bytes = (size_t)lg_radix_sort_temp_bytes(L);
-    f.temp = take(f.temp_bytes);
+    f.tsort_table_words = (size_t)lg_radix_table_words(L, 4);
+    f.tsort_table = take(4 * f.tsort_table_words);
     f.tile_start = take(sizeof(int) * ((size_t)ntiles + 2));
     f.total = o;
     return f;
@@ -322,9 +325,8 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (do_cull) {
-        rc = lg_frustum_culling_aabb(aabb_origin, aabb_ext, planes_dev, 1, chunks, visibility, vis_num, vis_ids, stream);
+        rc = lg_frustum_culling_fb(aabb_origin, aabb_ext, planes_dev, 1, chunks, visibility, vis_num, vis_ids, host_feedback_vis, stream);
         if (rc) return rc;
-        if (host_feedback_vis) { rc = lg_feedback_d2h(host_feedback_vis, vis_num, stream); if (rc) return rc; }
     }
     if (A <= 0) return 0;
     if (S > 1024 || S <= 0) return (int)hipErrorInvalidValue;
@@ -333,12 +335,12 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
     if ((long long)f.total > ws1_bytes) return (int)hipErrorInvalidValue;
     char* w = (char*)ws1;
     Camera cam = make_camera(view_host, proj_host, H, W);
-    float* ndc = (float*)(w + f.ndc); float* view_z = (float*)(w + f.view_z); float* inv_cov = (float*)(w + f.inv_cov);
-    float* opacity = (float*)(w + f.opacity); float4* packed = (float4*)(w + f.packed);
+    float* view_z = (float*)(w + f.view_z); float4* packed = (float4*)(w + f.packed);
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     int* alloc = (int*)(w + f.alloc);
 #define LAUNCH_PF(D, A_, B_) hipLaunchKernelGGL((project_fused_kernel<D, A_, B_>), dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, pos, scale, rot, \
-                                                sh0, shr, opa, chunks, S, A, ndc, view_z, inv_cov, opacity, alloc, packed, gx, gy)
+                                                sh0, shr, opa, chunks, S, A, view_z, alloc, packed, gx, gy,             \
+                                                (uint32_t*)(w + f.zeroed), (long long)(f.zero_bytes / 4))
 #define DISPATCH_PF(A_, B_)                                                  \
     switch (degree) {                                                        \
     case 0: LAUNCH_PF(0, A_, B_); break;                                     \
@@ -355,20 +357,21 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
 #undef DISPATCH_PF
 #undef LAUNCH_PF
     rc = (int)hipGetLastError(); if (rc) return rc;
-    rc = lg_depth_sort_keys(view_z, N, (uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), stream); if (rc) return rc;
-    rc = lg_radix_sort_pairs((uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (uint32_t*)(w + f.dk_b), (uint32_t*)(w + f.dv_b), N, 0, 32,
-                             w + f.temp, (long long)f.temp_bytes, stream);
+    rc = lg_depth_keys_hist(view_z, N, (uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (int*)(w + f.dsort_hdr), stream); if (rc) return rc;
+    rc = lg_radix_sort_prepared((uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (uint32_t*)(w + f.dk_b), (uint32_t*)(w + f.dv_b), N, nullptr, 0, 32,
+                                (int*)(w + f.dsort_hdr), (uint32_t*)(w + f.dsort_table), stream);
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, 32) % 2 == 1;
     const void* order = odd ? (w + f.dv_b) : (w + f.dv_a);
-    rc = lg_gather_inclusive_scan((const int32_t*)(w + f.alloc), order, 0, N, (int32_t*)(w + f.prefix), w + f.temp, (long long)f.temp_bytes, stream);
+    // depth-ordered inclusive scan of the tile counts; prefix[N-1] (the exact table length) also goes to the host feedback slot
+    rc = lg_gather_scan_prepared((const int32_t*)(w + f.alloc), (const int32_t*)order, N, (int32_t*)(w + f.prefix),
+                                 (uint32_t*)(w + f.scan_status), host_feedback_total, stream);
     if (rc) return rc;
-    if (host_feedback_total) { rc = lg_feedback_d2h(host_feedback_total, (const int*)(w + f.prefix) + (N - 1), stream); if (rc) return rc; }
     return 0;
 }
 
 // Stage 2: key/value emission -> stable tile sort -> tile ranges -> blend forward.  L = table length of the layout.
-LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
+LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                            void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
                            float* img, float* trans, short* last, int* frag_count, float* frag_weight, void* stream)
 {
@@ -378,28 +381,32 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
     Layout1 f1 = layout1(N);
     Layout2 f = layout2(L, ntiles);
     if ((long long)f1.total > ws1_bytes || (long long)f.total > ws2_bytes) return (int)hipErrorInvalidValue;
-    const char* w1 = (const char*)ws1;
+    char* w1 = (char*)ws1;            // stage 2 updates the tile-sort header and the big-splat queue that live in workspace 1
     char* w = (char*)ws2;
     int rc;
     const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
     const void* order = odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a);
-    rc = lg_memset_async(w + f.tk_a, 0, 4 * L, stream); if (rc) return rc;
-    rc = lg_duplicate_with_keys((const float*)(w1 + f1.ndc), (const float*)(w1 + f1.inv_cov), (const float*)(w1 + f1.opacity),
-                                (const int32_t*)(w1 + f1.prefix), order, 0, 1, (int)N, H, W, TH, TW, L,
-                                (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a), stream);
-    if (rc) return rc;
     int bits = 0;
     for (unsigned int mt = (unsigned int)ntiles; mt >>= 1;) bits++;
     bits++;
+    // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
+    // clears the sort's look-back table.  No table memset: the bounded sort only reads the first prefix[N-1] entries, and a
+    // truncated table (L < total) gets its tail zeroed by the first splat that does not fit.
+    rc = lg_dup_emit(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
+                     (const int32_t*)(w1 + f1.prefix), order, 0, 1, (int)N, H, W, TH, TW, L, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
+                     (int*)(w1 + f1.dup_queue), (int*)(w1 + f1.tsort_hdr), 0, bits, (uint32_t*)(w + f.tsort_table),
+                     (long long)lg_radix_table_words(L, lg_radix_sort_num_passes(0, bits)),
+                     (uint32_t*)(w + f.tile_start), (long long)ntiles + 2, stream);
+    if (rc) return rc;
     // exact instance count on the device (prefix[N-1]): only that many entries are sorted and range-scanned
     const int* total_dev = (const int*)(w1 + f1.prefix) + (N - 1);
-    rc = lg_radix_sort_pairs_bounded((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), L,
-                                     total_dev, 0, bits, w + f.temp, (long long)f.temp_bytes, stream);
+    rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), L,
+                                total_dev, 0, bits, (int*)(w1 + f1.tsort_hdr), (uint32_t*)(w + f.tsort_table), stream);
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
     const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
-    rc = lg_tile_range_bounded(sorted_keys, 1, L, total_dev, ntiles, (int32_t*)(w + f.tile_start), stream); if (rc) return rc;
+    rc = lg_tile_range_prefilled(sorted_keys, 1, L, total_dev, ntiles, (int32_t*)(w + f.tile_start), stream); if (rc) return rc;
     return lg_raster_forward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
                              enable_stat, img, trans, last, frag_count, frag_weight, stream);
 }

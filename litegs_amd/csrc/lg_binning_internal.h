@@ -1,0 +1,39 @@
+// Library-internal entry points of binning.hip used by the fused executor (fused.hip): same kernels as the C ABI, but with
+// the scratch clearing ("zero duty") and the radix digit counts folded into the producer kernels instead of separate launches.
+// Not part of include/litegs_hip.h.
+#pragma once
+#include <stdint.h>
+
+#define LG_SORT_HEADER_INTS (4 * 256 + 64)      // totals[4][256] | ticket[4] | pad
+
+// words of look-back status a prepared sort of n keys with `passes` passes needs (zero on entry)
+long long lg_radix_table_words(long long n, int passes);
+
+// keys/vals of the depth sort + the digit counts of all four passes into header[0..1023]; header must be zero on entry
+int lg_depth_keys_hist(const float* depth, long long n, uint32_t* keys, uint32_t* vals, int* header, void* stream);
+
+// radix sort whose header (totals filled, tickets zero) and status table (zero) were prepared by earlier kernels
+int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
+                           int begin_bit, int end_bit, int* header, uint32_t* table, void* stream);
+
+// ints of big-splat queue per view (lg_dup_queue_ints(N)); its first 64 ints (sub-queue counters) must be zero on entry
+long long lg_dup_queue_ints(long long N);
+
+// duplicate_with_keys; queue[V][lg_dup_queue_ints(N)]; totals (nullable) receives the digit counts of the emitted keys for a
+// sort on bits [begin_bit, end_bit); zero_ptr/zero_words: scratch cleared on the side
+int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, const float* packed /*nullable: [V*N][16] records instead of the SoA*/,
+                const int32_t* prefix, const void* sorted_id,
+                int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
+                int* queue, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
+                uint32_t* ones_ptr /*filled with 0xffffffff*/, long long ones_words, void* stream);
+
+// gathered inclusive scan in one launch; status = lg_scan_status_words(n) zero words; host_total (nullable) = pinned host int
+long long lg_scan_status_words(long long n);
+int lg_gather_scan_prepared(const int32_t* src, const int32_t* idx, long long n, int32_t* out, uint32_t* status, int* host_total, void* stream);
+
+// tileRange on a table whose output was pre-filled with -1
+int lg_tile_range_prefilled(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream);
+
+// frustum culling that also stores the visible-chunk count into pinned host memory (nullable)
+int lg_frustum_culling_fb(const float* origin, const float* ext, const float* planes, int V, int M, uint8_t* visibility, int* visible_num,
+                          int64_t* visible_chunk_id, int* host_feedback, void* stream);
