@@ -168,6 +168,13 @@ int lg_l1_ssim_forward(const float* img, const float* gt, int planes, int H, int
                        float* dmaps, float* partial, float* loss, void* stream);
 int lg_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, const float* grad_out /*[1] or NULL*/,
                         int planes, int H, int W, float lam, float* d_img, void* stream);
+/* The same loss taken straight on the raw tile-padded raster output [planes][Hp][Wp]: clamp(0,1) (litegs/render/__init__.py, the
+ * image returned to the trainer is clamped) is applied on load, and the backward writes the gradient w.r.t. the raw image in the
+ * padded layout (0 in the padding and where the clamp saturates) -- what rasterize_backward consumes. */
+int lg_l1_ssim_forward_raster(const float* img, int Hp, int Wp, const float* gt, int planes, int H, int W, float lam,
+                              float* dmaps, float* partial, float* loss, void* stream);
+int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt, const float* dmaps, const float* grad_out,
+                               int planes, int H, int W, float lam, float* d_img, void* stream);
 
 /* ---- fused.hip : native executor of the whole path (one C call enqueues a stage; same arithmetic as the operators above).
  * There is no counterpart in the reference (its executor is the Python in litegs/render/__init__.py:11-94 + wrapper.py); these

@@ -82,6 +82,7 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 #define DUP_SMALL 32
 #define DUP_LDS_ENTRIES (TPB * DUP_SMALL)
 #define DUP_MAX_SLICES 256
+#define DUP_MAX_RUN 32768      // tiles one splat may touch on the cooperative path (bitmap of 4 KiB per wave)
 #define SORT_MAX_PASSES_DUP 4
 // Big splats are appended to DUP_NQ sub-queues (group g of 256 depth slots -> sub-queue g % DUP_NQ) with ONE returning atomic
 // per group: returning atomics on a single address serialise at ~8 ns each in L2, and one counter for the whole launch
@@ -152,6 +153,16 @@ __device__ __forceinline__ void slice_bounds(const SplatExtent& e, const WalkFra
 // the end of the workgroup).  Keys emitted by one wave instruction are often equal in their high digits (neighbouring tiles,
 // similar depths): when the whole wave agrees on a digit, one lane adds the wave's count instead of 64 same-address atomics.
 struct DigitSpec { int begin_bit, passes; uint32_t last_mask; };
+// The LDS table is indexed through a bijection of the digit: tile keys emitted by one wave instruction step by the grid width (120 at
+// 1080p), whose digits land on only 4 of the 32 LDS banks; d ^ (d >> 3) spreads any power-of-two-strided digit sequence over all banks.
+#define HPERM(d) ((d) ^ ((d) >> 3))
+__device__ __forceinline__ void digit_hist_flush(const int* __restrict__ h, int* __restrict__ totals, int passes)
+{
+    for (int k = threadIdx.x; k < passes * 256; k += blockDim.x) {
+        const int v = h[(k & ~255) + HPERM(k & 255)];
+        if (v) atomicAdd(&totals[k], v);
+    }
+}
 
 __device__ __forceinline__ void digit_hist_add(int* __restrict__ h, uint32_t key, bool active, const DigitSpec& ds)
 {
@@ -163,14 +174,14 @@ __device__ __forceinline__ void digit_hist_add(int* __restrict__ h, uint32_t key
     for (int p = 0; p < ds.passes; p++) {
         const uint32_t d = (key >> (ds.begin_bit + p * 8)) & ((p == ds.passes - 1) ? ds.last_mask : 255u);
         if (p < first_uniform) {
-            if (active) atomicAdd(&h[p * 256 + d], 1);
+            if (active) atomicAdd(&h[p * 256 + HPERM(d)], 1);
             continue;
         }
         const uint32_t d0 = (uint32_t)__shfl((int)d, leader);
         if (__ballot(active && d != d0) == 0ull) {
-            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[p * 256 + d0], __popcll(m));
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[p * 256 + HPERM(d0)], __popcll(m));
         } else if (active) {
-            atomicAdd(&h[p * 256 + d], 1);
+            atomicAdd(&h[p * 256 + HPERM(d)], 1);
         }
     }
 }
@@ -211,7 +222,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
                                                         int* __restrict__ queue /*[V][N+1]: count, entries*/,
                                                         int* __restrict__ totals /*nullable [passes][256]*/, DigitSpec ds,
                                                         uint32_t* __restrict__ zero_ptr, long long zero_words,
-                                                        uint32_t* __restrict__ ones_ptr, long long ones_words, int dbg)
+                                                        uint32_t* __restrict__ ones_ptr, long long ones_words)
 {
     __shared__ int32_t buf[DUP_LDS_ENTRIES];              // 32 KiB: compacted keys of the small splats
     __shared__ int t_loff[TPB + 1];                       // per-thread start in buf
@@ -248,12 +259,9 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         if (c > 0 && off + c <= table_len) {
             idx = (int)sorted_id[(size_t)b * N + j];
             float nx, ny, a, bb, cc, o;
-            if (dbg & 16) { nx = 0.001f * (idx & 255); ny = 0.002f * (idx & 127); a = 0.05f; bb = 0.01f; cc = 0.07f; o = 0.5f; }
-            else load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
-            if (!(dbg & 8)) {
+            load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
             splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
             if ((e.rmaxy - e.rminy) * (e.rmaxx - e.rminx) > 0) { live = true; cnt = (int)c; }
-            } else { e.a = nx + ny + a + bb + cc + o; if (e.a == 123.0f) live = true; }
         } else if (c > 0 && off < table_len) {
             // first splat that does not fit (GR/binning.cu:63 drops it and, prefix being monotone, every later one): the rest of
             // the table stays key 0 = "no tile"
@@ -298,9 +306,9 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     t_goff[tid] = (int)off;
     t_idx[tid] = idx;
     if (tid == 0) t_loff[TPB] = total_small;
-    if (small && !(dbg & 1)) walk_tiles<TH, TW, true>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf);
+    if (small) walk_tiles<TH, TW, true>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf);
     __syncthreads();
-    for (int p0 = 0; p0 < ((dbg & 2) ? 0 : total_small); p0 += TPB) {
+    for (int p0 = 0; p0 < total_small; p0 += TPB) {
         const int p = p0 + tid;
         const bool act = p < total_small;
         int32_t key = 0;
@@ -322,8 +330,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     }
     if (totals) {
         __syncthreads();
-        for (int k = tid; k < ds.passes * 256; k += TPB)
-            if (hist[k]) atomicAdd(&totals[k], hist[k]);
+        digit_hist_flush(hist, totals, ds.passes);
     }
 }
 
@@ -340,13 +347,16 @@ template <int TH, int TW, typename IdxT, bool PACKED>
 __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
                                                       const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                       long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
-                                                      const int* __restrict__ queue, int* __restrict__ totals, DigitSpec ds, int dbg)
+                                                      const int* __restrict__ queue, int* __restrict__ totals, DigitSpec ds)
 {
     __shared__ int w_minv[TPB / 64][DUP_MAX_SLICES];      // per-wave slice scratch
     __shared__ int w_off[TPB / 64][DUP_MAX_SLICES + 1];
+    __shared__ int c_idx[TPB / 64][DUP_MAX_SLICES];       // r-th non-empty slice
+    __shared__ uint32_t bitmap[TPB / 64][DUP_MAX_RUN / 32 + 2];   // bit k = an output run starts at k; all-zero between splats
     __shared__ int hist[SORT_MAX_PASSES_DUP * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
+    for (int k = tid; k < (TPB / 64) * (DUP_MAX_RUN / 32 + 2); k += TPB) (&bitmap[0][0])[k] = 0u;
     const int32_t* pf = prefix + (size_t)b * N;
     int32_t* kout = keys + (size_t)b * table_len;
     int32_t* vout = values + (size_t)b * table_len;
@@ -417,7 +427,6 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                 }
                 continue;
             }
-            if (dbg & 64) { if (sidx == -12345) kout[0] = nsl; continue; }
             // K = number of leading slices whose upper line is <= bmax_u
             int K = 0;
             for (int i0 = 0; i0 < nsl; i0 += 64) {
@@ -425,7 +434,10 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                 bool c = (i < nsl) && ((float)(f.rect_min_u + i) * f.BLOCK_U + f.BLOCK_U <= f.bmax_u);
                 K += __popcll(__ballot(c));
             }
-            int run = 0;
+            // slice i -> (first tile w_minv[i], output offset w_off[i]); the r-th NON-EMPTY slice is c_idx[r] and sets bit w_off[i] of a
+            // bitmap over the splat's output range: the owner of output k is then "number of set bits at positions <= k" - 1, i.e.
+            // one uniform 64-bit LDS read and a popcount per 64 outputs instead of a binary search per output
+            int run = 0, nne = 0;
             for (int i0 = 0; i0 < nsl; i0 += 64) {
                 int i = i0 + lane;
                 int mn = 0, n = 0;
@@ -440,29 +452,50 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                     int nbv = __shfl_up(inc, o);
                     if (lane >= o) inc += nbv;
                 }
-                if (i < nsl) { w_minv[wave][i] = mn; w_off[wave][i] = run + inc - n; }
+                const unsigned long long ne = __ballot(n > 0);
+                if (n > 0) {
+                    const int off = run + inc - n;
+                    w_minv[wave][i] = mn; w_off[wave][i] = off;
+                    c_idx[wave][nne + __popcll(ne & ((1ull << lane) - 1ull))] = i;
+                    if (off < DUP_MAX_RUN) atomicOr(&bitmap[wave][off >> 5], 1u << (off & 31));
+                }
+                nne += __popcll(ne);
                 run += __shfl(inc, 63);
             }
-            if (lane == 0) w_off[wave][nsl] = run;
             __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order: no fence (a fence would also wait for the global stores)
-            if (dbg & 32) run = 0;
+            if (run > DUP_MAX_RUN) {              // cannot happen below ~8K x 8K images; keep the table consistent and walk serially
+                for (int wq = lane; wq < DUP_MAX_RUN / 32; wq += 64) bitmap[wave][wq] = 0u;
+                if (lane == srcl) walk_tiles<TH, TW, true>(e, gx, my_idx, my_off, kout, vout);
+                if (totals) {
+                    __threadfence();
+                    for (int k0 = 0; k0 < run; k0 += 64) {
+                        const bool act = k0 + lane < run;
+                        const int32_t key = act ? __hip_atomic_load(kout + sgoff + k0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                        digit_hist_add(hist, (uint32_t)key, act, ds);
+                    }
+                }
+                continue;
+            }
+            int before = 0;                       // non-empty slices that start before k0
             for (int k0 = 0; k0 < run; k0 += 64) {
                 const int k = k0 + lane;
                 const bool act = k < run;
+                const uint32_t wlo = bitmap[wave][(k0 >> 5)], whi = bitmap[wave][(k0 >> 5) + 1];
+                const unsigned long long word = ((unsigned long long)whi << 32) | wlo;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) { bitmap[wave][(k0 >> 5)] = 0u; bitmap[wave][(k0 >> 5) + 1] = 0u; }      // leave the bitmap clean for the next splat
                 int32_t key = 0;
                 if (act) {
-                    int lo = 0, hi = nsl - 1;
-                    while (lo < hi) {
-                        int mid = (lo + hi + 1) >> 1;
-                        if (w_off[wave][mid] <= k) lo = mid; else hi = mid - 1;
-                    }
-                    const int u = f.rect_min_u + lo;
-                    const int v = w_minv[wave][lo] + (k - w_off[wave][lo]);
+                    const int r = before + __popcll(word & ((2ull << lane) - 1ull)) - 1;
+                    const int sl = c_idx[wave][r];
+                    const int u = f.rect_min_u + sl;
+                    const int v = w_minv[wave][sl] + (k - w_off[wave][sl]);
                     const uint32_t tk = f.isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
                     key = (int32_t)(tk + 1);
                     kout[sgoff + k] = key;
                     vout[sgoff + k] = sidx;
                 }
+                before += __popcll(word);
                 if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
             }
             __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order: no fence (a fence would also wait for the global stores)
@@ -470,8 +503,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
     }
     if (totals) {
         __syncthreads();
-        for (int k = tid; k < ds.passes * 256; k += TPB)
-            if (hist[k]) atomicAdd(&totals[k], hist[k]);
+        digit_hist_flush(hist, totals, ds.passes);
     }
 }
 
@@ -495,13 +527,12 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
         ds.last_mask = (1u << ((end_bit - begin_bit) - (ds.passes - 1) * 8)) - 1u;
     }
     SplatSrc src = { ndc, inv_cov, opacity, (const float4*)packed };
-    static int dbg = getenv("LG_DUP_DBG") ? atoi(getenv("LG_DUP_DBG")) : 0;
 #define LAUNCH_DUP(A_, B_, T_, P_)                                                                                                          \
     do {                                                                                                                                   \
         hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,                \
-                           H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, dbg);                           \
-        if (!(dbg & 4)) hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
-                           N, H, W, gx, gy, table_len, keys, values, (const int*)queue, totals, ds, dbg);                                  \
+                           H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words);                                \
+        hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
+                           N, H, W, gx, gy, table_len, keys, values, (const int*)queue, totals, ds);                                       \
     } while (0)
 #define DISPATCH_DUP(A_, B_)                                              \
     do {                                                                  \
@@ -1001,8 +1032,7 @@ __global__ void __launch_bounds__(TPB) depth_keys_hist_kernel(const float* __res
         digit_hist_add(hist, u, act, ds);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 4 * 256; k += TPB)
-        if (hist[k]) atomicAdd(&totals[k], hist[k]);
+    digit_hist_flush(hist, totals, 4);
 }
 
 int lg_depth_keys_hist(const float* depth, long long n, uint32_t* keys, uint32_t* vals, int* header, void* stream)

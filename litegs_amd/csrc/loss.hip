@@ -23,7 +23,10 @@ __constant__ float c_gauss[11] = { 0.001028380123898387f, 0.0075987582094967365f
 // Sliding-window separable blur: a work item that produces SEG consecutive outputs reads SEG+10 inputs once into registers and
 // feeds each into the (up to 11) accumulators it contributes to, so the LDS read count per output drops from 11 to (SEG+10)/SEG.
 // Tap order per output is t = 0..10, as in a plain 11-tap loop.
-__global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W,
+// img may be a padded raster image (row stride img_rs, plane stride img_ps) that is clamped to [0,1] on load (clamp01): this is the
+// executor's "render -> clamp(0,1) -> loss" without the separate clamp launch; gt / dmaps are dense [planes][H][W].
+__global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __restrict__ img, long long img_ps, int img_rs, int clamp01,
+                                                              const float* __restrict__ gt, int H, int W,
                                                               float* __restrict__ dmaps /*[3][B*C][H][W]*/, float* __restrict__ partial /*[blocks][2]*/)
 {
     __shared__ float sx[TIN][TIN + 1], sy[TIN][TIN + 1];
@@ -31,7 +34,7 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
     __shared__ float red[2][4];
     const int plane_id = blockIdx.z;
     const size_t plane = (size_t)H * W;
-    const float* x = img + plane_id * plane;
+    const float* x = img + plane_id * img_ps;
     const float* y = gt + plane_id * plane;
     const int bx = blockIdx.x * TS, by = blockIdx.y * TS;
     const int tid = threadIdx.x;
@@ -39,7 +42,9 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
         int r = k / TIN, c = k % TIN;
         int gy = by + r - HALO, gx = bx + c - HALO;
         bool in = (gy >= 0 && gy < H && gx >= 0 && gx < W);
-        sx[r][c] = in ? x[(size_t)gy * W + gx] : 0.0f;
+        float xv = in ? x[(size_t)gy * img_rs + gx] : 0.0f;
+        if (clamp01) xv = fminf(fmaxf(xv, 0.0f), 1.0f);
+        sx[r][c] = xv;
         sy[r][c] = in ? y[(size_t)gy * W + gx] : 0.0f;
     }
     __syncthreads();
@@ -142,15 +147,29 @@ __global__ void __launch_bounds__(1024) l1_ssim_reduce_kernel(const float* __res
     }
 }
 
-LG_API int lg_l1_ssim_forward(const float* img, const float* gt, int planes, int H, int W, float lam,
-                              float* dmaps, float* partial, float* loss, void* stream)
+static int l1_ssim_forward_launch(const float* img, long long img_ps, int img_rs, int clamp01, const float* gt, int planes, int H, int W,
+                                  float lam, float* dmaps, float* partial, float* loss, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(lg_cdiv(W, TS), lg_cdiv(H, TS), planes);
-    hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(256), 0, s, img, gt, H, W, dmaps, partial);
+    hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(256), 0, s, img, img_ps, img_rs, clamp01, gt, H, W, dmaps, partial);
     int nblocks = grid.x * grid.y * grid.z;
     hipLaunchKernelGGL(l1_ssim_reduce_kernel, dim3(1), dim3(1024), 0, s, partial, nblocks, 1.0f / ((float)planes * H * W), lam, loss);
     LG_RETURN_LAST();
+}
+
+LG_API int lg_l1_ssim_forward(const float* img, const float* gt, int planes, int H, int W, float lam,
+                              float* dmaps, float* partial, float* loss, void* stream)
+{
+    return l1_ssim_forward_launch(img, (long long)H * W, W, 0, gt, planes, H, W, lam, dmaps, partial, loss, stream);
+}
+
+// img: raw raster output [planes][Hp][Wp] (tile-padded); the loss is taken on clamp(img[:, :H, :W], 0, 1)
+LG_API int lg_l1_ssim_forward_raster(const float* img, int Hp, int Wp, const float* gt, int planes, int H, int W, float lam,
+                                     float* dmaps, float* partial, float* loss, void* stream)
+{
+    if (Hp < H || Wp < W) return (int)hipErrorInvalidValue;
+    return l1_ssim_forward_launch(img, (long long)Hp * Wp, Wp, 1, gt, planes, H, W, lam, dmaps, partial, loss, stream);
 }
 
 LG_API long long lg_l1_ssim_partial_floats(int planes, int H, int W)
@@ -159,9 +178,12 @@ LG_API long long lg_l1_ssim_partial_floats(int planes, int H, int W)
 }
 
 // backward: d_img = g * [ lam*(-1/n) * ( blur(M1) + 2x*blur(M2) + y*blur(M3) ) + (1-lam)/n * sign(x-y) ]
-__global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+// With clamp01 the gradient is taken through clamp(img, 0, 1) (zero where the raw value lies outside [0,1], as torch's clamp backward)
+// and d_img has the padded raster layout [planes][Hp][Wp], padding written as 0 -- directly consumable by the blend backward.
+__global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __restrict__ img, long long img_ps, int img_rs, int clamp01,
+                                                               const float* __restrict__ gt,
                                                                const float* __restrict__ dmaps, const float* __restrict__ grad_out,
-                                                               int H, int W, float lam, float inv_n, float* __restrict__ d_img)
+                                                               int H, int W, int Hp, int Wp, float lam, float inv_n, float* __restrict__ d_img)
 {
     __shared__ float sm[3][TIN][TIN + 1];
     __shared__ float sh[3][TIN][TS + 1];
@@ -217,11 +239,16 @@ __global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __re
     for (int j = 0; j < VSEG; j++) {
         const int gy = by + r0 + j;
         if (gx < W && gy < H) {
-            size_t o = plane_id * plane + (size_t)gy * W + gx;
-            float xv = img[o], yv = gt[o];
+            const size_t oi = plane_id * img_ps + (size_t)gy * img_rs + gx;
+            float xr = img[oi], yv = gt[plane_id * plane + (size_t)gy * W + gx];
+            float xv = clamp01 ? fminf(fmaxf(xr, 0.0f), 1.0f) : xr;
             float d = xv - yv;
             float sgn = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);
-            d_img[o] = g * (-lam * inv_n * (b[0][j] + 2.0f * xv * b[1][j] + yv * b[2][j]) + (1.0f - lam) * inv_n * sgn);
+            float gr = g * (-lam * inv_n * (b[0][j] + 2.0f * xv * b[1][j] + yv * b[2][j]) + (1.0f - lam) * inv_n * sgn);
+            if (clamp01 && !(xr >= 0.0f && xr <= 1.0f)) gr = 0.0f;
+            d_img[oi] = gr;
+        } else if (gx < Wp && gy < Hp) {
+            d_img[plane_id * img_ps + (size_t)gy * img_rs + gx] = 0.0f;
         }
     }
 }
@@ -230,7 +257,18 @@ LG_API int lg_l1_ssim_backward(const float* img, const float* gt, const float* d
                                float lam, float* d_img, void* stream)
 {
     dim3 grid(lg_cdiv(W, TS), lg_cdiv(H, TS), planes);
-    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, dmaps, grad_out, H, W, lam,
-                       1.0f / ((float)planes * H * W), d_img);
+    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, (long long)H * W, W, 0, gt, dmaps, grad_out,
+                       H, W, H, W, lam, 1.0f / ((float)planes * H * W), d_img);
+    LG_RETURN_LAST();
+}
+
+// gradient w.r.t. the RAW raster image (see lg_l1_ssim_forward_raster); d_img [planes][Hp][Wp]
+LG_API int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt, const float* dmaps, const float* grad_out,
+                                      int planes, int H, int W, float lam, float* d_img, void* stream)
+{
+    if (Hp < H || Wp < W) return (int)hipErrorInvalidValue;
+    dim3 grid(lg_cdiv(Wp, TS), lg_cdiv(Hp, TS), planes);
+    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, (long long)Hp * Wp, Wp, 1, gt, dmaps, grad_out,
+                       H, W, Hp, Wp, lam, 1.0f / ((float)planes * H * W), d_img);
     LG_RETURN_LAST();
 }

@@ -55,6 +55,11 @@ class FusedRenderer:
         img = img[..., : self.H, : self.W].clamp(0, 1)
         return img, vis_ids, vis_num
 
+    def render_raw(self, frame: CameraFrame, cluster_origin, cluster_extend, xyz, scale, rot, sh_0, sh_rest, opacity, degree: int):
+        """-> (raw tile-padded image [1,3,Hp,Wp] as the blend kernel wrote it, visible_chunkid, visible_chunks_num); pair it with
+        loss_hip.raster_l1_ssim_loss, which applies the crop and the clamp inside the loss kernels."""
+        return _RenderFn.apply(self, frame, cluster_origin, cluster_extend, degree, xyz, scale, rot, sh_0, sh_rest, opacity)
+
 
 class _RenderFn(torch.autograd.Function):
     @staticmethod
@@ -118,6 +123,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.stat_bufs = (fc, fw)
         ctx.save_for_backward(ws1, ws2, vis_ids, vis_num, trans, last, xyz, scale, rot, sh_0, sh_rest, opacity)
         ctx.mark_non_differentiable(vis_ids, vis_num)
+        ctx.set_materialize_grads(False)          # no zero-filled gradients for the two index outputs
         R.last_sizes = (A, table_len)
         return img, vis_ids[:A], vis_num
 
@@ -129,6 +135,8 @@ class _RenderFn(torch.autograd.Function):
         L = lib()
         dev = xyz.device
         N = A * S
+        if g_img is None:
+            return (None,) * 11
         g_img = g_img.contiguous()
         pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev)
         esq = torch.zeros((1, 1, N), dtype=torch.float32, device=dev) if stat else None

@@ -54,18 +54,21 @@ class SyntheticTrainer:
             self.cluster_origin, self.cluster_extend = R.get_cluster_AABB(xyz, scale.exp(), torch.nn.functional.normalize(rot, dim=0))
         self.loss_fn = loss_mod.l1_ssim_loss_torch if use_torch_loss else loss_mod.fused_l1_ssim_loss
         self.fused = fused
+        # the native executor hands the raw raster image to the loss kernels (crop + clamp fused in); only with the HIP loss
+        self.raw_loss = fused and not use_torch_loss
+        self._unit = torch.ones((), dtype=torch.float32, device=self.device)      # d(loss)/d(loss): reused, no fill launch per step
         self.renderer = fast.FusedRenderer(n_frames, height, width, self.pp.tile_size, self.pp.cluster_size)
         self.fadam = fast.FusedAdam(self.opt, self.renderer)
         self.fuse_adam = fuse_adam
         self.last = {}
 
     # -------------------------------------------------------------------------------------------
-    def forward(self, frame: Frame):
+    def forward(self, frame: Frame, raw: bool = False):
         xyz, scale, rot, sh_0, sh_rest, opacity = self.params
         STATS.current_frame = int(frame.idx_tensor[0])
         if self.fused:
-            img, vis_id, vis_num = self.renderer.render(frame.cam, self.cluster_origin, self.cluster_extend, xyz, scale, rot, sh_0, sh_rest,
-                                                        opacity, self.degree)
+            fn = self.renderer.render_raw if raw else self.renderer.render
+            img, vis_id, vis_num = fn(frame.cam, self.cluster_origin, self.cluster_extend, xyz, scale, rot, sh_0, sh_rest, opacity, self.degree)
             return img, vis_id, vis_num, None
         vis_id, vis_num, cx, cs, cr, cc, co = R.render_preprocess(
             self.cluster_origin, self.cluster_extend, frame.planes, frame.view, xyz, scale, rot, sh_0, sh_rest, opacity,
@@ -80,9 +83,13 @@ class SyntheticTrainer:
         frame = self.frames[frame_index % len(self.frames)]
         # gradients are only materialised when something consumes them between backward and the optimizer (DP exchange)
         self.renderer.fuse_optimizer = self.fused and self.fuse_adam and grad_hook is None
-        img, vis_id, vis_num, prim_vis = self.forward(frame)
-        loss = self.loss_fn(img, frame.gt)
-        loss.backward()
+        img, vis_id, vis_num, prim_vis = self.forward(frame, raw=self.raw_loss)
+        if self.raw_loss:
+            from . import loss_hip
+            loss = loss_hip.raster_l1_ssim_loss(img, frame.gt)
+        else:
+            loss = self.loss_fn(img, frame.gt)
+        loss.backward(self._unit)
         if grad_hook is not None:            # data-parallel gradient exchange (litegs_amd/dp.py)
             vis_id, vis_num = grad_hook(self.params, vis_id, vis_num)
         if self.fused:

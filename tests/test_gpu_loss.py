@@ -23,3 +23,24 @@ def test_l1_ssim_loss_matches_torch(shape):
     assert abs(l_hip.item() - l_ref.item()) < 2e-6 * max(1.0, abs(l_ref.item()))
     scale = g_ref.abs().max().item()
     assert (g_hip - g_ref).abs().max().item() < 2e-5 * scale
+
+
+@pytest.mark.parametrize("H,W,Hp,Wp", [(70, 100, 72, 112), (64, 64, 64, 64), (33, 47, 40, 48)])
+def test_raster_loss_equals_clamp_crop_then_loss(H, W, Hp, Wp):
+    """raster_l1_ssim_loss(raw, gt) == loss(clamp(raw[..., :H, :W], 0, 1), gt), values and gradient w.r.t. the raw padded image
+    (zero in the padding and where the clamp saturates)."""
+    from litegs_amd import loss as Lm, loss_hip
+    g = torch.Generator().manual_seed(3)
+    raw = (torch.rand((1, 3, Hp, Wp), generator=g) * 1.6 - 0.3).cuda().requires_grad_(True)      # ~20% below 0, ~20% above 1
+    gt = torch.rand((1, 3, H, W), generator=g).cuda()
+    l_hip = loss_hip.raster_l1_ssim_loss(raw, gt)
+    l_hip.backward()
+    g_hip = raw.grad.clone()
+    raw64 = raw.detach().double().requires_grad_(True)
+    l_ref = Lm.l1_ssim_loss_torch(raw64[..., :H, :W].clamp(0, 1), gt.double())
+    l_ref.backward()
+    assert abs(l_hip.item() - l_ref.item()) < 1e-5
+    assert (g_hip.double() - raw64.grad).abs().max().item() < 1e-4 * raw64.grad.abs().max().item() + 1e-9
+    assert g_hip[..., H:, :].abs().max().item() == 0 if Hp > H else True
+    outside = (raw.detach() < 0) | (raw.detach() > 1)
+    assert g_hip[outside].abs().max().item() == 0
