@@ -205,6 +205,25 @@ __device__ __forceinline__ void adam_row(float* __restrict__ p, float* __restric
     v[o] = vv;
 }
 
+// NR rows of one parameter tensor at a time: all 3*NR loads are issued before the first store, so a wave keeps 3*NR cache lines in
+// flight (one row at a time leaves 3 -- stores to the same tensor cannot be proven disjoint from the next row's loads).
+template <int NR>
+__device__ __forceinline__ void adam_rows(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const size_t (&o)[NR],
+                                          const float (&g)[NR], float lr, float b1, float b2, float eps)
+{
+    float pp[NR], mm[NR], vv[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) { pp[i] = p[o[i]]; mm[i] = m[o[i]]; vv[i] = v[o[i]]; }
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const float m1 = b1 * mm[i] + (1.0f - b1) * g[i];
+        const float v1 = b2 * vv[i] + (1.0f - b2) * g[i] * g[i];
+        p[o[i]] = pp[i] + -lr * m1 / (sqrtf(v1) + eps);
+        m[o[i]] = m1;
+        v[o[i]] = v1;
+    }
+}
+
 template <int DEG>
 __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible_chunk_id, const int* __restrict__ visible_chunks_num,
                                              Camera cam, AdamRates ar, int C, int S, int A, int R,
@@ -226,20 +245,35 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
     GaussGrads G;
     gaussian_backward<DEG>(cam, packed_grad + od * (GREC / 4), sc, pos[sd], pos[CS + sd], pos[2 * CS + sd],
                            scale[sd], scale[CS + sd], scale[2 * CS + sd], rot[sd], rot[CS + sd], rot[2 * CS + sd], rot[3 * CS + sd], opa[sd], G);
+    {
+        const size_t o3[3] = { sd, CS + sd, 2 * CS + sd };
+        const size_t o4[4] = { sd, CS + sd, 2 * CS + sd, 3 * CS + sd };
+        const size_t o1[1] = { sd };
+        const float gp[3] = { G.pos[0], G.pos[1], G.pos[2] }, gs[3] = { G.scale[0], G.scale[1], G.scale[2] };
+        const float gr[4] = { G.rot[0], G.rot[1], G.rot[2], G.rot[3] }, go[1] = { G.opa };
+        const float g0[3] = { G.basis[0] * G.gc[0], G.basis[0] * G.gc[1], G.basis[0] * G.gc[2] };
+        adam_rows<3>(pos, m_pos, v_pos, o3, gp, ar.lr_pos, ar.b1, ar.b2, ar.eps);
+        adam_rows<3>(scale, m_scale, v_scale, o3, gs, ar.lr_scale, ar.b1, ar.b2, ar.eps);
+        adam_rows<4>(rot, m_rot, v_rot, o4, gr, ar.lr_rot, ar.b1, ar.b2, ar.eps);
+        adam_rows<1>(opa, m_opa, v_opa, o1, go, ar.lr_opa, ar.b1, ar.b2, ar.eps);
+        adam_rows<3>(sh0, m_sh0, v_sh0, o3, g0, ar.lr_sh0, ar.b1, ar.b2, ar.eps);
+    }
+    // SH rest: KB coefficients (3*KB rows, 9*KB loads) per batch
+    constexpr int KB = (DEG == 2) ? 4 : 3;
+    static_assert(NB == 1 || (NB - 1) % KB == 0, "SH-rest batches must tile the active coefficients");
 #pragma unroll
-    for (int k = 0; k < 3; k++) adam_row(pos, m_pos, v_pos, k * CS + sd, G.pos[k], ar.lr_pos, ar.b1, ar.b2, ar.eps);
+    for (int k0 = 1; k0 < NB; k0 += KB) {
+        size_t o9[KB * 3];
+        float g9[KB * 3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) adam_row(scale, m_scale, v_scale, k * CS + sd, G.scale[k], ar.lr_scale, ar.b1, ar.b2, ar.eps);
+        for (int kk = 0; kk < KB; kk++)
 #pragma unroll
-    for (int k = 0; k < 4; k++) adam_row(rot, m_rot, v_rot, k * CS + sd, G.rot[k], ar.lr_rot, ar.b1, ar.b2, ar.eps);
-    adam_row(opa, m_opa, v_opa, sd, G.opa, ar.lr_opa, ar.b1, ar.b2, ar.eps);
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) adam_row(sh0, m_sh0, v_sh0, ch * CS + sd, G.basis[0] * G.gc[ch], ar.lr_sh0, ar.b1, ar.b2, ar.eps);
-#pragma unroll
-    for (int k = 1; k < NB; k++)
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-            adam_row(shr, m_shr, v_shr, ((size_t)(k - 1) * 3 + ch) * CS + sd, G.basis[k] * G.gc[ch], ar.lr_shr, ar.b1, ar.b2, ar.eps);
+            for (int ch = 0; ch < 3; ch++) {
+                o9[kk * 3 + ch] = ((size_t)(k0 + kk - 1) * 3 + ch) * CS + sd;
+                g9[kk * 3 + ch] = G.basis[k0 + kk] * G.gc[ch];
+            }
+        adam_rows<KB * 3>(shr, m_shr, v_shr, o9, g9, ar.lr_shr, ar.b1, ar.b2, ar.eps);
+    }
     for (int k = NB - 1; k < R; k++)                         // inactive SH degrees: zero gradient, moments still decay (as adamUpdate)
         for (int ch = 0; ch < 3; ch++) adam_row(shr, m_shr, v_shr, ((size_t)k * 3 + ch) * CS + sd, 0.0f, ar.lr_shr, ar.b1, ar.b2, ar.eps);
 }
