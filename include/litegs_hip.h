@@ -190,13 +190,14 @@ int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float
                     void* ws1, long long ws1_bytes, int* host_feedback_vis, int* host_feedback_total, void* stream);
 int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                     void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
-                    float* img, float* trans, short* last, int* frag_count, float* frag_weight, void* stream);
+                    float* img, float* trans, short* last, int* frag_count, float* frag_weight,
+                    float* packed_grad_clear /*nullable [N,16]: zeroed on the side for the coming lg_fused_backward*/, void* stream);
 int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
                       const void* ws2, long long ws2_bytes, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                       const int64_t* vis_ids, const int* vis_num,
                       const float* pos, const float* scale, const float* rot, const float* opa,
                       const int* tiles, int K, const float* final_T, const short* last, const float* d_img, const float* d_trans,
-                      const float* grad_inv_scaler, int enable_stat, float* packed_grad, float* err_square_sum,
+                      const float* grad_inv_scaler, int enable_stat, float* packed_grad, int packed_grad_is_zero, float* err_square_sum,
                       float* d_pos, float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa, void* stream);
 int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                            const int64_t* vis_ids, const int* vis_num, const float* packed_grad, const float* grad_inv_scaler,

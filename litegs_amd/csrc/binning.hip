@@ -347,7 +347,8 @@ template <int TH, int TW, typename IdxT, bool PACKED>
 __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
                                                       const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                       long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
-                                                      const int* __restrict__ queue, int* __restrict__ totals, DigitSpec ds)
+                                                      const int* __restrict__ queue, int* __restrict__ totals, DigitSpec ds,
+                                                      uint32_t* __restrict__ zero2_ptr, long long zero2_words)
 {
     __shared__ int w_minv[TPB / 64][DUP_MAX_SLICES];      // per-wave slice scratch
     __shared__ int w_off[TPB / 64][DUP_MAX_SLICES + 1];
@@ -357,6 +358,13 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     for (int k = tid; k < (TPB / 64) * (DUP_MAX_RUN / 32 + 2); k += TPB) (&bitmap[0][0])[k] = 0u;
+    // zero duty for the blend backward's gradient accumulator: this kernel is latency bound, the memory pipes are idle
+    if (zero2_ptr) {
+        uint4* z4 = reinterpret_cast<uint4*>(zero2_ptr);
+        const long long n4 = zero2_words / 4, gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, nth = (long long)gridDim.x * gridDim.y * TPB;
+        for (long long i = gid; i < n4; i += nth) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (long long i = n4 * 4 + gid; i < zero2_words; i += nth) zero2_ptr[i] = 0u;
+    }
     const int32_t* pf = prefix + (size_t)b * N;
     int32_t* kout = keys + (size_t)b * table_len;
     int32_t* vout = values + (size_t)b * table_len;
@@ -511,7 +519,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
 int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
                 int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
                 int* queue, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
-                uint32_t* ones_ptr, long long ones_words, void* stream)
+                uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words, void* stream)
 {
     if (N <= 0) return 0;
     if (packed && sorted_id_is_int64) return (int)hipErrorInvalidValue;     // packed records: fused executor only (int32 order)
@@ -532,7 +540,7 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
         hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,                \
                            H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words);                                \
         hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
-                           N, H, W, gx, gy, table_len, keys, values, (const int*)queue, totals, ds);                                       \
+                           N, H, W, gx, gy, table_len, keys, values, (const int*)queue, totals, ds, zero2_ptr, zero2_words);               \
     } while (0)
 #define DISPATCH_DUP(A_, B_)                                              \
     do {                                                                  \
@@ -565,7 +573,7 @@ LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const 
         if (err != hipSuccess) return (int)err;
     }
     return lg_dup_emit(ndc, inv_cov, opacity, nullptr, prefix, sorted_id, sorted_id_is_int64, V, N, H, W, TH, TW, table_len, keys, values,
-                       (int*)temp, nullptr, 0, 0, nullptr, 0, nullptr, 0, stream);
+                       (int*)temp, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -407,7 +407,9 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
 // Stage 2: key/value emission -> stable tile sort -> tile ranges -> blend forward.  L = table length of the layout.
 LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                            void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
-                           float* img, float* trans, short* last, int* frag_count, float* frag_weight, void* stream)
+                           float* img, float* trans, short* last, int* frag_count, float* frag_weight,
+                           float* packed_grad_clear /*nullable: [N,16] gradient accumulator of the coming backward, zeroed on the side*/,
+                           void* stream)
 {
     if (A <= 0 || L <= 0) return (int)hipErrorInvalidValue;
     const long long N = (long long)A * S;
@@ -430,7 +432,8 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
                      (const int32_t*)(w1 + f1.prefix), order, 0, 1, (int)N, H, W, TH, TW, L, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
                      (int*)(w1 + f1.dup_queue), (int*)(w1 + f1.tsort_hdr), 0, bits, (uint32_t*)(w + f.tsort_table),
                      (long long)lg_radix_table_words(L, lg_radix_sort_num_passes(0, bits)),
-                     (uint32_t*)(w + f.tile_start), (long long)ntiles + 2, stream);
+                     (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
+                     (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * N : 0, stream);
     if (rc) return rc;
     // exact instance count on the device (prefix[N-1]): only that many entries are sorted and range-scanned
     const int* total_dev = (const int*)(w1 + f1.prefix) + (N - 1);
@@ -452,7 +455,7 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
                              const float* pos, const float* scale, const float* rot, const float* opa,
                              const int* tiles, int K, const float* final_T, const short* last, const float* d_img, const float* d_trans,
                              const float* grad_inv_scaler, int enable_stat,
-                             float* packed_grad /*[N,16] scratch*/, float* err_square_sum,
+                             float* packed_grad /*[N,16] scratch*/, int packed_grad_is_zero /*cleared by lg_fused_stage2*/, float* err_square_sum,
                              float* d_pos /*NULL: blend backward only (gradients consumed later by lg_fused_backward_adam)*/,
                              float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa, void* stream)
 {
@@ -470,7 +473,8 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
     bits++;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
-    int rc = lg_memset_async(packed_grad, 0, (long long)sizeof(float) * GREC * N, stream); if (rc) return rc;
+    int rc = 0;
+    if (!packed_grad_is_zero) { rc = lg_memset_async(packed_grad, 0, (long long)sizeof(float) * GREC * N, stream); if (rc) return rc; }
     rc = lg_raster_backward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, final_T, last, d_img, d_trans,
                             1, L, (int)N, H, W, TH, TW, enable_stat, packed_grad, err_square_sum, stream);
     if (rc) return rc;

@@ -113,9 +113,13 @@ class _RenderFn(torch.autograd.Function):
             STATS.set_compaction(vis_ids[:A], vis_num)
         if tiles is not None:
             img.zero_(); trans.fill_(1.0); last.zero_()
+        # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
+        pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
         check(L.lg_fused_stage2(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes, tp, K,
                                 1 if stat else 0, img.data_ptr(), trans.data_ptr(), last.data_ptr(),
-                                fc.data_ptr() if stat else None, fw.data_ptr() if stat else None, s), "fused stage2")
+                                fc.data_ptr() if stat else None, fw.data_ptr() if stat else None,
+                                pg.data_ptr() if pg is not None else None, s), "fused stage2")
+        ctx.pg = pg
         if stat:
             STATS.update_tile_schedule(last, R.TH, R.TW)
         ctx.R, ctx.frame, ctx.meta = R, frame, (A, S, table_len, int(degree), chunks, sh_rest.shape[0], ws1_bytes, ws2_bytes, stat)
@@ -138,7 +142,10 @@ class _RenderFn(torch.autograd.Function):
         if g_img is None:
             return (None,) * 11
         g_img = g_img.contiguous()
-        pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev)
+        pg, pg_zero = ctx.pg, 1
+        if pg is None:
+            pg, pg_zero = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev), 0
+        ctx.pg = None
         esq = torch.zeros((1, 1, N), dtype=torch.float32, device=dev) if stat else None
         tiles = ctx.tiles
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
@@ -147,7 +154,7 @@ class _RenderFn(torch.autograd.Function):
                                       frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
                                       xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
                                       trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
-                                      pg.data_ptr(), esq.data_ptr() if stat else None, None, None, None, None, None, None, _s()),
+                                      pg.data_ptr(), pg_zero, esq.data_ptr() if stat else None, None, None, None, None, None, None, _s()),
                   "fused blend backward")
             if stat:
                 fc, fw = ctx.stat_bufs
@@ -165,7 +172,7 @@ class _RenderFn(torch.autograd.Function):
                                   frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
                                   xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
                                   trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
-                                  pg.data_ptr(), esq.data_ptr() if stat else None,
+                                  pg.data_ptr(), pg_zero, esq.data_ptr() if stat else None,
                                   d_pos.data_ptr(), d_scale.data_ptr(), d_rot.data_ptr(), d_sh0.data_ptr(), d_shr.data_ptr(), d_opa.data_ptr(), _s()),
               "fused backward")
         if stat:
