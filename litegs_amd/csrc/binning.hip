@@ -588,7 +588,9 @@ LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const 
 // ---------------------------------------------------------------------------------------------
 #define RADIX_BITS 8
 #define RADIX (1 << RADIX_BITS)
+#ifndef SORT_ITEMS
 #define SORT_ITEMS 16
+#endif
 #define SORT_TILE (TPB * SORT_ITEMS)
 #define SORT_MAX_PASSES 4
 
@@ -764,7 +766,7 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
 // ---------------------------------------------------------------------------------------------
 // Single-launch radix pass ("onesweep"): the per-workgroup digit counts are chained through a status table with
 // decoupled look-back instead of a histogram launch + a scan launch per pass.  Workgroups take a ticket (so a workgroup's
-// logical predecessors have all started), rank their 4096 keys exactly like radix_scatter_kernel, publish their 256 digit
+// logical predecessors have all started), each wave ranks a contiguous run of 1024 keys (returning LDS adds), they publish their 256 digit
 // counts (flag AGG), thread d then walks back over the predecessors' words for digit d until it meets an inclusive prefix
 // (flag INC), publishes its own inclusive prefix and the tile is streamed out.  One status word carries flag and value, so
 // no ordering between separate flag/value stores is needed.  status[] and ticket[] must be zero on entry.
@@ -807,25 +809,17 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
         key[j] = ok ? keys_in[base + e] : 0u;
         val[j] = ok ? vals_in[base + e] : 0u;
     }
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // Rank of a key among the wave's earlier keys with the same digit = the value a returning LDS add hands back: rounds are
+    // sequential, and inside one ds_add_rtn instruction the LDS serves the lanes that hit the same address in increasing lane
+    // order, so equal digits keep their input order.  That order is a property of the CDNA LDS pipeline rather than of the
+    // programming model; tests/test_gpu_ops.py::test_radix_sort_is_stable_and_exact (duplicate-heavy keys) and the bit-exact
+    // full-size binning test pin it.  It replaces a "match-any" built from 8 ballots per key (~65 VALU per key).
     int* my_cnt = wave_cnt[wave];
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
         const bool ok = (wave * WAVE_KEYS + j * 64 + lane) < cnt_tile;
         const uint32_t d = (key[j] >> shift) & mask;
-        unsigned long long peers = __ballot(ok);
-#pragma unroll
-        for (int bit = 0; bit < RADIX_BITS; bit++) {
-            const bool set = (d >> bit) & 1u;
-            unsigned long long bal = __ballot(set);
-            peers &= set ? bal : ~bal;
-        }
-        const int rank = __popcll(peers & lt_mask);
-        const int prev = my_cnt[d];                      // wave-private counter: read by all peers, then bumped by the first one
-        __builtin_amdgcn_wave_barrier();
-        if (ok && rank == 0) my_cnt[d] = prev + __popcll(peers);
-        __builtin_amdgcn_wave_barrier();
-        lrank[j] = prev + rank;
+        lrank[j] = ok ? atomicAdd(&my_cnt[d], 1) : 0;
     }
     __syncthreads();
     // thread d: counts of digit d per wave -> wave offsets inside the digit, tile count of the digit

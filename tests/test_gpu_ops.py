@@ -207,6 +207,31 @@ def test_radix_sort_is_stable_and_exact(F, oracle, n, bits):
     assert np.array_equal(host(v).view(np.uint32), vals[order])
 
 
+@pytest.mark.parametrize("pattern", ["all_equal", "two_values", "three_bit", "runs_of_64", "tile_like"])
+def test_radix_sort_stability_under_heavy_duplicates(F, pattern):
+    """Equal digits inside one 64-key wave instruction must keep their input order (the ranking relies on the LDS serving
+    same-address returning adds in lane order): patterns where every instruction has many collisions, 1.2 M keys so that the
+    look-back chain spans ~300 workgroups."""
+    n = 1_200_011
+    rng = np.random.default_rng(7)
+    if pattern == "all_equal":
+        keys = np.full(n, 0x1234, np.uint32)
+    elif pattern == "two_values":
+        keys = np.where(rng.random(n) < 0.5, 0x00ff, 0x1f00).astype(np.uint32)
+    elif pattern == "three_bit":
+        keys = (rng.integers(0, 8, n) * 0x0421).astype(np.uint32)
+    elif pattern == "runs_of_64":
+        keys = (np.arange(n) // 64 % 5000).astype(np.uint32)
+    else:                                   # neighbouring tile ids, as duplicate_with_keys emits them
+        base = rng.integers(1, 8000, n // 16 + 1)
+        keys = (base[:, None] + (np.arange(16) % 4)[None, :] + 120 * (np.arange(16) // 4)[None, :]).reshape(-1)[:n].astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    k, v = F.radix_sort_pairs(dev(keys.view(np.int32)), dev(vals.view(np.int32)), 0, 14)
+    order = np.argsort(keys & 0x3fff, kind="stable")
+    assert np.array_equal(host(k).view(np.uint32), keys[order])
+    assert np.array_equal(host(v).view(np.uint32), vals[order])
+
+
 def test_depth_sort_and_scan_match_numpy(F):
     from litegs_amd import binning
     rng = np.random.default_rng(11)
