@@ -187,7 +187,10 @@ int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float
                     const float* view_host, const float* proj_host, int H, int W, int TH, int TW, int degree,
                     const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,
                     int do_cull, uint8_t* visibility, int* vis_num, int64_t* vis_ids, int A,
-                    void* ws1, long long ws1_bytes, int* host_feedback_vis, int* host_feedback_total, void* stream);
+                    void* ws1, long long ws1_bytes, int* host_feedback_vis, int* host_feedback_total,
+                    void* cull_scratch /*nullable: persistent, lg_fused_cull_scratch_bytes(chunks), zeroed once*/, uint32_t cull_epoch /*1,2,3,.. per call*/,
+                    void* stream);
+long long lg_fused_cull_scratch_bytes(int chunks);
 int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                     void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
                     float* img, float* trans, short* last, int* frag_count, float* frag_weight,

@@ -134,6 +134,99 @@ int lg_frustum_culling_fb(const float* origin, const float* ext, const float* pl
     LG_RETURN_LAST();
 }
 
+// Multi-workgroup variant for the native executor: 256 chunks per workgroup, the ordered compaction offsets are chained with
+// decoupled look-back (one 64-bit status word per workgroup = launch epoch | flag | count, so the table never needs clearing;
+// `scratch` is a persistent zero-initialised buffer owned by the caller: [0] ticket counter, [2..] status words).
+// 34 us (one workgroup, 23 sequential sweeps at 3 M Gaussians) -> a few us.
+#define CHAIN_TPB 256
+__global__ void __launch_bounds__(CHAIN_TPB) frustum_culling_chain_kernel(const float* __restrict__ origin, const float* __restrict__ ext,
+                                                                          const float* __restrict__ planes, int V, int M,
+                                                                          uint8_t* __restrict__ visibility, int* __restrict__ visible_num,
+                                                                          int64_t* __restrict__ visible_chunk_id,
+                                                                          unsigned long long* __restrict__ status, int* __restrict__ ticket,
+                                                                          unsigned int epoch, int ticket_base, int* __restrict__ host_feedback)
+{
+    __shared__ float planes_lds[8 * 24];
+    __shared__ int wcnt[CHAIN_TPB / 64];
+    __shared__ int bid_s, excl_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblocks = gridDim.x;
+    if (tid == 0) bid_s = atomicAdd(ticket, 1) - ticket_base;
+    for (int k = tid; k < V * 24; k += CHAIN_TPB) planes_lds[k] = planes[k];
+    __syncthreads();
+    const int bid = bid_s;
+    const int m = bid * CHAIN_TPB + tid;
+    bool vis = false;
+    if (m < M) {
+        vis = aabb_visible(planes_lds, V, origin[m], origin[(size_t)M + m], origin[2 * (size_t)M + m],
+                           ext[m], ext[(size_t)M + m], ext[2 * (size_t)M + m]);
+        visibility[m] = vis ? 1 : 0;
+    }
+    const unsigned long long bm = __ballot(vis);
+    if (lane == 0) wcnt[wave] = __popcll(bm);
+    __syncthreads();
+    const int block_total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    const unsigned long long tag = (unsigned long long)epoch << 34;          // bits 34..63 epoch, 32/33 flags, 0..31 count
+    const unsigned long long F_AGG = 1ull << 32, F_INC = 1ull << 33;
+    if (wave == 0) {
+        unsigned int excl = 0;
+        if (bid == 0) {
+            if (lane == 0) __hip_atomic_store(status, tag | F_INC | (unsigned long long)block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(status + bid, tag | F_AGG | (unsigned long long)block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int b = bid - 1;
+            while (true) {
+                unsigned long long w = (b - lane >= 0) ? __hip_atomic_load(status + (b - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag | F_INC);
+                const bool fresh = (w >> 34) == (unsigned long long)epoch;   // words of earlier launches count as "not ready"
+                const unsigned long long inc_m = __ballot(fresh && (w & F_INC));
+                const unsigned long long nr_m = __ballot(!fresh || (w & (F_AGG | F_INC)) == 0ull);
+                const int first_inc = inc_m ? __ffsll((long long)inc_m) - 1 : 64;
+                const int first_nr = nr_m ? __ffsll((long long)nr_m) - 1 : 64;
+                const int take = first_nr < first_inc ? first_nr : (first_inc < 64 ? first_inc + 1 : 64);
+                unsigned int part = (lane < take) ? (unsigned int)(w & 0xffffffffull) : 0u;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+                excl += __shfl(part, 0);
+                if (first_inc < first_nr) break;
+                b -= take;
+                if (take < 64) __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) __hip_atomic_store(status + bid, tag | F_INC | (unsigned long long)(excl + (unsigned int)block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) excl_s = (int)excl;
+    }
+    __syncthreads();
+    int pos = excl_s + __popcll(bm & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) pos += wcnt[w];
+    if (vis) visible_chunk_id[pos] = m;
+    if (bid == nblocks - 1) {                                            // the last workgroup knows the total
+        const int count = excl_s + block_total;
+        if (tid == 0) {
+            visible_num[0] = count;
+            if (host_feedback) __hip_atomic_store(host_feedback, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        for (int k = count + tid; k < M; k += CHAIN_TPB) visible_chunk_id[k] = k;      // arange() tail, as the reference
+    }
+}
+
+long long lg_cull_scratch_bytes(int M) { return 16 + 8LL * ((M + CHAIN_TPB - 1) / CHAIN_TPB); }
+
+// scratch: lg_cull_scratch_bytes(M) bytes, zero-initialised ONCE by the caller and then only passed to this function with the same M;
+// epoch = 1, 2, 3, ... (one per call on this scratch)
+int lg_frustum_culling_chain(const float* origin, const float* ext, const float* planes, int V, int M, uint8_t* visibility, int* visible_num,
+                             int64_t* visible_chunk_id, void* scratch, unsigned int epoch, int* host_feedback, void* stream)
+{
+    if (M <= 0) return 0;
+    if (V > 8 || epoch == 0 || epoch >= (1u << 30)) return (int)hipErrorInvalidValue;
+    const int nblocks = (M + CHAIN_TPB - 1) / CHAIN_TPB;
+    const long long base = (long long)(epoch - 1) * nblocks;
+    if (base > 0x7fffffffLL - nblocks) return (int)hipErrorInvalidValue;      // caller re-creates the scratch long before this
+    hipLaunchKernelGGL(frustum_culling_chain_kernel, dim3(nblocks), dim3(CHAIN_TPB), 0, (hipStream_t)stream, origin, ext, planes, V, M,
+                       visibility, visible_num, visible_chunk_id, (unsigned long long*)((char*)scratch + 16), (int*)scratch, epoch,
+                       (int)base, host_feedback);
+    LG_RETURN_LAST();
+}
+
 // Ordered compaction of an int32 mask (non-zero = keep) with the same output contract as frustum_culling_aabb:
 // used by the data-parallel path to turn the all-reduced visibility mask into the union chunk list.
 LG_API int lg_compact_mask(const int* mask, int M, int* count, int64_t* ids, void* stream)

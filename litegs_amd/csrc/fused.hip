@@ -335,6 +335,8 @@ LG_API long long lg_fused_workspace2_bytes(long long L, int H, int W, int TH, in
     return (long long)layout2(L > 0 ? L : 1, ntiles).total;
 }
 
+LG_API long long lg_fused_cull_scratch_bytes(int chunks) { return lg_cull_scratch_bytes(chunks); }
+
 // byte offset in workspace 1 of the exact instance total (prefix[N-1]) -- for the blocking first-visit path
 LG_API long long lg_fused_total_offset(long long N) { return (long long)(layout1(N).prefix + 4 * (size_t)(N - 1)); }
 
@@ -354,12 +356,17 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
                            const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,
                            int do_cull, uint8_t* visibility, int* vis_num, int64_t* vis_ids, int A,
                            void* ws1, long long ws1_bytes,
-                           int* host_feedback_vis, int* host_feedback_total, void* stream)
+                           int* host_feedback_vis, int* host_feedback_total,
+                           void* cull_scratch /*nullable: lg_fused_cull_scratch_bytes(chunks), zeroed once*/, unsigned int cull_epoch, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (do_cull) {
-        rc = lg_frustum_culling_fb(aabb_origin, aabb_ext, planes_dev, 1, chunks, visibility, vis_num, vis_ids, host_feedback_vis, stream);
+        if (cull_scratch)
+            rc = lg_frustum_culling_chain(aabb_origin, aabb_ext, planes_dev, 1, chunks, visibility, vis_num, vis_ids, cull_scratch, cull_epoch,
+                                          host_feedback_vis, stream);
+        else
+            rc = lg_frustum_culling_fb(aabb_origin, aabb_ext, planes_dev, 1, chunks, visibility, vis_num, vis_ids, host_feedback_vis, stream);
         if (rc) return rc;
     }
     if (A <= 0) return 0;

@@ -38,3 +38,8 @@ int lg_tile_range_prefilled(const int32_t* sorted_keys, int V, long long L, cons
 // frustum culling that also stores the visible-chunk count into pinned host memory (nullable)
 int lg_frustum_culling_fb(const float* origin, const float* ext, const float* planes, int V, int M, uint8_t* visibility, int* visible_num,
                           int64_t* visible_chunk_id, int* host_feedback, void* stream);
+
+// multi-workgroup ordered culling with a persistent, epoch-tagged look-back table (compact.hip)
+long long lg_cull_scratch_bytes(int M);
+int lg_frustum_culling_chain(const float* origin, const float* ext, const float* planes, int V, int M, uint8_t* visibility, int* visible_num,
+                             int64_t* visible_chunk_id, void* scratch, unsigned int epoch, int* host_feedback, void* stream);

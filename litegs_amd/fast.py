@@ -48,6 +48,15 @@ class FusedRenderer:
         # Only valid when nothing needs the gradients between backward and the optimizer step (no DP exchange).
         self.fuse_optimizer = False
         self.pending = None
+        self._cull_scratch, self._cull_chunks, self._cull_epoch = None, -1, 0
+
+    def cull_scratch(self, chunks: int, device):
+        """persistent look-back table of the multi-workgroup culling kernel (epoch-tagged: zeroed once, never cleared again)"""
+        if self._cull_scratch is None or self._cull_chunks != chunks or self._cull_epoch > 1_000_000:
+            self._cull_scratch = torch.zeros((lib().lg_fused_cull_scratch_bytes(chunks),), dtype=torch.uint8, device=device)
+            self._cull_chunks, self._cull_epoch = chunks, 0
+        self._cull_epoch += 1
+        return self._cull_scratch.data_ptr(), self._cull_epoch
 
     def render(self, frame: CameraFrame, cluster_origin, cluster_extend, xyz, scale, rot, sh_0, sh_rest, opacity, degree: int):
         """-> (img[1,3,H,W] clamped to [0,1], visible_chunkid, visible_chunks_num)."""
@@ -79,7 +88,8 @@ class _RenderFn(torch.autograd.Function):
         pred_vis = int(R.fb_vis[k])
         do_cull = 1
         if pred_vis <= 0:                                    # first visit: blocking count (GR/compact.cu:543-546)
-            check(L.lg_fused_stage1(*common, 1, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), 0, None, 0, fb_vis_ptr, None, s),
+            check(L.lg_fused_stage1(*common, 1, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), 0, None, 0, fb_vis_ptr, None,
+                                    *R.cull_scratch(chunks, dev), s),
                   "fused cull")
             A = int(vis_num.item())
             do_cull = 0
@@ -90,7 +100,7 @@ class _RenderFn(torch.autograd.Function):
         ws1_bytes = L.lg_fused_workspace1_bytes(N)
         ws1 = torch.empty((ws1_bytes,), dtype=torch.uint8, device=dev)
         check(L.lg_fused_stage1(*common, do_cull, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), A, ws1.data_ptr(), ws1_bytes,
-                                fb_vis_ptr if do_cull else None, fb_tot_ptr, s), "fused stage1")
+                                fb_vis_ptr if do_cull else None, fb_tot_ptr, *(R.cull_scratch(chunks, dev) if do_cull else (None, 0)), s), "fused stage1")
         pred_total = int(R.fb_total[k])
         if pred_total <= 0:                                  # first visit: blocking table size (GR/binning.cu:152-163)
             off = L.lg_fused_total_offset(N)
