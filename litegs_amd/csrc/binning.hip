@@ -69,7 +69,7 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 
 // a10 (first half) duplicate_with_keys: slot j (depth order) -> point sorted_id[j]; emits at prefix[j-1].
 // A 256-thread workgroup owns 256 consecutive depth slots.  Two paths, both bit-identical to walk_tiles<>:
-//  * small splats (<= DUP_SMALL tiles): the owning thread runs the serial AccuTile walk into a compacted LDS
+//  * small splats (<= 64 tiles while the group's entries fit the LDS buffer, else <= 32): the owning thread runs the serial AccuTile walk into a compacted LDS
 //    buffer; the workgroup then streams the buffer out (entry -> owner by binary search over 256 offsets), so
 //    global stores are coalesced instead of 64 scattered 4-byte stores per wave instruction;
 //  * big splats (near-camera Gaussians can touch thousands of tiles) are queued and emitted by a second launch whose
@@ -80,6 +80,7 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 //    256-byte coalesced stores.  Without this, one thread serialises a 16 200-tile splat and the launch
 //    waits for it (measured: 2.3 ms of a 4.9 ms training step at 3 M Gaussians).
 #define DUP_SMALL 32
+#define DUP_SMALL_HI 64
 #define DUP_LDS_ENTRIES (TPB * DUP_SMALL)
 #define DUP_MAX_SLICES 256
 #define DUP_MAX_RUN 32768      // tiles one splat may touch on the cooperative path (bitmap of 4 KiB per wave)
@@ -268,8 +269,20 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             for (long long q = off; q < table_len; q++) kout[q] = 0;
         }
     }
-    const bool small = live && cnt <= DUP_SMALL;
-    const bool big = live && cnt > DUP_SMALL;
+    // Threshold between the in-workgroup path and the queue: DUP_SMALL_HI when this group's entries still fit the LDS buffer
+    // (the usual case: ~8 tiles per splat on average), DUP_SMALL otherwise (then 256 x 32 entries fit by construction).
+    int thr = DUP_SMALL_HI;
+    {
+        int c64 = (live && cnt <= DUP_SMALL_HI) ? cnt : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
+        if (lane == 0) wbig[wave] = c64;
+        __syncthreads();
+        if (wbig[0] + wbig[1] + wbig[2] + wbig[3] > DUP_LDS_ENTRIES) thr = DUP_SMALL;
+        __syncthreads();
+    }
+    const bool small = live && cnt <= thr;
+    const bool big = live && cnt > thr;
 
     // ---- big splats: append the slots to this group's sub-queue (one returning atomic per group) ----
     {
