@@ -223,15 +223,16 @@ def main():
 
     # every frame must be seen once (blocking sizing path) before steady state
     warm = max(args.warmup, args.frames + 2)
+    n_slots = max(args.frames, 1)                     # step i trains the frame set {i*world + r}: it recurs every `frames` steps
     for i in range(warm):
-        tr.step(frame_of(i), hook)
+        tr.step(frame_of(i), hook, i % n_slots)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(warm, warm + args.steps):
-        tr.step(frame_of(i), hook)
+        tr.step(frame_of(i), hook, i % n_slots)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

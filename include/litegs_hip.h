@@ -69,6 +69,7 @@ int lg_sparse_scatter(void* A_, const void* B, const int64_t* chunk_ids, const i
  * int32 mask into (count, ids) with the output contract of lg_frustum_culling_aabb */
 int lg_mark_chunks(const int64_t* ids, const int* count, int A, int* mask, void* stream);
 int lg_compact_mask(const int* mask, int M, int* count, int64_t* ids, void* stream);
+int lg_compact_mask_rank(const int* mask, int M, int* count, int64_t* ids, int64_t* rank /*[M]: position of each kept chunk in ids*/, void* stream);
 
 /* the 4-byte async device->pinned-host feedback copy of GR/compact.cu:538 and GR/binning.cu:148 */
 int lg_feedback_d2h(int* host_dst, const int* device_src, void* stream);

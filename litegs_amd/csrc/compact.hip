@@ -41,7 +41,8 @@ template <bool FROM_MASK>
 __global__ void __launch_bounds__(CULL_TPB) frustum_culling_kernel(const float* __restrict__ origin, const float* __restrict__ ext,
                                                                    const float* __restrict__ planes, const int* __restrict__ mask, int V, int M,
                                                                    uint8_t* __restrict__ visibility, int* __restrict__ visible_num,
-                                                                   int64_t* __restrict__ visible_chunk_id, int* __restrict__ host_feedback)
+                                                                   int64_t* __restrict__ visible_chunk_id, int* __restrict__ host_feedback,
+                                                                   int64_t* __restrict__ rank_out /*nullable: rank_out[m] = position of chunk m*/)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int passes = (M + CULL_TPB - 1) / CULL_TPB;
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(CULL_TPB) frustum_culling_kernel(const float* 
         if ((mask >> lane) & 1ull) {
             int rank = __popcll(mask & ((1ull << lane) - 1ull));
             visible_chunk_id[counts[p * CULL_WAVES + wave] + rank] = m;
+            if (rank_out) rank_out[m] = counts[p * CULL_WAVES + wave] + rank;
         }
         if (m < M && m >= count) visible_chunk_id[m] = m;   // arange() tail (never overlaps the compacted prefix)
     }
@@ -118,7 +120,7 @@ LG_API int lg_frustum_culling_aabb(const float* origin, const float* ext, const 
     size_t lds = ((V * 24 * 4 + 15) & ~15) + (size_t)passes * CULL_WAVES * (8 + 4) + 16;
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(frustum_culling_kernel<false>, dim3(1), dim3(CULL_TPB), lds, (hipStream_t)stream,
-                       origin, ext, planes, (const int*)nullptr, V, M, visibility, visible_num, visible_chunk_id, (int*)nullptr);
+                       origin, ext, planes, (const int*)nullptr, V, M, visibility, visible_num, visible_chunk_id, (int*)nullptr, (int64_t*)nullptr);
     LG_RETURN_LAST();
 }
 
@@ -130,7 +132,7 @@ int lg_frustum_culling_fb(const float* origin, const float* ext, const float* pl
     size_t lds = ((V * 24 * 4 + 15) & ~15) + (size_t)passes * CULL_WAVES * (8 + 4) + 16;
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(frustum_culling_kernel<false>, dim3(1), dim3(CULL_TPB), lds, (hipStream_t)stream,
-                       origin, ext, planes, (const int*)nullptr, V, M, visibility, visible_num, visible_chunk_id, host_feedback);
+                       origin, ext, planes, (const int*)nullptr, V, M, visibility, visible_num, visible_chunk_id, host_feedback, (int64_t*)nullptr);
     LG_RETURN_LAST();
 }
 
@@ -229,14 +231,23 @@ int lg_frustum_culling_chain(const float* origin, const float* ext, const float*
 
 // Ordered compaction of an int32 mask (non-zero = keep) with the same output contract as frustum_culling_aabb:
 // used by the data-parallel path to turn the all-reduced visibility mask into the union chunk list.
+LG_API int lg_compact_mask_rank(const int* mask, int M, int* count, int64_t* ids, int64_t* rank, void* stream);
+
 LG_API int lg_compact_mask(const int* mask, int M, int* count, int64_t* ids, void* stream)
+{
+    return lg_compact_mask_rank(mask, M, count, ids, nullptr, stream);
+}
+
+// same, plus the inverse map: rank[m] = position of chunk m in ids for every kept chunk (other entries untouched)
+LG_API int lg_compact_mask_rank(const int* mask, int M, int* count, int64_t* ids, int64_t* rank, void* stream)
 {
     if (M <= 0) return 0;
     int passes = (M + CULL_TPB - 1) / CULL_TPB;
     size_t lds = 16 + (size_t)passes * CULL_WAVES * (8 + 4) + 16;
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(frustum_culling_kernel<true>, dim3(1), dim3(CULL_TPB), lds, (hipStream_t)stream,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, mask, 0, M, (uint8_t*)nullptr, count, ids, (int*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, mask, 0, M, (uint8_t*)nullptr, count, ids,
+                       (int*)nullptr, rank);
     LG_RETURN_LAST();
 }
 
@@ -560,6 +571,7 @@ __global__ void sparse_scatter_kernel(T* __restrict__ A, const T* __restrict__ B
     const int src = blockIdx.x, e = blockIdx.y;
     if (src >= valid_count[0]) return;
     const size_t dst = (size_t)chunk_ids[src];
+    if (dst >= (size_t)chunks) return;                  // id outside the destination (e.g. a truncated union list): dropped
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
         T b = B[((size_t)e * alloc + src) * S + i];
         T* p = A + ((size_t)e * chunks + dst) * S + i;

@@ -79,7 +79,7 @@ class SyntheticTrainer:
                                                        (self.H, self.W), self.pp)
         return img, vis_id, vis_num, prim_vis
 
-    def step(self, frame_index: int, grad_hook=None):
+    def step(self, frame_index: int, grad_hook=None, hook_slot: int = 0):
         frame = self.frames[frame_index % len(self.frames)]
         # gradients are only materialised when something consumes them between backward and the optimizer (DP exchange)
         self.renderer.fuse_optimizer = self.fused and self.fuse_adam and grad_hook is None
@@ -91,7 +91,7 @@ class SyntheticTrainer:
             loss = self.loss_fn(img, frame.gt)
         loss.backward(self._unit)
         if grad_hook is not None:            # data-parallel gradient exchange (litegs_amd/dp.py)
-            vis_id, vis_num = grad_hook(self.params, vis_id, vis_num)
+            vis_id, vis_num = grad_hook(self.params, vis_id, vis_num, hook_slot)
         if self.fused:
             self.fadam.step(vis_id, vis_num)
         else:

@@ -1,4 +1,4 @@
-"""world_size=2 data-parallel exchange on CPU (gloo): union visibility, one dense averaged buffer, replicas stay identical.
+"""world_size=2 data-parallel exchange on CPU (gloo): union visibility, one averaged buffer packed over the union, replicas stay identical.
 The device primitives are injected as plain-torch ops (the product's HipOps need a GPU)."""
 import os
 import socket
@@ -19,12 +19,19 @@ class TorchOps:
         ids = torch.nonzero(mask)[:, 0]
         full = torch.arange(mask.shape[0], dtype=torch.int64)
         full[: len(ids)] = ids
-        return full, torch.tensor([len(ids)], dtype=torch.int32)
+        rank = torch.zeros(mask.shape[0], dtype=torch.int64)
+        rank[ids] = torch.arange(len(ids))
+        return full, torch.tensor([len(ids)], dtype=torch.int32), rank
 
     @staticmethod
     def scatter_add(dense, compact, ids, count):
         n = int(count)
-        dense[:, ids[:n], :] += compact[:, :n, :]
+        keep = ids[:n] < dense.shape[1]
+        dense[:, ids[:n][keep], :] += compact[:, :n, :][:, keep]
+
+    @staticmethod
+    def feedback(host_slot, count):
+        host_slot.copy_(count)
 
 
 def _free_port():
@@ -58,15 +65,22 @@ def _worker(rank, world, port, out):
         d = torch.zeros(rows, chunks, S)
         d[:, vis[:4]] = vals[:, :4]
         dense_local.append(d)
-    union_ids, union_count = ex.hook(params, vis, cnt)
     gathered = [torch.zeros(sum(ex.rows), chunks, S) for _ in range(world)]
     dist.all_gather(gathered, torch.cat(dense_local))
     expect = sum(gathered) / world
-    got = torch.cat([p.grad.reshape(-1, chunks, S) for p in params])
-    ok = torch.allclose(got, expect, atol=1e-6)
-    ok &= int(union_count) == 6
-    ok &= union_ids[: int(union_count)].tolist() == [1, 4, 5, 6, 9, 11]
-    ok &= all(p.grad.shape == p.shape for p in params)
+    ok = True
+    for visit in range(2):                 # visit 0: blocking exact size; visit 1: size predicted from the feedback slot (1.2x + 1)
+        for p, d in zip(params, dense_local):
+            rows = p.numel() // (chunks * S)
+            p.grad = CompactedTensor(p.shape, vis, d[:, vis].clone())
+        union_ids, union_count = ex.hook(params, vis, cnt, slot=3)
+        got = torch.cat([p.grad.to_dense(int(union_count)).reshape(-1, chunks, S) for p in params])
+        ok &= torch.allclose(got, expect, atol=1e-6)
+        ok &= int(union_count) == 6
+        ok &= union_ids[: int(union_count)].tolist() == [1, 4, 5, 6, 9, 11]
+        ok &= all(p.grad.shape == p.shape and hasattr(p.grad, "compacted_values") for p in params)
+        ok &= ex.last_alloc == (6 if visit == 0 else 8) and int(ex.fb_union[3]) == 6
+        ok &= all(p.grad.compacted_values.shape[-2] == ex.last_alloc for p in params)
     ok &= dp.frame_for(3, rank, world, 8) == (3 * world + rank) % 8
     out[rank] = bool(ok)
     dist.destroy_process_group()

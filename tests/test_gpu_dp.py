@@ -1,5 +1,5 @@
 """Data-parallel exchange on the real device primitives (HipOps) with a single-rank RCCL group: with one rank the exchange must be
-an identity on the gradients, so a hooked trainer has to track an un-hooked one.  (The N>1 logic is covered on CPU by
+an identity on the gradients (packed over the union = the rank's own visible list), so a hooked trainer has to track an un-hooked one.  (The N>1 logic is covered on CPU by
 tests/test_dp_gloo.py; multi-GPU runs are the driver's.)"""
 import os
 import socket
@@ -34,7 +34,7 @@ def test_single_rank_exchange_is_identity():
         hook = dp.GradientExchange(tb.params, 1).hook
         for i in range(4):
             la = ta.step(i)
-            lb = tb.step(i, hook)
+            lb = tb.step(i, hook, i % 2)
             assert abs(la.item() - lb.item()) < 1e-5
         moved = 0.0
         for pa, pb, p0 in zip(ta.params, tb.params, scene):
@@ -46,9 +46,15 @@ def test_single_rank_exchange_is_identity():
         img, vis_id, vis_num, _ = tb.forward(fr)
         img.sum().backward()
         n = int(vis_num.item())
-        uid, ucnt = hook(tb.params, vis_id, vis_num)
+        local = [p.grad.compacted_values.clone() for p in tb.params]
+        uid, ucnt = hook(tb.params, vis_id, vis_num, 0)
         assert int(ucnt.item()) == n
         assert torch.equal(uid[:n], vis_id[:n])
-        assert all(p.grad.shape == p.shape and not hasattr(p.grad, "compacted_values") for p in tb.params)
+        # one rank: the packed union buffer must hold exactly this rank's compact gradients
+        for p, g0 in zip(tb.params, local):
+            assert p.grad.shape == p.shape and hasattr(p.grad, "compacted_values")
+            rows = g0.numel() // (g0.shape[-2] * g0.shape[-1])
+            a = p.grad.compacted_values.reshape(rows, -1, g0.shape[-1])[:, :n]
+            assert torch.equal(a, g0.reshape(rows, -1, g0.shape[-1])[:, :n])
     finally:
         dist.destroy_process_group()
