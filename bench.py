@@ -255,7 +255,8 @@ def main():
     if rank == 0:
         stats = tr.workload_stats(frame_of(0))
         result = {
-            "metric": "train iters/s (camera frames trained per second, whole job) + fwd Msplats/s, 3M Gaussians @1080p",
+            "metric": "train iters/s (camera frames trained per second, whole job) + fwd Msplats/s, "
+                      + ("3M Gaussians @1080p" if args.config == "3m_1080p" else f"{args.config} (not the BASELINE headline config)"),
             "value": round(world * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -266,10 +267,10 @@ def main():
             "n_vis": stats["n_vis"], "instances": stats["instances"],
             "reference_derived_rtx3090_iters_per_s": 103.0,
         }
+        result["roofline"] = roofline_probe(tr, frame_of(0))          # rank 0's blend kernels, outside the timed region
         if world == 1:
-            result["roofline"] = roofline_probe(tr, frame_of(0))
             traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(traffic_file):
+            if os.path.exists(traffic_file) and args.config == "3m_1080p":      # the PMC pass was taken on this workload only
                 try:
                     tj = json.load(open(traffic_file))     # rocprofv3 PMC pass (profiles/r01_pmc_summary.md): (2*FETCH_SIZE+WRITE_SIZE)*1024
                     kname = result["roofline"]["kernel"]
