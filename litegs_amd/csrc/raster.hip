@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
     const int y0 = ty * TH + (q >> 1) * (2 * PPL) + (q & 1);
     const float X = (float)x;
     const size_t plane = (size_t)Hp * Wp;
-    float Y[PPL], T[PPL], Br[PPL], Bg[PPL], Bb[PPL], gR[PPL], gG[PPL], gB[PPL], gT[PPL];
+    float Y[PPL], T[PPL], Bd[PPL], gR[PPL], gG[PPL], gB[PPL], gT[PPL];
     int lc[PPL];
     int maxlast = 0;
 #pragma unroll
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
         gG[k] = d_img[((size_t)view * 3 + 1) * plane + o];
         gB[k] = d_img[((size_t)view * 3 + 2) * plane + o];
         gT[k] = TRANS ? T[k] * d_trans[(size_t)view * plane + o] : 0.0f;     // T_final * dL/dT (raster.cu:665)
-        Br[k] = Bg[k] = Bb[k] = 0.0f;
+        Bd[k] = 0.0f;                    // (colour blended BEHIND the current splat) . dL/dC of the pixel
         maxlast = max(maxlast, lc[k]);
     }
     maxlast = rfl(wave_max_i(maxlast));
@@ -306,6 +306,35 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
         if (!__any(anyv)) continue;
 
         float v_r = 0.f, v_g = 0.f, v_b = 0.f, v_o = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, esq = 0.f;
+        if constexpr (PPL == 2 && !STAT) {
+            // the lane's two pixels as one 2-vector: packed fp32 (v_pk_fma/mul/add_f32) halves the VALU issue of this block,
+            // which is what bounds the kernel (measured: ~150 VALU per (tile, splat), 8 waves/SIMD all issue-limited)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f am = { valid[0] ? alpha[0] : 0.0f, valid[1] ? alpha[1] : 0.0f };
+            const v2f Gm = { valid[0] ? G[0] : 0.0f, valid[1] ? G[1] : 0.0f };
+            const v2f om = 1.0f - am;
+            const v2f rc = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
+            v2f Tv = { T[0], T[1] };
+            Tv = Tv * rc;
+            Tv.x = fminf(1.0f, Tv.x); Tv.y = fminf(1.0f, Tv.y);
+            T[0] = Tv.x; T[1] = Tv.y;
+            const v2f gRv = { gR[0], gR[1] }, gGv = { gG[0], gG[1] }, gBv = { gB[0], gB[1] }, dyv = { dy[0], dy[1] };
+            const v2f w = am * Tv;
+            const v2f ar = w * gRv, ag = w * gGv, ab = w * gBv;
+            const v2f cdot = cr * gRv + cg * gGv + cb * gBv;
+            v2f Bdv = { Bd[0], Bd[1] };
+            const v2f diff = cdot - Bdv;
+            v2f d_alpha = diff * Tv;
+            Bdv = Bdv + am * diff;
+            Bd[0] = Bdv.x; Bd[1] = Bdv.y;
+            if (TRANS) { const v2f gTv = { gT[0], gT[1] }; d_alpha = d_alpha - gTv * rc; }
+            const v2f vo = d_alpha * Gm;
+            const v2f dP = (Gm * o) * d_alpha;
+            const v2f dPy = dP * dyv;
+            const v2f dPyy = dPy * dyv;
+            v_r = ar.x + ar.y; v_g = ag.x + ag.y; v_b = ab.x + ab.y; v_o = vo.x + vo.y;
+            s0 = dP.x + dP.y; s1 = dPy.x + dPy.y; s2 = dPyy.x + dPyy.y;
+        } else {
 #pragma unroll
         for (int k = 0; k < PPL; k++) {
             if (STAT && !__any(valid[k])) continue;         // reference's per-row-group gate (raster.cu:753)
@@ -314,13 +343,18 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
             T[k] = fminf(1.0f, T[k] * __builtin_amdgcn_rcpf(1.0f - am));
             const float w = am * T[k];
             v_r += w * gR[k]; v_g += w * gG[k]; v_b += w * gB[k];
-            float d_alpha = ((cr - Br[k]) * gR[k] + (cg - Bg[k]) * gG[k] + (cb - Bb[k]) * gB[k]) * T[k];
-            Br[k] += am * (cr - Br[k]); Bg[k] += am * (cg - Bg[k]); Bb[k] += am * (cb - Bb[k]);
+            // reference (raster.cu:757-776) keeps the three blended-behind colours; only their dot product with the pixel's colour
+            // gradient is ever used, and it obeys the same recurrence: B.g <- B.g + alpha * (c.g - B.g)
+            const float cdot = cr * gR[k] + cg * gG[k] + cb * gB[k];
+            const float diff = cdot - Bd[k];
+            float d_alpha = diff * T[k];
+            Bd[k] += am * diff;
             if (TRANS) d_alpha -= gT[k] * __builtin_amdgcn_rcpf(1.0f - am);
             v_o += d_alpha * Gm;
             if (STAT) esq += v_o * v_o;                      // running-sum quirk, raster.cu:781-783
             const float dP = Gm * o * d_alpha;
             s0 += dP; s1 += dP * dy[k]; s2 += dP * dy[k] * dy[k];
+        }
         }
         // gradients of the quadratic form (GR/raster.cu:826-841 restated without forward differences)
         float v_a = -0.5f * dx * dx * s0;
