@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
                 float alpha = o * __builtin_amdgcn_exp2f(p2);
                 const bool valid = active && (alpha >= 1.0f / 256);
                 alpha = fminf(255.0f / 256, alpha);
-                lc[k] += active ? 1 : 0;
+                lc[k] = active ? (i - start + 1) : lc[k];       // == number of splats visited while active (activity is monotone)
                 alpha = valid ? alpha : 0.0f;
                 const float w = T[k] * alpha;
                 if (STAT) { fc += valid ? 1 : 0; ws += w; }
