@@ -23,8 +23,8 @@ sizes the buffer of the next visit of that slot (x1.2); only the first visit blo
 from the all-reduced mask, so every rank reads the same value.  A union that outgrows the prediction loses its last
 chunks for that step (silent truncation, as everywhere in this protocol).
 
-Gradient semantics: MEAN over ranks (keeps the single-GPU learning rates).  Statistics for densification are
-not exchanged yet ("next").  The collective / bookkeeping logic is device agnostic: the primitive ops
+Gradient semantics: MEAN over ranks (keeps the single-GPU learning rates).  Densification statistics are summed across
+ranks by ``litegs_amd.statistics.Statistics.all_reduce`` right before the density controller reads them.  The collective / bookkeeping logic is device agnostic: the primitive ops
 (mark, compact, scatter-add) come from an ``ops`` object -- ``HipOps`` (the HIP kernels; default) -- so the N>1
 logic is covered by world_size-2 gloo tests on CPU that inject a plain-torch ``ops``.
 """

@@ -116,6 +116,23 @@ class Statistics:
     def never_visible(self) -> torch.Tensor:
         return (self.visible_count == 0).reshape(-1)
 
+    # -- data parallelism ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def all_reduce(self, group=None) -> None:
+        """Sum the accumulators over the ranks of a data-parallel job (each rank saw different frames): call once,
+        right before the density controller reads mean()/var()/never_visible(), so every rank takes identical prune/clone/split
+        decisions.  Sums, squared sums and counts are additive, so the reduced moments equal those of a single process that had
+        rendered all frames.  Keys are visited in sorted order (the same collective sequence on every rank)."""
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        if self.visible_count is not None:
+            dist.all_reduce(self.visible_count, op=dist.ReduceOp.SUM, group=group)
+        for key in sorted(self.moments):
+            mom = self.moments[key]
+            for t in (mom.sum, mom.square_sum, mom.count):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
 
 class _Guard:
     def __init__(self, stats: Optional[Statistics]):

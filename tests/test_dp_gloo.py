@@ -92,3 +92,38 @@ def test_gradient_exchange_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def _stats_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from litegs_amd.statistics import Statistics, _Moments
+    chunks, S = 5, 4
+    st = Statistics()
+    st.chunks, st.S, st.device = chunks, S, "cpu"
+    g = torch.Generator().manual_seed(rank)
+    st.visible_count = torch.randint(0, 3, (chunks, S), generator=g, dtype=torch.int32)
+    mom = _Moments((1,), chunks, S, "cpu")
+    mom.sum = torch.rand((1, chunks, S), generator=g)
+    mom.square_sum = torch.rand((1, chunks, S), generator=g)
+    mom.count = torch.randint(0, 5, (chunks, S), generator=g, dtype=torch.int32)
+    st.moments["fragment_err"] = mom
+    local = (st.visible_count.clone(), mom.sum.clone(), mom.square_sum.clone(), mom.count.clone())
+    st.all_reduce()
+    ok = True
+    for mine, reduced in zip(local, (st.visible_count, mom.sum, mom.square_sum, mom.count)):
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        ok &= torch.allclose(sum(parts).double(), reduced.double())
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_statistics_all_reduce_world2():
+    """densification inputs must be identical on every rank: sums / squared sums / counts are summed across the job"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_stats_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)
