@@ -63,20 +63,6 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     for (int k = 0; k < 3; k++) s3[k] = lg_act_scale(scale[k * CS + sd]);
     lg_act_quat(rot[sd], rot[CS + sd], rot[2 * CS + sd], rot[3 * CS + sd], q);
     const float o = lg_act_opacity(opa[sd]);
-    // ---- SH -> RGB (+0.5, no clamp)
-    float cx, cy, cz, dx, dy, dz;
-    lg_camera_center(cam.V, cx, cy, cz);
-    lg_view_dir(px, py, pz, cx, cy, cz, dx, dy, dz);
-    float b[16];
-    lg_sh_basis<DEG>(dx, dy, dz, b);
-    constexpr int NB = (DEG + 1) * (DEG + 1);
-    float r0 = b[0] * sh0[sd], r1 = b[0] * sh0[CS + sd], r2 = b[0] * sh0[2 * CS + sd];
-#pragma unroll
-    for (int k = 1; k < NB; k++) {
-        const float* s = shr + ((size_t)(k - 1) * 3) * CS + sd;
-        r0 += b[k] * s[0]; r1 += b[k] * s[CS]; r2 += b[k] * s[2 * CS];
-    }
-    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
     // ---- projection chain
     float v[4], n[4], T9[9], j4[4], J6[6], c4[4], i4[4];
     lg_mvp(cam.V, cam.P, px, py, pz, 1.0f, v, n);
@@ -85,9 +71,28 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     J6[0] = j4[0]; J6[1] = 0.0f; J6[2] = 0.0f; J6[3] = j4[1]; J6[4] = j4[2]; J6[5] = j4[3];
     lg_cov2d(T9, cam.V, J6, c4);
     lg_inv2x2(c4[0], c4[1], c4[2], c4[3], i4);
+    const int tiles = lg_tile_count<TH, TW>(n[0], n[1], v[2], i4[0], i4[1], i4[3], o, cam.H, cam.W, gx, gy);     // a8, fused
+    // ---- SH -> RGB (+0.5, no clamp).  Only for splats that touch a tile: a third of the Gaussians of the visible CHUNKS fail
+    // the fine test (frustum / opacity / degenerate), and the 48 SH coefficients are 76 % of a Gaussian's bytes
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+    if (tiles > 0) {
+        float cx, cy, cz, dx, dy, dz;
+        lg_camera_center(cam.V, cx, cy, cz);
+        lg_view_dir(px, py, pz, cx, cy, cz, dx, dy, dz);
+        float b[16];
+        lg_sh_basis<DEG>(dx, dy, dz, b);
+        constexpr int NB = (DEG + 1) * (DEG + 1);
+        r0 = b[0] * sh0[sd]; r1 = b[0] * sh0[CS + sd]; r2 = b[0] * sh0[2 * CS + sd];
+#pragma unroll
+        for (int k = 1; k < NB; k++) {
+            const float* s = shr + ((size_t)(k - 1) * 3) * CS + sd;
+            r0 += b[k] * s[0]; r1 += b[k] * s[CS]; r2 += b[k] * s[2 * CS];
+        }
+        r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+    }
     // ---- outputs
     view_z[i] = v[2];
-    alloc[i] = lg_tile_count<TH, TW>(n[0], n[1], v[2], i4[0], i4[1], i4[3], o, cam.H, cam.W, gx, gy);     // a8, fused
+    alloc[i] = tiles;
     const float ppx = (n[0] + 1.0f) * 0.5f * cam.W - 0.5f;
     const float ppy = (n[1] + 1.0f) * 0.5f * cam.H - 0.5f;
     float4* rec = packed + i * (REC / 4);
