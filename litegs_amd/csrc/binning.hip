@@ -216,7 +216,9 @@ __device__ __forceinline__ void load_splat(const SplatSrc& src, size_t b, int N,
 
 // Kernel 1 of duplicate_with_keys: one thread per depth slot.  Small splats are walked serially into a compacted LDS buffer of
 // keys and streamed out coalesced; big splats (> DUP_SMALL tiles) are only QUEUED for kernel 2.
-template <int TH, int TW, typename IdxT, bool PACKED>
+// LdsKeyT: uint16_t when every tile id + 1 fits 16 bits (anything up to ~8 MPixel at 8x16 tiles) -- halves the staging buffer, one
+// more workgroup per CU for this latency-bound kernel.
+template <int TH, int TW, typename IdxT, bool PACKED, typename LdsKeyT>
 __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
                                                         const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                         long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
                                                         uint32_t* __restrict__ zero_ptr, long long zero_words,
                                                         uint32_t* __restrict__ ones_ptr, long long ones_words)
 {
-    __shared__ int32_t buf[DUP_LDS_ENTRIES];              // 32 KiB: compacted keys of the small splats
+    __shared__ LdsKeyT buf[DUP_LDS_ENTRIES];              // 16/32 KiB: compacted keys of the small splats
     __shared__ int t_loff[TPB + 1];                       // per-thread start in buf
     __shared__ int t_goff[TPB];                           // per-thread start in the table
     __shared__ int t_idx[TPB];                            // per-thread point id
@@ -319,7 +321,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     t_goff[tid] = (int)off;
     t_idx[tid] = idx;
     if (tid == 0) t_loff[TPB] = total_small;
-    if (small) walk_tiles<TH, TW, true>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf);
+    if (small) walk_tiles<TH, TW, true, LdsKeyT>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf);
     __syncthreads();
     for (int p0 = 0; p0 < total_small; p0 += TPB) {
         const int p = p0 + tid;
@@ -332,7 +334,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
                 int mid = (lo + hi + 1) >> 1;
                 if (t_loff[mid] <= p) lo = mid; else hi = mid - 1;
             }
-            key = buf[p];
+            key = (int32_t)buf[p];
             const int g = t_goff[lo] + (p - t_loff[lo]);
             kout[g] = key;
             vout[g] = t_idx[lo];
@@ -538,7 +540,7 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
     if (packed && sorted_id_is_int64) return (int)hipErrorInvalidValue;     // packed records: fused executor only (int32 order)
     int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ngroups = lg_cdiv(N, TPB);
-    dim3 grid(ngroups < 1024 ? ngroups : 1024, V);        // persistent workgroups, 256 depth slots at a time
+    dim3 grid(ngroups < 1280 ? ngroups : 1280, V);        // persistent workgroups (5 per CU), 256 depth slots at a time
     dim3 grid_big(1024, V);                               // persistent: 4096 waves drain the queue
     hipStream_t s = (hipStream_t)stream;
     DigitSpec ds = { begin_bit, 0, 0u };
@@ -550,8 +552,12 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
     SplatSrc src = { ndc, inv_cov, opacity, (const float4*)packed };
 #define LAUNCH_DUP(A_, B_, T_, P_)                                                                                                          \
     do {                                                                                                                                   \
-        hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,                \
-                           H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words);                                \
+        if (gx * gy + 1 <= 0xffff)                                                                                                         \
+            hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
+                               H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words);      \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,   \
+                               H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words);      \
         hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
                            N, H, W, gx, gy, table_len, keys, values, (const int*)queue, totals, ds, zero2_ptr, zero2_words);               \
     } while (0)

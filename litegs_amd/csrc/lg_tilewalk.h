@@ -55,9 +55,9 @@ __device__ __forceinline__ void splat_extent(float ndcx, float ndcy, float ic00,
 }
 
 // Walks tile slices along the shorter rect axis; returns tiles touched; EMIT writes (tile_id+1, idx).
-template <int TH, int TW, bool EMIT>
+template <int TH, int TW, bool EMIT, typename LdsKeyT = int32_t>
 __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int32_t idx, long long off,
-                                               int32_t* __restrict__ keys, int32_t* __restrict__ values, int32_t* lds_keys = nullptr)
+                                               int32_t* __restrict__ keys, int32_t* __restrict__ values, LdsKeyT* lds_keys = nullptr)
 {
     const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
     const bool isY = ys < xs;
@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int
         if (EMIT) {
             for (int v = min_tile_v; v < max_tile_v; v++) {
                 uint32_t key = isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
-                if (lds_keys) lds_keys[off] = (int32_t)(key + 1);
+                if (lds_keys) lds_keys[off] = (LdsKeyT)(key + 1);
                 else { keys[off] = (int32_t)(key + 1); values[off] = idx; }
                 off++;
             }
