@@ -3,9 +3,8 @@
 // (SURVEY.md 8a rows a8-a11).  Integer/index work: outputs are BIT-EXACT against the CPU oracle,
 // which is why this file is compiled with -ffp-contract=off and uses lg_logf (fixed polynomial).
 //
-// HBM traffic per tile instance (I of them): 8 B written by duplicate_with_keys, then per radix pass
-// 4 B (histogram read) + 8 B (scatter read) + 8 B (scatter write); 14 tile-id bits at 1080p = 2 passes
-// of 8 bits.  No MFMA: this is byte shuffling.
+// HBM traffic per tile instance (I of them): 8 B written by duplicate_with_keys, then per radix pass 8 B read + 8 B
+// written; 13 tile-id bits at 1080p = 2 passes of 8 bits.  No MFMA: this is byte shuffling.
 #include "lg_common.h"
 #include "lg_tilewalk.h"
 #include "lg_binning_internal.h"
@@ -598,12 +597,13 @@ LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const 
 // ---------------------------------------------------------------------------------------------
 // Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit), 8 bits per pass.
 // Replaces cub::DeviceRadixSort::SortPairs (GR/binning.cu:204-221) and torch.sort of the depth keys
-// (litegs/utils/wrapper.py:739).  Per pass: (1) per-tile digit histogram (tile = 4096 keys per 256-thread
-// workgroup, LDS atomics), (2) one workgroup per digit turns its histogram row into global offsets,
-// (3) scatter: 16 rounds of 256 keys; within a round a lane's rank among equal digits comes from
-// 8 wave ballots ("match-any"), wave totals are combined through LDS, so equal keys keep their input
-// order (stability is load-bearing: it preserves depth order inside a tile).
-// Digit totals for all passes are counted once up front (they are permutation invariant).
+// (litegs/utils/wrapper.py:739).  Two code paths: sorts of a few key tiles (tile = 4096 keys per 256-thread workgroup)
+// run histogram + scatter launches where every workgroup scans the raw histogram rows itself (radix_hist_kernel +
+// radix_scatter_kernel<true>: match-any ranking with 8 wave ballots); everything else runs ONE launch per pass
+// (radix_onesweep_kernel: decoupled look-back, lane-ordered LDS ranking).  Equal keys keep their input order in both
+// (stability is load-bearing: it preserves depth order inside a tile).  Digit totals for all passes are counted once up
+// front (they are permutation invariant) -- by radix_totals_kernel here, or by the kernel that produced the keys
+// (lg_radix_sort_prepared).
 // ---------------------------------------------------------------------------------------------
 #define RADIX_BITS 8
 #define RADIX (1 << RADIX_BITS)
