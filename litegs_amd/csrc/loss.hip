@@ -29,8 +29,15 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
                                                               const float* __restrict__ gt, int H, int W,
                                                               float* __restrict__ dmaps /*[3][B*C][H][W]*/, float* __restrict__ partial /*[blocks][2]*/)
 {
-    __shared__ float sx[TIN][TIN + 1], sy[TIN][TIN + 1];
-    __shared__ float sh[5][TIN][TS + 1];
+    // LDS: the x/y halo tiles (2 x 42 x 43 floats) and the five horizontally blurred maps (5 x 42 x 33 floats) share one buffer --
+    // every row segment first pulls its 18 + 18 inputs into registers, the workgroup synchronises, and only then are the blurred
+    // values written over the inputs.  27.7 KB instead of 42 KB per workgroup: one more resident workgroup per CU for a kernel whose
+    // time is the latency of its load -> blur -> blur -> store chain.
+    constexpr int SH_FLOATS = 5 * TIN * (TS + 1), SXY_FLOATS = 2 * TIN * (TIN + 1);
+    __shared__ float lds[SH_FLOATS > SXY_FLOATS ? SH_FLOATS : SXY_FLOATS];
+    float (*sx)[TIN + 1] = reinterpret_cast<float (*)[TIN + 1]>(lds);
+    float (*sy)[TIN + 1] = reinterpret_cast<float (*)[TIN + 1]>(lds + TIN * (TIN + 1));
+    float (*sh)[TIN][TS + 1] = reinterpret_cast<float (*)[TIN][TS + 1]>(lds);
     __shared__ float red[2][4];
     const int plane_id = blockIdx.z;
     const size_t plane = (size_t)H * W;
@@ -48,14 +55,30 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
         sy[r][c] = in ? y[(size_t)gy * W + gx] : 0.0f;
     }
     __syncthreads();
-    if (tid < TIN * (TS / HSEG)) {                       // 168 row segments
-        const int r = tid / (TS / HSEG), c0 = (tid % (TS / HSEG)) * HSEG;
+    const bool hwork = tid < TIN * (TS / HSEG);          // 168 row segments
+    const int hr = tid / (TS / HSEG), hc0 = (tid % (TS / HSEG)) * HSEG;
+    float xin[HSEG + 10], yin[HSEG + 10];
+    float l1_sum = 0.0f;
+    if (hwork) {
+#pragma unroll
+        for (int u = 0; u < HSEG + 10; u++) { xin[u] = sx[hr][hc0 + u]; yin[u] = sy[hr][hc0 + u]; }
+        // L1 term of the segment's own 8 output pixels (centre rows only; out-of-image pixels hold x = y = 0)
+        if (hr >= HALO && hr < HALO + TS) {
+#pragma unroll
+            for (int j = 0; j < HSEG; j++) {
+                const int gy = by + hr - HALO, gx = bx + hc0 + j;
+                if (gx < W && gy < H) l1_sum += fabsf(xin[j + HALO] - yin[j + HALO]);
+            }
+        }
+    }
+    __syncthreads();                                     // all inputs are in registers: the buffer may be overwritten
+    if (hwork) {
         float a[5][HSEG];
 #pragma unroll
         for (int j = 0; j < HSEG; j++) { a[0][j] = a[1][j] = a[2][j] = a[3][j] = a[4][j] = 0.0f; }
 #pragma unroll
         for (int u = 0; u < HSEG + 10; u++) {
-            float xv = sx[r][c0 + u], yv = sy[r][c0 + u];
+            float xv = xin[u], yv = yin[u];
             float xx = xv * xv, yy = yv * yv, xy = xv * yv;
 #pragma unroll
             for (int j = 0; j < HSEG; j++) {
@@ -68,8 +91,8 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
         }
 #pragma unroll
         for (int j = 0; j < HSEG; j++) {
-            sh[0][r][c0 + j] = a[0][j]; sh[1][r][c0 + j] = a[1][j]; sh[2][r][c0 + j] = a[2][j];
-            sh[3][r][c0 + j] = a[3][j]; sh[4][r][c0 + j] = a[4][j];
+            sh[0][hr][hc0 + j] = a[0][j]; sh[1][hr][hc0 + j] = a[1][j]; sh[2][hr][hc0 + j] = a[2][j];
+            sh[3][hr][hc0 + j] = a[3][j]; sh[4][hr][hc0 + j] = a[4][j];
         }
     }
     __syncthreads();
@@ -90,7 +113,7 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
         }
     }
     const int gx = bx + tx;
-    float s_sum = 0.0f, l1_sum = 0.0f;
+    float s_sum = 0.0f;
     const size_t stride = (size_t)gridDim.z * plane;
 #pragma unroll
     for (int j = 0; j < VSEG; j++) {
@@ -114,7 +137,6 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
             dmaps[stride + o] = dex2;
             dmaps[2 * stride + o] = dexy;
             s_sum += s_val;
-            l1_sum += fabsf(sx[r0 + j + HALO][tx + HALO] - sy[r0 + j + HALO][tx + HALO]);
         }
     }
     // block reduce (fixed order)
@@ -185,8 +207,11 @@ __global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __re
                                                                const float* __restrict__ dmaps, const float* __restrict__ grad_out,
                                                                int H, int W, int Hp, int Wp, float lam, float inv_n, float* __restrict__ d_img)
 {
-    __shared__ float sm[3][TIN][TIN + 1];
-    __shared__ float sh[3][TIN][TS + 1];
+    // one LDS buffer for the three input halo tiles and their horizontally blurred versions (see the forward kernel)
+    constexpr int SM_FLOATS = 3 * TIN * (TIN + 1), SHB_FLOATS = 3 * TIN * (TS + 1);
+    __shared__ float lds[SM_FLOATS > SHB_FLOATS ? SM_FLOATS : SHB_FLOATS];
+    float (*sm)[TIN][TIN + 1] = reinterpret_cast<float (*)[TIN][TIN + 1]>(lds);
+    float (*sh)[TIN][TS + 1] = reinterpret_cast<float (*)[TIN][TS + 1]>(lds);
     const int plane_id = blockIdx.z;
     const size_t plane = (size_t)H * W;
     const size_t stride = (size_t)gridDim.z * plane;
@@ -202,14 +227,21 @@ __global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __re
         sm[2][r][c] = in ? dmaps[2 * stride + o] : 0.0f;
     }
     __syncthreads();
-    if (tid < TIN * (TS / HSEG)) {
-        const int r = tid / (TS / HSEG), c0 = (tid % (TS / HSEG)) * HSEG;
+    const bool hwork = tid < TIN * (TS / HSEG);
+    const int hr = tid / (TS / HSEG), hc0 = (tid % (TS / HSEG)) * HSEG;
+    float vin[3][HSEG + 10];
+    if (hwork) {
+#pragma unroll
+        for (int u = 0; u < HSEG + 10; u++) { vin[0][u] = sm[0][hr][hc0 + u]; vin[1][u] = sm[1][hr][hc0 + u]; vin[2][u] = sm[2][hr][hc0 + u]; }
+    }
+    __syncthreads();                                     // inputs are in registers: the buffer may be overwritten
+    if (hwork) {
         float a[3][HSEG];
 #pragma unroll
         for (int j = 0; j < HSEG; j++) { a[0][j] = a[1][j] = a[2][j] = 0.0f; }
 #pragma unroll
         for (int u = 0; u < HSEG + 10; u++) {
-            float v0 = sm[0][r][c0 + u], v1 = sm[1][r][c0 + u], v2 = sm[2][r][c0 + u];
+            float v0 = vin[0][u], v1 = vin[1][u], v2 = vin[2][u];
 #pragma unroll
             for (int j = 0; j < HSEG; j++) {
                 const int t = u - j;
@@ -217,7 +249,7 @@ __global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __re
             }
         }
 #pragma unroll
-        for (int j = 0; j < HSEG; j++) { sh[0][r][c0 + j] = a[0][j]; sh[1][r][c0 + j] = a[1][j]; sh[2][r][c0 + j] = a[2][j]; }
+        for (int j = 0; j < HSEG; j++) { sh[0][hr][hc0 + j] = a[0][j]; sh[1][hr][hc0 + j] = a[1][j]; sh[2][hr][hc0 + j] = a[2][j]; }
     }
     __syncthreads();
     const int tx = tid % TS, r0 = (tid / TS) * VSEG;
