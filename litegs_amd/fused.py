@@ -371,7 +371,7 @@ def create_table(ndc, inv_cov2d, opacity, offset, depth_sorted_pointid, feedback
             pred = max(pred, int(feedback_buffer_cpu[idx]))
             check(L.lg_feedback_d2h(base + 4 * idx, offset.data_ptr() + 4 * (i * N + N - 1), _s()), "feedback copy")
     pred = int(1.5 * pred)
-    if pred <= 0:                          # blocking path (binning.cu:152-163)
+    if pred <= 0 and N > 0:                # blocking path (binning.cu:152-163)
         pred = int(offset[:, -1].max().item())
     if pred <= 0:
         raise RuntimeError("error pred_allocate_size")

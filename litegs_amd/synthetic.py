@@ -31,7 +31,8 @@ def cluster(t: np.ndarray, chunk: int = 128) -> np.ndarray:
     n = t.shape[-1]
     if n % chunk:
         pad = chunk - n % chunk
-        t = np.concatenate([t, t[..., -pad:]], axis=-1)
+        src = n - 1 - (np.arange(pad)[::-1] % n)          # the last `pad` entries; cyclic when the cloud is smaller than the padding
+        t = np.concatenate([t, t[..., src]], axis=-1)
     return np.ascontiguousarray(t.reshape(*t.shape[:-1], t.shape[-1] // chunk, chunk))
 
 

@@ -391,6 +391,16 @@ def render_forward(params, view, proj, planes, H, W, degree=3, tile=(8, 16), clu
     origin, extend = cluster_aabb
     _, chunk_id = frustum_culling_aabb(origin, extend, planes)
     nvis = len(chunk_id)
+    if nvis == 0:                                   # nothing in the frustum: empty tables, background image (the kernels are never launched)
+        V = view.shape[0]
+        Hp, Wp = (H + TH - 1) // TH * TH, (W + TW - 1) // TW * TW
+        ntiles = (Hp // TH) * (Wp // TW)
+        e = lambda *shape: np.zeros(shape, np.float32)
+        ei = lambda *shape: np.zeros(shape, np.int32)
+        return PipelineResult(chunk_id, 0, (e(4, 0), e(3, 0), e(4, 0), e(V, 3, 0), e(1, 0)), e(V, 4, 0), e(V, 4, 0), e(3, 3, 0), e(V, 3, 3, 0),
+                              e(V, 2, 2, 0), e(V, 2, 2, 0), ei(V, 0), np.zeros((V, 0), np.int64), ei(V, 0), ei(V, 0), ei(V, 0),
+                              np.full((V, ntiles + 2), -1, np.int32), e(V, 0, 16), e(V, 3, Hp, Wp), np.ones((V, 1, Hp, Wp), np.float32),
+                              np.zeros((V, 1, Hp, Wp), np.int16), ei(V, 1, 0), e(V, 1, 0), 0)
     a_pos, a_scale, a_rot, a_color, a_opa = activate_forward(degree, chunk_id, nvis, view, xyz, scale, rot, sh0, shr, opa)
     N = nvis * S
     pos = a_pos.reshape(4, N); sc = a_scale.reshape(3, N); rt = a_rot.reshape(4, N)

@@ -1,0 +1,97 @@
+"""Edge cases of the path, fused executor and operator path side by side against the CPU oracle: nothing visible, nothing
+rasterisable, images smaller than one tile, a single chunk, ragged chunk counts."""
+import numpy as np
+import pytest
+import torch
+
+from litegs_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(scene, view, proj, planes, H, W, degree=3, backward=True, ops_must_raise=False):
+    """-> [(img, grads, n_vis) for the fused executor, same for the operator path].  ops_must_raise: frames without a single tile
+    instance make the reference's create_table fail its TORCH_CHECK("error pred_allocate_size", GR/binning.cu:164); the operator
+    surface keeps that behaviour (RuntimeError), the executor renders the background."""
+    from litegs_amd import fast, render as R
+    outs = []
+    for mode in ("fused", "ops"):
+        params = [torch.nn.Parameter(torch.from_numpy(p).cuda()) for p in scene]
+        v, pj, pl = [torch.from_numpy(x).cuda() for x in (view, proj, planes)]
+        with torch.no_grad():
+            origin, extend = R.get_cluster_AABB(params[0], params[1].exp(), torch.nn.functional.normalize(params[2], dim=0))
+        if mode == "fused":
+            rd = fast.FusedRenderer(1, H, W)
+            img, vis_id, vis_num = rd.render(fast.CameraFrame(v, pj, pl, 0), origin, extend, *params, degree)
+            n_inst = None
+        else:
+            pp = R.PipelineParams()
+            vis_id, vis_num, xyz, scale, rot, color, opacity = R.render_preprocess(origin, extend, pl, v, *params, None, None, pp, degree)
+            if ops_must_raise:
+                with pytest.raises(RuntimeError, match="pred_allocate_size"):
+                    R.render(v, pj, xyz, scale, rot, color, opacity, vis_num * pp.cluster_size, None, None, degree, (H, W), pp)
+                outs.append((None, None, int(vis_num.item())))
+                continue
+            img, *_ = R.render(v, pj, xyz, scale, rot, color, opacity, vis_num * pp.cluster_size, None, None, degree, (H, W), pp)
+        if backward:
+            img.sum().backward()
+        torch.cuda.synchronize()
+        grads = [None if p.grad is None else p.grad.compacted_values.detach().cpu().numpy() for p in params]
+        outs.append((img.detach().cpu().numpy(), grads, int(vis_num.item())))
+    return outs
+
+
+def test_camera_looking_away_sees_nothing():
+    """No chunk passes the frustum test: zero image, zero-sized work, finite (zero) gradients, no crash in either path."""
+    scene = S.make_scene(3000, seed=1)
+    view, proj, planes = S.make_camera(160, 96, 150.0, 150.0, (0.0, 0.0, 30.0), target=(0.0, 0.0, 60.0))     # cloud is behind the camera
+    (img_f, g_f, nv_f), (_, _, nv_o) = _run_both(scene, view, proj, planes, 96, 160, ops_must_raise=True)
+    assert nv_f == 0 and nv_o == 0
+    assert np.all(img_f == 0)
+    # compact gradients exist (one allocated chunk) but hold no valid row: everything >= visible_chunks_num is dirty by design
+
+
+def test_transparent_cloud_emits_no_instances(oracle):
+    """Every Gaussian fails the 1/255 opacity test (binning.cu:346): chunks are visible, the table is empty."""
+    scene = list(S.make_scene(2500, seed=2))
+    scene[5] = np.full_like(scene[5], -12.0)                      # sigmoid(-12) = 6e-6 < 1/255
+    view, proj, planes = S.make_camera(200, 120, 180.0, 180.0, (1.8, -0.3, 0.8))
+    ref = oracle.render_forward(scene, view, proj, planes, 120, 200, 3)
+    assert ref.n_instances == 0 and ref.nvis > 0
+    (img_f, g_f, nv_f), (_, _, nv_o) = _run_both(scene, view, proj, planes, 120, 200, ops_must_raise=True)
+    assert nv_f == ref.nvis and nv_o == ref.nvis
+    assert np.all(img_f == 0)
+    for g in g_f:
+        valid = g.reshape(-1, g.shape[-2], g.shape[-1])[:, :ref.nvis]
+        assert np.isfinite(valid).all() and np.all(valid == 0)
+
+
+@pytest.mark.parametrize("W,H", [(5, 3), (16, 8), (17, 9)])
+def test_images_around_one_tile(oracle, W, H):
+    """Image smaller than / equal to / just over one 8x16 tile (padded tiles, 1-2 tile grids)."""
+    scene = S.make_scene(1500, seed=3, scale_mult=1.5)
+    view, proj, planes = S.make_camera(W, H, 12.0, 12.0, (1.5, -0.2, 0.6))
+    ref = oracle.render_forward(scene, view, proj, planes, H, W, 3)
+    ref_img = np.clip(ref.img[..., :H, :W], 0, 1)
+    (img_f, _, nv_f), (img_o, _, nv_o) = _run_both(scene, view, proj, planes, H, W, backward=True)
+    assert nv_f == ref.nvis == nv_o
+    assert np.array_equal(img_f, img_o)
+    assert np.abs(img_f - ref_img).max() < 2e-2 and (np.abs(img_f - ref_img) > 1e-4).mean() < 1e-3
+
+
+@pytest.mark.parametrize("n", [1, 128, 129, 1000])
+def test_ragged_gaussian_counts(oracle, n):
+    """1 Gaussian, exactly one chunk, one chunk + 1, a count that is not a multiple of the chunk size (padding Gaussians)."""
+    scene = S.make_scene(n, seed=4, scale_mult=2.0)
+    view, proj, planes = S.make_camera(96, 64, 80.0, 80.0, (1.6, -0.3, 0.7))
+    ref = oracle.render_forward(scene, view, proj, planes, 64, 96, 3)
+    ref_img = np.clip(ref.img[..., :64, :96], 0, 1)
+    empty = ref.n_instances == 0
+    (img_f, g_f, nv_f), (img_o, g_o, nv_o) = _run_both(scene, view, proj, planes, 64, 96, ops_must_raise=empty)
+    assert nv_f == ref.nvis == nv_o
+    if empty:
+        assert np.all(img_f == 0)
+        return
+    assert np.array_equal(img_f, img_o)
+    assert np.abs(img_f - ref_img).max() < 2e-2 and (np.abs(img_f - ref_img) > 1e-4).mean() < 1e-3
+    assert all(np.isfinite(g.reshape(-1, g.shape[-2], g.shape[-1])[:, :ref.nvis]).all() for g in g_f + g_o)
