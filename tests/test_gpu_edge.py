@@ -95,3 +95,27 @@ def test_ragged_gaussian_counts(oracle, n):
     assert np.array_equal(img_f, img_o)
     assert np.abs(img_f - ref_img).max() < 2e-2 and (np.abs(img_f - ref_img) > 1e-4).mean() < 1e-3
     assert all(np.isfinite(g.reshape(-1, g.shape[-2], g.shape[-1])[:, :ref.nvis]).all() for g in g_f + g_o)
+
+
+def test_8k_image_with_giant_splats(oracle):
+    """7680x4320: 259 200 tiles (> 16-bit staging keys, 19 key bits = 3 radix passes) and near-camera splats whose tile rectangle has
+    more than 256 slices (the serial fallback of the cooperative emission); fused executor vs oracle, tables included."""
+    from litegs_amd import fast, render as R
+    H, W = 4320, 7680
+    scene = list(S.make_scene(600, seed=9, scale_mult=3.0))
+    view, proj, planes = S.make_camera(W, H, 5000.0, 5000.0, (1.2, -0.2, 0.5))
+    ref = oracle.render_forward(scene, view, proj, planes, H, W, 3)
+    assert ref.n_instances > 1_000_000 and ref.alloc.max() > 70_000, (ref.n_instances, int(ref.alloc.max()))
+    params = [torch.nn.Parameter(torch.from_numpy(p).cuda()) for p in scene]
+    v, pj, pl = [torch.from_numpy(x).cuda() for x in (view, proj, planes)]
+    with torch.no_grad():
+        origin, extend = R.get_cluster_AABB(params[0], params[1].exp(), torch.nn.functional.normalize(params[2], dim=0))
+    rd = fast.FusedRenderer(1, H, W)
+    img, vis_id, vis_num = rd.render(fast.CameraFrame(v, pj, pl, 0), origin, extend, *params, 3)
+    img.sum().backward()
+    torch.cuda.synchronize()
+    assert int(vis_num.item()) == ref.nvis
+    assert abs(int(rd.fb_total[0]) - ref.n_instances) <= max(2, int(2e-6 * ref.n_instances))
+    err = np.abs(img.detach().cpu().numpy() - np.clip(ref.img[..., :H, :W], 0, 1))
+    assert err.max() < 2e-2 and (err > 1e-4).mean() < 5e-5
+    assert all(torch.isfinite(p.grad.compacted_values[..., :ref.nvis, :]).all() for p in params)
