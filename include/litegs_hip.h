@@ -213,6 +213,11 @@ int lg_adam_update_multi(int ngroups, void* const* param, const void* const* gra
                          const int* rows, const float* lr, const int64_t* visible_chunk_id, const int* valid_length,
                          int chunks, int A, int S, int grad_dense, float b1, float b2, float eps, void* stream);
 
+/* ---- knn.hip : simple_knn._C.distCUDA2 (litegs/submodules/simple-knn/simple_knn.cu:186-222; caller litegs/scene/point.py:8) --------
+ * mean squared distance of every point to its 3 nearest neighbours (exact).  points [P,3] fp32, mean_dist2 [P]. */
+long long lg_knn3_temp_bytes(int P);
+int lg_knn3_mean_dist2(const float* points, int P, float* mean_dist2, void* temp, long long temp_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ SOURCES = {
     "raster.hip": ["-munsafe-fp-atomics"],
     "loss.hip": ["-munsafe-fp-atomics"],
     "fused.hip": ["-ffp-contract=off"],
+    "knn.hip": [],
 }
 
 
