@@ -37,7 +37,8 @@ def parse_args():
     ap.add_argument("--config", default="3m_1080p", help="key of litegs_amd.synthetic.CONFIGS")
     ap.add_argument("--frames", type=int, default=8, help="camera frames per rank (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tile-stride", type=int, default=24, help="CPU baseline rasterises every n-th tile")
+    ap.add_argument("--cpu-tile-stride", type=int, default=0,
+                    help="CPU baseline rasterises every n-th tile (x n extrapolated); 0 = auto: the whole frame on >= 32 host threads, every 24th tile otherwise")
     return ap.parse_args()
 
 
@@ -130,6 +131,8 @@ def cpu_baseline(scene, cam, H, W, degree, tile_stride):
     from oracle import oracle as O
     view, proj, planes = cam
     cores = os.cpu_count() or 1
+    if tile_stride <= 0:
+        tile_stride = 1 if cores >= 32 else 24
     t0 = time.time()
     xyz, scale, rot, sh0, shr, opa = scene
     origin, extend = O.cluster_AABB(xyz, scale, rot)
@@ -179,8 +182,10 @@ def cpu_baseline(scene, cam, H, W, degree, tile_stride):
     return {
         "value": round(1.0 / t_iter, 5), "unit": "frames/s", "cores": cores, "kind": "port",
         "fwd_msplats_per_s": round(n_total / t_fwd / 1e6, 4),
-        "sample": f"full per-Gaussian chain+binning+sort+Adam of one frame, blend fwd+bwd on every {tile_stride}th tile "
-                  f"(x{tile_stride} extrapolated); measured {t_chain + t_bchain + t_rf + t_rb:.1f}s of CPU work, OpenMP {cores} threads",
+        "sample": ("one whole frame of the same workload: per-Gaussian chain + binning + sort + blend fwd+bwd + Adam"
+                   if tile_stride == 1 else
+                   f"full per-Gaussian chain+binning+sort+Adam of one frame, blend fwd+bwd on every {tile_stride}th tile (x{tile_stride} extrapolated)")
+                  + f"; measured {t_chain + t_bchain + t_rf + t_rb:.1f}s of CPU work, OpenMP {cores} threads",
         "cpu_model": _cpu_model(), "n_vis": int(N), "instances": int(prefix[0, -1]),
     }
 
