@@ -798,7 +798,8 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              const int* __restrict__ totals /*[RADIX] of this pass*/,
                                                              uint32_t* __restrict__ status /*[ntiles][RADIX], zero*/, int* __restrict__ ticket,
-                                                             long long n, const int* __restrict__ n_dev, int shift, uint32_t mask)
+                                                             long long n, const int* __restrict__ n_dev, int shift, uint32_t mask,
+                                                             const int32_t* __restrict__ aux_in, int32_t* __restrict__ aux_out)
 {
     constexpr int NW = TPB / 64;
     constexpr int WAVE_KEYS = SORT_ITEMS * 64;       // each wave ranks a contiguous run of 1024 keys on its own (no block barriers)
@@ -913,8 +914,10 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
             const uint32_t k = lds_k[p];
             const uint32_t d = (k >> shift) & mask;
             const int g = global_base[d] + (p - digit_base[d]);
+            const uint32_t v = lds_v[p];
             keys_out[g] = k;
-            vals_out[g] = lds_v[p];
+            vals_out[g] = v;
+            if (aux_in) aux_out[g] = aux_in[v];          // last pass of the depth sort: tile counts gathered into depth order on the way out
         }
     }
 }
@@ -978,7 +981,8 @@ LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint3
             hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, table, n, n_dev, shift, mask, ntiles);
         } else {
             hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, totals + p * RADIX,
-                               (uint32_t*)table + (size_t)p * RADIX * ntiles, ticket + p, n, n_dev, shift, mask);
+                               (uint32_t*)table + (size_t)p * RADIX * ntiles, ticket + p, n, n_dev, shift, mask,
+                               (const int32_t*)nullptr, (int32_t*)nullptr);
         }
         uint32_t* t;
         t = kin; kin = kout; kout = t;
@@ -995,7 +999,7 @@ long long lg_radix_table_words(long long n, int passes)
 }
 
 int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
-                           int begin_bit, int end_bit, int* header, uint32_t* table, void* stream)
+                           int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted, void* stream)
 {
     int passes = lg_radix_sort_num_passes(begin_bit, end_bit);
     if (n <= 0 || passes == 0) return 0;
@@ -1010,8 +1014,10 @@ int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
     for (int p = 0; p < passes; p++) {
         int shift = begin_bit + p * RADIX_BITS;
         uint32_t mask = (p == passes - 1) ? last_mask : (uint32_t)(RADIX - 1);
+        const bool last = p == passes - 1;
         hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, totals + p * RADIX,
-                           table + (size_t)p * RADIX * ntiles, ticket + p, n, n_dev, shift, mask);
+                           table + (size_t)p * RADIX * ntiles, ticket + p, n, n_dev, shift, mask,
+                           last ? aux_in : (const int32_t*)nullptr, last ? aux_sorted : (int32_t*)nullptr);
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;

@@ -404,13 +404,16 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
 #undef LAUNCH_PF
     rc = (int)hipGetLastError(); if (rc) return rc;
     rc = lg_depth_keys_hist(view_z, N, (uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (int*)(w + f.dsort_hdr), stream); if (rc) return rc;
+    // the last pass also gathers the tile counts into depth order (into the prefix buffer, scanned in place below)
     rc = lg_radix_sort_prepared((uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (uint32_t*)(w + f.dk_b), (uint32_t*)(w + f.dv_b), N, nullptr, 0, 32,
-                                (int*)(w + f.dsort_hdr), (uint32_t*)(w + f.dsort_table), stream);
+                                (int*)(w + f.dsort_hdr), (uint32_t*)(w + f.dsort_table), (const int32_t*)(w + f.alloc), (int32_t*)(w + f.prefix),
+                                stream);
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, 32) % 2 == 1;
     const void* order = odd ? (w + f.dv_b) : (w + f.dv_a);
     // depth-ordered inclusive scan of the tile counts; prefix[N-1] (the exact table length) also goes to the host feedback slot
-    rc = lg_gather_scan_prepared((const int32_t*)(w + f.alloc), (const int32_t*)order, N, (int32_t*)(w + f.prefix),
+    (void)order;
+    rc = lg_gather_scan_prepared((const int32_t*)(w + f.prefix), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
                                  (uint32_t*)(w + f.scan_status), host_feedback_total, stream);
     if (rc) return rc;
     return 0;
@@ -450,7 +453,7 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
     // exact instance count on the device (prefix[N-1]): only that many entries are sorted and range-scanned
     const int* total_dev = (const int*)(w1 + f1.prefix) + (N - 1);
     rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), L,
-                                total_dev, 0, bits, (int*)(w1 + f1.tsort_hdr), (uint32_t*)(w + f.tsort_table), stream);
+                                total_dev, 0, bits, (int*)(w1 + f1.tsort_hdr), (uint32_t*)(w + f.tsort_table), nullptr, nullptr, stream);
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));

@@ -12,9 +12,10 @@ long long lg_radix_table_words(long long n, int passes);
 // keys/vals of the depth sort + the digit counts of all four passes into header[0..1023]; header must be zero on entry
 int lg_depth_keys_hist(const float* depth, long long n, uint32_t* keys, uint32_t* vals, int* header, void* stream);
 
-// radix sort whose header (totals filled, tickets zero) and status table (zero) were prepared by earlier kernels
+// radix sort whose header (totals filled, tickets zero) and status table (zero) were prepared by earlier kernels.
+// aux_in/aux_sorted (nullable): the last pass also writes aux_sorted[g] = aux_in[sorted value at g] (a gather in sorted order)
 int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
-                           int begin_bit, int end_bit, int* header, uint32_t* table, void* stream);
+                           int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted, void* stream);
 
 // ints of big-splat queue per view (lg_dup_queue_ints(N)); its first 64 ints (sub-queue counters) must be zero on entry
 long long lg_dup_queue_ints(long long N);
