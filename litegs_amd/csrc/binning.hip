@@ -266,8 +266,11 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             if ((e.rmaxy - e.rminy) * (e.rmaxx - e.rminx) > 0) { live = true; cnt = (int)c; }
         } else if (c > 0 && off < table_len) {
             // first splat that does not fit (GR/binning.cu:63 drops it and, prefix being monotone, every later one): the rest of
-            // the table stays key 0 = "no tile"
-            for (long long q = off; q < table_len; q++) kout[q] = 0;
+            // the table becomes key 0 = "no tile".  Values too (the table is not pre-cleared on the fused path), and the padding keys
+            // are counted into the sort's digit totals (digit 0 of every pass) -- the sort then handles exactly table_len keys.
+            for (long long q = off; q < table_len; q++) { kout[q] = 0; vout[q] = 0; }
+            if (totals)
+                for (int p = 0; p < ds.passes; p++) atomicAdd(&totals[p * 256], (int)(table_len - off));
         }
     }
     // Threshold between the in-workgroup path and the queue: DUP_SMALL_HI when this group's entries still fit the LDS buffer

@@ -133,3 +133,35 @@ def test_backward_fused_with_adam_equals_separate_kernels():
     assert worst < 5e-4, worst
     for sa, sb in zip(ta.opt.state.values(), tb.opt.state.values()):
         assert (sa["exp_avg"] - sb["exp_avg"]).abs().max().item() <= 1e-4 * max(sb["exp_avg"].abs().max().item(), 1e-12)
+
+
+def test_fused_render_with_underpredicted_table(oracle):
+    """GPU-driven sizing with a feedback value that is far too small: the instance table is truncated (the far splats of the depth order
+    are dropped, GR/binning.cu:63) -- the executor must produce exactly the image of the truncated table, not garbage: the padding
+    keys have to be part of the tile sort's digit totals, and no table entry may stay uninitialised."""
+    from litegs_amd import fast
+    name = "small"
+    c, params, view, proj, planes, origin, extend = _setup(name)
+    res = oracle_forward(name)
+    H, W = c["H"], c["W"]
+    rd = fast.FusedRenderer(1, H, W)
+    cam = fast.CameraFrame(view, proj, planes, 0)
+    with torch.no_grad():
+        rd.render(cam, origin, extend, *params, c["degree"])           # first visit: exact sizes, fills the feedback slots
+        torch.cuda.synchronize()
+        total = int(rd.fb_total[0])
+        assert total == res.n_instances
+        rd.fb_total[0] = int(0.3 * total)                               # next visit allocates 1.5 * 0.3 = 45 % of what is needed
+        img, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
+        torch.cuda.synchronize()
+    want = int(1.5 * int(0.3 * total))
+    assert rd.last_sizes[1] == want and int(rd.fb_total[0]) == total
+    op = res.act[4]
+    ks, vs, _, _ = oracle.create_table(res.ndc, res.inv_cov, op, res.prefix, res.depth_sorted_index, H, W, 8, 16, table_len=want)
+    ntiles = ((H + 7) // 8) * ((W + 15) // 16)
+    ts = oracle.tile_range(ks, ntiles)
+    ref_img, *_ = oracle.raster_forward(vs, ts, res.packed, H, W, 8, 16)
+    ref_img = np.clip(ref_img[..., :H, :W], 0, 1)
+    full_img = np.clip(res.img[..., :H, :W], 0, 1)
+    assert np.abs(ref_img - full_img).max() > 0.05, "the truncation must be visible in this case"
+    assert_close(img.cpu().numpy(), ref_img, flip_frac=5e-5, name="truncated img")
