@@ -216,3 +216,56 @@ def test_tile_walk_drops_nan_cuts(oracle):
     vd = np.array([[7.118446350097656, 5.324782848358154]], np.float32)
     lu, rd, al = oracle.get_allocate_size(ndc, vd, inv, op, 1080, 1920, 8, 16)
     assert al.tolist() == [[5, 13]]
+
+
+# ------------------------------------------------------------------------------------- exact tile binning
+def _min_quadratic_on_rect(a, b, c, px, py, x0, x1, y0, y1):
+    """min over the closed rectangle of a dx^2 + 2 b dx dy + c dy^2 (positive definite), float64, exact up to rounding:
+    0 if the centre is inside, otherwise the minimum over the four edges (1-D quadratics clamped to the edge)."""
+    if x0 <= px <= x1 and y0 <= py <= y1:
+        return 0.0
+    best = np.inf
+    for y in (y0, y1):                      # horizontal edges: minimise over x
+        dy = y - py
+        x = np.clip(px - b * dy / a, x0, x1)
+        dx = x - px
+        best = min(best, a * dx * dx + 2 * b * dx * dy + c * dy * dy)
+    for x in (x0, x1):                      # vertical edges: minimise over y
+        dx = x - px
+        y = np.clip(py - b * dx / c, y0, y1)
+        dy = y - py
+        best = min(best, a * dx * dx + 2 * b * dx * dy + c * dy * dy)
+    return best
+
+
+def test_accutile_emits_exactly_the_tiles_the_ellipse_touches(oracle):
+    """The SpeedySplat/AccuTile walk restated in the oracle (GR/speedy_splat.cuh:16-149, GR/binning.cu:310-373) against an
+    independent float64 geometric test: tile (tx,ty) is emitted iff its rectangle [tx*TW,(tx+1)*TW] x [ty*TH,(ty+1)*TH] (pixel-centre
+    coordinates) intersects {x : (x-p)^T A (x-p) <= 2 ln(255 o)}.  Disagreements are only tolerated where the minimum of the
+    quadratic over the rectangle is within 1e-3 (relative) of the threshold, or on the far open edge of a tile."""
+    params, view, proj, planes, H, W = tiny_case()
+    res = oracle.render_forward(params, view, proj, planes, H, W, 3)
+    TH, TW = 8, 16
+    gx, gy = (W + TW - 1) // TW, (H + TH - 1) // TH
+    op = res.act[4][0]
+    keys, vals = [a[0] for a in oracle.create_table(res.ndc, res.inv_cov, res.act[4], res.prefix, res.depth_sorted_index, H, W, TH, TW)[:2]]
+    emitted = set(zip((keys - 1).tolist(), vals.tolist()))
+    assert len(emitted) == res.n_instances > 1000
+    checked = borderline = 0
+    for i in np.nonzero(res.alloc[0] > 0)[0][:400]:
+        a, b, c = (float(res.inv_cov[0, 0, 0, i]), float(res.inv_cov[0, 0, 1, i]), float(res.inv_cov[0, 1, 1, i]))
+        px = (float(res.ndc[0, 0, i]) * 0.5 + 0.5) * W - 0.5
+        py = (float(res.ndc[0, 1, i]) * 0.5 + 0.5) * H - 0.5
+        t = 2.0 * np.log(float(op[i]) * 255.0)
+        for ty in range(gy):
+            for tx in range(gx):
+                qmin = _min_quadratic_on_rect(a, b, c, px, py, tx * TW, (tx + 1) * TW, ty * TH, (ty + 1) * TH)
+                want = qmin <= t
+                got = (ty * gx + tx, int(i)) in emitted
+                checked += 1
+                if want != got:
+                    # tolerated: threshold grazing, or the ellipse only touches the rectangle's far (open) boundary
+                    qin = _min_quadratic_on_rect(a, b, c, px, py, tx * TW, (tx + 1) * TW - 1e-3, ty * TH, (ty + 1) * TH - 1e-3)
+                    assert abs(qmin - t) <= 1e-3 * t or (qin > t) != want, (i, tx, ty, qmin, t, want, got)
+                    borderline += 1
+    assert checked > 5_000 and borderline <= 5e-3 * checked, (checked, borderline)
