@@ -6,9 +6,10 @@ TEST INFRASTRUCTURE ONLY (see the header of ``litegs_oracle.c``): imported by ``
 Pinning status: the per-Gaussian chain (SH, frustum planes/culling, transform matrix, ray-space
 Jacobian, cov2d, 2x2 eigen/inverse) is pinned against the reference's own ``_script`` twins and
 helpers imported from /root/reference (fixtures in ``tests/golden/``, generator
-``tests/golden/make_golden.py``).  The reference ships NO executable twin for binning, the tile
-sort, the blend forward/backward, cull/activate or Adam, so for those the oracle is
-pinned only against an independent dense torch-autograd formulation (``tests/test_oracle_autograd.py``):
+``tests/golden/make_golden.py``); so are the learnable-camera matrices (litegs/data.py).  The reference ships
+NO executable twin for binning, the tile sort, the blend forward/backward, cull/activate or Adam,
+so for those the oracle is pinned only against independent formulations (``tests/test_oracle_autograd.py``: dense
+float64 torch-autograd blend, float64 ellipse/rectangle intersection for the tile walk, numpy/torch for the rest):
 "parity unpinned vs the reference binary" for those rows, stated in DESIGN.md.
 
 Array conventions follow the reference: SoA with the Gaussian index innermost, float32, C-contiguous.
