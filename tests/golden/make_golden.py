@@ -18,6 +18,7 @@ StatisticsHelper allocates on 'cuda' at import), so the needed modules are loade
 `litegs_fused`, `simple_knn`, `cv2` and the statistics singleton.  Nothing of the reference is copied: its
 functions are CALLED and only their numeric outputs are stored.
 """
+import importlib
 import os
 import sys
 import types
@@ -42,6 +43,18 @@ def load_reference():
     stat.StatisticsHelper = _S
     sys.modules["litegs.utils.statistic_helper"] = stat
     sys.modules["cv2"] = types.ModuleType("cv2")
+    knn, knn_c = types.ModuleType("simple_knn"), types.ModuleType("simple_knn._C")
+    knn_c.distCUDA2 = None                                    # litegs/scene/__init__.py imports it; never called here
+    knn._C = knn_c
+    sys.modules["simple_knn"], sys.modules["simple_knn._C"] = knn, knn_c
+    for missing in ("plyfile",):                              # I/O packages absent from this image, imported at package import
+        if missing not in sys.modules:
+            try:
+                importlib.import_module(missing)
+            except Exception:
+                stub = types.ModuleType(missing)
+                stub.PlyData = stub.PlyElement = None
+                sys.modules[missing] = stub
     import importlib
     utils = importlib.import_module("litegs.utils")
     wrapper = importlib.import_module("litegs.utils.wrapper")
@@ -125,6 +138,25 @@ def main():
     ginv[:, 0, 1] = ginv[:, 1, 0]
     (inv * ginv).sum().backward()
     out.update(eig_val=val.numpy(), eig_vec=vec.numpy(), eig_inv=inv.detach().numpy(), eig_ginv=ginv.numpy(), eig_gcov=c2.grad.numpy())
+
+    # --- chunking and chunk AABBs (litegs/scene/cluster.py:7-46; the AABB routine calls CreateTransformMatrix.call == the fused
+    #     kernel, so it is pointed at the script twin for this run; its own RNG so the fixtures above keep their values) --------
+    cluster = importlib.import_module("litegs.scene.cluster")
+    g2 = torch.Generator().manual_seed(4321)
+    M = 300                                                   # not a multiple of 128: exercises the padding rule
+    cxyz = torch.randn((3, M), generator=g2) * 3
+    cscale = torch.rand((3, M), generator=g2) * 0.3 + 0.02     # ACTIVATED scale / rotation, as trainer.py passes them
+    crot = torch.nn.functional.normalize(torch.randn((4, M), generator=g2), dim=0)
+    kxyz, kscale, krot = cluster.cluster_points(128, cxyz, cscale, crot)
+    real_call, real_zeros = wrapper.CreateTransformMatrix.call, torch.zeros
+    wrapper.CreateTransformMatrix.call = wrapper.CreateTransformMatrix.call_script
+    torch.zeros = lambda *a, **k: real_zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    try:
+        origin_c, extend_c = cluster.get_cluster_AABB(kxyz, kscale, krot)
+    finally:
+        wrapper.CreateTransformMatrix.call, torch.zeros = real_call, real_zeros
+    out.update(cl_xyz=cxyz.numpy(), cl_scale=cscale.numpy(), cl_rot=crot.numpy(), cl_xyz_chunked=kxyz.numpy(),
+               cl_origin=origin_c.numpy(), cl_extend=extend_c.numpy())
 
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: v.shape for k, v in out.items()})

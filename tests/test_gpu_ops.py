@@ -396,3 +396,15 @@ def test_create_viewproj_autograd_wrapper(oracle):
     r7, rf = oracle.create_viewproj_backward(z, z, gvp, p7, fov, 48, 96, 0.01, 100.0)
     assert_close(host(tp.grad), r7, 1e-5, normalize=True)
     assert_close(host(tf.grad), rf, 1e-5, normalize=True)
+
+
+def test_cluster_aabb_matches_reference_fixture():
+    """render.get_cluster_AABB (activated scale/rotation, as litegs/training/trainer.py:86 calls it) vs the reference's own
+    litegs/scene/cluster.py output stored in the golden fixture."""
+    import os
+    from litegs_amd import render as R, synthetic as S
+    gold = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_chain.npz")))
+    xyz, scale, rot = (dev(S.cluster(gold[k], 128)) for k in ("cl_xyz", "cl_scale", "cl_rot"))
+    origin, extend = R.get_cluster_AABB(xyz, scale, rot)
+    assert_close(host(origin), gold["cl_origin"], 1e-5, normalize=True)
+    assert_close(host(extend), gold["cl_extend"], 1e-5, normalize=True)
