@@ -155,6 +155,24 @@ def main():
         origin_c, extend_c = cluster.get_cluster_AABB(kxyz, kscale, krot)
     finally:
         wrapper.CreateTransformMatrix.call, torch.zeros = real_call, real_zeros
+    # --- optimizer groups and the position learning-rate schedule (litegs/training/optimizer.py:46-108, arguments.py:80-92) ------
+    training_pkg = types.ModuleType("litegs.training")          # do not run training/__init__.py (it imports the trainer and its I/O stack)
+    training_pkg.__path__ = [os.path.join(REF, "litegs", "training")]
+    sys.modules["litegs.training"] = training_pkg
+    opt_ref = importlib.import_module("litegs.training.optimizer")
+    args_ref = importlib.import_module("litegs.arguments")
+    ps = [torch.nn.Parameter(torch.zeros(sh)) for sh in [(3, 2, 128), (3, 2, 128), (4, 2, 128), (1, 3, 2, 128), (15, 3, 2, 128), (1, 2, 128)]]
+    pipe = args_ref.PipelineParams
+    o_ref, s_ref = opt_ref.get_optimizer(*ps, 2.5, args_ref.OptimizationParams, pipe)
+    names = [grp["name"] for grp in o_ref.param_groups]
+    traj = []
+    for it in range(0, 30001, 1500):
+        s_ref.last_epoch = it - 1
+        o_ref.step = lambda *a, **k: None                      # the scheduler only needs the counter
+        s_ref.step()
+        traj.append([grp["lr"] for grp in o_ref.param_groups])
+    out.update(opt_group_names=np.array(names), opt_lr_traj=np.array(traj, np.float64), opt_eps=np.float64(o_ref.param_groups[0]["eps"]))
+
     out.update(cl_xyz=cxyz.numpy(), cl_scale=cscale.numpy(), cl_rot=crot.numpy(), cl_xyz_chunked=kxyz.numpy(),
                cl_origin=origin_c.numpy(), cl_extend=extend_c.numpy())
 
