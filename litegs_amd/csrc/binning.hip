@@ -797,7 +797,10 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
 #define ST_INC 0x80000000u
 #define ST_VAL 0x3fffffffu
 
-__global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+// TILES key tiles per workgroup (256 threads each, processed side by side) share ONE ticket: the ticket is a returning atomic on a
+// single address (~8 ns each, serialised in L2); at 2865 tiles per pass it delayed workgroup starts by ~16 us per pass.
+template <int TILES>
+__global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              const int* __restrict__ totals /*[RADIX] of this pass*/,
                                                              uint32_t* __restrict__ status /*[ntiles][RADIX], zero*/, int* __restrict__ ticket,
@@ -806,23 +809,30 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
 {
     constexpr int NW = TPB / 64;
     constexpr int WAVE_KEYS = SORT_ITEMS * 64;       // each wave ranks a contiguous run of 1024 keys on its own (no block barriers)
-    __shared__ uint32_t lds_k[SORT_TILE];
-    __shared__ uint32_t lds_v[SORT_TILE];
-    __shared__ int wave_cnt[NW][RADIX];              // running per-wave digit counts, then exclusive offset of the wave inside the digit
-    __shared__ int digit_base[RADIX];                // exclusive local base of the digit in the sorted tile
-    __shared__ int global_base[RADIX];
-    __shared__ int wsum[NW];
+    __shared__ uint32_t lds_k_[TILES][SORT_TILE];
+    __shared__ uint32_t lds_v_[TILES][SORT_TILE];
+    __shared__ int wave_cnt_[TILES][NW][RADIX];      // running per-wave digit counts, then exclusive offset of the wave inside the digit
+    __shared__ int digit_base_[TILES][RADIX];        // exclusive local base of the digit in the sorted tile
+    __shared__ int global_base_[TILES][RADIX];
+    __shared__ int wsum_[TILES][NW];
+    __shared__ int wsum_g_[TILES][NW];
     __shared__ int bid_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = threadIdx.x / TPB;              // which of the workgroup's tiles this thread works on
+    const int tid = threadIdx.x % TPB, lane = tid & 63, wave = tid >> 6;
+    uint32_t* lds_k = lds_k_[half]; uint32_t* lds_v = lds_v_[half];
+    int (*wave_cnt)[RADIX] = wave_cnt_[half];
+    int* digit_base = digit_base_[half]; int* global_base = global_base_[half];
+    int* wsum = wsum_[half]; int* wsum_g = wsum_g_[half];
     n = bounded_n(n, n_dev);
-    if (tid == 0) bid_s = atomicAdd(ticket, 1);
+    if (threadIdx.x == 0) bid_s = atomicAdd(ticket, 1);
 #pragma unroll
     for (int w = 0; w < NW; w++) wave_cnt[w][tid] = 0;
     __syncthreads();
-    const int bid = bid_s;
+    if ((long long)bid_s * TILES * SORT_TILE >= n) return;          // uniform: none of this workgroup's tiles holds keys
+    const int bid = bid_s * TILES + half;
     const long long base = (long long)bid * SORT_TILE;
-    if (base >= n) return;
-    const int cnt_tile = (int)((n - base) < SORT_TILE ? (n - base) : SORT_TILE);
+    const bool act = base < n;                       // a tile past the end stays in the barriers but neither publishes nor looks back
+    const int cnt_tile = act ? (int)((n - base) < SORT_TILE ? (n - base) : SORT_TILE) : 0;
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
     int lrank[SORT_ITEMS];
 #pragma unroll
@@ -850,8 +860,10 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
 #pragma unroll
     for (int w = 0; w < NW; w++) { int c = wave_cnt[w][tid]; wave_cnt[w][tid] = dcount; dcount += c; }
     uint32_t* my = status + (size_t)bid * RADIX + tid;
-    if (bid == 0) __hip_atomic_store(my, ST_INC | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_store(my, ST_AGG | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (act) {
+        if (bid == 0) __hip_atomic_store(my, ST_INC | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(my, ST_AGG | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // digit base in the output = exclusive scan over digits of the global totals; local base = same scan of the tile counts
     const int total = totals[tid];
     int inc_g = total, inc_l = dcount;
@@ -860,7 +872,6 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
         int ng = __shfl_up(inc_g, o), nl = __shfl_up(inc_l, o);
         if (lane >= o) { inc_g += ng; inc_l += nl; }
     }
-    __shared__ int wsum_g[NW];
     if (lane == 63) { wsum_g[wave] = inc_g; wsum[wave] = inc_l; }
     __syncthreads();
     int wbg = 0, wbl = 0;
@@ -878,7 +889,7 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
             lds_v[pos] = val[j];
         }
     }
-    if (bid != 0) {
+    if (act && bid != 0) {
         // look-back, LB predecessors per step: the loads of one step are independent, so the walk costs one L2 round trip per
         // LB workgroups instead of one per workgroup (matters when ~1000 resident workgroups start together)
         constexpr int LB = 8;
@@ -923,6 +934,20 @@ __global__ void __launch_bounds__(TPB) radix_onesweep_kernel(const uint32_t* __r
             if (aux_in) aux_out[g] = aux_in[v];          // last pass of the depth sort: tile counts gathered into depth order on the way out
         }
     }
+}
+
+// Two tiles per workgroup once there are more tiles than fit on the chip at once (the tile sort); small sorts keep one tile per
+// workgroup so that every CU gets work.
+static void launch_onesweep(int ntiles, hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, const int* totals,
+                            uint32_t* status, int* ticket, long long n, const int* n_dev, int shift, uint32_t mask, const int32_t* aux_in,
+                            int32_t* aux_out)
+{
+    if (ntiles >= 1024)                               // (4 tiles per workgroup measured slower: 97 vs 88 us per pass)
+        hipLaunchKernelGGL(radix_onesweep_kernel<2>, dim3((ntiles + 1) / 2), dim3(TPB * 2), 0, s, kin, vin, kout, vout, totals, status, ticket, n,
+                           n_dev, shift, mask, aux_in, aux_out);
+    else
+        hipLaunchKernelGGL(radix_onesweep_kernel<1>, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, totals, status, ticket, n, n_dev,
+                           shift, mask, aux_in, aux_out);
 }
 
 LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
@@ -983,9 +1008,8 @@ LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint3
             hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, n, n_dev, shift, mask, ntiles, table);
             hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, table, n, n_dev, shift, mask, ntiles);
         } else {
-            hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, totals + p * RADIX,
-                               (uint32_t*)table + (size_t)p * RADIX * ntiles, ticket + p, n, n_dev, shift, mask,
-                               (const int32_t*)nullptr, (int32_t*)nullptr);
+            launch_onesweep(ntiles, s, kin, vin, kout, vout, totals + p * RADIX, (uint32_t*)table + (size_t)p * RADIX * ntiles, ticket + p, n,
+                            n_dev, shift, mask, nullptr, nullptr);
         }
         uint32_t* t;
         t = kin; kin = kout; kout = t;
@@ -1018,9 +1042,8 @@ int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
         int shift = begin_bit + p * RADIX_BITS;
         uint32_t mask = (p == passes - 1) ? last_mask : (uint32_t)(RADIX - 1);
         const bool last = p == passes - 1;
-        hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, totals + p * RADIX,
-                           table + (size_t)p * RADIX * ntiles, ticket + p, n, n_dev, shift, mask,
-                           last ? aux_in : (const int32_t*)nullptr, last ? aux_sorted : (int32_t*)nullptr);
+        launch_onesweep(ntiles, s, kin, vin, kout, vout, totals + p * RADIX, table + (size_t)p * RADIX * ntiles, ticket + p, n, n_dev, shift, mask,
+                        last ? aux_in : (const int32_t*)nullptr, last ? aux_sorted : (int32_t*)nullptr);
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
