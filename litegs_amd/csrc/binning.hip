@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
                                                         int* __restrict__ queue /*[V][N+1]: count, entries*/,
                                                         int* __restrict__ totals /*nullable [passes][256]*/, DigitSpec ds,
                                                         uint32_t* __restrict__ zero_ptr, long long zero_words,
-                                                        uint32_t* __restrict__ ones_ptr, long long ones_words)
+                                                        uint32_t* __restrict__ ones_ptr, long long ones_words,
+                                                        uint32_t* __restrict__ zero2_ptr, long long zero2_words)
 {
     __shared__ LdsKeyT buf[DUP_LDS_ENTRIES];              // 16/32 KiB: compacted keys of the small splats
     __shared__ int t_loff[TPB + 1];                       // per-thread start in buf
@@ -244,6 +245,12 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         const long long gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, nthreads = (long long)gridDim.x * gridDim.y * TPB;
         if (zero_ptr) zero_duty(zero_ptr, zero_words, gid, nthreads);
         if (ones_ptr) for (long long i = gid; i < ones_words; i += nthreads) ones_ptr[i] = 0xffffffffu;      // tile range table: -1 = empty
+        if (zero2_ptr) {                                    // gradient accumulator of the coming blend backward (16-byte stores)
+            uint4* z4 = reinterpret_cast<uint4*>(zero2_ptr);
+            const long long n4 = zero2_words / 4;
+            for (long long i = gid; i < n4; i += nthreads) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (long long i = n4 * 4 + gid; i < zero2_words; i += nthreads) zero2_ptr[i] = 0u;
+        }
     }
     if (totals) for (int k = tid; k < ds.passes * 256; k += TPB) hist[k] = 0;
     // persistent workgroups (the digit table is flushed once per workgroup, not once per 256 splats)
@@ -364,8 +371,7 @@ template <int TH, int TW, typename IdxT, bool PACKED>
 __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
                                                       const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                       long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
-                                                      const int* __restrict__ queue, int* __restrict__ totals, DigitSpec ds,
-                                                      uint32_t* __restrict__ zero2_ptr, long long zero2_words)
+                                                      const int* __restrict__ queue, int* __restrict__ totals, DigitSpec ds)
 {
     __shared__ int w_minv[TPB / 64][DUP_MAX_SLICES];      // per-wave slice scratch
     __shared__ int w_off[TPB / 64][DUP_MAX_SLICES + 1];
@@ -375,13 +381,6 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     for (int k = tid; k < (TPB / 64) * (DUP_MAX_RUN / 32 + 2); k += TPB) (&bitmap[0][0])[k] = 0u;
-    // zero duty for the blend backward's gradient accumulator: this kernel is latency bound, the memory pipes are idle
-    if (zero2_ptr) {
-        uint4* z4 = reinterpret_cast<uint4*>(zero2_ptr);
-        const long long n4 = zero2_words / 4, gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, nth = (long long)gridDim.x * gridDim.y * TPB;
-        for (long long i = gid; i < n4; i += nth) z4[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (long long i = n4 * 4 + gid; i < zero2_words; i += nth) zero2_ptr[i] = 0u;
-    }
     const int32_t* pf = prefix + (size_t)b * N;
     int32_t* kout = keys + (size_t)b * table_len;
     int32_t* vout = values + (size_t)b * table_len;
@@ -556,12 +555,12 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
     do {                                                                                                                                   \
         if (gx * gy + 1 <= 0xffff)                                                                                                         \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
-                               H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words);      \
+                               H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words); \
         else                                                                                                                               \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,   \
-                               H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words);      \
+                               H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words); \
         hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
-                           N, H, W, gx, gy, table_len, keys, values, (const int*)queue, totals, ds, zero2_ptr, zero2_words);               \
+                           N, H, W, gx, gy, table_len, keys, values, (const int*)queue, totals, ds);                                       \
     } while (0)
 #define DISPATCH_DUP(A_, B_)                                              \
     do {                                                                  \

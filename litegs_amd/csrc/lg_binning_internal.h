@@ -27,7 +27,7 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
                 int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
                 int* queue, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
                 uint32_t* ones_ptr /*filled with 0xffffffff*/, long long ones_words,
-                uint32_t* zero2_ptr /*16-byte aligned, cleared by the big-splat launch*/, long long zero2_words, void* stream);
+                uint32_t* zero2_ptr /*16-byte aligned, also cleared on the side (the backward's gradient accumulator)*/, long long zero2_words, void* stream);
 
 // gathered inclusive scan in one launch; status = lg_scan_status_words(n) zero words; host_total (nullable) = pinned host int
 long long lg_scan_status_words(long long n);
