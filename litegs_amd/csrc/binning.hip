@@ -258,20 +258,14 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int j = grp * TPB + tid;
 
+    // 1. size of the slot (tile count > 0 <=> non-empty tile rectangle, so no geometry is needed to classify it)
     long long off = 0;
     int cnt = 0, idx = 0;
-    bool live = false;
-    SplatExtent e;
     if (j < N) {
         off = (j == 0) ? 0 : pf[j - 1];
-        long long c = pf[j] - off;
-        if (c > 0 && off + c <= table_len) {
-            idx = (int)sorted_id[(size_t)b * N + j];
-            float nx, ny, a, bb, cc, o;
-            load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
-            splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
-            if ((e.rmaxy - e.rminy) * (e.rmaxx - e.rminx) > 0) { live = true; cnt = (int)c; }
-        } else if (c > 0 && off < table_len) {
+        const long long c = pf[j] - off;
+        if (c > 0 && off + c <= table_len) cnt = (int)c;
+        else if (c > 0 && off < table_len) {
             // first splat that does not fit (GR/binning.cu:63 drops it and, prefix being monotone, every later one): the rest of
             // the table becomes key 0 = "no tile".  Values too (the table is not pre-cleared on the fused path), and the padding keys
             // are counted into the sort's digit totals (digit 0 of every pass) -- the sort then handles exactly table_len keys.
@@ -284,7 +278,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     // (the usual case: ~8 tiles per splat on average), DUP_SMALL otherwise (then 256 x 32 entries fit by construction).
     int thr = DUP_SMALL_HI;
     {
-        int c64 = (live && cnt <= DUP_SMALL_HI) ? cnt : 0;
+        int c64 = (cnt <= DUP_SMALL_HI) ? cnt : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
         if (lane == 0) wbig[wave] = c64;
@@ -292,24 +286,34 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         if (wbig[0] + wbig[1] + wbig[2] + wbig[3] > DUP_LDS_ENTRIES) thr = DUP_SMALL;
         __syncthreads();
     }
-    const bool small = live && cnt <= thr;
-    const bool big = live && cnt > thr;
+    const bool small = cnt > 0 && cnt <= thr;
+    const bool big = cnt > thr;
 
-    // ---- big splats: append the slots to this group's sub-queue (one returning atomic per group) ----
-    {
-        const unsigned long long bm = __ballot(big);
-        if (lane == 0) wbig[wave] = __popcll(bm);
-        __syncthreads();
-        if (tid == 0) {
-            const int nbig = wbig[0] + wbig[1] + wbig[2] + wbig[3];
-            qbase_s = nbig ? atomicAdd(queue + (size_t)b * qints + (grp % DUP_NQ), nbig) : 0;
-        }
-        __syncthreads();
-        if (big) {
-            int pos = qbase_s + __popcll(bm & ((1ull << lane) - 1ull));
-            for (int w = 0; w < wave; w++) pos += wbig[w];
-            queue[(size_t)b * qints + DUP_NQ + (size_t)(grp % DUP_NQ) * qcap + pos] = j;
-        }
+    // 2. big splats: reserve their queue slots (one returning atomic per group, issued now, consumed after the geometry below so that
+    //    its L2 round trip overlaps the record loads)
+    const unsigned long long bm = __ballot(big);
+    if (lane == 0) wbig[wave] = __popcll(bm);
+    __syncthreads();
+    int qb = 0;
+    if (tid == 0) {
+        const int nbig = wbig[0] + wbig[1] + wbig[2] + wbig[3];
+        if (nbig) qb = atomicAdd(queue + (size_t)b * qints + (grp % DUP_NQ), nbig);
+    }
+
+    // 3. geometry of the small splats
+    SplatExtent e;
+    if (small) {
+        idx = (int)sorted_id[(size_t)b * N + j];
+        float nx, ny, a, bb, cc, o;
+        load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
+        splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
+    }
+    if (tid == 0) qbase_s = qb;
+    __syncthreads();
+    if (big) {
+        int pos = qbase_s + __popcll(bm & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) pos += wbig[w];
+        queue[(size_t)b * qints + DUP_NQ + (size_t)(grp % DUP_NQ) * qcap + pos] = j;
     }
 
     // ---- small splats: exclusive block scan of their counts -> compacted LDS layout ----
