@@ -33,11 +33,11 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
     // every row segment first pulls its 18 + 18 inputs into registers, the workgroup synchronises, and only then are the blurred
     // values written over the inputs.  27.7 KB instead of 42 KB per workgroup: one more resident workgroup per CU for a kernel whose
     // time is the latency of its load -> blur -> blur -> store chain.
-    constexpr int SH_FLOATS = 5 * TIN * (TS + 1), SXY_FLOATS = 2 * TIN * (TIN + 1);
+    constexpr int SH_FLOATS = 4 * TIN * (TS + 1), SXY_FLOATS = 2 * TIN * (TIN + 1);
     __shared__ float lds[SH_FLOATS > SXY_FLOATS ? SH_FLOATS : SXY_FLOATS];
     float (*sx)[TIN + 1] = reinterpret_cast<float (*)[TIN + 1]>(lds);
     float (*sy)[TIN + 1] = reinterpret_cast<float (*)[TIN + 1]>(lds + TIN * (TIN + 1));
-    float (*sh)[TIN][TS + 1] = reinterpret_cast<float (*)[TIN][TS + 1]>(lds);
+    float (*sh)[TIN][TS + 1] = reinterpret_cast<float (*)[TIN][TS + 1]>(lds);       // 4 maps: blur x, blur y, blur (x+y)^2, blur (x-y)^2
     __shared__ float red[2][4];
     const int plane_id = blockIdx.z;
     const size_t plane = (size_t)H * W;
@@ -73,42 +73,45 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
     }
     __syncthreads();                                     // all inputs are in registers: the buffer may be overwritten
     if (hwork) {
-        float a[5][HSEG];
+        // Four blurred maps instead of five: SSIM needs E[x^2]+E[y^2] and E[xy] only, and both follow from P = blur((x+y)^2) and
+        // Q = blur((x-y)^2):  E[x^2]+E[y^2] = (P+Q)/2,  E[xy] = (P-Q)/4  (the blur is linear).  -20 % of the FMAs and LDS traffic.
+        float a[4][HSEG];
 #pragma unroll
-        for (int j = 0; j < HSEG; j++) { a[0][j] = a[1][j] = a[2][j] = a[3][j] = a[4][j] = 0.0f; }
+        for (int j = 0; j < HSEG; j++) { a[0][j] = a[1][j] = a[2][j] = a[3][j] = 0.0f; }
 #pragma unroll
         for (int u = 0; u < HSEG + 10; u++) {
             float xv = xin[u], yv = yin[u];
-            float xx = xv * xv, yy = yv * yv, xy = xv * yv;
+            float sp = xv + yv, sm = xv - yv;
+            float pp = sp * sp, qq = sm * sm;
 #pragma unroll
             for (int j = 0; j < HSEG; j++) {
                 const int t = u - j;
                 if (t >= 0 && t <= 10) {
                     float w = c_gauss[t];
-                    a[0][j] += w * xv; a[1][j] += w * yv; a[2][j] += w * xx; a[3][j] += w * yy; a[4][j] += w * xy;
+                    a[0][j] += w * xv; a[1][j] += w * yv; a[2][j] += w * pp; a[3][j] += w * qq;
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < HSEG; j++) {
             sh[0][hr][hc0 + j] = a[0][j]; sh[1][hr][hc0 + j] = a[1][j]; sh[2][hr][hc0 + j] = a[2][j];
-            sh[3][hr][hc0 + j] = a[3][j]; sh[4][hr][hc0 + j] = a[4][j];
+            sh[3][hr][hc0 + j] = a[3][j];
         }
     }
     __syncthreads();
     const int tx = tid % TS, r0 = (tid / TS) * VSEG;
-    float m[5][VSEG];
+    float m[4][VSEG];
 #pragma unroll
-    for (int j = 0; j < VSEG; j++) { m[0][j] = m[1][j] = m[2][j] = m[3][j] = m[4][j] = 0.0f; }
+    for (int j = 0; j < VSEG; j++) { m[0][j] = m[1][j] = m[2][j] = m[3][j] = 0.0f; }
 #pragma unroll
     for (int u = 0; u < VSEG + 10; u++) {
-        float v0 = sh[0][r0 + u][tx], v1 = sh[1][r0 + u][tx], v2 = sh[2][r0 + u][tx], v3 = sh[3][r0 + u][tx], v4 = sh[4][r0 + u][tx];
+        float v0 = sh[0][r0 + u][tx], v1 = sh[1][r0 + u][tx], v2 = sh[2][r0 + u][tx], v3 = sh[3][r0 + u][tx];
 #pragma unroll
         for (int j = 0; j < VSEG; j++) {
             const int t = u - j;
             if (t >= 0 && t <= 10) {
                 float w = c_gauss[t];
-                m[0][j] += w * v0; m[1][j] += w * v1; m[2][j] += w * v2; m[3][j] += w * v3; m[4][j] += w * v4;
+                m[0][j] += w * v0; m[1][j] += w * v1; m[2][j] += w * v2; m[3][j] += w * v3;
             }
         }
     }
@@ -120,10 +123,11 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
         const int gy = by + r0 + j;
         if (gx < W && gy < H) {
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-            float mu1 = m[0][j], mu2 = m[1][j], ex2 = m[2][j], ey2 = m[3][j], exy = m[4][j];
-            float s11 = ex2 - mu1 * mu1, s22 = ey2 - mu2 * mu2, s12 = exy - mu1 * mu2;
+            float mu1 = m[0][j], mu2 = m[1][j];
+            float e2sum = 0.5f * (m[2][j] + m[3][j]), exy = 0.25f * (m[2][j] - m[3][j]);       // E[x^2]+E[y^2], E[xy]
+            float s12 = exy - mu1 * mu2;
             float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * s12 + C2;
-            float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+            float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = (e2sum - mu1 * mu1 - mu2 * mu2) + C2;
             float inv = 1.0f / (B1 * B2);
             float s_val = A1 * A2 * inv;
             // partial derivatives of S wrt the three blurred moments that depend on x
