@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
     }
     maxlast = rfl(wave_max_i(maxlast));
     maxlast = min(maxlast, end - start);
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 
     for (int idx = maxlast - 1; idx >= 0; idx--) {
         const int pid = rfl(sp[idx]);
@@ -371,14 +371,16 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
         BFLY(v_px, v_a, b1, xor_dpp2)
         BFLY(v_c, v_g, b1, xor_dpp2)
         BFLY(v_px, v_c, b2, xor_swz4)
-        v_px += xor_swz8(v_px); v_px += xor_swz16(v_px); v_px += xor_32(v_px);
-        v_o = wave_sum(v_o);
+        // ninth value (opacity): reduced over xor 1,2,4 on its own, then merged into the xor-8 level -- lanes with bit 3 set carry it
+        // through the last two levels, so lane 8 ends up with the opacity sum next to the eight others in lanes 0..7
+        v_o += xor_dpp1(v_o); v_o += xor_dpp2(v_o); v_o += xor_swz4(v_o);
+        BFLY(v_px, v_o, b3, xor_swz8)
+        v_px += xor_swz16(v_px); v_px += xor_32(v_px);
         // lane (l&7) -> record slot: bit0 picks second of pair, bit1 second pair-of-pairs, bit2 second quad
         // pairs: (px,py) (a,bq) (c,r) (g,b) -> slots (0,1) (2,3) (4,5) (6,7)
         if (lane < 9) {
             const int sl = (lane == 8) ? 8 : (((lane >> 2) & 1) * 4 + ((lane >> 1) & 1) * 2 + (lane & 1));
-            const float val = (lane == 8) ? v_o : v_px;
-            unsafeAtomicAdd(pg + (size_t)pid * GREC + sl, val);
+            unsafeAtomicAdd(pg + (size_t)pid * GREC + sl, v_px);
         }
         if (STAT) {
             esq = wave_sum(esq);
