@@ -207,12 +207,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (litegs_amd has no CPU path)")
+    # LITEGS_BENCH_ONE_GPU=1 (test hook, never set by the driver): all ranks share cuda:0 and talk over gloo, so that the N>1 control
+    # flow of this script can be exercised on a one-GPU box; RCCL refuses two ranks on one device.  Such a run is not a measurement.
+    one_gpu = os.environ.get("LITEGS_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from litegs_amd import synthetic as S
     from litegs_amd.trainer import SyntheticTrainer
     n, W, H, focal = S.CONFIGS[args.config]
