@@ -118,8 +118,9 @@ int lg_get_allocate_size(const float* ndc, const float* view_z, const float* inv
                          int32_t* left_up /*[V,2,N] or NULL*/, int32_t* right_down, int32_t* allocate_size /*[V,N]*/,
                          void* stream);                                                                             /* binning.cu:290-440 */
 /* create_table, first half (binning.cu:34-110): keys must be zero-filled; sorted_id int64 (torch.sort) or int32.
- * temp (lg_duplicate_with_keys_temp_bytes): queue of the splats that touch many tiles, emitted by a second launch. */
-long long lg_duplicate_with_keys_temp_bytes(int V, int N);
+ * temp (lg_duplicate_with_keys_temp_bytes): queue of the splats that touch many tiles, emitted by a second launch (giants in
+ * parts of 1024 tiles).  N < 2^24. */
+long long lg_duplicate_with_keys_temp_bytes(int V, int N, long long table_len);
 int lg_duplicate_with_keys(const float* ndc, const float* inv_cov2d, const float* opacity, const int32_t* prefix_sum,
                            const void* depth_sorted_id, int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW,
                            long long table_len, int32_t* keys, int32_t* values, void* temp, long long temp_bytes, void* stream);
@@ -182,7 +183,7 @@ int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt
  * entry points are what litegs_amd/fast.py binds.  view_host/proj_host are HOST float[16] (row-vector 4x4, passed to kernels by value).
  * Workspace 1 holds per-Gaussian buffers for N = A*S, workspace 2 the tile-instance table of length L. */
 long long lg_fused_workspace1_bytes(long long N);
-long long lg_fused_workspace2_bytes(long long L, int H, int W, int TH, int TW);
+long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW);
 long long lg_fused_total_offset(long long N);
 int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
                     const float* view_host, const float* proj_host, int H, int W, int TH, int TW, int degree,

@@ -88,8 +88,17 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 // per group: returning atomics on a single address serialise at ~8 ns each in L2, and one counter for the whole launch
 // (10 k wave-level appends at 3 M Gaussians) cost 85 us -- more than the rest of the kernel.
 #define DUP_NQ 64
-__host__ __device__ static inline long long dup_queue_cap(long long N) { return ((N + TPB - 1) / TPB + DUP_NQ - 1) / DUP_NQ * TPB; }     // entries per sub-queue
-__host__ __device__ static inline long long dup_queue_ints(long long N) { return DUP_NQ + DUP_NQ * dup_queue_cap(N); }                  // counters | entries
+// A queue entry is (depth slot << 8 | part): a splat with more than DUP_PART tiles is emitted in parts of DUP_PART outputs by different
+// waves (every part recomputes the slices, which is cheap next to 1024 outputs) -- otherwise the launch waits for the one wave that
+// owns the largest splat (11 033 tiles at 500 k Gaussians: 172 store instructions in a row).  Sub-queue capacity: one entry per slot
+// of its groups plus one per DUP_PART outputs of the whole table.
+#define DUP_PART 1024
+#define DUP_MAX_PARTS 255
+__host__ __device__ static inline int dup_num_parts(int cnt) { int p = (cnt + DUP_PART - 1) / DUP_PART; return p < 1 ? 1 : (p > DUP_MAX_PARTS ? DUP_MAX_PARTS : p); }
+__host__ __device__ static inline long long dup_queue_cap(long long N, long long L)
+{
+    return ((N + TPB - 1) / TPB + DUP_NQ - 1) / DUP_NQ * TPB + (L + DUP_PART - 1) / DUP_PART + TPB;
+}
 
 struct WalkFrame {          // per-splat constants of the (u,v) walk, derivable from SplatExtent
     bool isY;
@@ -221,7 +230,7 @@ template <int TH, int TW, typename IdxT, bool PACKED, typename LdsKeyT>
 __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
                                                         const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                         long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
-                                                        int* __restrict__ queue /*[V][N+1]: count, entries*/,
+                                                        int* __restrict__ qcount /*[V][DUP_NQ], zero*/, uint32_t* __restrict__ qentries /*[V][DUP_NQ][cap]*/,
                                                         int* __restrict__ totals /*nullable [passes][256]*/, DigitSpec ds,
                                                         uint32_t* __restrict__ zero_ptr, long long zero_words,
                                                         uint32_t* __restrict__ ones_ptr, long long ones_words,
@@ -237,7 +246,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     __shared__ int qbase_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
-    const long long qcap = dup_queue_cap(N), qints = dup_queue_ints(N);
+    const long long qcap = dup_queue_cap(N, table_len);
     const int32_t* pf = prefix + (size_t)b * N;
     int32_t* kout = keys + (size_t)b * table_len;
     int32_t* vout = values + (size_t)b * table_len;
@@ -291,13 +300,19 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
 
     // 2. big splats: reserve their queue slots (one returning atomic per group, issued now, consumed after the geometry below so that
     //    its L2 round trip overlaps the record loads)
-    const unsigned long long bm = __ballot(big);
-    if (lane == 0) wbig[wave] = __popcll(bm);
+    const int np = big ? dup_num_parts(cnt) : 0;           // queue entries of this slot
+    int np_inc = np;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int nb = __shfl_up(np_inc, o);
+        if (lane >= o) np_inc += nb;
+    }
+    if (lane == 63) wbig[wave] = np_inc;
     __syncthreads();
     int qb = 0;
     if (tid == 0) {
-        const int nbig = wbig[0] + wbig[1] + wbig[2] + wbig[3];
-        if (nbig) qb = atomicAdd(queue + (size_t)b * qints + (grp % DUP_NQ), nbig);
+        const int nent = wbig[0] + wbig[1] + wbig[2] + wbig[3];
+        if (nent) qb = atomicAdd(qcount + (size_t)b * DUP_NQ + (grp % DUP_NQ), nent);
     }
 
     // 3. geometry of the small splats
@@ -311,9 +326,10 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     if (tid == 0) qbase_s = qb;
     __syncthreads();
     if (big) {
-        int pos = qbase_s + __popcll(bm & ((1ull << lane) - 1ull));
+        int pos = qbase_s + np_inc - np;
         for (int w = 0; w < wave; w++) pos += wbig[w];
-        queue[(size_t)b * qints + DUP_NQ + (size_t)(grp % DUP_NQ) * qcap + pos] = j;
+        uint32_t* q = qentries + ((size_t)b * DUP_NQ + (grp % DUP_NQ)) * qcap + pos;
+        for (int p = 0; p < np; p++) q[p] = ((uint32_t)j << 8) | (uint32_t)p;
     }
 
     // ---- small splats: exclusive block scan of their counts -> compacted LDS layout ----
@@ -375,7 +391,8 @@ template <int TH, int TW, typename IdxT, bool PACKED>
 __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
                                                       const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                       long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
-                                                      const int* __restrict__ queue, int* __restrict__ totals, DigitSpec ds)
+                                                      const int* __restrict__ qcount, const uint32_t* __restrict__ qentries,
+                                                      int* __restrict__ totals, DigitSpec ds)
 {
     __shared__ int w_minv[TPB / 64][DUP_MAX_SLICES];      // per-wave slice scratch
     __shared__ int w_off[TPB / 64][DUP_MAX_SLICES + 1];
@@ -388,11 +405,11 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
     const int32_t* pf = prefix + (size_t)b * N;
     int32_t* kout = keys + (size_t)b * table_len;
     int32_t* vout = values + (size_t)b * table_len;
-    const long long qcap = dup_queue_cap(N);
-    const int* q = queue + (size_t)b * dup_queue_ints(N);
+    const long long qcap = dup_queue_cap(N, table_len);
+    const uint32_t* q = qentries + (size_t)b * DUP_NQ * qcap;
     __shared__ int qstart[DUP_NQ + 1];                     // exclusive prefix of the sub-queue lengths
     if (tid < 64) {
-        const int c = q[tid];
+        const int c = qcount[(size_t)b * DUP_NQ + tid];
         int inc = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -413,7 +430,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
         const int left = (nq - gw - r0 * nwaves + nwaves - 1) / nwaves;          // entries of this wave from slot r0 on
         const int nb = left < DUP_BATCH ? left : DUP_BATCH;
         SplatExtent e;
-        int my_off = 0, my_idx = 0;
+        int my_off = 0, my_idx = 0, my_part = 0;
         if (lane < nb) {
             const int t = (r0 + lane) * nwaves + gw;               // flat entry -> (sub-queue, position)
             int lo = 0, hi = DUP_NQ - 1;
@@ -421,7 +438,9 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                 int mid = (lo + hi + 1) >> 1;
                 if (qstart[mid] <= t) lo = mid; else hi = mid - 1;
             }
-            const int j = q[DUP_NQ + (size_t)lo * qcap + (t - qstart[lo])];
+            const uint32_t ent = q[(size_t)lo * qcap + (t - qstart[lo])];
+            const int j = (int)(ent >> 8);
+            my_part = (int)(ent & 255u);
             my_off = (j == 0) ? 0 : pf[j - 1];
             my_idx = (int)sorted_id[(size_t)b * N + j];
             float nx, ny, a, bb, cc, o;
@@ -439,9 +458,11 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             s.rminx = bcast_i(e.rminx, srcl); s.rminy = bcast_i(e.rminy, srcl); s.rmaxx = bcast_i(e.rmaxx, srcl); s.rmaxy = bcast_i(e.rmaxy, srcl);
             const int sidx = bcast_i(my_idx, srcl);
             const int sgoff = bcast_i(my_off, srcl);
+            const int part = bcast_i(my_part, srcl);
             const WalkFrame f = walk_frame<TH, TW>(s);
             const int nsl = f.rect_max_u - f.rect_min_u;                   // <= min(grid.x, grid.y) slices
             if (nsl > DUP_MAX_SLICES) {                                    // > 4K-class images: the owner lane walks serially
+                if (part != 0) continue;                                   // (the whole splat, by the wave that holds its first part)
                 int c = 0;
                 if (lane == srcl) c = (int)walk_tiles<TH, TW, true>(e, gx, my_idx, my_off, kout, vout);
                 if (totals) {                                              // count what was just written
@@ -493,6 +514,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order: no fence (a fence would also wait for the global stores)
             if (run > DUP_MAX_RUN) {              // cannot happen below ~8K x 8K images; keep the table consistent and walk serially
                 for (int wq = lane; wq < DUP_MAX_RUN / 32; wq += 64) bitmap[wave][wq] = 0u;
+                if (part != 0) continue;
                 if (lane == srcl) walk_tiles<TH, TW, true>(e, gx, my_idx, my_off, kout, vout);
                 if (totals) {
                     __threadfence();
@@ -504,14 +526,21 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                 }
                 continue;
             }
-            int before = 0;                       // non-empty slices that start before k0
-            for (int k0 = 0; k0 < run; k0 += 64) {
+            // this wave's part of the output range (whole splat when it has DUP_PART outputs or fewer)
+            const int nparts = dup_num_parts(run);
+            const int k_begin = part * DUP_PART;
+            const int k_end = (part == nparts - 1) ? run : (k_begin + DUP_PART < run ? k_begin + DUP_PART : run);
+            int before = 0;                       // non-empty slices that start before k_begin
+            if (k_begin > 0) {
+                for (int wq = lane; wq < (k_begin >> 5); wq += 64) before += __popc(bitmap[wave][wq]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+            }
+            for (int k0 = k_begin; k0 < k_end; k0 += 64) {
                 const int k = k0 + lane;
-                const bool act = k < run;
+                const bool act = k < k_end;
                 const uint32_t wlo = bitmap[wave][(k0 >> 5)], whi = bitmap[wave][(k0 >> 5) + 1];
                 const unsigned long long word = ((unsigned long long)whi << 32) | wlo;
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) { bitmap[wave][(k0 >> 5)] = 0u; bitmap[wave][(k0 >> 5) + 1] = 0u; }      // leave the bitmap clean for the next splat
                 int32_t key = 0;
                 if (act) {
                     const int r = before + __popcll(word & ((2ull << lane) - 1ull)) - 1;
@@ -526,6 +555,9 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                 before += __popcll(word);
                 if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
             }
+            __builtin_amdgcn_wave_barrier();
+            // leave the bitmap clean for the next splat: every non-empty slice clears the word that holds its start bit
+            for (int r = lane; r < nne; r += 64) bitmap[wave][w_off[wave][c_idx[wave][r]] >> 5] = 0u;
             __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order: no fence (a fence would also wait for the global stores)
         }
     }
@@ -535,14 +567,16 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
     }
 }
 
-// queue: int32 [V][dup_queue_ints(N)], the DUP_NQ counters at the head of each view's block must be 0 on entry.  totals (nullable): the tile sort's digit counts, accumulated here.
+// qcount: int32 [V][DUP_NQ], zero on entry; qentries: uint32 [V][lg_dup_queue_entries(N, table_len)].  totals (nullable): the tile sort's
+// digit counts, accumulated here.
 int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
                 int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
-                int* queue, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
+                int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
                 uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words, void* stream)
 {
     if (N <= 0) return 0;
     if (packed && sorted_id_is_int64) return (int)hipErrorInvalidValue;     // packed records: fused executor only (int32 order)
+    if (N >= (1 << 24)) return (int)hipErrorInvalidValue;                   // queue entries carry the depth slot in 24 bits
     int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ngroups = lg_cdiv(N, TPB);
     dim3 grid(ngroups < 1280 ? ngroups : 1280, V);        // persistent workgroups (5 per CU), 256 depth slots at a time
@@ -559,12 +593,12 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
     do {                                                                                                                                   \
         if (gx * gy + 1 <= 0xffff)                                                                                                         \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
-                               H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words); \
         else                                                                                                                               \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,   \
-                               H, W, gx, gy, table_len, keys, values, queue, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words); \
         hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
-                           N, H, W, gx, gy, table_len, keys, values, (const int*)queue, totals, ds);                                       \
+                           N, H, W, gx, gy, table_len, keys, values, (const int*)qcount, (const uint32_t*)qentries, totals, ds);            \
     } while (0)
 #define DISPATCH_DUP(A_, B_)                                              \
     do {                                                                  \
@@ -582,22 +616,26 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
     LG_RETURN_LAST();
 }
 
-long long lg_dup_queue_ints(long long N) { return dup_queue_ints(N); }
+long long lg_dup_queue_entries(long long N, long long table_len) { return DUP_NQ * dup_queue_cap(N, table_len); }
 
-LG_API long long lg_duplicate_with_keys_temp_bytes(int V, int N) { return (long long)sizeof(int) * (long long)V * dup_queue_ints(N); }
+// temp: per view DUP_NQ counters followed by the queue entries
+LG_API long long lg_duplicate_with_keys_temp_bytes(int V, int N, long long table_len)
+{
+    return (long long)sizeof(int) * (long long)V * (DUP_NQ + lg_dup_queue_entries(N, table_len));
+}
 
 LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const float* opacity, const int32_t* prefix,
                                   const void* sorted_id, int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW,
                                   long long table_len, int32_t* keys, int32_t* values, void* temp, long long temp_bytes, void* stream)
 {
     if (N <= 0) return 0;
-    if (temp == nullptr || temp_bytes < lg_duplicate_with_keys_temp_bytes(V, N)) return (int)hipErrorInvalidValue;
-    for (int v = 0; v < V; v++) {                                                                    // sub-queue counters
-        hipError_t err = hipMemsetAsync((int*)temp + (size_t)v * dup_queue_ints(N), 0, sizeof(int) * DUP_NQ, (hipStream_t)stream);
-        if (err != hipSuccess) return (int)err;
-    }
+    if (temp == nullptr || temp_bytes < lg_duplicate_with_keys_temp_bytes(V, N, table_len)) return (int)hipErrorInvalidValue;
+    int* qcount = (int*)temp;                                                                        // [V][DUP_NQ]
+    uint32_t* qentries = (uint32_t*)(qcount + (size_t)V * DUP_NQ);
+    hipError_t err = hipMemsetAsync(qcount, 0, sizeof(int) * (size_t)V * DUP_NQ, (hipStream_t)stream);
+    if (err != hipSuccess) return (int)err;
     return lg_dup_emit(ndc, inv_cov, opacity, nullptr, prefix, sorted_id, sorted_id_is_int64, V, N, H, W, TH, TW, table_len, keys, values,
-                       (int*)temp, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+                       qcount, qentries, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

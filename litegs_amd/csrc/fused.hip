@@ -293,7 +293,7 @@ struct Layout1 {      // sized by N = A*S (per-Gaussian buffers)
     size_t zeroed, zero_bytes, dsort_hdr, tsort_hdr, dsort_table, scan_status, dup_queue;
 };
 struct Layout2 {      // sized by the tile-instance table length L
-    size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, total;
+    size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, dup_entries, total;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -313,13 +313,13 @@ static Layout1 layout1(long long N)
     f.zeroed = take(2 * hdr + 4 * (size_t)lg_radix_table_words(N, 4) + 4 * (size_t)lg_scan_status_words(N));
     f.dsort_hdr = f.zeroed; f.tsort_hdr = f.zeroed + hdr; f.dsort_table = f.zeroed + 2 * hdr;
     f.scan_status = f.dsort_table + 4 * (size_t)lg_radix_table_words(N, 4);
-    f.dup_queue = take(4 * (size_t)lg_dup_queue_ints(N));
-    f.zero_bytes = f.dup_queue + 4 * 64 - f.zeroed;            // ... + the 64 sub-queue counters
+    f.dup_queue = take(4 * 64);                                // the 64 sub-queue counters (the entries live in workspace 2: their number depends on L)
+    f.zero_bytes = f.dup_queue + 4 * 64 - f.zeroed;
     f.total = o;
     return f;
 }
 
-static Layout2 layout2(long long L, int ntiles)
+static Layout2 layout2(long long L, int ntiles, long long N)
 {
     Layout2 f;
     size_t o = 0;
@@ -328,16 +328,17 @@ static Layout2 layout2(long long L, int ntiles)
     f.tsort_table_words = (size_t)lg_radix_table_words(L, 4);
     f.tsort_table = take(4 * f.tsort_table_words);
     f.tile_start = take(sizeof(int) * ((size_t)ntiles + 2));
+    f.dup_entries = take(4 * (size_t)lg_dup_queue_entries(N, L));
     f.total = o;
     return f;
 }
 
 LG_API long long lg_fused_workspace1_bytes(long long N) { return (long long)layout1(N > 0 ? N : 1).total; }
 
-LG_API long long lg_fused_workspace2_bytes(long long L, int H, int W, int TH, int TW)
+LG_API long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW)
 {
     int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    return (long long)layout2(L > 0 ? L : 1, ntiles).total;
+    return (long long)layout2(L > 0 ? L : 1, ntiles, N).total;
 }
 
 LG_API long long lg_fused_cull_scratch_bytes(int chunks) { return lg_cull_scratch_bytes(chunks); }
@@ -430,7 +431,7 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
     const long long N = (long long)A * S;
     const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     Layout1 f1 = layout1(N);
-    Layout2 f = layout2(L, ntiles);
+    Layout2 f = layout2(L, ntiles, N);
     if ((long long)f1.total > ws1_bytes || (long long)f.total > ws2_bytes) return (int)hipErrorInvalidValue;
     char* w1 = (char*)ws1;            // stage 2 updates the tile-sort header and the big-splat queue that live in workspace 1
     char* w = (char*)ws2;
@@ -445,7 +446,7 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
     // truncated table (L < total) gets its tail zeroed by the first splat that does not fit.
     rc = lg_dup_emit(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
                      (const int32_t*)(w1 + f1.prefix), order, 0, 1, (int)N, H, W, TH, TW, L, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
-                     (int*)(w1 + f1.dup_queue), (int*)(w1 + f1.tsort_hdr), 0, bits, (uint32_t*)(w + f.tsort_table),
+                     (int*)(w1 + f1.dup_queue), (uint32_t*)(w + f.dup_entries), (int*)(w1 + f1.tsort_hdr), 0, bits, (uint32_t*)(w + f.tsort_table),
                      (long long)lg_radix_table_words(L, lg_radix_sort_num_passes(0, bits)),
                      (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
                      (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * N : 0, stream);
@@ -479,7 +480,7 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
     const long long N = (long long)A * S;
     const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     Layout1 f1 = layout1(N);
-    Layout2 f = layout2(L, ntiles);
+    Layout2 f = layout2(L, ntiles, N);
     if ((long long)f1.total > ws1_bytes || (long long)f.total > ws2_bytes) return (int)hipErrorInvalidValue;
     const char* w1 = (const char*)ws1;
     const char* w = (const char*)ws2;

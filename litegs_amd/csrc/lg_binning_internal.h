@@ -17,15 +17,15 @@ int lg_depth_keys_hist(const float* depth, long long n, uint32_t* keys, uint32_t
 int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                            int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted, void* stream);
 
-// ints of big-splat queue per view (lg_dup_queue_ints(N)); its first 64 ints (sub-queue counters) must be zero on entry
-long long lg_dup_queue_ints(long long N);
+// big-splat queue: 64 sub-queue counters per view (zero on entry) and lg_dup_queue_entries(N, table_len) uint32 entries per view
+long long lg_dup_queue_entries(long long N, long long table_len);
 
-// duplicate_with_keys; queue[V][lg_dup_queue_ints(N)]; totals (nullable) receives the digit counts of the emitted keys for a
+// duplicate_with_keys; totals (nullable) receives the digit counts of the emitted keys for a
 // sort on bits [begin_bit, end_bit); zero_ptr/zero_words: scratch cleared on the side
 int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, const float* packed /*nullable: [V*N][16] records instead of the SoA*/,
                 const int32_t* prefix, const void* sorted_id,
                 int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
-                int* queue, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
+                int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
                 uint32_t* ones_ptr /*filled with 0xffffffff*/, long long ones_words,
                 uint32_t* zero2_ptr /*16-byte aligned, also cleared on the side (the backward's gradient accumulator)*/, long long zero2_words, void* stream);
 

@@ -108,7 +108,7 @@ class _RenderFn(torch.autograd.Function):
         else:
             table_len = int(1.5 * pred_total)
         table_len = max(table_len, 1)
-        ws2_bytes = L.lg_fused_workspace2_bytes(table_len, R.H, R.W, R.TH, R.TW)
+        ws2_bytes = L.lg_fused_workspace2_bytes(table_len, N, R.H, R.W, R.TH, R.TW)
         ws2 = torch.empty((ws2_bytes,), dtype=torch.uint8, device=dev)
         img = torch.empty((1, 3, R.Hp, R.Wp), dtype=torch.float32, device=dev)
         trans = torch.empty((1, 1, R.Hp, R.Wp), dtype=torch.float32, device=dev)

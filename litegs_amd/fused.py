@@ -378,7 +378,7 @@ def create_table(ndc, inv_cov2d, opacity, offset, depth_sorted_pointid, feedback
     dev = ndc.device
     keys = torch.zeros((V, pred), dtype=torch.int32, device=dev)
     vals = torch.empty((V, pred), dtype=torch.int32, device=dev)
-    tb = L.lg_duplicate_with_keys_temp_bytes(V, N)
+    tb = L.lg_duplicate_with_keys_temp_bytes(V, N, pred)
     temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
     check(L.lg_duplicate_with_keys(_p(ndc), _p(ic), _p(opacity), _p(offset), _p(ids), 1 if ids.dtype == torch.int64 else 0, V, N,
                                    int(height), int(width), int(tile_size_h), int(tile_size_w), pred, _p(keys), _p(vals), _p(temp), tb, _s()),

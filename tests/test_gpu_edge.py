@@ -119,3 +119,29 @@ def test_8k_image_with_giant_splats(oracle):
     err = np.abs(img.detach().cpu().numpy() - np.clip(ref.img[..., :H, :W], 0, 1))
     assert err.max() < 2e-2 and (err > 1e-4).mean() < 5e-5
     assert all(torch.isfinite(p.grad.compacted_values[..., :ref.nvis, :]).all() for p in params)
+
+
+def test_giant_splats_are_emitted_in_parts(oracle):
+    """1080p with near-camera splats of 1 000..16 000 tiles: the second emission launch splits every splat of more than 1024 tiles
+    into parts handled by different waves; the table (operator path, exact and truncated length) stays bit-exact."""
+    from litegs_amd import fused as F
+    H, W = 1080, 1920
+    scene = list(S.make_scene(2048, seed=21, scale_mult=1.5))
+    view, proj, planes = S.make_camera(W, H, 1200.0, 1200.0, (0.4, -0.1, 0.3))
+    ref = oracle.render_forward(scene, view, proj, planes, H, W, 3)
+    alloc = ref.alloc[0]
+    assert (alloc > 1024).sum() >= 20 and (alloc > 4096).sum() >= 3, ((alloc > 1024).sum(), (alloc > 4096).sum(), int(alloc.max()))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    op = ref.act[4]
+    ks, vs = F.create_table(dev(ref.ndc), dev(ref.inv_cov), dev(op), dev(ref.prefix), dev(ref.depth_sorted_index), None, None, H, W, 8, 16)
+    assert np.array_equal(ks.cpu().numpy(), ref.sorted_tile) and np.array_equal(vs.cpu().numpy(), ref.sorted_point)
+    total = int(ref.prefix[0, -1])
+    want = int(1.5 * int(0.45 * total))                         # sized from a much smaller "previous frame": drops whole splats
+    ks_r, vs_r, _, _ = oracle.create_table(ref.ndc, ref.inv_cov, op, ref.prefix, ref.depth_sorted_index, H, W, 8, 16, table_len=want)
+    fb = torch.tensor([int(0.45 * total)], dtype=torch.int32).pin_memory()
+    ks, vs = F.create_table(dev(ref.ndc), dev(ref.inv_cov), dev(op), dev(ref.prefix), dev(ref.depth_sorted_index), fb, torch.tensor([0]),
+                            H, W, 8, 16)
+    torch.cuda.synchronize()
+    assert want < total and np.array_equal(ks.cpu().numpy(), ks_r)
+    live = ks_r[0] > 0
+    assert np.array_equal(vs.cpu().numpy()[0][live], vs_r[0][live])

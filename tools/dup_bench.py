@@ -13,7 +13,7 @@ ndc, ic, op, prefix = dev(res.ndc), dev(res.inv_cov), dev(res.act[4]), dev(res.p
 ids = dev(res.depth_sorted_index.astype(np.int32))
 N = ndc.shape[-1]; Ltab = int(res.n_instances)
 keys = torch.zeros((1, Ltab), dtype=torch.int32, device="cuda"); vals = torch.empty_like(keys)
-L = lib(); tb = L.lg_duplicate_with_keys_temp_bytes(1, N); temp = torch.empty((tb,), dtype=torch.uint8, device="cuda")
+L = lib(); tb = L.lg_duplicate_with_keys_temp_bytes(1, N, Ltab); temp = torch.empty((tb,), dtype=torch.uint8, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 def run():
     check(L.lg_duplicate_with_keys(ndc.data_ptr(), ic.data_ptr(), op.data_ptr(), prefix.data_ptr(), ids.data_ptr(), 0, 1, N, H, W, 8, 16, Ltab,
