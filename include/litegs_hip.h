@@ -185,6 +185,7 @@ int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt
 long long lg_fused_workspace1_bytes(long long N);
 long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW);
 long long lg_fused_total_offset(long long N);
+long long lg_fused_alloc_offset(long long N);   /* int32[N] tile counts per compacted Gaussian (valid after stage 1) */
 int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
                     const float* view_host, const float* proj_host, int H, int W, int TH, int TW, int degree,
                     const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,
@@ -218,6 +219,15 @@ int lg_adam_update_multi(int ngroups, void* const* param, const void* const* gra
  * mean squared distance of every point to its 3 nearest neighbours (exact).  points [P,3] fp32, mean_dist2 [P]. */
 long long lg_knn3_temp_bytes(int P);
 int lg_knn3_mean_dist2(const float* points, int P, float* mean_dist2, void* temp, long long temp_bytes, void* stream);
+
+/* ---- refine.hip : litegs/scene/point.py:29-154 (_gen_morton_code, spatial_refine) and the column gathers of
+ * litegs/training/densify.py:75-101 (_prune_optimizer) ---------------------------------------------------------------------------
+ * lg_morton_order: 3x21-bit Morton codes of xyz [3,n] (bounding-box normalised, the reference's fp32 arithmetic) and their STABLE
+ * ascending argsort (torch.sort(stable=True) of point.py:94).  codes may be NULL.  n < 2^31.
+ * lg_permute_columns: dst[r,i] = src[r,order[i]] -- the per-tensor gather applied to every parameter, gradient and Adam moment. */
+long long lg_morton_order_temp_bytes(long long n);
+int lg_morton_order(const float* xyz, long long n, int64_t* codes, int32_t* order, void* temp, long long temp_bytes, void* stream);
+int lg_permute_columns(const float* src, const int32_t* order, long long rows, long long n_src, long long n_dst, float* dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@ SOURCES = {
     "loss.hip": ["-munsafe-fp-atomics"],
     "fused.hip": ["-ffp-contract=off"],
     "knn.hip": [],
+    "refine.hip": ["-ffp-contract=off"],
 }
 
 

@@ -346,6 +346,9 @@ LG_API long long lg_fused_cull_scratch_bytes(int chunks) { return lg_cull_scratc
 // byte offset in workspace 1 of the exact instance total (prefix[N-1]) -- for the blocking first-visit path
 LG_API long long lg_fused_total_offset(long long N) { return (long long)(layout1(N).prefix + 4 * (size_t)(N - 1)); }
 
+// byte offset in workspace 1 of the per-Gaussian tile counts int32[N] (allocate_size, wrapper.py:726-733): read by the statistics hook
+LG_API long long lg_fused_alloc_offset(long long N) { return (long long)layout1(N).alloc; }
+
 static Camera make_camera(const float* view_host, const float* proj_host, int H, int W)
 {
     Camera c;

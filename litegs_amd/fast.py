@@ -121,6 +121,8 @@ class _RenderFn(torch.autograd.Function):
             fc = torch.zeros((1, 1, N), dtype=torch.int32, device=dev)
             fw = torch.zeros((1, 1, N), dtype=torch.float32, device=dev)
             STATS.set_compaction(vis_ids[:A], vis_num)
+            a_off = L.lg_fused_alloc_offset(N)                # b_visible = allocate_size != 0 (wrapper.py:733-736)
+            STATS.add_visible((ws1[a_off:a_off + 4 * N].view(torch.int32) != 0).view(1, N))
         if tiles is not None:
             img.zero_(); trans.fill_(1.0); last.zero_()
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)

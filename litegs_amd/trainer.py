@@ -106,6 +106,47 @@ class SyntheticTrainer:
         frame = self.frames[frame_index % len(self.frames)]
         return self.forward(frame)[0]
 
+    # -- epoch-boundary callers of the path (trainer.py:111-118, 195): Morton re-sort, density control ---------------------------
+    def _rebind(self):
+        """parameters were replaced / re-sorted: refresh everything derived from them (chunk AABBs, cached pointers, the per-frame
+        size predictions of the GPU-driven protocol -- a first-visit blocking read is cheaper than a truncated table)."""
+        by_name = {g["name"]: g["params"][0] for g in self.opt.param_groups}
+        self.params = [by_name[n] for n in ("xyz", "scale", "rot", "sh_0", "sh_rest", "opacity")]
+        self.n_chunks, self.S = self.params[0].shape[-2], self.params[0].shape[-1]
+        with torch.no_grad():
+            xyz, scale, rot = self.params[0], self.params[1], self.params[2]
+            self.cluster_origin, self.cluster_extend = R.get_cluster_AABB(xyz, scale.exp(), torch.nn.functional.normalize(rot, dim=0))
+        self.fadam._ready = False
+        self.renderer.pending = None
+        torch.cuda.current_stream().synchronize()               # pinned feedback words may still be in flight
+        self.renderer.fb_vis.zero_()
+        self.renderer.fb_total.zero_()
+        self.feedback_visible_chunks_num.zero_()
+        self.feedback_binning_allocate_size.zero_()
+
+    def enable_densify(self, params=None, total_epochs: int = 100, screen_extent: float = 1.0, seed: int = 0, group=None):
+        from . import densify as D
+        dp = params or D.DensifyParams()
+        dp.resolve_until(total_epochs)
+        self.controller = D.DensityController(screen_extent, dp, self.S, self.n_chunks * self.S, STATS, D.Sampler(seed), group)
+        self.controller.on_change = self._rebind
+        STATS.reset(self.n_chunks, self.S, self.controller.is_densify_actived, device=self.device)
+        return self.controller
+
+    def begin_epoch(self, epoch: int):
+        """Morton re-sort one epoch after every densification (trainer.py:113-116); returns the statistics guard for the epoch."""
+        ctl = getattr(self, "controller", None)
+        if ctl is not None and (epoch - 1) % ctl.p.densification_interval == 0:
+            from . import scene
+            scene.spatial_refine(True, self.opt, self.params[0])
+            self._rebind()
+        return STATS.epoch(epoch)
+
+    def end_epoch(self, epoch: int):
+        ctl = getattr(self, "controller", None)
+        if ctl is not None:
+            ctl.step(self.opt, epoch)
+
     def workload_stats(self, frame_index: int = 0):
         """N_vis (Gaussians after chunk culling), I (tile instances) for one frame -- host sync, call outside timed regions."""
         frame = self.frames[frame_index % len(self.frames)]

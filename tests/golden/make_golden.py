@@ -23,6 +23,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True          # /root/reference is read-only by contract: importing it must not drop __pycache__ there
+
 import numpy as np
 import torch
 
@@ -175,6 +177,103 @@ def main():
 
     out.update(cl_xyz=cxyz.numpy(), cl_scale=cscale.numpy(), cl_rot=crot.numpy(), cl_xyz_chunked=kxyz.numpy(),
                cl_origin=origin_c.numpy(), cl_extend=extend_c.numpy())
+
+    # --- Morton codes and the stable re-sort order (litegs/scene/point.py:29-76, :94) ---------------------------------------------
+    point = importlib.import_module("litegs.scene.point")
+    g3 = torch.Generator().manual_seed(99)
+    mxyz = torch.randn((3, 5000), generator=g3) * 2
+    mxyz[:, 100:200] = mxyz[:, 300:400]                     # exact duplicates: ties must keep the input order
+    mxyz[:, 4000:4100] = mxyz[:, 4000:4001]                 # a run of identical points
+    codes = point._gen_morton_code(mxyz)
+    out.update(mo_xyz=mxyz.numpy(), mo_codes=codes.numpy(), mo_order=codes.sort(stable=True)[1].numpy().astype(np.int32))
+    flat = mxyz[:, :700].clone()
+    flat[2] = 0.25                                          # degenerate axis: extent 0 -> the 1e-12 clamp
+    codes_flat = point._gen_morton_code(flat)
+    out.update(mo_flat_xyz=flat.numpy(), mo_flat_codes=codes_flat.numpy(),
+               mo_flat_order=codes_flat.sort(stable=True)[1].numpy().astype(np.int32))
+
+    # --- density control (litegs/training/densify.py:245-363 DensityControllerTamingGS; :228-243 step) on the CPU ------------------
+    # statistics are injected (a stand-in for StatisticsHelperInst), the two random draws are recorded so that the test can replay them
+    densify_ref = importlib.import_module("litegs.training.densify")
+    g4 = torch.Generator().manual_seed(2024)
+    S_, C_ = 128, 4
+    N_ = S_ * C_
+    shapes = dict(xyz=(3, C_, S_), scale=(3, C_, S_), rot=(4, C_, S_), sh_0=(1, 3, C_, S_), sh_rest=(3, 3, C_, S_), opacity=(1, C_, S_))
+    init = {k: torch.randn(v, generator=g4) for k, v in shapes.items()}
+    init["scale"] = init["scale"] * 0.5 - 3.0                # exp(scale) around 0.05: both sides of percent_dense * extent
+    init["opacity"] = init["opacity"] * 2.0
+    ps = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+    o_ref, _ = opt_ref.get_optimizer(ps["xyz"], ps["scale"], ps["rot"], ps["sh_0"], ps["sh_rest"], ps["opacity"], 2.5,
+                                     args_ref.OptimizationParams, pipe)
+    mom = {}
+    for grp in o_ref.param_groups:
+        p0 = grp["params"][0]
+        m0, v0 = torch.randn(p0.shape, generator=g4) * 0.01, torch.rand(p0.shape, generator=g4) * 0.001
+        o_ref.state[p0] = {"step": torch.tensor(7.0), "exp_avg": m0.clone(), "exp_avg_sq": v0.clone()}
+        mom[grp["name"]] = (m0, v0)
+
+    class FakeStats:
+        def __init__(self, n, gen):
+            self.err_var = torch.rand((1, n), generator=gen)
+            self.err_cnt = torch.randint(0, 40, (n,), generator=gen, dtype=torch.int32)
+            self.w_mean = torch.rand((1, n), generator=gen)
+            self.w_cnt = torch.randint(0, 3, (n,), generator=gen, dtype=torch.int32)      # ~1/3 never contributed -> pruned
+            self.culled = torch.rand((n,), generator=gen) < 0.1
+        def get_var(self, key): return self.err_var, self.err_cnt
+        def get_mean(self, key): return self.w_mean, self.w_cnt
+        def get_global_culling(self): return self.culled
+        def reset(self, *a, **k): pass
+
+    class NS:
+        pass
+    dparams = NS()
+    for k_, v_ in vars(args_ref.DensifyParams).items():
+        if not k_.startswith("_"):
+            setattr(dparams, k_, v_)
+    dparams.densify_until, dparams.target_primitives = 41, 3000
+    rec = {}
+    real_multinomial, real_normal, real_zeros2 = torch.multinomial, torch.normal, torch.zeros
+    real_fused = wrapper.CreateTransformMatrix.call_fused
+
+    def rec_multinomial(*a, **k):
+        r = real_multinomial(*a, **k); rec["picked"] = r.clone(); return r
+
+    def rec_normal(*a, **k):
+        r = real_normal(*a, **k); rec["samples"] = r.clone(); return r
+    torch.multinomial, torch.normal = rec_multinomial, rec_normal
+    torch.zeros = lambda *a, **k: real_zeros2(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    wrapper.CreateTransformMatrix.call_fused = wrapper.CreateTransformMatrix.call_script
+    real_empty_cache = torch.cuda.empty_cache
+    torch.cuda.empty_cache = lambda: None
+    try:
+        torch.manual_seed(777)
+        for tag, epoch, mode in (("a", 5, "weight"), ("b", 10, "threshold")):
+            n_now = o_ref.param_groups[0]["params"][0].shape[-2] * S_
+            stats = FakeStats(n_now, g4)
+            densify_ref.StatisticsHelperInst = stats
+            dparams.prune_mode = mode
+            ctrl = densify_ref.DensityControllerTamingGS(2.0, dparams, True, N_)
+            out.update({f"dn_{tag}_err_var": stats.err_var.numpy(), f"dn_{tag}_err_cnt": stats.err_cnt.numpy(),
+                        f"dn_{tag}_w_mean": stats.w_mean.numpy(), f"dn_{tag}_w_cnt": stats.w_cnt.numpy(),
+                        f"dn_{tag}_culled": stats.culled.numpy()})
+            ctrl.step(o_ref, epoch)
+            out.update({f"dn_{tag}_picked": rec["picked"].numpy(), f"dn_{tag}_samples": rec["samples"].numpy()})
+            for grp in o_ref.param_groups:
+                p0 = grp["params"][0]
+                out[f"dn_{tag}_p_{grp['name']}"] = p0.detach().numpy().copy()
+                st = o_ref.state.get(p0)
+                out[f"dn_{tag}_has_state_{grp['name']}"] = np.array(bool(st))
+                if st:
+                    out[f"dn_{tag}_m_{grp['name']}"] = st["exp_avg"].numpy().copy()
+                    out[f"dn_{tag}_v_{grp['name']}"] = st["exp_avg_sq"].numpy().copy()
+    finally:
+        torch.multinomial, torch.normal, torch.zeros = real_multinomial, real_normal, real_zeros2
+        wrapper.CreateTransformMatrix.call_fused = real_fused
+        torch.cuda.empty_cache = real_empty_cache
+    for k_, v_ in init.items():
+        out[f"dn_init_{k_}"] = v_.numpy()
+        out[f"dn_init_m_{k_}"], out[f"dn_init_v_{k_}"] = mom[k_][0].numpy(), mom[k_][1].numpy()
+    out.update(dn_until=np.int64(41), dn_target=np.int64(3000), dn_extent=np.float64(2.0))
 
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: v.shape for k, v in out.items()})

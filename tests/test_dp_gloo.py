@@ -127,3 +127,56 @@ def test_statistics_all_reduce_world2():
     out = mgr.dict()
     mp.spawn(_stats_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def _densify_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from litegs_amd import densify as D
+    from litegs_amd import optimizer as opt_mod
+    from litegs_amd.statistics import Statistics, _Moments
+    chunks, S = 6, 32
+    g = torch.Generator().manual_seed(5)                                  # identical replicas
+    shapes = [(3, chunks, S), (3, chunks, S), (4, chunks, S), (1, 3, chunks, S), (3, 3, chunks, S), (1, chunks, S)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    with torch.no_grad():
+        ps[1].mul_(0.5).sub_(3.0)
+    opt, _ = opt_mod.get_optimizer(*ps, 1.0, opt_mod.OptimizationParams())
+    for grp in opt.param_groups:
+        p = grp["params"][0]
+        opt.state[p] = {"step": torch.tensor(1.0), "exp_avg": torch.randn(p.shape, generator=g), "exp_avg_sq": torch.rand(p.shape, generator=g)}
+    # every rank rendered DIFFERENT frames: rank-specific evidence
+    st = Statistics()
+    st.reset(chunks, S, None, device="cpu")
+    gr = torch.Generator().manual_seed(50 + rank)
+    for key in ("fragment_err", "fragment_weight"):
+        mom = _Moments((1,), chunks, S, "cpu")
+        mom.sum = torch.rand((1, chunks, S), generator=gr)
+        mom.square_sum = mom.sum ** 2 + torch.rand((1, chunks, S), generator=gr)
+        mom.count = torch.randint(0, 3, (chunks, S), generator=gr, dtype=torch.int32)
+        st.moments[key] = mom
+    dp_ = D.DensifyParams(densify_until=41, target_primitives=2000)
+    ctl = D.DensityController(2.0, dp_, S, chunks * S, st, D.Sampler(11))
+    new = ctl.step(opt, 5)
+    flat = torch.cat([t.detach().reshape(-1) for t in new] + [opt.state[t]["exp_avg"].reshape(-1) for t in new])
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([flat.numel()]))
+    same_size = all(int(s) == flat.numel() for s in sizes)
+    ok = same_size
+    if same_size:
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        ok = all(torch.equal(both[0], b) for b in both) and new[0].shape[-2] != chunks and st.chunks == new[0].shape[-2]
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_density_control_is_identical_on_every_rank_world2():
+    """rank-specific statistics are summed first and the random draws depend on (seed, epoch) only: after a densification step the
+    replicas hold bit-identical parameters and Adam moments (SURVEY 8f-1 "deterministic densify")"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_densify_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)

@@ -24,6 +24,7 @@ def _run(fused_path: bool, steps: int = 2):
         g["lr"] = 0.0                                          # keep the cloud fixed: both visits see the same scene
     tr.sched = type("NoSchedule", (), {"step": lambda self: None})()
     STATS.reset(tr.n_chunks, tr.S, enabled_for_epoch=lambda e: True, device="cuda")
+    STATS.tile_schedule.clear(); STATS.tile_blend_count.clear()      # the singleton outlives other tests' trainers
     imgs = []
     with STATS.epoch(0):
         for i in range(steps):
