@@ -84,6 +84,17 @@ class GradientExchange:
         self.use_avg = backend == "nccl"           # RCCL implements AVG; gloo does not
         self.last_alloc = 0
 
+    def rebind(self, params: Sequence[torch.Tensor]) -> None:
+        """after density control / a re-sort replaced the parameters: new chunk count -> new buffers, size predictions dropped"""
+        p0 = params[0]
+        if p0.is_cuda:
+            torch.cuda.current_stream().synchronize()            # feedback words may still be in flight
+        self.fb_union.zero_()
+        if p0.shape[-2] != self.chunks:
+            self.chunks = p0.shape[-2]
+            self.flat = torch.zeros((self.nrows * self.chunks * self.S,), dtype=torch.float32, device=p0.device)
+            self.mask = torch.zeros((self.chunks,), dtype=torch.int32, device=p0.device)
+
     def hook(self, params: List[torch.Tensor], vis_id: torch.Tensor, vis_num: torch.Tensor, slot: int = 0):
         """Called between backward and the optimizer step.  ``slot``: any integer that is the same on all ranks and recurs with the
         same set of frames (e.g. the step index modulo the steps per epoch).  Returns (union_ids[:U_alloc], union_count)."""

@@ -155,3 +155,25 @@ class SyntheticTrainer:
         if self.fused:
             return dict(n_vis=int(self.renderer.fb_vis[k]) * self.S, instances=int(self.renderer.fb_total[k]))
         return dict(n_vis=int(self.feedback_visible_chunks_num[k]) * self.S, instances=int(self.feedback_binning_allocate_size[k]))
+
+
+def train(trainer: SyntheticTrainer, epochs: int, exchange=None, rank: int = 0, world: int = 1, start_epoch: int = 0, on_epoch=None):
+    """The reference's epoch loop (trainer.py:108-195) around the hot path, data-parallel when ``exchange`` (dp.GradientExchange) is
+    given: each step trains ``world`` different frames (one per rank), gradients are averaged over the union of the ranks' visible
+    chunks, and at the epoch boundaries every rank performs the same Morton re-sort and the same density-control decisions
+    (statistics summed across ranks, shared random draws) -- replicas stay bit-identical without ever broadcasting parameters."""
+    from . import dp
+    n_frames = len(trainer.frames)
+    steps_per_epoch = (n_frames + world - 1) // world
+    step = start_epoch * steps_per_epoch
+    for epoch in range(start_epoch, epochs):
+        with trainer.begin_epoch(epoch):
+            if exchange is not None:
+                exchange.rebind(trainer.params)
+            for k in range(steps_per_epoch):
+                trainer.step(dp.frame_for(step, rank, world, n_frames), exchange.hook if exchange is not None else None, k)
+                step += 1
+        trainer.end_epoch(epoch)
+        if on_epoch is not None:
+            on_epoch(epoch, trainer)
+    return trainer

@@ -120,3 +120,48 @@ def test_two_ranks_share_one_gpu_over_gloo():
     for r in range(world):
         c = dict(out.get(r) or {})
         assert c and all(v for k, v in c.items() if k != "max_err"), (r, c)
+
+
+def _two_rank_epochs_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from litegs_amd import densify as D, dp
+        from litegs_amd.statistics import STATS
+        from litegs_amd.trainer import SyntheticTrainer, train
+        tr = SyntheticTrainer(8192, 320, 240, 300.0, n_frames=8, seed=2)
+        n0 = tr.n_chunks
+        tr.enable_densify(D.DensifyParams(densify_from=1, densification_interval=2, opacity_reset_interval=4, target_primitives=20000,
+                                          prune_mode="threshold"), total_epochs=10, seed=1)
+        ex = dp.GradientExchange(tr.params, world)
+        sizes = []
+        train(tr, 6, ex, rank, world, on_epoch=lambda e, t: sizes.append(t.n_chunks))
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in tr.params]).cpu()
+        n = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(n, torch.tensor([flat.numel()]))
+        checks = {"same_size": all(int(x) == flat.numel() for x in n), "grew": sizes[2] != n0 and sizes[1] == n0,
+                  "stats_follow": STATS.chunks == tr.n_chunks, "finite": bool(torch.isfinite(flat).all())}
+        if checks["same_size"]:
+            both = [torch.zeros_like(flat) for _ in range(world)]
+            dist.all_gather(both, flat)
+            checks["replicas_identical"] = torch.equal(both[0], both[1])
+        out[rank] = checks
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_epochs_with_density_control_stay_identical():
+    """six epochs of the data-parallel loop on two ranks (one GPU, gloo transport): statistic epochs, density control (append + prune +
+    opacity reset), Morton re-sort, exchange buffers re-bound to the new chunk count -- and the replicas never diverge"""
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_rank_epochs_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        c = dict(out.get(r) or {})
+        assert c and all(c.values()), (r, c)
