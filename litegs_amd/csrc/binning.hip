@@ -243,7 +243,12 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     __shared__ int hist[SORT_MAX_PASSES_DUP * 256];
     __shared__ int wsum[TPB / 64];
     __shared__ int wbig[TPB / 64];
+    __shared__ int wnz[TPB / 64];
     __shared__ int qbase_s;
+    // owner lookup of the stream-out: bit p of `starts` = some thread's entries begin at buf[p]; the r-th set bit belongs to c_tid[r]
+    // (one 64-bit LDS broadcast + a popcount per output instead of an 8-step binary search over t_loff)
+    __shared__ unsigned long long starts[DUP_LDS_ENTRIES / 64 + 4];
+    __shared__ int c_tid[TPB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const long long qcap = dup_queue_cap(N, table_len);
@@ -266,6 +271,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     const int ngroups = (N + TPB - 1) / TPB;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int j = grp * TPB + tid;
+    if (tid < DUP_LDS_ENTRIES / 64 + 4) starts[tid] = 0ull;          // (barriers below separate this from the bit sets)
 
     // 1. size of the slot (tile count > 0 <=> non-empty tile rectangle, so no geometry is needed to classify it)
     long long off = 0;
@@ -340,11 +346,17 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         int nb = __shfl_up(incl, o);
         if (lane >= o) incl += nb;
     }
+    const unsigned long long nzb = __ballot(scnt > 0);
     if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) wnz[wave] = __popcll(nzb);
     __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < wave; w++) wbase += wsum[w];
+    int wbase = 0, rbase = 0;
+    for (int w = 0; w < wave; w++) { wbase += wsum[w]; rbase += wnz[w]; }
     const int loff = wbase + incl - scnt;
+    if (scnt > 0) {
+        c_tid[rbase + __popcll(nzb & ((1ull << lane) - 1ull))] = tid;
+        atomicOr(reinterpret_cast<unsigned int*>(starts) + (loff >> 5), 1u << (loff & 31));
+    }
     const int total_small = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     t_loff[tid] = loff;
     t_goff[tid] = (int)off;
@@ -352,21 +364,24 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     if (tid == 0) t_loff[TPB] = total_small;
     if (small) walk_tiles<TH, TW, true, LdsKeyT>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf);
     __syncthreads();
+    int sbase = 0;                                        // set bits below position p0
     for (int p0 = 0; p0 < total_small; p0 += TPB) {
         const int p = p0 + tid;
         const bool act = p < total_small;
+        // the four 64-position blocks of this round (one per wave): uniform addresses, LDS broadcasts
+        const unsigned long long q0 = starts[(p0 >> 6)], q1 = starts[(p0 >> 6) + 1], q2 = starts[(p0 >> 6) + 2], q3 = starts[(p0 >> 6) + 3];
+        const int c0 = __popcll(q0), c1 = __popcll(q1), c2 = __popcll(q2);
+        const unsigned long long word = wave == 0 ? q0 : (wave == 1 ? q1 : (wave == 2 ? q2 : q3));
+        const int before = sbase + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        sbase += c0 + c1 + c2 + __popcll(q3);
         int32_t key = 0;
         if (act) {
-            // owner = last thread t with t_loff[t] <= p  (threads with no small entries have empty ranges)
-            int lo = 0, hi = TPB - 1;
-            while (lo < hi) {
-                int mid = (lo + hi + 1) >> 1;
-                if (t_loff[mid] <= p) lo = mid; else hi = mid - 1;
-            }
+            // owner = the thread whose start bit is the last one at or below p (threads without entries set no bit)
+            const int t = c_tid[before + __popcll(word & ((2ull << lane) - 1ull)) - 1];
             key = (int32_t)buf[p];
-            const int g = t_goff[lo] + (p - t_loff[lo]);
+            const int g = t_goff[t] + (p - t_loff[t]);
             kout[g] = key;
-            vout[g] = t_idx[lo];
+            vout[g] = t_idx[t];
         }
         if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
     }
