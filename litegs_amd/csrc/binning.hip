@@ -249,6 +249,10 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     // (one 64-bit LDS broadcast + a popcount per output instead of an 8-step binary search over t_loff)
     __shared__ unsigned long long starts[DUP_LDS_ENTRIES / 64 + 4];
     __shared__ int c_tid[TPB];
+    // the walk leaves one entry per tile SLICE (first key at the slice's first position, bit in `sstarts`); the stream-out rebuilds
+    // key = first + (position - slice start) * stride -- no per-tile loop in the serial, divergent walk
+    __shared__ unsigned long long sstarts[DUP_LDS_ENTRIES / 64 + 4];
+    __shared__ int t_stride[TPB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const long long qcap = dup_queue_cap(N, table_len);
@@ -271,7 +275,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     const int ngroups = (N + TPB - 1) / TPB;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int j = grp * TPB + tid;
-    if (tid < DUP_LDS_ENTRIES / 64 + 4) starts[tid] = 0ull;          // (barriers below separate this from the bit sets)
+    if (tid < DUP_LDS_ENTRIES / 64 + 4) { starts[tid] = 0ull; sstarts[tid] = 0ull; }       // (barriers below separate this from the bit sets)
 
     // 1. size of the slot (tile count > 0 <=> non-empty tile rectangle, so no geometry is needed to classify it)
     long long off = 0;
@@ -362,9 +366,13 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     t_goff[tid] = (int)off;
     t_idx[tid] = idx;
     if (tid == 0) t_loff[TPB] = total_small;
-    if (small) walk_tiles<TH, TW, true, LdsKeyT>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf);
+    if (small) {
+        t_stride[tid] = ((e.rmaxy - e.rminy) < (e.rmaxx - e.rminx)) ? 1 : gx;       // walk_tiles' isY rule
+        walk_tiles<TH, TW, true, LdsKeyT>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf, reinterpret_cast<unsigned int*>(sstarts));
+    }
     __syncthreads();
     int sbase = 0;                                        // set bits below position p0
+    int scarry = 0;                                       // position of the last slice start below p0
     for (int p0 = 0; p0 < total_small; p0 += TPB) {
         const int p = p0 + tid;
         const bool act = p < total_small;
@@ -374,11 +382,21 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         const unsigned long long word = wave == 0 ? q0 : (wave == 1 ? q1 : (wave == 2 ? q2 : q3));
         const int before = sbase + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
         sbase += c0 + c1 + c2 + __popcll(q3);
+        // same four blocks of the slice-start bitmap; l_k = last slice start at or below the end of block k (uniform)
+        const unsigned long long s0 = sstarts[(p0 >> 6)], s1 = sstarts[(p0 >> 6) + 1], s2 = sstarts[(p0 >> 6) + 2], s3 = sstarts[(p0 >> 6) + 3];
+        const int l0 = s0 ? p0 + 63 - __clzll(s0) : scarry;
+        const int l1 = s1 ? p0 + 127 - __clzll(s1) : l0;
+        const int l2 = s2 ? p0 + 191 - __clzll(s2) : l1;
+        const unsigned long long sword = wave == 0 ? s0 : (wave == 1 ? s1 : (wave == 2 ? s2 : s3));
+        const int sprev = wave == 0 ? scarry : (wave == 1 ? l0 : (wave == 2 ? l1 : l2));
+        scarry = s3 ? p0 + 255 - __clzll(s3) : l2;
         int32_t key = 0;
         if (act) {
             // owner = the thread whose start bit is the last one at or below p (threads without entries set no bit)
             const int t = c_tid[before + __popcll(word & ((2ull << lane) - 1ull)) - 1];
-            key = (int32_t)buf[p];
+            const unsigned long long sm = sword & ((2ull << lane) - 1ull);
+            const int ps = sm ? p0 + wave * 64 + 63 - __clzll(sm) : sprev;
+            key = (int32_t)buf[ps] + (p - ps) * t_stride[t];
             const int g = t_goff[t] + (p - t_loff[t]);
             kout[g] = key;
             vout[g] = t_idx[t];

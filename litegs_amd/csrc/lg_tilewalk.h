@@ -55,9 +55,13 @@ __device__ __forceinline__ void splat_extent(float ndcx, float ndcy, float ic00,
 }
 
 // Walks tile slices along the shorter rect axis; returns tiles touched; EMIT writes (tile_id+1, idx).
+// lds_slice_starts (with lds_keys): instead of one key per tile, ONE entry per non-empty slice -- the slice's first key at the slice's
+// first position plus a bit in a bitmap over positions; the consumer rebuilds key = first + (position - start) * stride, stride = 1
+// when slices run along y (isY: consecutive tiles in x) and gx otherwise.  Removes the per-tile loop from the serial walk.
 template <int TH, int TW, bool EMIT, typename LdsKeyT = int32_t>
 __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int32_t idx, long long off,
-                                               int32_t* __restrict__ keys, int32_t* __restrict__ values, LdsKeyT* lds_keys = nullptr)
+                                               int32_t* __restrict__ keys, int32_t* __restrict__ values, LdsKeyT* lds_keys = nullptr,
+                                               unsigned int* lds_slice_starts = nullptr)
 {
     const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
     const bool isY = ys < xs;
@@ -89,7 +93,14 @@ __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int
         int min_tile_v = max(rect_min_v, min(rect_max_v, lg_f2i(ellipse_min / BLOCK_V)));
         int max_tile_v = min(rect_max_v, max(rect_min_v, lg_f2i(ellipse_max / BLOCK_V + 1)));
         count += (uint32_t)(max_tile_v - min_tile_v);
-        if (EMIT) {
+        if (EMIT && lds_slice_starts) {
+            if (max_tile_v > min_tile_v) {
+                const uint32_t key = isY ? (uint32_t)(u * gx + min_tile_v) : (uint32_t)(min_tile_v * gx + u);
+                lds_keys[off] = (LdsKeyT)(key + 1);
+                atomicOr(lds_slice_starts + (off >> 5), 1u << (off & 31));
+                off += max_tile_v - min_tile_v;
+            }
+        } else if (EMIT) {
             for (int v = min_tile_v; v < max_tile_v; v++) {
                 uint32_t key = isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
                 if (lds_keys) lds_keys[off] = (LdsKeyT)(key + 1);
