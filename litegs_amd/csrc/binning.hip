@@ -79,7 +79,7 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 //    256-byte coalesced stores.  Without this, one thread serialises a 16 200-tile splat and the launch
 //    waits for it (measured: 2.3 ms of a 4.9 ms training step at 3 M Gaussians).
 #define DUP_SMALL 32
-#define DUP_SMALL_HI 128
+#define DUP_SMALL_HI 256
 #define DUP_LDS_ENTRIES (TPB * DUP_SMALL)
 #define DUP_MAX_SLICES 256
 #define DUP_MAX_RUN 32768      // tiles one splat may touch on the cooperative path (bitmap of 4 KiB per wave)
