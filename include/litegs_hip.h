@@ -124,6 +124,13 @@ long long lg_duplicate_with_keys_temp_bytes(int V, int N, long long table_len);
 int lg_duplicate_with_keys(const float* ndc, const float* inv_cov2d, const float* opacity, const int32_t* prefix_sum,
                            const void* depth_sorted_id, int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW,
                            long long table_len, int32_t* keys, int32_t* values, void* temp, long long temp_bytes, void* stream);
+/* create_table as ONE call for a single view (binning.cu:123-226): emission that also counts the sort's digits, zero padding of an
+ * over-allocated table (key 0 = no tile, sorts to the front), stable sort over bits [0, end_bit).  keys/vals need no initialisation;
+ * the result is in the b pair when lg_radix_sort_num_passes(0, end_bit) is odd, else in the a pair. */
+long long lg_create_table_temp_bytes(int N, long long table_len, int end_bit);
+int lg_create_table(const float* ndc, const float* inv_cov2d, const float* opacity, const int32_t* prefix_sum, const void* depth_sorted_id,
+                    int sorted_id_is_int64, int N, int H, int W, int TH, int TW, long long table_len, int end_bit,
+                    int32_t* keys_a, int32_t* vals_a, int32_t* keys_b, int32_t* vals_b, void* temp, long long temp_bytes, void* stream);
 /* create_table, second half: stable LSD radix sort replacing cub::DeviceRadixSort::SortPairs (binning.cu:204-221).
  * Ping-pongs a->b->a...; result is in the b pair when lg_radix_sort_num_passes() is odd, else in the a pair. */
 long long lg_radix_sort_temp_bytes(long long n);

@@ -1125,6 +1125,65 @@ int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
     LG_RETURN_LAST();
 }
 
+// ---------------------------------------------------------------------------------------------
+// create_table (GR/binning.cu:123-226) as one entry point for a single view: key/value emission that also counts the sort's digits,
+// zero padding of an over-allocated table, then the prepared radix sort -- no counting pass over the keys, no pre-cleared key table.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) table_pad_kernel(const int32_t* __restrict__ total_ptr, long long L, int32_t* __restrict__ keys,
+                                                        int* __restrict__ totals, int passes)
+{
+    const long long total = *total_ptr;
+    if (total >= L) return;                                  // exact or truncated table: dup_small already closed it
+    const long long gid = (long long)blockIdx.x * TPB + threadIdx.x, nth = (long long)gridDim.x * TPB;
+    for (long long i = total + gid; i < L; i += nth) keys[i] = 0;             // key 0 = "no tile": sorts to the front (binning.cu:139-150)
+    if (gid == 0)
+        for (int p = 0; p < passes; p++) atomicAdd(&totals[p * RADIX], (int)(L - total));
+}
+
+struct TableLayout { size_t header, table, qcount, cleared, qentries, total; };
+static TableLayout table_layout(int N, long long L, int passes)
+{
+    TableLayout f;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+    f.header = take(sizeof(int) * SORT_HEADER_INTS);
+    f.table = take(sizeof(int) * (size_t)lg_radix_table_words(L, passes));
+    f.qcount = take(sizeof(int) * DUP_NQ);
+    f.cleared = o;                                           // everything up to here must be zero on entry: one memset
+    f.qentries = take(sizeof(int) * (size_t)lg_dup_queue_entries(N, L));
+    f.total = o;
+    return f;
+}
+
+LG_API long long lg_create_table_temp_bytes(int N, long long table_len, int end_bit)
+{
+    return (long long)table_layout(N, table_len, lg_radix_sort_num_passes(0, end_bit)).total;
+}
+
+// Result in (keys_b, vals_b) when lg_radix_sort_num_passes(0, end_bit) is odd, else in (keys_a, vals_a).  keys/vals need no initialisation.
+LG_API int lg_create_table(const float* ndc, const float* inv_cov, const float* opacity, const int32_t* prefix, const void* sorted_id,
+                           int sorted_id_is_int64, int N, int H, int W, int TH, int TW, long long table_len, int end_bit,
+                           int32_t* keys_a, int32_t* vals_a, int32_t* keys_b, int32_t* vals_b, void* temp, long long temp_bytes, void* stream)
+{
+    const int passes = lg_radix_sort_num_passes(0, end_bit);
+    if (N <= 0 || table_len <= 0 || passes < 1 || passes > SORT_MAX_PASSES_DUP) return (int)hipErrorInvalidValue;
+    const TableLayout f = table_layout(N, table_len, passes);
+    if (temp == nullptr || temp_bytes < (long long)f.total) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)temp;
+    hipError_t err = hipMemsetAsync(w, 0, f.cleared, s);
+    if (err != hipSuccess) return (int)err;
+    int* header = (int*)(w + f.header);
+    int rc = lg_dup_emit(ndc, inv_cov, opacity, nullptr, prefix, sorted_id, sorted_id_is_int64, 1, N, H, W, TH, TW, table_len, keys_a, vals_a,
+                         (int*)(w + f.qcount), (uint32_t*)(w + f.qentries), header, 0, end_bit, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+    if (rc) return rc;
+    long long pad_blocks = lg_cdiv(table_len, (long long)TPB * 16);
+    if (pad_blocks > 1024) pad_blocks = 1024;
+    hipLaunchKernelGGL(table_pad_kernel, dim3((unsigned)pad_blocks), dim3(TPB), 0, s, prefix + (N - 1), table_len, keys_a, header, passes);
+    return lg_radix_sort_prepared((uint32_t*)keys_a, (uint32_t*)vals_a, (uint32_t*)keys_b, (uint32_t*)vals_b, table_len, nullptr, 0, end_bit,
+                                  header, (uint32_t*)(w + f.table), nullptr, nullptr, stream);
+}
+
 // depth keys: monotone float -> uint32 map (sign flip) + identity payload; replaces the key side of torch.sort
 __global__ void __launch_bounds__(TPB) depth_keys_kernel(const float* __restrict__ depth, long long n, uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ vals)

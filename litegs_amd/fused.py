@@ -376,6 +376,15 @@ def create_table(ndc, inv_cov2d, opacity, offset, depth_sorted_pointid, feedback
     if pred <= 0:
         raise RuntimeError("error pred_allocate_size")
     dev = ndc.device
+    bits = sort_bits(int(height), int(width), int(tile_size_h), int(tile_size_w))
+    if V == 1:                             # one native call: emission counts the sort's digits, no counting pass, no pre-cleared table
+        ka, va = torch.empty((1, pred), dtype=torch.int32, device=dev), torch.empty((1, pred), dtype=torch.int32, device=dev)
+        kb, vb = torch.empty_like(ka), torch.empty_like(va)
+        tb = L.lg_create_table_temp_bytes(N, pred, bits)
+        temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
+        check(L.lg_create_table(_p(ndc), _p(ic), _p(opacity), _p(offset), _p(ids), 1 if ids.dtype == torch.int64 else 0, N, int(height), int(width),
+                                int(tile_size_h), int(tile_size_w), pred, bits, _p(ka), _p(va), _p(kb), _p(vb), _p(temp), tb, _s()), "create_table")
+        return [kb, vb] if L.lg_radix_sort_num_passes(0, bits) % 2 == 1 else [ka, va]
     keys = torch.zeros((V, pred), dtype=torch.int32, device=dev)
     vals = torch.empty((V, pred), dtype=torch.int32, device=dev)
     tb = L.lg_duplicate_with_keys_temp_bytes(V, N, pred)
@@ -383,7 +392,7 @@ def create_table(ndc, inv_cov2d, opacity, offset, depth_sorted_pointid, feedback
     check(L.lg_duplicate_with_keys(_p(ndc), _p(ic), _p(opacity), _p(offset), _p(ids), 1 if ids.dtype == torch.int64 else 0, V, N,
                                    int(height), int(width), int(tile_size_h), int(tile_size_w), pred, _p(keys), _p(vals), _p(temp), tb, _s()),
           "duplicate_with_keys")
-    ks, vs = radix_sort_pairs(keys, vals, 0, sort_bits(int(height), int(width), int(tile_size_h), int(tile_size_w)))
+    ks, vs = radix_sort_pairs(keys, vals, 0, bits)
     return [ks, vs]
 
 
