@@ -68,11 +68,12 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 
 // a10 (first half) duplicate_with_keys: slot j (depth order) -> point sorted_id[j]; emits at prefix[j-1].
 // A 256-thread workgroup owns 256 consecutive depth slots.  Two paths, both bit-identical to walk_tiles<>:
-//  * small splats (<= 64 tiles while the group's entries fit the LDS buffer, else <= 32): the owning thread runs the serial AccuTile walk into a compacted LDS
-//    buffer; the workgroup then streams the buffer out (entry -> owner by binary search over 256 offsets), so
-//    global stores are coalesced instead of 64 scattered 4-byte stores per wave instruction;
+//  * small splats (<= DUP_SMALL_HI tiles while the group's entries fit the LDS buffer, else <= DUP_SMALL): the owning thread runs the serial
+//    AccuTile walk, leaving one LDS entry per tile slice (first key) and a bit per slice start; the workgroup then streams the
+//    positions out -- owner thread and slice by bitmap + popcount / leading-zero count, key = first key + distance * stride -- so
+//    global stores are coalesced instead of 64 scattered 4-byte stores per wave instruction and the walk has no per-tile loop;
 //  * big splats (near-camera Gaussians can touch thousands of tiles) are queued and emitted by a second launch whose
-//    persistent waves take one queued splat at a time (57 k of 590 k visible splats hold 39 % of the instances at 3 M):
+//    persistent waves take one queue entry at a time (3 % of the 590 k visible splats hold a quarter of the instances at 3 M):
 //    one lane per tile slice computes that slice's [min_tile_v, max_tile_v) independently (the serial walk's
 //    carried intersections are pure functions of the slice index, see slice_bounds), a wave scan turns the
 //    slice counts into offsets, and the 64 lanes then write the splat's contiguous output range in
