@@ -168,6 +168,7 @@ struct DigitSpec { int begin_bit, passes; uint32_t last_mask; };
 #define HPERM(d) ((d) ^ ((d) >> 3))
 __device__ __forceinline__ void digit_hist_flush(const int* __restrict__ h, int* __restrict__ totals, int passes)
 {
+    totals += (blockIdx.x % LG_SORT_TOTALS_COPIES) * LG_SORT_TOTALS_STRIDE;
     for (int k = threadIdx.x; k < passes * 256; k += blockDim.x) {
         const int v = h[(k & ~255) + HPERM(k & 255)];
         if (v) atomicAdd(&totals[k], v);
@@ -715,7 +716,7 @@ __global__ void __launch_bounds__(TPB) radix_totals_kernel(const uint32_t* __res
     }
     __syncthreads();
     for (int k = threadIdx.x; k < passes * RADIX; k += TPB)
-        if (h[k]) atomicAdd(&totals[k], h[k]);
+        if (h[k]) atomicAdd(&totals[(blockIdx.x % LG_SORT_TOTALS_COPIES) * LG_SORT_TOTALS_STRIDE + k], h[k]);
 }
 
 __global__ void __launch_bounds__(TPB) radix_hist_kernel(const uint32_t* __restrict__ keys, long long n, const int* __restrict__ n_dev,
@@ -940,7 +941,9 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
         else __hip_atomic_store(my, ST_AGG | (uint32_t)dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // digit base in the output = exclusive scan over digits of the global totals; local base = same scan of the tile counts
-    const int total = totals[tid];
+    int total = 0;
+#pragma unroll
+    for (int c = 0; c < LG_SORT_TOTALS_COPIES; c++) total += totals[c * LG_SORT_TOTALS_STRIDE + tid];
     int inc_g = total, inc_l = dcount;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1064,7 +1067,7 @@ LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint3
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
     int* totals = (int*)temp;
-    int* ticket = totals + SORT_MAX_PASSES * RADIX;
+    int* ticket = totals + LG_SORT_TOTALS_COPIES * LG_SORT_TOTALS_STRIDE;
     int* table = totals + SORT_HEADER_INTS;
     int last_bits = (end_bit - begin_bit) - (passes - 1) * RADIX_BITS;
     uint32_t last_mask = (1u << last_bits) - 1u;
@@ -1109,7 +1112,7 @@ int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
     int* totals = header;
-    int* ticket = header + SORT_MAX_PASSES * RADIX;
+    int* ticket = header + LG_SORT_TOTALS_COPIES * LG_SORT_TOTALS_STRIDE;
     int last_bits = (end_bit - begin_bit) - (passes - 1) * RADIX_BITS;
     uint32_t last_mask = (1u << last_bits) - 1u;
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;

@@ -4,7 +4,11 @@
 #pragma once
 #include <stdint.h>
 
-#define LG_SORT_HEADER_INTS (4 * 256 + 64)      // totals[4][256] | ticket[4] | pad
+// Digit totals are accumulated in LG_SORT_TOTALS_COPIES interleaved copies (workgroup b adds into copy b % COPIES, the sort sums them):
+// a thousand persistent workgroups flushing 512 counters each into ONE copy serialise on its 32 cache lines at the end of the launch.
+#define LG_SORT_TOTALS_COPIES 8
+#define LG_SORT_TOTALS_STRIDE (4 * 256)
+#define LG_SORT_HEADER_INTS (LG_SORT_TOTALS_COPIES * LG_SORT_TOTALS_STRIDE + 64)      // totals[copies][4][256] | ticket[4] | pad
 
 // words of look-back status a prepared sort of n keys with `passes` passes needs (zero on entry)
 long long lg_radix_table_words(long long n, int passes);
