@@ -275,7 +275,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} Gaussians SH3, {W}x{H}, 1 camera frame per GPU per step, full training iteration "
                                    "(render_preprocess+render+L1/SSIM loss+backward+sparse Adam), seed 0 (SURVEY 8d)",
-                       "frames_per_rank": args.frames, "tile": [8, 16], "parallelism": f"dp{world} (one frame per GPU, RCCL gradient all-reduce)" if world > 1 else "single GPU"},
+                       "frames_per_rank": args.frames, "tile": [8, 16], "parallelism": f"dp{world} (one frame per GPU, RCCL exchange of the non-zero gradient rows, replicated sparse Adam)" if world > 1 else "single GPU"},
             "fwd_msplats_per_s": round(n / fwd_s / 1e6, 2), "fwd_ms": round(fwd_s * 1e3, 4),
             "n_vis": stats["n_vis"], "instances": stats["instances"],
             "reference_derived_rtx3090_iters_per_s": 103.0,

@@ -23,6 +23,20 @@ sizes the buffer of the next visit of that slot (x1.2); only the first visit blo
 from the all-reduced mask, so every rank reads the same value.  A union that outgrows the prediction loses its last
 chunks for that step (silent truncation, as everywhere in this protocol).
 
+That dense exchange (mode "dense") moves 2(W-1)/W x 360..665 MB per step: on xGMI, where two GPUs share ONE link (~77 GB/s per
+direction), it costs several compute steps.  The default is therefore mode "sparse": a frame leaves a non-zero gradient on only
+~10 % of the Gaussians (the ones it actually blended), so every rank
+
+ a. compacts the Gaussians whose 59 gradient values are not all zero (exact test: a row of zeros contributes nothing to a sum),
+    ~0.35 M of 3 M -> [59 values + global index] x K, ~85 MB instead of 360..665 MB;
+ b. learns the largest K of the job from the SAME small collective that builds the union of visible chunks (K rides as one more
+    element of the MAX-reduced mask) -- one host read per step, which is affordable here: the step is communication bound and the
+    host has nothing to enqueue ahead of the exchange anyway;
+ c. ``all_gather``s the fixed-size [60, Kmax + 1] blocks: (W-1) x 85 MB arrive over the W-1 direct links in parallel;
+ d. adds the W blocks in RANK ORDER (one ``index_add_`` per rank: deterministic, the replicas stay bit-identical) into one dense
+    gradient buffer, pre-scaled by 1/W; padding entries add 0.0 to element 0.  Adam then runs over the union of visible chunks
+    with the dense-gradient kernel path.
+
 Gradient semantics: MEAN over ranks (keeps the single-GPU learning rates).  Densification statistics are summed across
 ranks by ``litegs_amd.statistics.Statistics.all_reduce`` right before the density controller reads them.  The collective / bookkeeping logic is device agnostic: the primitive ops
 (mark, compact, scatter-add) come from an ``ops`` object -- ``HipOps`` (the HIP kernels; default) -- so the N>1
@@ -69,14 +83,19 @@ class HipOps:
 
 
 class GradientExchange:
-    def __init__(self, params: Sequence[torch.Tensor], world: int, ops=HipOps, group=None, n_slots: int = 64):
+    def __init__(self, params: Sequence[torch.Tensor], world: int, ops=HipOps, group=None, n_slots: int = 64, mode: str = None):
+        import os
+        self.mode = mode or os.environ.get("LITEGS_DP_EXCHANGE", "sparse")
+        if self.mode not in ("sparse", "dense"):
+            raise ValueError("GradientExchange mode must be 'sparse' or 'dense'")
         self.world, self.ops, self.group = world, ops, group
         p0 = params[0]
         self.chunks, self.S = p0.shape[-2], p0.shape[-1]
         self.rows = [int(p.numel() // (self.chunks * self.S)) for p in params]
         self.nrows = sum(self.rows)
         self.flat = torch.zeros((self.nrows * self.chunks * self.S,), dtype=torch.float32, device=p0.device)   # capacity: dense
-        self.mask = torch.zeros((self.chunks,), dtype=torch.int32, device=p0.device)
+        self.mask = torch.zeros((self.chunks + 1,), dtype=torch.int32, device=p0.device)        # [chunks] visibility | [1] nonzero count
+        self.last_k = (0, 0)
         self.fb_union = torch.zeros((n_slots,), dtype=torch.int32)
         if p0.is_cuda:
             self.fb_union = self.fb_union.pin_memory()
@@ -93,19 +112,21 @@ class GradientExchange:
         if p0.shape[-2] != self.chunks:
             self.chunks = p0.shape[-2]
             self.flat = torch.zeros((self.nrows * self.chunks * self.S,), dtype=torch.float32, device=p0.device)
-            self.mask = torch.zeros((self.chunks,), dtype=torch.int32, device=p0.device)
+            self.mask = torch.zeros((self.chunks + 1,), dtype=torch.int32, device=p0.device)
 
     def hook(self, params: List[torch.Tensor], vis_id: torch.Tensor, vis_num: torch.Tensor, slot: int = 0):
         """Called between backward and the optimizer step.  ``slot``: any integer that is the same on all ranks and recurs with the
         same set of frames (e.g. the step index modulo the steps per epoch).  Returns (union_ids[:U_alloc], union_count)."""
         from .wrapper import CompactedTensor
+        if self.mode == "sparse":
+            return self._hook_sparse(params, vis_id, vis_num)
         slot %= self.fb_union.shape[0]
         # 1. union of visibility
         self.mask.zero_()
-        self.ops.mark(self.mask, vis_id, vis_num)
+        self.ops.mark(self.mask[: self.chunks], vis_id, vis_num)
         dist.all_reduce(self.mask, op=dist.ReduceOp.MAX, group=self.group)
         # 2. ordered union list + inverse map, on the device
-        union_ids, union_count, rank = self.ops.compact(self.mask)
+        union_ids, union_count, rank = self.ops.compact(self.mask[: self.chunks])
         # 3. size of the packed buffer: predicted from the last visit of this slot, exact (blocking) on the first
         pred = int(self.fb_union[slot])
         if pred <= 0:
@@ -139,6 +160,58 @@ class GradientExchange:
             p.grad = CompactedTensor(p.shape, ids, buf[row:row + r].reshape(*p.shape[:-2], U, self.S))
             row += r
         return ids, union_count
+
+
+    # -- sparse mode ----------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _hook_sparse(self, params: List[torch.Tensor], vis_id: torch.Tensor, vis_num: torch.Tensor):
+        S, chunks, W = self.S, self.chunks, self.world
+        A = vis_id.shape[0]
+        dev = vis_id.device
+        # a. Gaussians of this rank with a non-zero gradient (slots at or beyond vis_num are dirty by design: masked out)
+        nz = torch.zeros((A, S), dtype=torch.bool, device=dev)
+        comp = []
+        for p, r in zip(params, self.rows):
+            g = p.grad
+            if g is None:
+                comp.append(None)
+                continue
+            v = g.compacted_values.reshape(r, -1, S) if hasattr(g, "compacted_values") else g.reshape(r, chunks, S)[:, vis_id, :]
+            comp.append(v)
+            nz |= (v != 0).any(dim=0)
+        nz &= (torch.arange(A, device=dev) < vis_num.to(dev)).unsqueeze(1)
+        idx = nz.reshape(-1).nonzero().squeeze(1)                       # host sync: K is needed to size the collective
+        K = int(idx.shape[0])
+        # b. union of visible chunks and the job's largest K in one small collective
+        self.mask.zero_()
+        self.ops.mark(self.mask[:chunks], vis_id, vis_num)
+        self.mask[chunks] = K
+        dist.all_reduce(self.mask, op=dist.ReduceOp.MAX, group=self.group)
+        union_ids, union_count, _ = self.ops.compact(self.mask[:chunks])
+        kmax = max(int(self.mask[chunks].item()), 1)
+        self.last_k = (K, kmax)
+        # c. fixed-size block [nrows + 1, kmax + 1]: values | global Gaussian index (int32 bits); padding = index 0, value 0
+        block = torch.zeros((self.nrows + 1, kmax), dtype=torch.float32, device=dev)
+        gidx = (vis_id[idx // S] * S + idx % S).to(torch.int32)
+        block[self.nrows, :K] = gidx.view(torch.float32)
+        row = 0
+        for v, r in zip(comp, self.rows):
+            if v is not None:
+                block[row:row + r, :K] = v.reshape(r, -1)[:, idx]
+            row += r
+        gathered = torch.empty((W * (self.nrows + 1), kmax), dtype=torch.float32, device=dev)       # concatenation along dim 0
+        dist.all_gather_into_tensor(gathered, block, group=self.group)
+        gathered = gathered.view(W, self.nrows + 1, kmax)
+        # d. rank-ordered accumulation into the dense gradient (deterministic: replicas stay bit-identical)
+        dense = self.flat.view(self.nrows, chunks * S)
+        dense.zero_()
+        for w in range(W):
+            dense.index_add_(1, gathered[w, self.nrows].view(torch.int32).long(), gathered[w, : self.nrows], alpha=1.0 / W)
+        row = 0
+        for p, r in zip(params, self.rows):
+            p.grad = dense[row:row + r].view(p.shape)
+            row += r
+        return union_ids, union_count
 
 
 def frame_for(step: int, rank: int, world: int, n_frames: int, perm=None) -> int:

@@ -52,7 +52,7 @@ def _worker(rank, world, port, out):
     g = torch.Generator().manual_seed(0)
     shapes = [(3, chunks, S), (3, chunks, S), (4, chunks, S), (1, 3, chunks, S), (15, 3, chunks, S), (1, chunks, S)]
     params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]            # identical replicas
-    ex = dp.GradientExchange(params, world, ops=TorchOps)
+    ex = dp.GradientExchange(params, world, ops=TorchOps, mode="dense")
     # rank-specific visibility (over-allocated id list, as with the 1.2x prediction) and compact gradients
     vis = [torch.tensor([1, 4, 5, 9, 0, 0]), torch.tensor([4, 5, 6, 11, 2, 0])][rank]
     cnt = torch.tensor([4], dtype=torch.int32)
@@ -179,4 +179,69 @@ def test_density_control_is_identical_on_every_rank_world2():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_densify_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def _sparse_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from litegs_amd import dp
+    from litegs_amd.wrapper import CompactedTensor
+    chunks, S = 12, 4
+    g = torch.Generator().manual_seed(0)
+    shapes = [(3, chunks, S), (3, chunks, S), (4, chunks, S), (1, 3, chunks, S), (15, 3, chunks, S), (1, chunks, S)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    ex = dp.GradientExchange(params, world, ops=TorchOps)                 # default mode
+    assert ex.mode == "sparse"
+    vis = [torch.tensor([1, 4, 5, 9, 0, 0]), torch.tensor([4, 5, 6, 11, 2, 0])][rank]      # over-allocated id lists, 4 valid each
+    cnt = torch.tensor([4], dtype=torch.int32)
+    gr = torch.Generator().manual_seed(100 + rank)
+    # which Gaussians of the visible chunks got a gradient at all (about a third); the rest are exact zeros
+    touched = torch.rand((len(vis), S), generator=gr) < 0.35
+    touched[4:] = True                                                     # dirty tail beyond the valid count: must be ignored
+    dense_local, compact = [], []
+    for p in params:
+        rows = p.numel() // (chunks * S)
+        vals = torch.randn((rows, len(vis), S), generator=gr) * touched
+        vals[:, 4:] = 7.0                                                  # garbage in the tail
+        compact.append(vals)
+        d = torch.zeros(rows, chunks, S)
+        d[:, vis[:4]] = vals[:, :4]
+        dense_local.append(d)
+    gathered = [torch.zeros(sum(ex.rows), chunks, S) for _ in range(world)]
+    dist.all_gather(gathered, torch.cat(dense_local))
+    expect = sum(gathered) / world
+    ok = True
+    for visit in range(2):
+        for p, v in zip(params, compact):
+            p.grad = CompactedTensor(p.shape, vis, v.clone())
+        union_ids, union_count = ex.hook(params, vis, cnt, slot=visit)
+        got = torch.cat([p.grad.reshape(-1, chunks, S) for p in params])
+        ok &= torch.allclose(got, expect, atol=1e-6)
+        ok &= all(type(p.grad) is torch.Tensor and p.grad.shape == p.shape for p in params)
+        ok &= int(union_count) == 6 and union_ids[:6].tolist() == [1, 4, 5, 6, 9, 11]
+        ok &= ex.last_k[0] == int(touched[:4].sum()) and ex.last_k[1] >= ex.last_k[0]
+    # bit-identical on every rank (rank-ordered accumulation), not merely close
+    both = [torch.zeros_like(got) for _ in range(world)]
+    dist.all_gather(both, got)
+    ok &= torch.equal(both[0], both[1])
+    # a rank that saw nothing still takes part
+    for p, v in zip(params, compact):
+        p.grad = CompactedTensor(p.shape, vis, v.clone())
+    zero_cnt = torch.tensor([0 if rank == 1 else 4], dtype=torch.int32)
+    union_ids, union_count = ex.hook(params, vis, zero_cnt, slot=0)
+    got = torch.cat([p.grad.reshape(-1, chunks, S) for p in params])
+    ok &= torch.allclose(got, gathered[0] / world, atol=1e-6) and int(union_count) == 4
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_sparse_gradient_exchange_world2():
+    """default exchange: only Gaussians with a non-zero gradient travel (all_gather of [values | index] blocks sized by the job's
+    largest count), accumulated in rank order into a dense gradient: equals the mean of the dense gradients, identical on all ranks"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sparse_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)

@@ -31,14 +31,17 @@ def test_single_rank_exchange_is_identity():
         scene = S.make_scene(6000, seed=4)
         ta = SyntheticTrainer(6000, 320, 200, 300.0, n_frames=2, scene=scene)
         tb = SyntheticTrainer(6000, 320, 200, 300.0, n_frames=2, scene=scene)
-        hook = dp.GradientExchange(tb.params, 1).hook
+        tc = SyntheticTrainer(6000, 320, 200, 300.0, n_frames=2, scene=scene)
+        hook = dp.GradientExchange(tb.params, 1, mode="dense").hook
+        hook_sparse = dp.GradientExchange(tc.params, 1).hook              # default: sparse all_gather exchange
         for i in range(4):
             la = ta.step(i)
             lb = tb.step(i, hook, i % 2)
-            assert abs(la.item() - lb.item()) < 1e-5
+            lc = tc.step(i, hook_sparse, i % 2)
+            assert abs(la.item() - lb.item()) < 1e-5 and abs(la.item() - lc.item()) < 1e-5
         moved = 0.0
-        for pa, pb, p0 in zip(ta.params, tb.params, scene):
-            assert (pa - pb).abs().max().item() < 5e-4
+        for pa, pb, pc, p0 in zip(ta.params, tb.params, tc.params, scene):
+            assert (pa - pb).abs().max().item() < 5e-4 and (pa - pc).abs().max().item() < 5e-4
             moved = max(moved, (pa.detach().cpu() - torch.from_numpy(p0)).abs().max().item())
         assert moved > 1e-4, "parameters must actually have been updated"
         # union list == own visible set, ascending
@@ -60,7 +63,12 @@ def test_single_rank_exchange_is_identity():
         dist.destroy_process_group()
 
 
-def _two_rank_worker(rank, world, port, out):
+def _dense_grad(p, n_valid, chunks, S):
+    g = p.grad
+    return (g.to_dense(n_valid) if hasattr(g, "compacted_values") else g).reshape(-1, chunks, S)
+
+
+def _two_rank_worker(rank, world, port, mode, out):
     """Both ranks share cuda:0; the collective transport is gloo (RCCL refuses two ranks on one device), everything else -- the HIP
     mark / compact+rank / scatter primitives, the union-packed buffer, the sizing feedback, Adam over the union -- is the product path."""
     import torch.distributed as dist
@@ -73,7 +81,7 @@ def _two_rank_worker(rank, world, port, out):
         from litegs_amd.trainer import SyntheticTrainer
         scene = S.make_scene(20000, seed=4)                             # identical replicas
         tr = SyntheticTrainer(20000, 320, 200, 700.0, n_frames=2 * world, scene=scene)     # narrow field of view: frames see different chunks
-        ex = dp.GradientExchange(tr.params, world)
+        ex = dp.GradientExchange(tr.params, world, mode=mode)
         checks = {}
         # step 0 by hand: the exchanged gradient must be the mean of the two ranks' own dense gradients, over the union of their chunks
         fr = tr.frames[dp.frame_for(0, rank, world, len(tr.frames))]
@@ -92,7 +100,7 @@ def _two_rank_worker(rank, world, port, out):
         U = int(ucnt.item())
         checks['union'] = U == len(union) and torch.equal(uid[:U].cpu(), union)
         checks['differs'] = len(union) > n_local                        # the two frames really see different chunks
-        got = torch.cat([p.grad.to_dense(U).reshape(-1, tr.n_chunks, tr.S) for p in tr.params]).cpu()
+        got = torch.cat([_dense_grad(p, U, tr.n_chunks, tr.S) for p in tr.params]).cpu()
         expect = sum(gathered) / world
         checks['mean_grad'] = torch.allclose(got, expect, rtol=1e-5, atol=1e-7 * expect.abs().max().item())
         checks['max_err'] = float((got - expect).abs().max() / expect.abs().max())
@@ -111,12 +119,13 @@ def _two_rank_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_share_one_gpu_over_gloo():
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
+def test_two_ranks_share_one_gpu_over_gloo(mode):
     import torch.multiprocessing as mp
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_two_rank_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_two_rank_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
     for r in range(world):
         c = dict(out.get(r) or {})
         assert c and all(v for k, v in c.items() if k != "max_err"), (r, c)
