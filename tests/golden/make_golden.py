@@ -12,6 +12,11 @@ committed).  The reference's rasteriser, binning, sort, cull/activate and Adam h
   * litegs/utils/wrapper.py:419-442  (call_script)      CreateCov2dDirectly, forward and autograd backward
   * litegs/utils/wrapper.py:569-577  (_script)          EighAndInverse2x2Matrix (torch.linalg eigh / inv), fwd + inverse backward
   * litegs/data.py:35-57, 139-176                       PinHoleCameraInfo projection matrix, frustum planes
+  * litegs/scene/cluster.py:7-46                        cluster_points padding rule, get_cluster_AABB (keys cl_*)
+  * litegs/training/optimizer.py:46-108                 parameter groups, learning rates, position-lr schedule (keys opt_*)
+  * litegs/scene/point.py:29-76, :94                    _gen_morton_code and the stable re-sort order (keys mo_*)
+  * litegs/training/densify.py:228-363                  DensityControllerTamingGS.step on the CPU with injected statistics; the two
+                                                        random draws are recorded so that the test can replay them (keys dn_*)
 
 The reference package cannot be imported as a whole here (litegs/__init__.py pulls in CUDA-only extensions and
 StatisticsHelper allocates on 'cuda' at import), so the needed modules are loaded with stub modules for
