@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument("--config", default="3m_1080p", help="key of litegs_amd.synthetic.CONFIGS")
     ap.add_argument("--frames", type=int, default=8, help="camera frames per rank (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--operator-path", action="store_true",
+                    help="run the iteration operator by operator through the litegs_fused drop-in surface instead of the native executor "
+                         "(not the headline configuration; single GPU only)")
     ap.add_argument("--cpu-tile-stride", type=int, default=0,
                     help="CPU baseline rasterises every n-th tile (x n extrapolated); 0 = auto: the whole frame on >= 32 host threads, every 24th tile otherwise")
     return ap.parse_args()
@@ -225,7 +228,9 @@ def main():
     from litegs_amd.trainer import SyntheticTrainer
     n, W, H, focal = S.CONFIGS[args.config]
     scene = S.make_scene(n, seed=0)                   # identical replica on every rank
-    tr = SyntheticTrainer(n, W, H, focal, n_frames=args.frames * world, scene=scene)
+    if args.operator_path and world > 1:
+        raise SystemExit("--operator-path is a single-GPU measurement")
+    tr = SyntheticTrainer(n, W, H, focal, n_frames=args.frames * world, scene=scene, fused=not args.operator_path)
     hook = None
     if world > 1:
         from litegs_amd import dp
@@ -275,7 +280,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} Gaussians SH3, {W}x{H}, 1 camera frame per GPU per step, full training iteration "
                                    "(render_preprocess+render+L1/SSIM loss+backward+sparse Adam), seed 0 (SURVEY 8d)",
-                       "frames_per_rank": args.frames, "tile": [8, 16], "parallelism": f"dp{world} (one frame per GPU, RCCL exchange of the non-zero gradient rows, replicated sparse Adam)" if world > 1 else "single GPU"},
+                       "frames_per_rank": args.frames, "tile": [8, 16], "path": "litegs_fused operator surface" if args.operator_path else "native executor", "parallelism": f"dp{world} (one frame per GPU, RCCL exchange of the non-zero gradient rows, replicated sparse Adam)" if world > 1 else "single GPU"},
             "fwd_msplats_per_s": round(n / fwd_s / 1e6, 2), "fwd_ms": round(fwd_s * 1e3, 4),
             "n_vis": stats["n_vis"], "instances": stats["instances"],
             "reference_derived_rtx3090_iters_per_s": 103.0,
