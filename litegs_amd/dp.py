@@ -97,6 +97,7 @@ class GradientExchange:
         self.flat = torch.zeros((self.nrows * self.chunks * self.S,), dtype=torch.float32, device=p0.device)   # capacity: dense
         self.mask = torch.zeros((self.chunks + 1,), dtype=torch.int32, device=p0.device)        # [chunks] visibility | [1] nonzero count
         self.last_k = (0, 0)
+        self._touched = None                       # columns of the dense gradient buffer the previous sparse exchange added to
         self.fb_union = torch.zeros((n_slots,), dtype=torch.int32)
         if p0.is_cuda:
             self.fb_union = self.fb_union.pin_memory()
@@ -110,6 +111,9 @@ class GradientExchange:
         if p0.is_cuda:
             torch.cuda.current_stream().synchronize()            # feedback words may still be in flight
         self.fb_union.zero_()
+        if self._touched is not None:
+            self.flat.view(self.nrows, -1)[:, self._touched] = 0.0
+            self._touched = None
         if p0.shape[-2] != self.chunks:
             self.chunks = p0.shape[-2]
             self.flat = torch.zeros((self.nrows * self.chunks * self.S,), dtype=torch.float32, device=p0.device)
@@ -179,7 +183,7 @@ class GradientExchange:
                 continue
             v = g.compacted_values.reshape(r, -1, S) if hasattr(g, "compacted_values") else g.reshape(r, chunks, S)[:, vis_id, :]
             comp.append(v)
-            nz |= (v != 0).any(dim=0)
+            nz |= v.any(dim=0)                      # non-zero test without a boolean temporary (NaN counts as non-zero, -0.0 does not)
         nz &= (torch.arange(A, device=dev) < vis_num.to(dev)).unsqueeze(1)
         idx = nz.reshape(-1).nonzero().squeeze(1)                       # host sync: K is needed to size the collective
         K = int(idx.shape[0])
@@ -203,11 +207,15 @@ class GradientExchange:
         gathered = torch.empty((W * (self.nrows + 1), kmax), dtype=torch.float32, device=dev)       # concatenation along dim 0
         dist.all_gather_into_tensor(gathered, block, group=self.group)
         gathered = gathered.view(W, self.nrows + 1, kmax)
-        # d. rank-ordered accumulation into the dense gradient (deterministic: replicas stay bit-identical)
+        # d. rank-ordered accumulation into the dense gradient (deterministic: replicas stay bit-identical).  The buffer is all zeros
+        #    except for the columns the previous exchange added to: clearing those instead of zeroing 708 MB saves ~0.1 ms per step
         dense = self.flat.view(self.nrows, chunks * S)
-        dense.zero_()
+        if self._touched is not None:
+            dense[:, self._touched] = 0.0
+        index = gathered[:, self.nrows].contiguous().view(torch.int32).long()                  # [W, kmax]
         for w in range(W):
-            dense.index_add_(1, gathered[w, self.nrows].view(torch.int32).long(), gathered[w, : self.nrows], alpha=1.0 / W)
+            dense.index_add_(1, index[w], gathered[w, : self.nrows], alpha=1.0 / W)
+        self._touched = index.reshape(-1)
         row = 0
         for p, r in zip(params, self.rows):
             p.grad = dense[row:row + r].view(p.shape)

@@ -233,6 +233,14 @@ def _sparse_worker(rank, world, port, out):
     union_ids, union_count = ex.hook(params, vis, zero_cnt, slot=0)
     got = torch.cat([p.grad.reshape(-1, chunks, S) for p in params])
     ok &= torch.allclose(got, gathered[0] / world, atol=1e-6) and int(union_count) == 4
+    # after a re-sort / density control the exchange is re-bound: the gradient buffer must be clean again
+    ex.rebind(params)
+    ok &= float(ex.flat.abs().max()) == 0.0
+    for p, v in zip(params, compact):
+        p.grad = CompactedTensor(p.shape, vis, v.clone())
+    ex.hook(params, vis, cnt, slot=1)
+    got = torch.cat([p.grad.reshape(-1, chunks, S) for p in params])
+    ok &= torch.allclose(got, expect, atol=1e-6)
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
