@@ -1,6 +1,8 @@
-"""Parity at BASELINE.json's full sizes (configs[1] 500k @1080p, configs[2] 3M @1080p): the HIP path against the CPU oracle on
-the same seeded cloud and camera -- the C oracle renders 3M Gaussians @1080p in seconds on the host cores -- plus
-size-independent invariants of the binning stage (sorted keys, tile ranges partition the instance list, exact counts)."""
+"""Parity at every BASELINE.json size (configs[0] 10k @400x400, configs[1] 500k @1080p, configs[2] 3M @1080p, configs[4] 10M
+@1600x1200, all SH degree 3): the HIP path against the CPU oracle on the same seeded cloud and camera -- the C oracle renders 10M
+Gaussians in seconds on the host cores -- plus size-independent invariants of the binning stage (sorted keys, tile ranges partition
+the instance list, exact counts).  Every comparison with a flip allowance logs its observed count and is held to the pinned count
+(tests/util.py: pinned_count)."""
 import numpy as np
 import pytest
 import torch
@@ -20,7 +22,7 @@ def _setup(name):
     return c, params, view, proj, planes, origin, extend
 
 
-@pytest.mark.parametrize("name", ["500k_1080p", "3m_1080p"])
+@pytest.mark.parametrize("name", ["10k_400", "500k_1080p", "3m_1080p", "10m_1600x1200"])
 def test_fullsize_render_forward_backward_matches_oracle(oracle, name):
     from litegs_amd import fast
     c, params, view, proj, planes, origin, extend = _setup(name)
@@ -54,10 +56,10 @@ def test_fullsize_render_forward_backward_matches_oracle(oracle, name):
         assert_close(got.reshape(g_ref.shape), g_ref, atol=1e-4, flip_frac=1e-3, flip_atol=5e-2, normalize=True, name=f"grad.{nm}")
 
 
-def test_fullsize_operator_path_500k(oracle):
-    """configs[1] through the litegs_fused operator surface (render_preprocess + render + autograd)."""
+@pytest.mark.parametrize("name", ["10k_400", "500k_1080p"])
+def test_fullsize_operator_path(oracle, name):
+    """configs[0] / configs[1] through the litegs_fused operator surface (render_preprocess + render + autograd)."""
     from litegs_amd import render as R
-    name = "500k_1080p"
     c, params, view, proj, planes, origin, extend = _setup(name)
     res = oracle_forward(name)
     H, W = c["H"], c["W"]
@@ -72,11 +74,11 @@ def test_fullsize_operator_path_500k(oracle):
     assert all(torch.isfinite(p.grad.compacted_values).all() for p in params)
 
 
-def test_fullsize_binning_bit_exact_3m(oracle):
-    """Tile keys, the stable (tile, depth) order and the tile ranges at 3M @1080p: bit for bit against the oracle's tables, plus the
-    size-independent properties (sorted keys, ranges partition [0, L), every splat emitted exactly allocate_size times)."""
+@pytest.mark.parametrize("name", ["10k_400", "3m_1080p", "10m_1600x1200"])
+def test_fullsize_binning_bit_exact(oracle, name):
+    """Tile keys, the stable (tile, depth) order and the tile ranges at 3M @1080p / 10M @1600x1200: bit for bit against the oracle's
+    tables, plus the size-independent properties (sorted keys, ranges partition [0, L), every splat emitted exactly allocate_size times)."""
     from litegs_amd import fused as F
-    name = "3m_1080p"
     c = case(name)
     res = oracle_forward(name)
     H, W = c["H"], c["W"]

@@ -2,6 +2,8 @@
 from __future__ import annotations
 
 import functools
+import json
+import os
 
 import numpy as np
 
@@ -17,7 +19,49 @@ FLIP_FRAC = 2e-5
 FLIP_ATOL = 2e-2
 
 
+_PINS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flip_pins.json")
+_FLIP_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "flip_counts.jsonl")
+
+
+@functools.lru_cache(maxsize=1)
+def flip_pins():
+    """{"<test node id>::<tensor name>": max allowed number of elements beyond atol}.  Written by tools/pin_flips.py from the counts a
+    GPU run observed (2x the observation + 2), so the flip_frac allowance is a ceiling, not a blank cheque."""
+    try:
+        with open(_PINS_PATH) as f:
+            return json.load(f)
+    except OSError:
+        return {}
+
+
+def _flip_key(name):
+    node = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    return f"{node}::{name}"
+
+
+def pinned_count(name, count, size, ceiling, max_err=0.0, atol=ATOL):
+    """Log an observed out-of-tolerance count and hold it to the pinned value for this (test, tensor)."""
+    key = _flip_key(name)
+    rec = {"key": key, "flips": int(count), "size": int(size), "max_err": float(max_err), "ceiling": int(ceiling)}
+    print(f"[flips] {key}: {count} of {size} beyond {atol:g} (max err {max_err:.3e}, ceiling {ceiling})")
+    try:
+        os.makedirs(os.path.dirname(_FLIP_LOG), exist_ok=True)
+        with open(_FLIP_LOG, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    pin = flip_pins().get(key)
+    if pin is None:
+        assert os.environ.get("LITEGS_COLLECT_FLIPS") == "1", f"{key}: no pinned flip count (run tools/pin_flips.py after a collection run)"
+    else:
+        assert count <= pin, f"{key}: {count} flipped elements, pinned at {pin}"
+
+
 def assert_close(got, ref, atol=ATOL, flip_frac=0.0, flip_atol=FLIP_ATOL, normalize=False, name=""):
+    """|got - ref| <= atol everywhere, except for at most ceil(flip_frac * size) "flipped" elements, which must still be within
+    flip_atol.  Whenever an allowance is given, the OBSERVED count is logged (gpurun_out/flip_counts.jsonl, and printed) and must not
+    exceed the count pinned for this (test, tensor) in tests/golden/flip_pins.json; an unpinned comparison fails unless
+    LITEGS_COLLECT_FLIPS=1 (the collection run that produces the pins)."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
@@ -29,10 +73,12 @@ def assert_close(got, ref, atol=ATOL, flip_frac=0.0, flip_atol=FLIP_ATOL, normal
     bad = err > atol
     nbad = int(bad.sum())
     allowed = int(np.ceil(flip_frac * err.size))
+    if flip_frac > 0:
+        pinned_count(name, nbad, int(err.size), allowed, float(err.max()) if err.size else 0.0, atol)
     assert nbad <= allowed, f"{name}: {nbad} elements exceed {atol} (allowed {allowed}); max err {err.max():.3e}"
     if nbad:
         assert err.max() <= flip_atol, f"{name}: flipped element error {err.max():.3e} > {flip_atol}"
-    return float(err.max())
+    return float(err.max()) if err.size else 0.0
 
 
 @functools.lru_cache(maxsize=8)

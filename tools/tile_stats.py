@@ -31,5 +31,9 @@ with torch.no_grad():
     lens = (ts[0, 2:] - ts[0, 1:-1]).float()
     q = torch.tensor([0.5, 0.9, 0.99, 0.999])
     print("tiles", per_tile.numel(), "visited-per-tile mean %.1f max %d quantiles" % (per_tile.mean().item(), int(per_tile.max().item())), torch.quantile(per_tile, q.cuda()).tolist())
+    import numpy as np
+    os.makedirs("gpurun_out", exist_ok=True)
+    np.savez_compressed(f"gpurun_out/tile_stats_{cfg}.npz", visited=per_tile.cpu().numpy().astype(np.int32), length=lens.cpu().numpy().astype(np.int32),
+                        last=last.cpu().numpy().astype(np.int16))
     print("list-length-per-tile mean %.1f max %d" % (lens[lens >= 0].mean().item(), int(lens.max().item())), "sum visited", int(per_tile.sum().item()))
 print(bench.roofline_probe(tr, 0))
