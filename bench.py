@@ -33,7 +33,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="3m_1080p", help="key of litegs_amd.synthetic.CONFIGS")
     ap.add_argument("--frames", type=int, default=8, help="camera frames per rank (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -45,26 +45,15 @@ def parse_args():
     return ap.parse_args()
 
 
-def time_kernel(fn, iters=10):
-    """Average duration (ms) of `fn` measured with events on the current stream (the stream fn launches on)."""
-    for _ in range(2):
-        fn()
-    torch.cuda.synchronize()
-    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(iters):
-        fn()
-    end.record()
-    end.synchronize()
-    return start.elapsed_time(end) / iters
+BWD_FLOP_PER_PAIR = 60.0       # blend backward, fp32 flop per (pixel, splat) pair visited
+FWD_FLOP_PER_PAIR = 26.0
 
 
-def roofline_probe(tr, frame_index=0):
-    """Re-runs the blend kernels of one frame in isolation and prices them against the roofline.
-
-    Algorithmic bytes (SURVEY.md 8d): forward blend  = I*36 [id 4 + packed 32] + P*18 [img 12 + T 4 + last 2];
-    backward blend = P*18 + I*36 + I_c*36 [9-float atomic RMW per contributing instance].
-    Algorithmic flops: forward 2 px * ... counted as 26 flop per (pixel, splat) visited, backward 60."""
+def frame_units(tr, frame_index):
+    """Work units of one frame at the current parameters, measured on the device (not timed): P padded pixels, I emitted tile
+    instances, I_vis = sum over tiles of the list prefix the blend actually walks (the forward's early exit), I_c = (tile, splat)
+    iterations that issue a gradient atomic (counted by the backward kernel's measurement hook), pairs = (pixel, splat) pairs
+    visited (sum of last_contributor)."""
     from litegs_amd import fused, wrapper, render as R
     from litegs_amd._lib import lib, check
     frame = tr.frames[frame_index]
@@ -82,49 +71,60 @@ def roofline_probe(tr, frame_index=0):
         cov = fused.createCov2dDirectly_forward(J, frame.view, T, vl)
         _, _, inv = fused.eigh_and_inv_2x2matrix_forward(cov, vl)
         tile_start, sorted_pt, _ = wrapper.Binning.call_fused(ndc, view_pos[:, 2, :], inv, co, vl, None, None, (H, W), pp.tile_size)
-        out = fused.rasterize_forward(sorted_pt, tile_start, ndc, inv, cc, co, None, H, W, th, tw, False, False, False)
-        img, trans, _, last, packed, _, _ = out
+        img, trans, _, last, packed, _, _ = fused.rasterize_forward(sorted_pt, tile_start, ndc, inv, cc, co, None, H, W, th, tw, False, False, False)
         d_img = torch.rand_like(img) - 0.5
-        n_inst = int((tile_start[0, -1] - tile_start[0, 1]).item()) if tile_start[0, 1] >= 0 else int(sorted_pt.shape[1])
-        n_inst = int(sorted_pt.shape[1])
-        visited = int(last.to(torch.int64).sum().item())            # (pixel, splat) pairs visited by the forward
+        n_inst = int(sorted_pt.shape[1])                 # exact: the table is allocated from the prefix sum on this path
         P = img.shape[2] * img.shape[3]
         N = packed.shape[1]
+        ntiles = (img.shape[2] // th) * (img.shape[3] // tw)
         L = lib()
         pg = torch.zeros((1, N, L.lg_packed_grad_floats()), device=img.device)
-        esq = torch.zeros((1, 1, N), device=img.device)
+        counters = torch.zeros((1, ntiles + 1, 2), dtype=torch.int32, device=img.device)
         s = torch.cuda.current_stream().cuda_stream
-        fc = torch.zeros((1, 1, N), dtype=torch.int32, device=img.device)
-        fw = torch.zeros((1, 1, N), device=img.device)
+        check(L.lg_raster_backward(sorted_pt.data_ptr(), tile_start.data_ptr(), packed.data_ptr(), None, 0, trans.data_ptr(), last.data_ptr(),
+                                   d_img.data_ptr(), None, 1, n_inst, N, H, W, th, tw, 0, pg.data_ptr(), None, counters.data_ptr(), None, s), "bwd(count)")
+        c = counters.to(torch.int64).sum(dim=(0, 1))
+        return dict(P=int(P), I=n_inst, I_vis=int(c[0].item()), I_c=int(c[1].item()), pairs=int(last.to(torch.int64).sum().item()),
+                    n_vis=int(vl.item()))
 
-        def fwd():
-            check(L.lg_raster_forward(sorted_pt.data_ptr(), tile_start.data_ptr(), packed.data_ptr(), None, 0, 1, n_inst, N, H, W, th, tw, 0,
-                                      img.data_ptr(), trans.data_ptr(), last.data_ptr(), fc.data_ptr(), fw.data_ptr(), s), "fwd")
 
-        def bwd():
-            check(L.lg_raster_backward(sorted_pt.data_ptr(), tile_start.data_ptr(), packed.data_ptr(), None, 0, trans.data_ptr(), last.data_ptr(),
-                                       d_img.data_ptr(), None, 1, n_inst, N, H, W, th, tw, 0, pg.data_ptr(), esq.data_ptr(), s), "bwd")
+def roofline_probe(tr, frames, steps_per_frame=2):
+    """Roofline of the dominant kernel (the blend backward), measured IN SITU: extra training steps after the timed region with a
+    pair of events (on the launch stream) around the blend backward launch of every step, so the kernel runs in the cache state it
+    has in the real iteration.  Units are measured per frame (frame_units) and averaged over the same frames.
 
-        t_fwd = time_kernel(fwd)
-        t_bwd = time_kernel(bwd)
-        # contributing instances: count gradient records touched by one backward pass (lower bound on I_c per Gaussian
-        # is not what we need; use visited-pair statistics instead): I_c is bounded by I; report the bound used.
-        bytes_fwd = n_inst * 36 + P * 18
-        bytes_bwd = P * 18 + n_inst * 36 + n_inst * 36
-        dom = "raster_backward_kernel" if t_bwd >= t_fwd else "raster_forward_kernel"
-        t_dom = max(t_bwd, t_fwd)
-        b_dom = bytes_bwd if t_bwd >= t_fwd else bytes_fwd
-        flop_dom = visited * (60.0 if t_bwd >= t_fwd else 26.0)
-        achieved = b_dom / (t_dom * 1e-3) / 1e9
-        return {
-            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "avg_launch_ms": round(t_dom, 4), "algorithmic_bytes_per_launch": int(b_dom),
-            "note": "blend kernels are VALU-bound, not HBM-bound (SURVEY 8d): see valu_frac",
-            "valu_achieved_tflops": round(flop_dom / (t_dom * 1e-3) / 1e12, 3), "valu_peak_tflops": VALU_PEAK_TFLOPS,
-            "valu_frac": round(flop_dom / (t_dom * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
-            "forward_ms": round(t_fwd, 4), "backward_ms": round(t_bwd, 4), "instances": n_inst, "pixel_splat_pairs": visited,
-        }
+    Algorithmic bytes (per launch): P*18 [d_img 12 + T 4 + last 2] + I_vis*36 [splat id 4 + record 32, for the list
+    prefix the kernel walks] + I_c*36 [9-float atomic read-modify-write per contributing (tile, splat)].
+    Algorithmic flops: 60 per (pixel, splat) pair visited.  The larger of the two fractions is the binding roofline."""
+    units = [frame_units(tr, f) for f in frames]
+    mean = {k: sum(u[k] for u in units) / len(units) for k in units[0]}
+    events = []
+    tr.renderer.probe_events = events
+    for rep in range(steps_per_frame):
+        for f in frames:
+            tr.step(f)
+    tr.renderer.probe_events = None
+    torch.cuda.synchronize()
+    times = sorted(a.elapsed_time(b) for a, b in events)
+    t_ms = sum(times) / len(times)
+    b_bwd = mean["P"] * 18 + mean["I_vis"] * 36 + mean["I_c"] * 36
+    flop = mean["pairs"] * BWD_FLOP_PER_PAIR
+    hbm = b_bwd / (t_ms * 1e-3) / 1e9
+    valu = flop / (t_ms * 1e-3) / 1e12
+    hbm_frac, valu_frac = hbm / HBM_PEAK_GBS, valu / VALU_PEAK_TFLOPS
+    binding_valu = valu_frac >= hbm_frac
+    return {
+        "bound": "valu" if binding_valu else "hbm", "kernel": "raster_backward_kernel",
+        "achieved": round(valu if binding_valu else hbm, 3), "peak": VALU_PEAK_TFLOPS if binding_valu else HBM_PEAK_GBS,
+        "unit": "TFLOP/s" if binding_valu else "GB/s", "frac": round(valu_frac if binding_valu else hbm_frac, 4),
+        "traffic": None,
+        "avg_launch_ms": round(t_ms, 4), "launches_timed": len(times), "min_launch_ms": round(times[0], 4), "max_launch_ms": round(times[-1], 4),
+        "hbm_frac": round(hbm_frac, 4), "hbm_achieved_gbs": round(hbm, 1), "algorithmic_bytes_per_launch": int(b_bwd),
+        "valu_frac": round(valu_frac, 4), "valu_achieved_tflops": round(valu, 3), "algorithmic_flop_per_launch": int(flop),
+        "units_per_launch": {k: int(round(v)) for k, v in mean.items()},
+        "note": "fp32 vector (VALU) roofline binds the blend kernels, not HBM; units averaged over the frames timed; traffic (PMC) is in "
+                "profiles/, not re-measured in this run",
+    }
 
 
 def cpu_baseline(scene, cam, H, W, degree, tile_stride):
@@ -239,18 +239,24 @@ def main():
     def frame_of(step):                               # rank r trains frame (step*world + r): disjoint frames per step
         return (step * world + rank) % len(tr.frames)
 
-    # every frame must be seen once (blocking sizing path) before steady state
-    warm = max(args.warmup, args.frames + 2)
+    # Setup, not warm-up: every frame set is visited once so that the GPU-driven sizing protocol has its per-frame feedback (the first
+    # visit of a frame takes the reference's blocking read, GR/compact.cu:543-546); then exactly W warm-up and K timed steps.
     n_slots = max(args.frames, 1)                     # step i trains the frame set {i*world + r}: it recurs every `frames` steps
-    for i in range(warm):
-        tr.step(frame_of(i), hook, i % n_slots)
+    step_no = 0
+    for i in range(n_slots):
+        tr.step(frame_of(step_no), hook, step_no % n_slots)
+        step_no += 1
+    for i in range(args.warmup):
+        tr.step(frame_of(step_no), hook, step_no % n_slots)
+        step_no += 1
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(warm, warm + args.steps):
-        tr.step(frame_of(i), hook, i % n_slots)
+    for i in range(args.steps):
+        tr.step(frame_of(step_no), hook, step_no % n_slots)
+        step_no += 1
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -275,7 +281,7 @@ def main():
         result = {
             "metric": "train iters/s (camera frames trained per second, whole job) + fwd Msplats/s, "
                       + ("3M Gaussians @1080p" if args.config == "3m_1080p" else f"{args.config} (not the BASELINE headline config)"),
-            "value": round(world * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
+            "value": round(world * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} Gaussians SH3, {W}x{H}, 1 camera frame per GPU per step, full training iteration "
@@ -285,16 +291,9 @@ def main():
             "n_vis": stats["n_vis"], "instances": stats["instances"],
             "reference_derived_rtx3090_iters_per_s": 103.0,
         }
-        result["roofline"] = roofline_probe(tr, frame_of(0))          # rank 0's blend kernels, outside the timed region
+        if world == 1 and not args.operator_path:
+            result["roofline"] = roofline_probe(tr, list(range(len(tr.frames))))    # in situ, after the timed region
         if world == 1:
-            traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(traffic_file) and args.config == "3m_1080p":      # the PMC pass was taken on this workload only
-                try:
-                    tj = json.load(open(traffic_file))     # rocprofv3 PMC pass (profiles/r01_pmc_summary.md): (2*FETCH_SIZE+WRITE_SIZE)*1024
-                    kname = result["roofline"]["kernel"]
-                    result["roofline"]["traffic"] = next((v for k, v in tj.items() if k.startswith(kname)), None)
-                except Exception:
-                    pass
             if not args.no_cpu_baseline:
                 fr = tr.frames[frame_of(0)]
                 cam = (fr.view.cpu().numpy(), fr.proj.cpu().numpy(), fr.planes.cpu().numpy())

@@ -159,15 +159,28 @@ int lg_pack_forward_params(const float* ndc, const float* inv_cov2d, const float
 int lg_raster_forward(const int* sorted_points /*[V,L]*/, const int* start_index /*[V,T+2]*/, const float* packed,
                       const int* tiles, int K, int V, long long L, int N, int H, int W, int TH, int TW, int enable_statistic,
                       float* img /*[V,3,Hp,Wp]*/, float* transmitance /*[V,1,Hp,Wp]*/, short* last_contributor /*[V,1,Hp,Wp]*/,
-                      int* fragment_count /*[V,1,N] zeroed*/, float* fragment_weight_sum /*[V,1,N] zeroed*/, void* stream);
-/* rasterize_backward (raster.cu:600-853,917-1037): accumulates into packed_grad [V,N,16] (zeroed by the caller) */
+                      int* fragment_count /*[V,1,N] zeroed*/, float* fragment_weight_sum /*[V,1,N] zeroed*/,
+                      const int* order /*nullable int32[V,T]: tile schedule, a permutation of 1..T*/,
+                      int* tile_work /*nullable int32[V,T+1]: receives the splats walked per tile*/, void* stream);
+/* heaviest-first tile schedule (no reference kernel; statistic_helper.py:77 builds the same order in torch for specific_tiles) */
+int lg_tile_order(const int* tile_work /*[V,T+1]*/, int V, int ntiles, int* order /*[V,T]*/, void* stream);
+int lg_tile_work_from_last(const short* last_contributor /*[V,1,Hp,Wp]*/, int V, int H, int W, int TH, int TW, int* tile_work /*[V,T+1]*/, void* stream);
+/* rasterize_backward (raster.cu:600-853,917-1037): accumulates per-splat MOMENTS into packed_grad [V,N,16] (zeroed by the caller;
+ * layout in raster.hip: Mx My Mxx Mxy Myy dr dg db M0); lg_unpack_gradient turns them into the reference's four gradient tensors.
+ * tile_counters (nullable, int32 [V,T+1,2]): measurement hook, per tile the visited and the contributing (tile, splat) iterations. */
 int lg_raster_backward(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
                        const float* final_transmitance, const short* last_contributor, const float* d_img,
                        const float* d_trans /*or NULL*/, int V, long long L, int N, int H, int W, int TH, int TW,
-                       int enable_statistic, float* packed_grad, float* err_square_sum /*[V,1,N] zeroed*/, void* stream);
-int lg_unpack_gradient(const float* packed_grad, const float* grad_inv_scaler /*[1] or NULL*/, const int* valid_length,
+                       int enable_statistic, float* packed_grad, float* err_square_sum /*[V,1,N] zeroed*/,
+                       int* tile_counters, const int* order /*nullable int32[V,T]: tile schedule*/, void* stream);
+int lg_unpack_gradient(const float* packed_grad, const float* packed /*[V,N,16] records of lg_pack_forward_params*/,
+                       const float* grad_inv_scaler /*[1] or NULL*/, const int* valid_length,
                        int V, int N, int H, int W, float* d_ndc /*[V,4,N]*/, float* d_cov2d_inv /*[V,2,2,N]*/,
                        float* d_color /*[V,3,N]*/, float* d_opacity /*[1,N]*/, void* stream);                        /* raster.cu:855-886 */
+/* developer hook (no reference counterpart): selects launch variants of the blend kernels for A/B measurements.
+ * key 0: tiles per workgroup of the blend backward (1, 2, 4); key 1 / 2: workgroup -> tile map of the backward / forward
+ * (0 = one band per XCD, 1 = identity, C >= 2 = runs of C workgroups interleaved over the XCDs). */
+int lg_set_tuning(int key, int value);
 
 /* ---- loss.hip : fused_ssim.fused_l1_ssim_loss (litegs/training/trainer.py:145; un-vendored submodule, formula in
  * litegs_amd/loss.py).  planes = B*C image planes of H x W.  dmaps [3,planes,H,W] carries dS/dmu1, dS/dE[x^2], dS/dE[xy]
@@ -204,14 +217,17 @@ long long lg_fused_cull_scratch_bytes(int chunks);
 int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                     void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
                     float* img, float* trans, short* last, int* frag_count, float* frag_weight,
-                    float* packed_grad_clear /*nullable [N,16]: zeroed on the side for the coming lg_fused_backward*/, void* stream);
+                    float* packed_grad_clear /*nullable [N,16]: zeroed on the side for the coming lg_fused_backward*/,
+                    const int* order_in /*nullable [T]: tile schedule for the blend forward*/,
+                    int* order_out /*nullable [T]: receives this visit's heaviest-first schedule; may alias order_in*/, void* stream);
 int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
                       const void* ws2, long long ws2_bytes, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                       const int64_t* vis_ids, const int* vis_num,
                       const float* pos, const float* scale, const float* rot, const float* opa,
                       const int* tiles, int K, const float* final_T, const short* last, const float* d_img, const float* d_trans,
                       const float* grad_inv_scaler, int enable_stat, float* packed_grad, int packed_grad_is_zero, float* err_square_sum,
-                      float* d_pos, float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa, void* stream);
+                      float* d_pos, float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa,
+                      const int* order /*nullable [T]: tile schedule of the blend backward*/, void* stream);
 int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                            const int64_t* vis_ids, const int* vis_num, const float* packed_grad, const float* grad_inv_scaler,
                            float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,

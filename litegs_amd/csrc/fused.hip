@@ -118,12 +118,6 @@ __device__ __forceinline__ void gaussian_backward(const Camera& cam, const float
                                                   float px, float py, float pz, float sr0, float sr1, float sr2,
                                                   float rw, float rx, float ry, float rz, float opa_raw, GaussGrads& G)
 {
-    const float4 g0 = rec[0], g1 = rec[1];
-    const float g8 = rec[2].x;
-    float gn[4] = { g0.x * 0.5f * cam.W * sc, g0.y * 0.5f * cam.H * sc, 0.0f, 0.0f };
-    float ginv[4] = { g0.z * sc, g0.w * sc, g0.w * sc, g1.x * sc };
-    G.gc[0] = g1.y * sc; G.gc[1] = g1.z * sc; G.gc[2] = g1.w * sc;
-    const float gop = g8 * sc;
     // ---- recompute the forward chain from the raw parameters
     float s3[3] = { lg_act_scale(sr0), lg_act_scale(sr1), lg_act_scale(sr2) }, q[4];
     const float rn = lg_act_quat(rw, rx, ry, rz, q);
@@ -134,6 +128,14 @@ __device__ __forceinline__ void gaussian_backward(const Camera& cam, const float
     J6[0] = j4[0]; J6[1] = 0.0f; J6[2] = 0.0f; J6[3] = j4[1]; J6[4] = j4[2]; J6[5] = j4[3];
     lg_cov2d(T9, cam.V, J6, c4);
     lg_inv2x2(c4[0], c4[1], c4[2], c4[3], i4);
+    // ---- unpack: blend-backward moments -> d_pixel, d_conic, d_opacity (raster.hip), then GR/raster.cu:866-884
+    const float4 m0 = rec[0], m1 = rec[1];
+    float gm[9];
+    lg_moments_to_grads(m0.x, m0.y, m0.z, m0.w, m1.x, rec[2].x, i4[0], i4[1], i4[3], lg_act_opacity(opa_raw), gm);
+    float gn[4] = { gm[0] * 0.5f * cam.W * sc, gm[1] * 0.5f * cam.H * sc, 0.0f, 0.0f };
+    float ginv[4] = { gm[2] * sc, gm[3] * sc, gm[3] * sc, gm[4] * sc };
+    G.gc[0] = m1.y * sc; G.gc[1] = m1.z * sc; G.gc[2] = m1.w * sc;
+    const float gop = gm[8] * sc;
     // ---- chain backward
     float gcov[4], gT[9], gq[4], gs[3];
     lg_inv2x2_bwd(i4, ginv, true, gcov);
@@ -293,7 +295,7 @@ struct Layout1 {      // sized by N = A*S (per-Gaussian buffers)
     size_t zeroed, zero_bytes, dsort_hdr, tsort_hdr, dsort_table, scan_status, dup_queue;
 };
 struct Layout2 {      // sized by the tile-instance table length L
-    size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, dup_entries, total;
+    size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, tile_work, dup_entries, total;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -328,6 +330,7 @@ static Layout2 layout2(long long L, int ntiles, long long N)
     f.tsort_table_words = (size_t)lg_radix_table_words(L, 4);
     f.tsort_table = take(4 * f.tsort_table_words);
     f.tile_start = take(sizeof(int) * ((size_t)ntiles + 2));
+    f.tile_work = take(sizeof(int) * ((size_t)ntiles + 1));
     f.dup_entries = take(4 * (size_t)lg_dup_queue_entries(N, L));
     f.total = o;
     return f;
@@ -428,6 +431,8 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
                            void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
                            float* img, float* trans, short* last, int* frag_count, float* frag_weight,
                            float* packed_grad_clear /*nullable: [N,16] gradient accumulator of the coming backward, zeroed on the side*/,
+                           const int* order_in /*nullable [T]: tile schedule of the blend forward (this frame's previous visit)*/,
+                           int* order_out /*nullable [T]: receives the heaviest-first schedule of THIS visit (may alias order_in)*/,
                            void* stream)
 {
     if (A <= 0 || L <= 0) return (int)hipErrorInvalidValue;
@@ -463,8 +468,11 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
     const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
     rc = lg_tile_range_prefilled(sorted_keys, 1, L, total_dev, ntiles, (int32_t*)(w + f.tile_start), stream); if (rc) return rc;
-    return lg_raster_forward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
-                             enable_stat, img, trans, last, frag_count, frag_weight, stream);
+    rc = lg_raster_forward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
+                           enable_stat, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order_in,
+                           (order_out && !tiles) ? (int*)(w + f.tile_work) : nullptr, stream);
+    if (rc || order_out == nullptr || tiles != nullptr) return rc;
+    return lg_tile_order((const int*)(w + f.tile_work), 1, ntiles, order_out, stream);
 }
 
 // Backward: blend backward (atomics into packed_grad) -> fused per-Gaussian backward -> six compact gradients.
@@ -476,7 +484,8 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
                              const float* grad_inv_scaler, int enable_stat,
                              float* packed_grad /*[N,16] scratch*/, int packed_grad_is_zero /*cleared by lg_fused_stage2*/, float* err_square_sum,
                              float* d_pos /*NULL: blend backward only (gradients consumed later by lg_fused_backward_adam)*/,
-                             float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa, void* stream)
+                             float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa,
+                             const int* order /*nullable [T]: tile schedule (lg_fused_stage2's order_out)*/, void* stream)
 {
     if (A <= 0 || L <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
@@ -495,7 +504,7 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
     int rc = 0;
     if (!packed_grad_is_zero) { rc = lg_memset_async(packed_grad, 0, (long long)sizeof(float) * GREC * N, stream); if (rc) return rc; }
     rc = lg_raster_backward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, final_T, last, d_img, d_trans,
-                            1, L, (int)N, H, W, TH, TW, enable_stat, packed_grad, err_square_sum, stream);
+                            1, L, (int)N, H, W, TH, TW, enable_stat, packed_grad, err_square_sum, nullptr, tiles ? nullptr : order, stream);
     if (rc) return rc;
     if (d_pos == nullptr) return 0;
     Camera cam = make_camera(view_host, proj_host, H, W);

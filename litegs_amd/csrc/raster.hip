@@ -20,6 +20,7 @@
 // This gives each lane exactly the pixel set of one reference (thread, half2-lane) pair, which is what
 // the statistic-mode err_square running sum (GR/raster.cu:781-783) is defined over.
 #include "lg_common.h"
+#include "lg_chain.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #define REC 16                 // floats per packed splat record (64 B, one cache line)
@@ -99,6 +100,18 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
     const int k = b & 7, j = b >> 3;
     return k * cpx + (k < rem ? k : rem) + j;
 }
+// mode 0: one contiguous band of tiles per XCD (xcd_remap); mode 1: identity; mode C >= 2: XCD k takes runs of C consecutive blocks,
+// the eight XCDs interleaved (L2 locality inside a run, the image's work spread over all XCDs); the tail that does not fill a
+// group of 8*C blocks keeps the identity map.  All modes are bijections of [0, nb).
+__device__ __forceinline__ int block_remap(int b, int nb, int mode)
+{
+    if (mode == 0) return xcd_remap(b, nb);
+    if (mode == 1) return b;
+    const int C = mode, k = b & 7, j = b >> 3;
+    const int groups = nb / (8 * C);
+    if (j >= groups * C) return b;
+    return (j / C) * (8 * C) + k * C + (j % C);
+}
 
 template <int TH, int TW>
 struct TileMap {
@@ -106,6 +119,19 @@ struct TileMap {
     static_assert(TH * TW % 64 == 0 && 64 % TW == 0 && (64 / TW) % 2 == 0, "unsupported tile");
     static_assert(TH % (2 * PPL) == 0, "unsupported tile");
 };
+
+// dwords 0-7 and 8 of the 64-byte splat record, fetched through the scalar path (the address is wave-uniform)
+struct FwdRec { f32x8 lo; float cb; };
+__device__ __forceinline__ FwdRec load_fwd(const float* __restrict__ pk, int pid)
+{
+    const float* __restrict__ r = pk + (size_t)pid * REC;
+    FwdRec s;
+    s.lo = *reinterpret_cast<const f32x8*>(r);
+    s.cb = r[8];
+    return s;
+}
+
+static int g_bwd_wpb = 4, g_bwd_map = 0, g_fwd_map = 0, g_bwd_dbg = 0, g_use_order = 1;       // launch variants (lg_set_tuning)
 
 // ---------------------------------------------------------------------------------------------
 // a13 rasterize_forward (reference: GR/raster.cu:162-332)
@@ -115,16 +141,17 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
                                                              const float* __restrict__ packed, const int* __restrict__ tiles, int K,
                                                              float* __restrict__ img, float* __restrict__ trans, short* __restrict__ last,
                                                              int* __restrict__ frag_count, float* __restrict__ frag_weight,
-                                                             int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots)
+                                                             const int* __restrict__ order, int* __restrict__ tile_work,
+                                                             int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode)
 {
     constexpr int PPL = TileMap<TH, TW>::PPL;
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
     const int nb = gridDim.x;
-    int blk = (tiles == nullptr) ? xcd_remap(blockIdx.x, nb) : (int)blockIdx.x;
+    int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
     const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
     if (slot >= nslots) return;
-    int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : slot + 1;
+    int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
     tile = rfl(tile);
     if (tile <= 0 || tile > ntiles) return;
     const int* __restrict__ si = start_index + (size_t)view * (ntiles + 2);
@@ -143,15 +170,24 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
 #pragma unroll
     for (int k = 0; k < PPL; k++) { Y[k] = (float)(y0 + 2 * k); T[k] = 1.0f; Cr[k] = Cg[k] = Cb[k] = 0.0f; lc[k] = 0; }
 
-    if (start >= 0) {
-        for (int i = start; i < end; i++) {
+    int visited = 0;
+    if (start >= 0 && end > start) {
+        // scalar-path software pipeline: splat id two iterations ahead, record one iteration ahead (see the backward kernel)
+        const int n = end - start;
+        const int* __restrict__ spt = sp + start;
+        int pid = rfl(spt[0]);
+        int pid_next = rfl(spt[min(1, n - 1)]);
+        FwdRec rec = load_fwd(pk, pid);
+        for (int i = 0; i < n; i++) {
             bool any_act = false;
 #pragma unroll
             for (int k = 0; k < PPL; k++) any_act |= (T[k] > 1.0f / 8192);
             if (!__any(any_act)) break;
-            const int pid = rfl(sp[i]);
-            const float* __restrict__ r = pk + (size_t)pid * REC;
-            const float spx = r[0], spy = r[1], A2 = r[2], B2 = r[3], C2 = r[4], o = r[5], cr = r[6], cg = r[7], cb = r[8];
+            visited = i + 1;
+            const FwdRec rec_next = load_fwd(pk, pid_next);
+            const int pid_next2 = rfl(spt[min(i + 2, n - 1)]);
+            const float spx = rec.lo[0], spy = rec.lo[1], A2 = rec.lo[2], B2 = rec.lo[3], C2 = rec.lo[4], o = rec.lo[5];
+            const float cr = rec.lo[6], cg = rec.lo[7], cb = rec.cb;
             const float dx = spx - X;
             const float t0 = A2 * dx * dx, t1 = B2 * dx;
             int fc = 0;
@@ -164,7 +200,7 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
                 float alpha = o * __builtin_amdgcn_exp2f(p2);
                 const bool valid = active && (alpha >= 1.0f / 256);
                 alpha = fminf(255.0f / 256, alpha);
-                lc[k] = active ? (i - start + 1) : lc[k];       // == number of splats visited while active (activity is monotone)
+                lc[k] = active ? (i + 1) : lc[k];               // == number of splats visited while active (activity is monotone)
                 alpha = valid ? alpha : 0.0f;
                 const float w = T[k] * alpha;
                 if (STAT) { fc += valid ? 1 : 0; ws += w; }
@@ -184,8 +220,11 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
                     }
                 }
             }
+            rec = rec_next; pid = pid_next; pid_next = pid_next2;
         }
     }
+    // work done for this tile (splats walked before every pixel saturated): the schedule key of the backward and of the next visit
+    if (tile_work != nullptr && lane == 0) tile_work[(size_t)view * (ntiles + 1) + tile] = visited;
     const size_t plane = (size_t)Hp * Wp;
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
@@ -200,16 +239,18 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
 
 LG_API int lg_raster_forward(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
                              int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
-                             float* img, float* trans, short* last, int* frag_count, float* frag_weight, void* stream)
+                             float* img, float* trans, short* last, int* frag_count, float* frag_weight,
+                             const int* order /*nullable [V,T]: tile schedule (a permutation of 1..T)*/, int* tile_work /*nullable [V,T+1]*/, void* stream)
 {
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
     const int nslots = tiles ? K : ntiles;
     if (nslots <= 0) return 0;
+    if (!g_use_order) order = nullptr;
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_RF(A_, B_, S_) hipLaunchKernelGGL((raster_forward_kernel<A_, B_, S_>), grid, block, 0, s, sorted_points, start_index, packed, \
-                                                 tiles, K, img, trans, last, frag_count, frag_weight, gx, ntiles, L, N, Hp, Wp, nslots)
+                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map)
 #define DISPATCH_RF(A_, B_) do { if (enable_stat) LAUNCH_RF(A_, B_, true); else LAUNCH_RF(A_, B_, false); } while (0)
     if (TH == 8 && TW == 16) DISPATCH_RF(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RF(16, 16);
@@ -221,34 +262,166 @@ LG_API int lg_raster_forward(const int* sorted_points, const int* start_index, c
     LG_RETURN_LAST();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Tile schedule: heaviest tiles first.  A frame has only ~2 tiles per resident wave slot (16 200 tiles, 8 192 slots), so the
+// blend kernels' duration is set by which tiles happen to be started last; started in descending order of work the tail is made
+// of the lightest tiles (longest-processing-time-first list scheduling).  Work = splats walked before the tile saturated, written
+// by the forward (or derived from last_contributor); the order is a counting sort on min(work, 1023).  The schedule only
+// permutes independent tiles: results do not depend on it.  (The reference has the same idea for its statistic epochs:
+// litegs/utils/statistic_helper.py:77 sorts tiles by blend count and passes them as specific_tiles.)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) tile_order_kernel(const int* __restrict__ tile_work, int ntiles, int* __restrict__ order)
+{
+    __shared__ int hist[1024];
+    __shared__ int wsum[16];
+    const int view = blockIdx.x, t = threadIdx.x;
+    const int* __restrict__ w = tile_work + (size_t)view * (ntiles + 1) + 1;
+    int* __restrict__ o = order + (size_t)view * ntiles;
+    hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < ntiles; i += 1024) atomicAdd(&hist[1023 - min(max(w[i], 0), 1023)], 1);
+    __syncthreads();
+    // exclusive scan of the 1024 bins
+    const int mine = hist[t];
+    int v = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int u = __shfl_up(v, d); if ((t & 63) >= d) v += u; }
+    if ((t & 63) == 63) wsum[t >> 6] = v;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < (t >> 6); k++) base += wsum[k];
+    __syncthreads();
+    hist[t] = base + v - mine;
+    __syncthreads();
+    for (int i = t; i < ntiles; i += 1024) o[atomicAdd(&hist[1023 - min(max(w[i], 0), 1023)], 1)] = i + 1;
+}
+
+LG_API int lg_tile_order(const int* tile_work /*[V,T+1]*/, int V, int ntiles, int* order /*[V,T]*/, void* stream)
+{
+    if (V <= 0 || ntiles <= 0) return 0;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(V), dim3(1024), 0, (hipStream_t)stream, tile_work, ntiles, order);
+    LG_RETURN_LAST();
+}
+
+// work per tile from last_contributor (operator path: the forward and the backward are separate calls): one wave per tile
+template <int TH, int TW>
+__global__ void __launch_bounds__(256) tile_work_kernel(const short* __restrict__ last, int gx, int ntiles, int Hp, int Wp, int* __restrict__ tile_work)
+{
+    constexpr int PPL = TileMap<TH, TW>::PPL;
+    const int lane = threadIdx.x & 63, view = blockIdx.y;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
+    if (tile > ntiles) return;
+    const int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
+    const int x = tx * TW + lane % TW, q = lane / TW;
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < PPL; k++) m = max(m, (int)last[(size_t)view * Hp * Wp + (size_t)(ty * TH + q * PPL + k) * Wp + x]);
+    m = wave_max_i(m);
+    if (lane == 0) tile_work[(size_t)view * (ntiles + 1) + tile] = m;
+}
+
+LG_API int lg_tile_work_from_last(const short* last, int V, int H, int W, int TH, int TW, int* tile_work /*[V,T+1]*/, void* stream)
+{
+    const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
+    const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
+    dim3 grid(lg_cdiv(ntiles, 4), V), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (TH == 8 && TW == 16) hipLaunchKernelGGL((tile_work_kernel<8, 16>), grid, block, 0, s, last, gx, ntiles, Hp, Wp, tile_work);
+    else if (TH == 16 && TW == 16) hipLaunchKernelGGL((tile_work_kernel<16, 16>), grid, block, 0, s, last, gx, ntiles, Hp, Wp, tile_work);
+    else if (TH == 12 && TW == 16) hipLaunchKernelGGL((tile_work_kernel<12, 16>), grid, block, 0, s, last, gx, ntiles, Hp, Wp, tile_work);
+    else if (TH == 8 && TW == 8) hipLaunchKernelGGL((tile_work_kernel<8, 8>), grid, block, 0, s, last, gx, ntiles, Hp, Wp, tile_work);
+    else return (int)hipErrorInvalidValue;
+    LG_RETURN_LAST();
+}
+
 // ---------------------------------------------------------------------------------------------
 // a14 rasterize_backward (reference: GR/raster.cu:600-853)
-// packed_grad record (GREC floats): 0 dpx, 1 dpy, 2 da, 3 db(01), 4 dc, 5 dr, 6 dg, 7 db, 8 dopacity
+//
+// packed_grad record (GREC floats), MOMENT form.  With m = dL/dalpha * G per (pixel, splat) (G = exp(power), alpha = opacity * G),
+// dx = px - X, dy = py - Y, and w = alpha * T the blend weight:
+//   0 Mx = sum m dx     1 My = sum m dy     2 Mxx = sum m dx^2     3 Mxy = sum m dx dy     4 Myy = sum m dy^2
+//   5 dr = sum w dL/dR  6 dg                7 db                   8 M0 = sum m  (== d_opacity of the ACTIVATED opacity)
+// The reference kernel (raster.cu:826-841) multiplies the conic coefficients into these sums per (tile, splat); they are linear in
+// the moments with per-splat constants, so the consumer does it once per splat instead (lg_moments_to_grads in lg_chain.h):
+//   d_px = -o (a Mx + b My)   d_py = -o (c My + b Mx)   d_a = -o/2 Mxx   d_b01 = d_b10 = -o/2 Mxy   d_c = -o/2 Myy   d_opacity = M0
 // ---------------------------------------------------------------------------------------------
-// One butterfly level: lanes with `bit` clear keep u (own + partner's), lanes with it set keep w.
-#define BFLY(u, w, bit, XOR)                      \
-    {                                             \
-        const float send_ = (bit) ? (u) : (w);    \
-        const float keep_ = (bit) ? (w) : (u);    \
-        (u) = keep_ + XOR(send_);                 \
-    }
+__device__ __forceinline__ void swap32(float& u, float& w)       // lanes 32-63 of u <-> lanes 0-31 of w (v_permlane32_swap)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(w), false, false);
+    u = __uint_as_float(r[0]); w = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float& u, float& w)       // odd 16-lane rows of u <-> even rows of w (v_permlane16_swap)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(w), false, false);
+    u = __uint_as_float(r[0]); w = __uint_as_float(r[1]);
+}
+// Transposing reduction steps.  After BF32(u, w): lanes 0-31 hold u[l] + u[l+32], lanes 32-63 hold w[l-32] + w[l] -- two values
+// reduced by one level in swap + add, no select.  BF16: even rows hold the u sums, odd rows the w sums.
+#define BF32(u, w) { swap32(u, w); (u) += (w); }
+#define BF16(u, w) { swap16(u, w); (u) += (w); }
+__device__ __forceinline__ float sum32(float v) { float t = v; swap32(t, v); return t + v; }
+__device__ __forceinline__ float sum16(float v) { float t = v; swap16(t, v); return t + v; }
+__device__ __forceinline__ float mirror16(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true)); }
+// Within a row of 16: lanes 0-7 get u[l] + u[15-l], lanes 8-15 get w[l] + w[15-l]  (two bank-masked DPP adds, no select)
+__device__ __forceinline__ float bfly_mirror8(float u, float w)
+{
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(u) : "v"(w));
+    return u;
+}
+// Within a half row of 8: lanes with bit 2 clear get u[l] + u[l^7], lanes with bit 2 set get w[l] + w[l^7]
+__device__ __forceinline__ float bfly_hmirror4(float u, float w)
+{
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(u) : "v"(w));
+    return u;
+}
 
-template <int TH, int TW, bool STAT, bool TRANS>
-__global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
-                                                              const float* __restrict__ packed, const int* __restrict__ tiles, int K,
-                                                              const float* __restrict__ final_T, const short* __restrict__ last,
-                                                              const float* __restrict__ d_img, const float* __restrict__ d_trans,
-                                                              float* __restrict__ packed_grad, float* __restrict__ err_square_sum,
-                                                              int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots)
+// Sum nine per-lane values over the wave; the nine totals end up in nine different lanes (wave_slot() tells which).
+// 8 swaps + 17 adds/moves, all VALU (no LDS-pipe swizzles: a dependent ds_swizzle costs ~58 cycles, a dependent DPP add ~18).
+__device__ __forceinline__ float reduce9(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8)
+{
+    BF32(v0, v1) BF32(v2, v3) BF32(v4, v5) BF32(v6, v7)
+    v8 = sum32(v8);
+    BF16(v0, v2) BF16(v4, v6)
+    v8 = sum16(v8);
+    v0 = bfly_mirror8(v0, v4);
+    v8 += mirror16(v8);
+    v0 = bfly_hmirror4(v0, v8);
+    v0 += xor_dpp2(v0);
+    v0 += xor_dpp1(v0);
+    return v0;
+}
+// record slot whose total lane `lane` holds after reduce9 (-1: none).  Values v0..v7 -> lanes with (lane & 7) == 0:
+// bit 3 picks v4.. over v0.., row parity picks the BF16 partner, the upper half picks the BF32 partner; v8 -> lane 4.
+__device__ __forceinline__ int wave_slot(int lane)
+{
+    if (lane == 4) return 8;
+    if (lane & 7) return -1;
+    const int row = lane >> 4;
+    return ((lane >> 3) & 1) * 4 + (row & 1) * 2 + (row >> 1);
+}
+
+template <int TH, int TW, bool STAT, bool TRANS, int WPB>
+__global__ void __launch_bounds__(64 * WPB) raster_backward_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
+                                                                   const float* __restrict__ packed, const int* __restrict__ tiles, int K,
+                                                                   const float* __restrict__ final_T, const short* __restrict__ last,
+                                                                   const float* __restrict__ d_img, const float* __restrict__ d_trans,
+                                                                   float* __restrict__ packed_grad, float* __restrict__ err_square_sum,
+                                                                   int* __restrict__ tile_counters, const int* __restrict__ order,
+                                                                   int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int dbg)
 {
     constexpr int PPL = TileMap<TH, TW>::PPL;
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
     const int nb = gridDim.x;
-    int blk = (tiles == nullptr) ? xcd_remap(blockIdx.x, nb) : (int)blockIdx.x;
-    const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
+    int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
+    const int slot = rfl(blk * WPB + (int)(threadIdx.x >> 6));
     if (slot >= nslots) return;
-    int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : slot + 1;
+    int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
     tile = rfl(tile);
     if (tile <= 0 || tile > ntiles) return;
     const int* __restrict__ si = start_index + (size_t)view * (ntiles + 2);
@@ -283,13 +456,19 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
     }
     maxlast = rfl(wave_max_i(maxlast));
     maxlast = min(maxlast, end - start);
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    const int myslot = wave_slot(lane);
+    int contributing = 0;
 
+    // Software pipeline over the wave-uniform (scalar-path) loads: the splat id is fetched two iterations ahead and the record one
+    // iteration ahead, so neither dependent s_load (~150 cycles each) sits on the iteration's critical path.
+    int pid = maxlast > 0 ? rfl(sp[maxlast - 1]) : 0;
+    int pid_next = rfl(sp[max(maxlast - 2, 0)]);
+    FwdRec rec = load_fwd(pk, pid);
     for (int idx = maxlast - 1; idx >= 0; idx--) {
-        const int pid = rfl(sp[idx]);
-        const float* __restrict__ r = pk + (size_t)pid * REC;
-        const float spx = r[0], spy = r[1], A2 = r[2], B2 = r[3], C2 = r[4], o = r[5], cr = r[6], cg = r[7], cb = r[8];
-        const float a = r[9], b = r[10], c = r[11];
+        const FwdRec rec_next = load_fwd(pk, pid_next);
+        const int pid_next2 = (dbg & 8) ? 0 : rfl(sp[max(idx - 2, 0)]);
+        const float spx = rec.lo[0], spy = rec.lo[1], A2 = rec.lo[2], B2 = rec.lo[3], C2 = rec.lo[4], o = rec.lo[5];
+        const float cr = rec.lo[6], cg = rec.lo[7], cb = rec.cb;
         const float dx = spx - X;
         const float t0 = A2 * dx * dx, t1 = B2 * dx;
         float G[PPL], alpha[PPL], dy[PPL];
@@ -303,110 +482,113 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
             valid[k] = (alpha[k] >= 1.0f / 256) && (idx < lc[k]);
             anyv |= valid[k];
         }
-        if (!__any(anyv)) continue;
-
-        float v_r = 0.f, v_g = 0.f, v_b = 0.f, v_o = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, esq = 0.f;
-        if constexpr (PPL == 2 && !STAT) {
-            // the lane's two pixels as one 2-vector: packed fp32 (v_pk_fma/mul/add_f32) halves the VALU issue of this block,
-            // which is what bounds the kernel (measured: ~150 VALU per (tile, splat), 8 waves/SIMD all issue-limited)
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            const v2f am = { valid[0] ? alpha[0] : 0.0f, valid[1] ? alpha[1] : 0.0f };
-            const v2f Gm = { valid[0] ? G[0] : 0.0f, valid[1] ? G[1] : 0.0f };
-            const v2f om = 1.0f - am;
-            const v2f rc = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
-            v2f Tv = { T[0], T[1] };
-            Tv = Tv * rc;
-            Tv.x = fminf(1.0f, Tv.x); Tv.y = fminf(1.0f, Tv.y);
-            T[0] = Tv.x; T[1] = Tv.y;
-            const v2f gRv = { gR[0], gR[1] }, gGv = { gG[0], gG[1] }, gBv = { gB[0], gB[1] }, dyv = { dy[0], dy[1] };
-            const v2f w = am * Tv;
-            const v2f ar = w * gRv, ag = w * gGv, ab = w * gBv;
-            const v2f cdot = cr * gRv + cg * gGv + cb * gBv;
-            v2f Bdv = { Bd[0], Bd[1] };
-            const v2f diff = cdot - Bdv;
-            v2f d_alpha = diff * Tv;
-            Bdv = Bdv + am * diff;
-            Bd[0] = Bdv.x; Bd[1] = Bdv.y;
-            if (TRANS) { const v2f gTv = { gT[0], gT[1] }; d_alpha = d_alpha - gTv * rc; }
-            const v2f vo = d_alpha * Gm;
-            const v2f dP = (Gm * o) * d_alpha;
-            const v2f dPy = dP * dyv;
-            const v2f dPyy = dPy * dyv;
-            v_r = ar.x + ar.y; v_g = ag.x + ag.y; v_b = ab.x + ab.y; v_o = vo.x + vo.y;
-            s0 = dP.x + dP.y; s1 = dPy.x + dPy.y; s2 = dPyy.x + dPyy.y;
-        } else {
+        if (__any(anyv) && !(dbg & 4)) {
+            contributing++;
+            float v_r = 0.f, v_g = 0.f, v_b = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, esq = 0.f;
+            if constexpr (PPL == 2 && !STAT) {
+                // the lane's two pixels as one 2-vector: packed fp32 ops do two pixels per issue slot
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f am = { valid[0] ? alpha[0] : 0.0f, valid[1] ? alpha[1] : 0.0f };
+                const v2f Gm = { valid[0] ? G[0] : 0.0f, valid[1] ? G[1] : 0.0f };
+                const v2f om = 1.0f - am;
+                const v2f rc = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
+                v2f Tv = { T[0], T[1] };
+                Tv = Tv * rc;
+                Tv.x = fminf(1.0f, Tv.x); Tv.y = fminf(1.0f, Tv.y);
+                T[0] = Tv.x; T[1] = Tv.y;
+                const v2f gRv = { gR[0], gR[1] }, gGv = { gG[0], gG[1] }, gBv = { gB[0], gB[1] }, dyv = { dy[0], dy[1] };
+                const v2f w = am * Tv;
+                const v2f ar = w * gRv, ag = w * gGv, ab = w * gBv;
+                const v2f cdot = cr * gRv + cg * gGv + cb * gBv;
+                v2f Bdv = { Bd[0], Bd[1] };
+                const v2f diff = cdot - Bdv;
+                v2f d_alpha = diff * Tv;
+                Bdv = Bdv + am * diff;
+                Bd[0] = Bdv.x; Bd[1] = Bdv.y;
+                if (TRANS) { const v2f gTv = { gT[0], gT[1] }; d_alpha = d_alpha - gTv * rc; }
+                const v2f m = d_alpha * Gm;
+                const v2f my = m * dyv;
+                const v2f myy = my * dyv;
+                v_r = ar.x + ar.y; v_g = ag.x + ag.y; v_b = ab.x + ab.y;
+                s0 = m.x + m.y; s1 = my.x + my.y; s2 = myy.x + myy.y;
+            } else {
 #pragma unroll
-        for (int k = 0; k < PPL; k++) {
-            if (STAT && !__any(valid[k])) continue;         // reference's per-row-group gate (raster.cu:753)
-            const float am = valid[k] ? alpha[k] : 0.0f;
-            const float Gm = valid[k] ? G[k] : 0.0f;
-            T[k] = fminf(1.0f, T[k] * __builtin_amdgcn_rcpf(1.0f - am));
-            const float w = am * T[k];
-            v_r += w * gR[k]; v_g += w * gG[k]; v_b += w * gB[k];
-            // reference (raster.cu:757-776) keeps the three blended-behind colours; only their dot product with the pixel's colour
-            // gradient is ever used, and it obeys the same recurrence: B.g <- B.g + alpha * (c.g - B.g)
-            const float cdot = cr * gR[k] + cg * gG[k] + cb * gB[k];
-            const float diff = cdot - Bd[k];
-            float d_alpha = diff * T[k];
-            Bd[k] += am * diff;
-            if (TRANS) d_alpha -= gT[k] * __builtin_amdgcn_rcpf(1.0f - am);
-            v_o += d_alpha * Gm;
-            if (STAT) esq += v_o * v_o;                      // running-sum quirk, raster.cu:781-783
-            const float dP = Gm * o * d_alpha;
-            s0 += dP; s1 += dP * dy[k]; s2 += dP * dy[k] * dy[k];
+                for (int k = 0; k < PPL; k++) {
+                    if (STAT && !__any(valid[k])) continue;         // reference's per-row-group gate (raster.cu:753)
+                    const float am = valid[k] ? alpha[k] : 0.0f;
+                    const float Gm = valid[k] ? G[k] : 0.0f;
+                    const float rc = __builtin_amdgcn_rcpf(1.0f - am);
+                    T[k] = fminf(1.0f, T[k] * rc);
+                    const float w = am * T[k];
+                    v_r += w * gR[k]; v_g += w * gG[k]; v_b += w * gB[k];
+                    // reference (raster.cu:757-776) keeps the three blended-behind colours; only their dot product with the pixel's
+                    // colour gradient is ever used, and it obeys the same recurrence: B.g <- B.g + alpha * (c.g - B.g)
+                    const float cdot = cr * gR[k] + cg * gG[k] + cb * gB[k];
+                    const float diff = cdot - Bd[k];
+                    float d_alpha = diff * T[k];
+                    Bd[k] += am * diff;
+                    if (TRANS) d_alpha -= gT[k] * rc;
+                    const float m = d_alpha * Gm;
+                    s0 += m;
+                    if (STAT) esq += s0 * s0;                        // running-sum quirk of d_opacity, raster.cu:781-783
+                    s1 += m * dy[k]; s2 += m * dy[k] * dy[k];
+                }
+            }
+            const float mx = dx * s0;
+            float tot;
+            if (dbg & 2) tot = mx + s1 + dx * mx + dx * s1 + s2 + v_r + v_g + v_b + s0;
+            else tot = reduce9(mx, s1, dx * mx, dx * s1, s2, v_r, v_g, v_b, s0);
+            if (dbg & 16) { if (myslot >= 0) pg[(size_t)pid * GREC + myslot] = tot; }
+            else if (dbg & 32) { if (myslot >= 0) unsafeAtomicAdd(pg + ((size_t)tile * 64 + (idx & 63)) * GREC + myslot, tot); }
+            else if (!(dbg & 1)) { if (myslot >= 0) unsafeAtomicAdd(pg + (size_t)pid * GREC + myslot, tot); }
+            else if (tot == 1.2345f) pg[0] = tot;
+            if (STAT) {
+                esq = wave_sum(esq);
+                if (lane == 0) unsafeAtomicAdd(&err_square_sum[(size_t)view * N + pid], esq);
+            }
         }
-        }
-        // gradients of the quadratic form (GR/raster.cu:826-841 restated without forward differences)
-        float v_a = -0.5f * dx * dx * s0;
-        float v_bq = -0.5f * dx * s1;
-        float v_c = -0.5f * s2;
-        float v_px = -(a * dx * s0 + b * s1);
-        float v_py = -(c * s1 + b * dx * s0);
+        rec = rec_next; pid = pid_next; pid_next = pid_next2;
+    }
+    if (tile_counters != nullptr && lane == 0) {          // measurement hook (bench.py roofline): visited / contributing (tile, splat) iterations
+        tile_counters[((size_t)view * (ntiles + 1) + tile) * 2] = maxlast;
+        tile_counters[((size_t)view * (ntiles + 1) + tile) * 2 + 1] = contributing;
+    }
+}
 
-        // 8-value butterfly: after xor 1,2,4 lane (l&7) holds one value; xor 8,16,32 complete the sums.
-        BFLY(v_px, v_py, b0, xor_dpp1)
-        BFLY(v_a, v_bq, b0, xor_dpp1)
-        BFLY(v_c, v_r, b0, xor_dpp1)
-        BFLY(v_g, v_b, b0, xor_dpp1)
-        BFLY(v_px, v_a, b1, xor_dpp2)
-        BFLY(v_c, v_g, b1, xor_dpp2)
-        BFLY(v_px, v_c, b2, xor_swz4)
-        // ninth value (opacity): reduced over xor 1,2,4 on its own, then merged into the xor-8 level -- lanes with bit 3 set carry it
-        // through the last two levels, so lane 8 ends up with the opacity sum next to the eight others in lanes 0..7
-        v_o += xor_dpp1(v_o); v_o += xor_dpp2(v_o); v_o += xor_swz4(v_o);
-        BFLY(v_px, v_o, b3, xor_swz8)
-        v_px += xor_swz16(v_px); v_px += xor_32(v_px);
-        // lane (l&7) -> record slot: bit0 picks second of pair, bit1 second pair-of-pairs, bit2 second quad
-        // pairs: (px,py) (a,bq) (c,r) (g,b) -> slots (0,1) (2,3) (4,5) (6,7)
-        if (lane < 9) {
-            const int sl = (lane == 8) ? 8 : (((lane >> 2) & 1) * 4 + ((lane >> 1) & 1) * 2 + (lane & 1));
-            unsafeAtomicAdd(pg + (size_t)pid * GREC + sl, v_px);
-        }
-        if (STAT) {
-            esq = wave_sum(esq);
-            if (lane == 0) unsafeAtomicAdd(&err_square_sum[(size_t)view * N + pid], esq);
-        }
+LG_API int lg_set_tuning(int key, int value)
+{
+    switch (key) {
+    case 0: g_bwd_wpb = (value == 1 || value == 2) ? value : 4; return 0;     // waves (tiles) per workgroup of the blend backward
+    case 1: g_bwd_map = value; return 0;                                      // workgroup -> tile map of the blend backward (block_remap)
+    case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
+    case 3: g_bwd_dbg = value; return 0;                                      // ablation bits of the blend backward (WRONG results; timing experiments only)
+    case 2: g_fwd_map = value; return 0;                                      // ... of the blend forward
+    default: return (int)hipErrorInvalidValue;
     }
 }
 
 LG_API int lg_raster_backward(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
                               const float* final_T, const short* last, const float* d_img, const float* d_trans,
                               int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
-                              float* packed_grad /*[V,N,16] zeroed*/, float* err_square_sum /*[V,1,N] zeroed*/, void* stream)
+                              float* packed_grad /*[V,N,16] zeroed*/, float* err_square_sum /*[V,1,N] zeroed*/,
+                              int* tile_counters /*nullable [V,T+1,2]*/, const int* order /*nullable [V,T]*/, void* stream)
 {
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
     const int nslots = tiles ? K : ntiles;
     if (nslots <= 0) return 0;
-    dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_RB(A_, B_, S_, T_) hipLaunchKernelGGL((raster_backward_kernel<A_, B_, S_, T_>), grid, block, 0, s, sorted_points, start_index, \
-                                                     packed, tiles, K, final_T, last, d_img, d_trans, packed_grad, err_square_sum,              \
-                                                     gx, ntiles, L, N, Hp, Wp, nslots)
+    if (!g_use_order) order = nullptr;
+    const int wpb = g_bwd_wpb;
+    dim3 grid(lg_cdiv(nslots, wpb), V), block(64 * wpb);
+#define LAUNCH_RB(A_, B_, S_, T_, W_) hipLaunchKernelGGL((raster_backward_kernel<A_, B_, S_, T_, W_>), grid, block, 0, s, sorted_points, start_index, \
+                                                         packed, tiles, K, final_T, last, d_img, d_trans, packed_grad, err_square_sum, tile_counters, order, \
+                                                         gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_dbg)
+#define LAUNCH_RBW(A_, B_, S_, T_) do { if (wpb == 1) LAUNCH_RB(A_, B_, S_, T_, 1); else if (wpb == 2) LAUNCH_RB(A_, B_, S_, T_, 2); else LAUNCH_RB(A_, B_, S_, T_, 4); } while (0)
 #define DISPATCH_RB(A_, B_)                                                   \
     do {                                                                      \
-        if (enable_stat) { if (d_trans) LAUNCH_RB(A_, B_, true, true); else LAUNCH_RB(A_, B_, true, false); } \
-        else { if (d_trans) LAUNCH_RB(A_, B_, false, true); else LAUNCH_RB(A_, B_, false, false); }           \
+        if (enable_stat) { if (d_trans) LAUNCH_RBW(A_, B_, true, true); else LAUNCH_RBW(A_, B_, true, false); } \
+        else { if (d_trans) LAUNCH_RBW(A_, B_, false, true); else LAUNCH_RBW(A_, B_, false, false); }           \
     } while (0)
     if (TH == 8 && TW == 16) DISPATCH_RB(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RB(16, 16);
@@ -414,15 +596,18 @@ LG_API int lg_raster_backward(const int* sorted_points, const int* start_index, 
     else if (TH == 8 && TW == 8) DISPATCH_RB(8, 8);
     else return (int)hipErrorInvalidValue;
 #undef DISPATCH_RB
+#undef LAUNCH_RBW
 #undef LAUNCH_RB
     LG_RETURN_LAST();
 }
 
 // ---------------------------------------------------------------------------------------------
-// unpack_gradient (reference: GR/raster.cu:855-886).  inv_scaler = *grad_inv_scaler (the reference's extra
-// 1/128 undoes its fp16 transmittance scale, which does not exist here).  d_opacity is summed over views.
+// unpack_gradient (reference: GR/raster.cu:855-886): moments -> d_ndc / d_cov2d_inv / d_color / d_opacity.  inv_scaler =
+// *grad_inv_scaler (the reference's extra 1/128 undoes its fp16 transmittance scale, which does not exist here).
+// d_opacity is summed over views.  `packed` supplies the per-splat constants (conic a, b, c and opacity) of the moment combination.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) unpack_gradient_kernel(const float4* __restrict__ packed_grad, const float* __restrict__ grad_inv_scaler,
+__global__ void __launch_bounds__(256) unpack_gradient_kernel(const float4* __restrict__ packed_grad, const float4* __restrict__ packed,
+                                                              const float* __restrict__ grad_inv_scaler,
                                                               const int* __restrict__ valid_length, int V, int N, int H, int W,
                                                               float* __restrict__ d_ndc, float* __restrict__ d_inv_cov,
                                                               float* __restrict__ d_color, float* __restrict__ d_opacity)
@@ -433,34 +618,38 @@ __global__ void __launch_bounds__(256) unpack_gradient_kernel(const float4* __re
     const float sc = grad_inv_scaler ? grad_inv_scaler[0] : 1.0f;
     float dop = 0.0f;
     for (int b = 0; b < V; b++) {
-        float4 g0 = make_float4(0, 0, 0, 0), g1 = g0;
-        float g8 = 0.0f;
+        float g[9] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
         if (live) {
             const float4* rec = packed_grad + ((size_t)b * N + i) * (GREC / 4);
-            g0 = rec[0]; g1 = rec[1]; g8 = rec[2].x;
+            const float4* pr = packed + ((size_t)b * N + i) * (REC / 4);
+            const float4 m0 = rec[0], m1 = rec[1];
+            const float M0 = rec[2].x;
+            const float4 p1 = pr[1], p2 = pr[2];
+            lg_moments_to_grads(m0.x, m0.y, m0.z, m0.w, m1.x, M0, p2.y, p2.z, p2.w, p1.y, g);
+            g[5] = m1.y; g[6] = m1.z; g[7] = m1.w;
         }
-        d_ndc[((size_t)b * 4) * N + i] = g0.x * 0.5f * W * sc;
-        d_ndc[((size_t)b * 4 + 1) * N + i] = g0.y * 0.5f * H * sc;
+        d_ndc[((size_t)b * 4) * N + i] = g[0] * 0.5f * W * sc;
+        d_ndc[((size_t)b * 4 + 1) * N + i] = g[1] * 0.5f * H * sc;
         d_ndc[((size_t)b * 4 + 2) * N + i] = 0.0f;
         d_ndc[((size_t)b * 4 + 3) * N + i] = 0.0f;
-        d_inv_cov[((size_t)b * 4) * N + i] = g0.z * sc;
-        d_inv_cov[((size_t)b * 4 + 1) * N + i] = g0.w * sc;
-        d_inv_cov[((size_t)b * 4 + 2) * N + i] = g0.w * sc;
-        d_inv_cov[((size_t)b * 4 + 3) * N + i] = g1.x * sc;
-        d_color[((size_t)b * 3) * N + i] = g1.y * sc;
-        d_color[((size_t)b * 3 + 1) * N + i] = g1.z * sc;
-        d_color[((size_t)b * 3 + 2) * N + i] = g1.w * sc;
-        dop += g8 * sc;
+        d_inv_cov[((size_t)b * 4) * N + i] = g[2] * sc;
+        d_inv_cov[((size_t)b * 4 + 1) * N + i] = g[3] * sc;
+        d_inv_cov[((size_t)b * 4 + 2) * N + i] = g[3] * sc;
+        d_inv_cov[((size_t)b * 4 + 3) * N + i] = g[4] * sc;
+        d_color[((size_t)b * 3) * N + i] = g[5] * sc;
+        d_color[((size_t)b * 3 + 1) * N + i] = g[6] * sc;
+        d_color[((size_t)b * 3 + 2) * N + i] = g[7] * sc;
+        dop += g[8] * sc;
     }
     d_opacity[i] = dop;
 }
 
-LG_API int lg_unpack_gradient(const float* packed_grad, const float* grad_inv_scaler, const int* valid_length, int V, int N, int H, int W,
+LG_API int lg_unpack_gradient(const float* packed_grad, const float* packed, const float* grad_inv_scaler, const int* valid_length, int V, int N, int H, int W,
                               float* d_ndc, float* d_inv_cov, float* d_color, float* d_opacity, void* stream)
 {
     if (N <= 0) return 0;
     hipLaunchKernelGGL(unpack_gradient_kernel, dim3(lg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)packed_grad, grad_inv_scaler, valid_length, V, N, H, W, d_ndc, d_inv_cov, d_color, d_opacity);
+                       (const float4*)packed_grad, (const float4*)packed, grad_inv_scaler, valid_length, V, N, H, W, d_ndc, d_inv_cov, d_color, d_opacity);
     LG_RETURN_LAST();
 }
 

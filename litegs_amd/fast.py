@@ -43,11 +43,18 @@ class FusedRenderer:
         self.Hp = (height + tile[0] - 1) // tile[0] * tile[0]
         self.Wp = (width + tile[1] - 1) // tile[1] * tile[1]
         self.last_sizes = (0, 0)
+        # per-frame tile schedule (heaviest tiles first), produced by every visit's forward and used by its backward and by the next
+        # visit's forward; a scheduling hint only -- results do not depend on it
+        self.ntiles = (self.Hp // tile[0]) * (self.Wp // tile[1])
+        self.tile_order = None
+        self.tile_order_valid = [False] * n_frames
+        self.n_frames = n_frames
         # fuse_optimizer: backward stops after the blend backward; FusedAdam.step() then runs the per-Gaussian backward fused
         # with the Adam update (csrc/fused.hip: project_backward_adam_kernel) -- parameter gradients never go to HBM.
         # Only valid when nothing needs the gradients between backward and the optimizer step (no DP exchange).
         self.fuse_optimizer = False
         self.pending = None
+        self.probe_events = None      # measurement hook (bench.py): a list that receives an event pair around every blend backward launch
         self._cull_scratch, self._cull_chunks, self._cull_epoch = None, -1, 0
 
     def cull_scratch(self, chunks: int, device):
@@ -127,10 +134,18 @@ class _RenderFn(torch.autograd.Function):
             img.zero_(); trans.fill_(1.0); last.zero_()
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
         pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
+        if R.tile_order is None:
+            R.tile_order = torch.empty((R.n_frames, R.ntiles), dtype=torch.int32, device=dev)
+        order_ptr = R.tile_order.data_ptr() + 4 * R.ntiles * k
+        use_order = tiles is None
         check(L.lg_fused_stage2(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes, tp, K,
                                 1 if stat else 0, img.data_ptr(), trans.data_ptr(), last.data_ptr(),
                                 fc.data_ptr() if stat else None, fw.data_ptr() if stat else None,
-                                pg.data_ptr() if pg is not None else None, s), "fused stage2")
+                                pg.data_ptr() if pg is not None else None,
+                                order_ptr if (use_order and R.tile_order_valid[k]) else None, order_ptr if use_order else None, s), "fused stage2")
+        if use_order:
+            R.tile_order_valid[k] = True
+        ctx.order_ptr = order_ptr if use_order else None
         ctx.pg = pg
         if stat:
             STATS.update_tile_schedule(last, R.TH, R.TW)
@@ -162,12 +177,19 @@ class _RenderFn(torch.autograd.Function):
         tiles = ctx.tiles
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
         if R.fuse_optimizer:
+            if R.probe_events is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
             check(L.lg_fused_backward(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes,
                                       frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
                                       xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
                                       trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
-                                      pg.data_ptr(), pg_zero, esq.data_ptr() if stat else None, None, None, None, None, None, None, _s()),
+                                      pg.data_ptr(), pg_zero, esq.data_ptr() if stat else None, None, None, None, None, None, None, ctx.order_ptr, _s()),
                   "fused blend backward")
+            if R.probe_events is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                R.probe_events.append((ev0, ev1))
             if stat:
                 fc, fw = ctx.stat_bufs
                 STATS.add_moments("fragment_weight", fw, fw * fw, fc)
@@ -185,7 +207,8 @@ class _RenderFn(torch.autograd.Function):
                                   xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
                                   trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
                                   pg.data_ptr(), pg_zero, esq.data_ptr() if stat else None,
-                                  d_pos.data_ptr(), d_scale.data_ptr(), d_rot.data_ptr(), d_sh0.data_ptr(), d_shr.data_ptr(), d_opa.data_ptr(), _s()),
+                                  d_pos.data_ptr(), d_scale.data_ptr(), d_rot.data_ptr(), d_sh0.data_ptr(), d_shr.data_ptr(), d_opa.data_ptr(),
+                                  ctx.order_ptr, _s()),
               "fused backward")
         if stat:
             fc, fw = ctx.stat_bufs

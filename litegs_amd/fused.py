@@ -424,7 +424,7 @@ def _raster_forward_impl(sorted_points, start_index, packed, specific_tiles, img
         # tiles not listed are not rendered; give them a defined value
         img.zero_(); trans.fill_(1.0); last.zero_()
     check(lib().lg_raster_forward(_p(sorted_points), _p(start_index), _p(packed), tp, K, V, Lh, N, int(img_h), int(img_w), int(tile_h), int(tile_w),
-                                  1 if enable_statistic else 0, _p(img), _p(trans), _p(last), _p(fc), _p(fw), _s()), "rasterize_forward")
+                                  1 if enable_statistic else 0, _p(img), _p(trans), _p(last), _p(fc), _p(fw), None, None, _s()), "rasterize_forward")
     return img, trans, depth, last, fc, fw
 
 
@@ -468,9 +468,17 @@ def rasterize_backward(sorted_points, start_index, packed_params, specific_tiles
         specific_tiles = _dev(specific_tiles, "specific_tiles")
         K, tp = specific_tiles.shape[1], specific_tiles.data_ptr()
     d_trans = _f32(d_trans_img_arg, "d_trans") if d_trans_img_arg is not None else None
+    order = None
+    if specific_tiles is None:
+        # heaviest tiles first (raster.hip: tile schedule): work per tile from last_contributor, then a counting sort
+        gx, gy, ntiles, Hp, Wp = _tiles_shape(int(img_h), int(img_w), int(tilesize_h), int(tilesize_w))
+        work = torch.empty((V, ntiles + 1), dtype=torch.int32, device=dev)
+        order = torch.empty((V, ntiles), dtype=torch.int32, device=dev)
+        check(L.lg_tile_work_from_last(_p(last), V, int(img_h), int(img_w), int(tilesize_h), int(tilesize_w), _p(work), _s()), "tile_work")
+        check(L.lg_tile_order(_p(work), V, ntiles, _p(order), _s()), "tile_order")
     check(L.lg_raster_backward(_p(sorted_points), _p(start_index), _p(packed), tp, K, _p(final_T), _p(last), _p(d_img), _p(d_trans),
                                V, Lh, N, int(img_h), int(img_w), int(tilesize_h), int(tilesize_w), 1 if enable_statistic else 0,
-                               _p(pg), _p(err_sq), _s()), "rasterize_backward")
+                               _p(pg), _p(err_sq), None, _p(order), _s()), "rasterize_backward")
     d_ndc = torch.empty((V, 4, N), dtype=torch.float32, device=dev)
     d_ic = torch.empty((V, 2, 2, N), dtype=torch.float32, device=dev)
     d_color = torch.empty((V, 3, N), dtype=torch.float32, device=dev)
@@ -478,7 +486,7 @@ def rasterize_backward(sorted_points, start_index, packed_params, specific_tiles
     sc = None
     if grad_inv_sacler_arg is not None:
         sc = _f32(grad_inv_sacler_arg.reshape(1), "grad_inv_scaler")
-    check(L.lg_unpack_gradient(_p(pg), _p(sc), None, V, N, int(img_h), int(img_w), _p(d_ndc), _p(d_ic), _p(d_color), _p(d_opa), _s()), "unpack_gradient")
+    check(L.lg_unpack_gradient(_p(pg), _p(packed), _p(sc), None, V, N, int(img_h), int(img_w), _p(d_ndc), _p(d_ic), _p(d_color), _p(d_opa), _s()), "unpack_gradient")
     return [d_ndc, d_ic, d_color, d_opa, err_sum, err_sq]
 
 

@@ -36,4 +36,4 @@ with torch.no_grad():
     np.savez_compressed(f"gpurun_out/tile_stats_{cfg}.npz", visited=per_tile.cpu().numpy().astype(np.int32), length=lens.cpu().numpy().astype(np.int32),
                         last=last.cpu().numpy().astype(np.int16))
     print("list-length-per-tile mean %.1f max %d" % (lens[lens >= 0].mean().item(), int(lens.max().item())), "sum visited", int(per_tile.sum().item()))
-print(bench.roofline_probe(tr, 0))
+print(bench.frame_units(tr, 0))
