@@ -206,6 +206,7 @@ long long lg_fused_workspace1_bytes(long long N);
 long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW);
 long long lg_fused_total_offset(long long N);
 long long lg_fused_alloc_offset(long long N);   /* int32[N] tile counts per compacted Gaussian (valid after stage 1) */
+long long lg_fused_packed_offset(long long N);  /* float[N,16] packed splat records (valid after stage 1) */
 int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
                     const float* view_host, const float* proj_host, int H, int W, int TH, int TW, int degree,
                     const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,

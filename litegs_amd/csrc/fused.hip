@@ -99,7 +99,7 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     rec[0] = make_float4(ppx, ppy, -0.5f * i4[0] * LOG2E, -i4[1] * LOG2E);       // layout: raster.hip
     rec[1] = make_float4(-0.5f * i4[3] * LOG2E, o, r0, r1);
     rec[2] = make_float4(r2, i4[0], i4[1], i4[3]);
-    rec[3] = make_float4(n[2], n[0], n[1], 0.0f);                               // 13,14: ndc for the tile walk (binning.hip load_splat)
+    rec[3] = make_float4(n[2], n[0], n[1], lg_log2_opacity(o));                 // 13,14: ndc for the tile walk (binning.hip load_splat); 15: blend exponent offset
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -348,6 +348,9 @@ LG_API long long lg_fused_cull_scratch_bytes(int chunks) { return lg_cull_scratc
 
 // byte offset in workspace 1 of the exact instance total (prefix[N-1]) -- for the blocking first-visit path
 LG_API long long lg_fused_total_offset(long long N) { return (long long)(layout1(N).prefix + 4 * (size_t)(N - 1)); }
+
+// byte offset in workspace 1 of the packed splat records float[N,16] (raster.hip layout): read by the statistics hook
+LG_API long long lg_fused_packed_offset(long long N) { return (long long)layout1(N).packed; }
 
 // byte offset in workspace 1 of the per-Gaussian tile counts int32[N] (allocate_size, wrapper.py:726-733): read by the statistics hook
 LG_API long long lg_fused_alloc_offset(long long N) { return (long long)layout1(N).alloc; }

@@ -189,17 +189,22 @@ __device__ __forceinline__ void lg_inv2x2_bwd(const float* a, const float* g, bo
     }
 }
 
+// log2 of the activated opacity, folded into the blend exponent by the record packers (raster.hip): one hardware instruction, so the
+// operator path's pack kernel and the fused projection produce the same bits
+__device__ __forceinline__ float lg_log2_opacity(float o) { return __builtin_amdgcn_logf(o); }
+
 // Blend-backward moments -> gradients of the splat's screen position, conic and opacity (reference: GR/raster.cu:826-841, where the
 // same products are formed per (tile, splat) before the atomics; they are linear in the moments, so they are formed once per splat
-// here).  Moments are sums over the splat's pixels of m = dL/dalpha * G: Mx = sum m dx, ... (layout: raster.hip).  conic = (a, b, c)
-// of power = -0.5 a dx^2 - b dx dy - 0.5 c dy^2, o = activated opacity.  g[0..4] = d_px, d_py, d_a, d_b (each off-diagonal), d_c; g[8] = d_opacity.
+// here).  Moments are sums over the splat's pixels of m = dL/dalpha * (opacity * G): Mx = sum m dx, ... (layout: raster.hip).
+// conic = (a, b, c) of power = -0.5 a dx^2 - b dx dy - 0.5 c dy^2, o = activated opacity (alpha = o G, so dL/dpower = m and
+// dL/do = sum m / o).  g[0..4] = d_px, d_py, d_a, d_b (each off-diagonal), d_c; g[8] = d_opacity.
 __device__ __forceinline__ void lg_moments_to_grads(float Mx, float My, float Mxx, float Mxy, float Myy, float M0,
                                                     float a, float b, float c, float o, float* g)
 {
-    g[0] = -o * (a * Mx + b * My);
-    g[1] = -o * (c * My + b * Mx);
-    g[2] = -0.5f * o * Mxx;
-    g[3] = -0.5f * o * Mxy;
-    g[4] = -0.5f * o * Myy;
-    g[8] = M0;
+    g[0] = -(a * Mx + b * My);
+    g[1] = -(c * My + b * Mx);
+    g[2] = -0.5f * Mxx;
+    g[3] = -0.5f * Mxy;
+    g[4] = -0.5f * Myy;
+    g[8] = o > 0.0f ? M0 / o : 0.0f;
 }

@@ -3,18 +3,26 @@
 // CDNA4 design (not a translation of GR/raster.cu):
 //  * one wave64 owns one tile (8x16 = 128 px -> 2 px per lane; 16x16 -> 4; 8x8 -> 1); four independent
 //    waves per 256-thread workgroup, no LDS and no barriers in the blend loops;
-//  * the per-tile splat list and the 64-byte splat records are WAVE-UNIFORM, so they are fetched through
-//    the scalar memory path (s_load_dwordx8/x4 into SGPRs): zero VGPRs, zero LDS bandwidth, and VALU
+//  * the per-tile splat list and the 64-byte splat records are WAVE-UNIFORM, so the records are fetched through
+//    the scalar memory path (one s_load_dwordx16 per splat into SGPRs): zero VGPRs, zero LDS bandwidth, and VALU
 //    ops read the splat constants straight from SGPRs.  This is the CDNA-native replacement for the
 //    "stage the splat list in shared memory" idiom of warp-32 rasterisers;
+//  * measured on gfx950 (tools/ubench, profiles/r02_sq_counters.md): a SIMD issues one plain VALU instruction per 4 cycles
+//    (packed fp32 ~5, transcendentals and v_permlane*_swap ~7.5), a single wave at most one instruction of any kind per ~9
+//    cycles, and SQ_ACTIVE_INST_VALU of the backward equals its duration: the blend kernels are bound by VALU ISSUE, then by
+//    the per-wave instruction latency in the tail (only ~2 tiles per wave slot).  Hence: two pixels per lane as packed 2-vectors;
+//    nothing on the VALU that another pipe can do -- splat ids are loaded 64 at a time with one vector load and handed out by
+//    v_readlane, the record of the NEXT splat is requested by a scalar load (32-bit scalar offset form) before the current one
+//    is blended and waited for once per iteration, the loops are unrolled by two over a ping-pong pair of record registers
+//    (no register rotation), the atomic's lane mask is applied by two s_mov of exec (no branch);
 //  * fp32 blend (the reference blends in half2 with a x128 transmittance scale; 1e-4 parity needs fp32);
-//    the exponent is pre-scaled by log2(e) at pack time so the inner loop is 2 FMA + v_exp_f32 per pixel;
-//  * wave-level early exit through a 64-bit ballot; XCD-aware tile order (each XCD renders a contiguous
-//    band of tiles so vertically adjacent tiles hit the same 4 MiB L2 for their shared splats);
-//  * backward: reverse traversal, per-splat gradients reduced across the wave with a multi-value
-//    butterfly (8 values in 3+3 exchange levels, DPP / ds_swizzle / permlane32) that leaves the 9
-//    results in 9 different lanes, which then issue ONE coalesced global_atomic_add_f32 instruction
-//    into a 64-byte-aligned gradient record (the reference issues 9 serial atomics from lane 0).
+//    the exponent is pre-scaled by log2(e) and log2(opacity) is folded into it at pack time, so alpha is
+//    2 FMA + v_exp_f32 per pixel;
+//  * wave-level early exit through a 64-bit ballot; heaviest-first tile schedule (below);
+//  * backward: reverse traversal; nine per-splat sums reduced across the wave by a transposing butterfly made of
+//    v_permlane32/16_swap and bank-masked DPP adds (the ninth value crosses rows through the LDS crossbar) that leaves the 9
+//    totals in 9 different lanes, which issue ONE coalesced global_atomic_add_f32 instruction into a 64-byte-aligned
+//    gradient record (the reference issues 9 serial atomics from lane 0).
 //
 // Lane -> pixel map: x = lane % TW; q = lane / TW; strip = q >> 1; p = q & 1; row(k) = strip*2*PPL + 2k + p.
 // This gives each lane exactly the pixel set of one reference (thread, half2-lane) pair, which is what
@@ -28,10 +36,19 @@
 #define LOG2E 1.4426950408889634f
 
 // record layout (dwords): 0 px, 1 py, 2 A2=-0.5*a*log2e, 3 B2=-b*log2e, 4 C2=-0.5*c*log2e, 5 opacity, 6 r, 7 g | 8 b,
-//                          9 a=ic00, 10 b=ic01, 11 c=ic11 | 12 depth, 13..15 = 0
-// forward reads dwords 0-8 (one s_load_dwordx8 + one s_load_dword), backward 0-11 (x8 + x4): tuples land in adjacent SGPRs,
-// which is what lets the compiler feed v_pk_* ops straight from SGPR pairs.
-// power*log2e = A2*dx^2 + B2*dx*dy + C2*dy^2   (power as in GR/raster.cu:237-240)
+//                          9 a=ic00, 10 b=ic01, 11 c=ic11 | 12 depth, 13 ndc.x, 14 ndc.y (fused executor only), 15 log2(opacity)
+// alpha = min(255/256, exp2(A2*dx^2 + B2*dx*dy + C2*dy^2 + log2(opacity)))     (power as in GR/raster.cu:237-240)
+// The blend kernels read 0-4, 6-8 and 15; the key emission 5, 9-11, 13-14; lg_unpack_gradient 5 and 9-11.
+#define R_PX 0
+#define R_PY 1
+#define R_A2 2
+#define R_B2 3
+#define R_C2 4
+#define R_O 5
+#define R_CR 6
+#define R_CG 7
+#define R_CB 8
+#define R_LO 15
 
 // ---------------------------------------------------------------------------------------------
 // a12 pack_forward_params (reference: GR/raster.cu:334-356), fp32 colours (no half2 rounding)
@@ -55,7 +72,7 @@ __global__ void __launch_bounds__(256) pack_params_kernel(const float* __restric
     rec[0] = make_float4(px, py, -0.5f * a * LOG2E, -bb * LOG2E);
     rec[1] = make_float4(-0.5f * c * LOG2E, o, r, g);
     rec[2] = make_float4(bl, a, bb, c);
-    rec[3] = make_float4(depth, 0.0f, 0.0f, 0.0f);
+    rec[3] = make_float4(depth, 0.0f, 0.0f, lg_log2_opacity(o));
 }
 
 LG_API int lg_pack_forward_params(const float* ndc, const float* inv_cov, const float* color, const float* opacity,
@@ -70,8 +87,8 @@ LG_API int lg_pack_forward_params(const float* ndc, const float* inv_cov, const 
 // ---------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ float xor_dpp1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
@@ -120,22 +137,72 @@ struct TileMap {
     static_assert(TH % (2 * PPL) == 0, "unsupported tile");
 };
 
-// dwords 0-7 and 8 of the 64-byte splat record, fetched through the scalar path (the address is wave-uniform)
-struct FwdRec { f32x8 lo; float cb; };
-__device__ __forceinline__ FwdRec load_fwd(const float* __restrict__ pk, int pid)
+// The whole 64-byte record of splat `byte_off / 64` into 16 SGPRs: one scalar load, 32-bit scalar offset (records of one view span
+// < 4 GiB: N < 2^26, checked by the launchers).  Written as asm because the compiler neither forms the soffset addressing from a
+// 64-bit pointer sum nor keeps the request in flight across the loop body; the matching wait is rec_wait().
+__device__ __forceinline__ void rec_request(f32x16& rec, const float* __restrict__ pk, unsigned byte_off)
 {
-    const float* __restrict__ r = pk + (size_t)pid * REC;
-    FwdRec s;
-    s.lo = *reinterpret_cast<const f32x8*>(r);
-    s.cb = r[8];
-    return s;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(rec) : "s"(pk), "s"(byte_off));
 }
+__device__ __forceinline__ void rec_wait(f32x16& rec) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rec)); }
 
-static int g_bwd_wpb = 4, g_bwd_map = 0, g_fwd_map = 0, g_bwd_dbg = 0, g_use_order = 1;       // launch variants (lg_set_tuning)
+static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1;       // launch variants (lg_set_tuning)
 
 // ---------------------------------------------------------------------------------------------
 // a13 rasterize_forward (reference: GR/raster.cu:162-332)
 // ---------------------------------------------------------------------------------------------
+template <int PPL>
+struct FwdState {
+    float X, Y[PPL], T[PPL], Cr[PPL], Cg[PPL], Cb[PPL];
+    int lc[PPL];
+};
+
+// one splat blended into the lane's pixels; i1 = (list position + 1).  Returns false when no pixel of the wave is active any more
+// (checked BEFORE blending, as the reference does).
+template <int PPL, bool STAT>
+__device__ __forceinline__ bool fwd_splat(FwdState<PPL>& st, const f32x16& rec, int i1, int lane, unsigned pid_off,
+                                          int* __restrict__ frag_count, float* __restrict__ frag_weight)
+{
+    bool any_act = false;
+#pragma unroll
+    for (int k = 0; k < PPL; k++) any_act |= (st.T[k] > 1.0f / 8192);
+    if (!__any(any_act)) return false;
+    const float dx = rec[R_PX] - st.X;
+    const float t1 = rec[R_B2] * dx;
+    const float t0 = __builtin_fmaf(rec[R_A2] * dx, dx, rec[R_LO]);
+    int fc = 0;
+    float ws = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        const bool active = st.T[k] > 1.0f / 8192;
+        const float dy = rec[R_PY] - st.Y[k];
+        const float E = __builtin_amdgcn_exp2f(__builtin_fmaf(dy, __builtin_fmaf(rec[R_C2], dy, t1), t0));
+        const bool valid = active && (E >= 1.0f / 256);
+        st.lc[k] = active ? i1 : st.lc[k];               // == number of splats visited while active (activity is monotone)
+        const float alpha = valid ? fminf(255.0f / 256, E) : 0.0f;
+        const float w = st.T[k] * alpha;
+        if (STAT) { fc += valid ? 1 : 0; ws += w; }
+        st.Cr[k] = __builtin_fmaf(rec[R_CR], w, st.Cr[k]);
+        st.Cg[k] = __builtin_fmaf(rec[R_CG], w, st.Cg[k]);
+        st.Cb[k] = __builtin_fmaf(rec[R_CB], w, st.Cb[k]);
+        st.T[k] -= w;                       // T*(1-alpha)
+    }
+    if (STAT) {
+        unsigned long long m = __ballot(fc != 0);
+        if (m) {
+            int fct = fc;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) fct += __shfl_xor(fct, s);
+            float wst = wave_sum(ws);
+            if (lane == 0) {
+                atomicAdd(&frag_count[pid_off >> 6], fct);
+                unsafeAtomicAdd(&frag_weight[pid_off >> 6], wst);
+            }
+        }
+    }
+    return true;
+}
+
 template <int TH, int TW, bool STAT>
 __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
                                                              const float* __restrict__ packed, const int* __restrict__ tiles, int K,
@@ -157,70 +224,49 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     const int* __restrict__ si = start_index + (size_t)view * (ntiles + 2);
     const int start = rfl(si[tile]);
     const int end = rfl(si[tile + 1]);
-    const int* __restrict__ sp = sorted_points + (size_t)view * L;
     const float* __restrict__ pk = packed + (size_t)view * N * REC;
+    if (STAT) { frag_count += (size_t)view * N; frag_weight += (size_t)view * N; }
 
     const int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
     const int x = tx * TW + lane % TW;
     const int q = lane / TW;
     const int y0 = ty * TH + (q >> 1) * (2 * PPL) + (q & 1);
-    const float X = (float)x;
-    float Y[PPL], T[PPL], Cr[PPL], Cg[PPL], Cb[PPL];
-    int lc[PPL];
+    FwdState<PPL> st;
+    st.X = (float)x;
 #pragma unroll
-    for (int k = 0; k < PPL; k++) { Y[k] = (float)(y0 + 2 * k); T[k] = 1.0f; Cr[k] = Cg[k] = Cb[k] = 0.0f; lc[k] = 0; }
+    for (int k = 0; k < PPL; k++) { st.Y[k] = (float)(y0 + 2 * k); st.T[k] = 1.0f; st.Cr[k] = st.Cg[k] = st.Cb[k] = 0.0f; st.lc[k] = 0; }
 
     int visited = 0;
     if (start >= 0 && end > start) {
-        // scalar-path software pipeline: splat id two iterations ahead, record one iteration ahead (see the backward kernel)
         const int n = end - start;
-        const int* __restrict__ spt = sp + start;
-        int pid = rfl(spt[0]);
-        int pid_next = rfl(spt[min(1, n - 1)]);
-        FwdRec rec = load_fwd(pk, pid);
-        for (int i = 0; i < n; i++) {
-            bool any_act = false;
-#pragma unroll
-            for (int k = 0; k < PPL; k++) any_act |= (T[k] > 1.0f / 8192);
-            if (!__any(any_act)) break;
-            visited = i + 1;
-            const FwdRec rec_next = load_fwd(pk, pid_next);
-            const int pid_next2 = rfl(spt[min(i + 2, n - 1)]);
-            const float spx = rec.lo[0], spy = rec.lo[1], A2 = rec.lo[2], B2 = rec.lo[3], C2 = rec.lo[4], o = rec.lo[5];
-            const float cr = rec.lo[6], cg = rec.lo[7], cb = rec.cb;
-            const float dx = spx - X;
-            const float t0 = A2 * dx * dx, t1 = B2 * dx;
-            int fc = 0;
-            float ws = 0.0f;
-#pragma unroll
-            for (int k = 0; k < PPL; k++) {
-                const bool active = T[k] > 1.0f / 8192;
-                const float dy = spy - Y[k];
-                const float p2 = t0 + dy * (t1 + C2 * dy);
-                float alpha = o * __builtin_amdgcn_exp2f(p2);
-                const bool valid = active && (alpha >= 1.0f / 256);
-                alpha = fminf(255.0f / 256, alpha);
-                lc[k] = active ? (i + 1) : lc[k];               // == number of splats visited while active (activity is monotone)
-                alpha = valid ? alpha : 0.0f;
-                const float w = T[k] * alpha;
-                if (STAT) { fc += valid ? 1 : 0; ws += w; }
-                Cr[k] += cr * w; Cg[k] += cg * w; Cb[k] += cb * w;
-                T[k] -= w;                       // T*(1-alpha)
+        const int* __restrict__ sp = sorted_points + (size_t)view * L + start;
+        // ids of the list, 64 at a time: lane l of `nxt` holds the id at position c0 + l + 1, i.e. the splat to REQUEST while
+        // position c0 + l is blended (clamped at the list end: the surplus request is never used)
+        unsigned off_a = (unsigned)rfl(sp[0]) << 6, off_b = 0;
+        f32x16 ra, rb;
+        rec_request(ra, pk, off_a);
+        int nxt = sp[min(lane + 1, n - 1)];
+        rec_wait(ra);
+        bool live = true;
+        for (int c0 = 0; c0 < n && live; c0 += 64) {
+            const int cnt = min(64, n - c0);                            // positions c0 .. c0 + cnt - 1 in this chunk
+            const int nxt_next = sp[min(c0 + 64 + lane + 1, n - 1)];    // next chunk's ids, in flight while this chunk is blended
+            for (int j = 0; j < cnt; j += 2) {                          // cnt is even except possibly in the last chunk
+                off_b = (unsigned)__builtin_amdgcn_readlane(nxt, j) << 6;
+                rec_request(rb, pk, off_b);
+                live = fwd_splat<PPL, STAT>(st, ra, c0 + j + 1, lane, off_a, frag_count, frag_weight);
+                rec_wait(rb);
+                if (!live) break;
+                visited = c0 + j + 1;
+                if (j + 1 >= cnt) break;                                // odd tail: the list ends here
+                off_a = (unsigned)__builtin_amdgcn_readlane(nxt, j + 1) << 6;
+                rec_request(ra, pk, off_a);
+                live = fwd_splat<PPL, STAT>(st, rb, c0 + j + 2, lane, off_b, frag_count, frag_weight);
+                rec_wait(ra);
+                if (!live) break;
+                visited = c0 + j + 2;
             }
-            if (STAT) {
-                unsigned long long m = __ballot(fc != 0);
-                if (m) {
-                    int fct = fc;
-#pragma unroll
-                    for (int s = 1; s < 64; s <<= 1) fct += __shfl_xor(fct, s);
-                    float wst = wave_sum(ws);
-                    if (lane == 0) {
-                        atomicAdd(&frag_count[(size_t)view * N + pid], fct);
-                        unsafeAtomicAdd(&frag_weight[(size_t)view * N + pid], wst);
-                    }
-                }
-            }
-            rec = rec_next; pid = pid_next; pid_next = pid_next2;
+            nxt = nxt_next;
         }
     }
     // work done for this tile (splats walked before every pixel saturated): the schedule key of the backward and of the next visit
@@ -229,11 +275,11 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
         const size_t o = (size_t)(y0 + 2 * k) * Wp + x;
-        img[((size_t)view * 3) * plane + o] = fminf(Cr[k], 1.0f);
-        img[((size_t)view * 3 + 1) * plane + o] = fminf(Cg[k], 1.0f);
-        img[((size_t)view * 3 + 2) * plane + o] = fminf(Cb[k], 1.0f);
-        trans[(size_t)view * plane + o] = T[k];
-        last[(size_t)view * plane + o] = (short)lc[k];
+        img[((size_t)view * 3) * plane + o] = fminf(st.Cr[k], 1.0f);
+        img[((size_t)view * 3 + 1) * plane + o] = fminf(st.Cg[k], 1.0f);
+        img[((size_t)view * 3 + 2) * plane + o] = fminf(st.Cb[k], 1.0f);
+        trans[(size_t)view * plane + o] = st.T[k];
+        last[(size_t)view * plane + o] = (short)st.lc[k];
     }
 }
 
@@ -246,6 +292,7 @@ LG_API int lg_raster_forward(const int* sorted_points, const int* start_index, c
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
     const int nslots = tiles ? K : ntiles;
     if (nslots <= 0) return 0;
+    if (N >= (1 << 26)) return (int)hipErrorInvalidValue;          // 32-bit record offsets
     if (!g_use_order) order = nullptr;
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -261,7 +308,6 @@ LG_API int lg_raster_forward(const int* sorted_points, const int* start_index, c
 #undef LAUNCH_RF
     LG_RETURN_LAST();
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Tile schedule: heaviest tiles first.  A frame has only ~2 tiles per resident wave slot (16 200 tiles, 8 192 slots), so the
@@ -338,13 +384,14 @@ LG_API int lg_tile_work_from_last(const short* last, int V, int H, int W, int TH
 // ---------------------------------------------------------------------------------------------
 // a14 rasterize_backward (reference: GR/raster.cu:600-853)
 //
-// packed_grad record (GREC floats), MOMENT form.  With m = dL/dalpha * G per (pixel, splat) (G = exp(power), alpha = opacity * G),
-// dx = px - X, dy = py - Y, and w = alpha * T the blend weight:
+// packed_grad record (GREC floats), MOMENT form.  With E = exp2(power*log2e + log2 opacity) (= opacity * G, the unclamped alpha),
+// m = dL/dalpha * E per (pixel, splat) (the clamp at 255/256 passes the gradient, as the reference does), dx = px - X, dy = py - Y,
+// and w = alpha * T the blend weight:
 //   0 Mx = sum m dx     1 My = sum m dy     2 Mxx = sum m dx^2     3 Mxy = sum m dx dy     4 Myy = sum m dy^2
-//   5 dr = sum w dL/dR  6 dg                7 db                   8 M0 = sum m  (== d_opacity of the ACTIVATED opacity)
+//   5 dr = sum w dL/dR  6 dg                7 db                   8 M0 = sum m  (== opacity * d_opacity)
 // The reference kernel (raster.cu:826-841) multiplies the conic coefficients into these sums per (tile, splat); they are linear in
 // the moments with per-splat constants, so the consumer does it once per splat instead (lg_moments_to_grads in lg_chain.h):
-//   d_px = -o (a Mx + b My)   d_py = -o (c My + b Mx)   d_a = -o/2 Mxx   d_b01 = d_b10 = -o/2 Mxy   d_c = -o/2 Myy   d_opacity = M0
+//   d_px = -(a Mx + b My)   d_py = -(c My + b Mx)   d_a = -Mxx/2   d_b01 = d_b10 = -Mxy/2   d_c = -Myy/2   d_opacity = M0 / opacity
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void swap32(float& u, float& w)       // lanes 32-63 of u <-> lanes 0-31 of w (v_permlane32_swap)
 {
@@ -381,13 +428,16 @@ __device__ __forceinline__ float bfly_hmirror4(float u, float w)
 }
 
 // Sum nine per-lane values over the wave; the nine totals end up in nine different lanes (wave_slot() tells which).
-// 8 swaps + 17 adds/moves, all VALU (no LDS-pipe swizzles: a dependent ds_swizzle costs ~58 cycles, a dependent DPP add ~18).
+// The kernel is bound by VALU issue (SQ_ACTIVE_INST_VALU == its duration; a plain VALU op holds the SIMD 4 cycles, a
+// v_permlane*_swap ~7.5), so: eight values go through 6 swap + add steps and 2 bank-masked DPP pairs; the ninth, which has no
+// partner to be transposed with, takes its two cross-row levels through the LDS crossbar (ds_swizzle / ds_bpermute: no VALU
+// issue slot, and its ~58-cycle latency overlaps the other eight values' steps).
 __device__ __forceinline__ float reduce9(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8)
 {
+    v8 += xor_32(v8);
     BF32(v0, v1) BF32(v2, v3) BF32(v4, v5) BF32(v6, v7)
-    v8 = sum32(v8);
+    v8 += xor_swz16(v8);
     BF16(v0, v2) BF16(v4, v6)
-    v8 = sum16(v8);
     v0 = bfly_mirror8(v0, v4);
     v8 += mirror16(v8);
     v0 = bfly_hmirror4(v0, v8);
@@ -405,21 +455,118 @@ __device__ __forceinline__ int wave_slot(int lane)
     return ((lane >> 3) & 1) * 4 + (row & 1) * 2 + (row >> 1);
 }
 
-template <int TH, int TW, bool STAT, bool TRANS, int WPB>
-__global__ void __launch_bounds__(64 * WPB) raster_backward_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
-                                                                   const float* __restrict__ packed, const int* __restrict__ tiles, int K,
-                                                                   const float* __restrict__ final_T, const short* __restrict__ last,
-                                                                   const float* __restrict__ d_img, const float* __restrict__ d_trans,
-                                                                   float* __restrict__ packed_grad, float* __restrict__ err_square_sum,
-                                                                   int* __restrict__ tile_counters, const int* __restrict__ order,
-                                                                   int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int dbg)
+template <int PPL>
+struct BwdState {
+    float X, Y[PPL], T[PPL], Bd[PPL], gR[PPL], gG[PPL], gB[PPL], gT[PPL];
+    int lcrel[PPL];                  // last_contributor minus the first list position of the current 64-chunk
+};
+
+// one splat of the reverse traversal.  j = list position - chunk base (compared with lcrel); writers = exec mask of the nine lanes
+// that own a record slot; slot_off = 4 * slot of this lane.
+template <int PPL, bool STAT, bool TRANS, bool COUNT>
+__device__ __forceinline__ void bwd_splat(BwdState<PPL>& st, const f32x16& rec, int j, unsigned pid_off, unsigned slot_off,
+                                          unsigned long long writers, float* __restrict__ pg, float* __restrict__ err_square_sum,
+                                          int lane, int& contributing)
+{
+    const float dx = rec[R_PX] - st.X;
+    const float t1 = rec[R_B2] * dx;
+    const float t0 = __builtin_fmaf(rec[R_A2] * dx, dx, rec[R_LO]);
+    float v_r = 0.f, v_g = 0.f, v_b = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, esq = 0.f;
+    if constexpr (PPL == 2 && !STAT) {
+        // the lane's two pixels as one 2-vector: packed fp32 ops do two pixels per issue slot
+        const v2f dyv = { rec[R_PY] - st.Y[0], rec[R_PY] - st.Y[1] };
+        const v2f qv = dyv * (rec[R_C2] * dyv + t1) + t0;              // contracted to two v_pk_fma_f32
+        const float E0 = __builtin_amdgcn_exp2f(qv.x);
+        const float E1 = __builtin_amdgcn_exp2f(qv.y);
+        const bool val0 = (E0 >= 1.0f / 256) && (j < st.lcrel[0]);
+        const bool val1 = (E1 >= 1.0f / 256) && (j < st.lcrel[1]);
+        if (COUNT) contributing += __any(val0 || val1) ? 1 : 0;
+        const v2f Ev = { val0 ? E0 : 0.0f, val1 ? E1 : 0.0f };
+        const v2f am = { fminf(255.0f / 256, Ev.x), fminf(255.0f / 256, Ev.y) };
+        const v2f om = 1.0f - am;
+        const v2f rc = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
+        v2f Tv = { st.T[0], st.T[1] };
+        Tv = Tv * rc;
+        Tv.x = fminf(1.0f, Tv.x); Tv.y = fminf(1.0f, Tv.y);
+        st.T[0] = Tv.x; st.T[1] = Tv.y;
+        const v2f gRv = { st.gR[0], st.gR[1] }, gGv = { st.gG[0], st.gG[1] }, gBv = { st.gB[0], st.gB[1] };
+        const v2f w = am * Tv;
+        const v2f ar = w * gRv, ag = w * gGv, ab = w * gBv;
+        const v2f cdot = rec[R_CR] * gRv + rec[R_CG] * gGv + rec[R_CB] * gBv;
+        v2f Bdv = { st.Bd[0], st.Bd[1] };
+        const v2f diff = cdot - Bdv;
+        v2f d_alpha = diff * Tv;
+        Bdv = Bdv + am * diff;
+        st.Bd[0] = Bdv.x; st.Bd[1] = Bdv.y;
+        if (TRANS) { const v2f gTv = { st.gT[0], st.gT[1] }; d_alpha = d_alpha - gTv * rc; }
+        const v2f m = d_alpha * Ev;
+        const v2f my = m * dyv;
+        const v2f myy = my * dyv;
+        v_r = ar.x + ar.y; v_g = ag.x + ag.y; v_b = ab.x + ab.y;
+        s0 = m.x + m.y; s1 = my.x + my.y; s2 = myy.x + myy.y;
+    } else {
+        float E[PPL], dy[PPL];
+        bool valid[PPL];
+        bool anyv = false;
+#pragma unroll
+        for (int k = 0; k < PPL; k++) {
+            dy[k] = rec[R_PY] - st.Y[k];
+            E[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(dy[k], __builtin_fmaf(rec[R_C2], dy[k], t1), t0));
+            valid[k] = (E[k] >= 1.0f / 256) && (j < st.lcrel[k]);
+            anyv |= valid[k];
+        }
+        if (COUNT) contributing += __any(anyv) ? 1 : 0;
+        const float inv_o = STAT ? __builtin_amdgcn_rcpf(rec[R_O]) : 0.0f;
+#pragma unroll
+        for (int k = 0; k < PPL; k++) {
+            if (STAT && !__any(valid[k])) continue;         // reference's per-row-group gate (raster.cu:753)
+            const float Ev = valid[k] ? E[k] : 0.0f;
+            const float am = fminf(255.0f / 256, Ev);
+            const float rc = __builtin_amdgcn_rcpf(1.0f - am);
+            st.T[k] = fminf(1.0f, st.T[k] * rc);
+            const float w = am * st.T[k];
+            v_r += w * st.gR[k]; v_g += w * st.gG[k]; v_b += w * st.gB[k];
+            // reference (raster.cu:757-776) keeps the three blended-behind colours; only their dot product with the pixel's
+            // colour gradient is ever used, and it obeys the same recurrence: B.g <- B.g + alpha * (c.g - B.g)
+            const float cdot = rec[R_CR] * st.gR[k] + rec[R_CG] * st.gG[k] + rec[R_CB] * st.gB[k];
+            const float diff = cdot - st.Bd[k];
+            float d_alpha = diff * st.T[k];
+            st.Bd[k] += am * diff;
+            if (TRANS) d_alpha -= st.gT[k] * rc;
+            const float m = d_alpha * Ev;
+            s0 += m;
+            if (STAT) { const float vo = s0 * inv_o; esq += vo * vo; }      // running-sum quirk of d_opacity, raster.cu:781-783
+            s1 += m * dy[k]; s2 += m * dy[k] * dy[k];
+        }
+    }
+    const float mx = dx * s0;
+    const float tot = reduce9(mx, s1, dx * mx, dx * s1, s2, v_r, v_g, v_b, s0);
+    // ONE atomic instruction from the nine lanes that hold a total: exec is narrowed around it without a branch
+    const unsigned voff = pid_off + slot_off;
+    asm volatile("s_mov_b64 exec, %2\n\t"
+                 "global_atomic_add_f32 %0, %1, %3\n\t"
+                 "s_mov_b64 exec, -1" : : "v"(voff), "v"(tot), "s"(writers), "s"(pg) : "memory");
+    if (STAT) {
+        esq = wave_sum(esq);
+        if (lane == 0) unsafeAtomicAdd(&err_square_sum[pid_off >> 6], esq);
+    }
+}
+
+template <int TH, int TW, bool STAT, bool TRANS, bool COUNT>
+__global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
+                                                              const float* __restrict__ packed, const int* __restrict__ tiles, int K,
+                                                              const float* __restrict__ final_T, const short* __restrict__ last,
+                                                              const float* __restrict__ d_img, const float* __restrict__ d_trans,
+                                                              float* __restrict__ packed_grad, float* __restrict__ err_square_sum,
+                                                              int* __restrict__ tile_counters, const int* __restrict__ order,
+                                                              int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode)
 {
     constexpr int PPL = TileMap<TH, TW>::PPL;
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
     const int nb = gridDim.x;
     int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
-    const int slot = rfl(blk * WPB + (int)(threadIdx.x >> 6));
+    const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
     if (slot >= nslots) return;
     int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
     tile = rfl(tile);
@@ -431,126 +578,66 @@ __global__ void __launch_bounds__(64 * WPB) raster_backward_kernel(const int* __
     const int* __restrict__ sp = sorted_points + (size_t)view * L + start;
     const float* __restrict__ pk = packed + (size_t)view * N * REC;
     float* __restrict__ pg = packed_grad + (size_t)view * N * GREC;
+    if (STAT) err_square_sum += (size_t)view * N;
 
     const int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
     const int x = tx * TW + lane % TW;
     const int q = lane / TW;
     const int y0 = ty * TH + (q >> 1) * (2 * PPL) + (q & 1);
-    const float X = (float)x;
     const size_t plane = (size_t)Hp * Wp;
-    float Y[PPL], T[PPL], Bd[PPL], gR[PPL], gG[PPL], gB[PPL], gT[PPL];
+    BwdState<PPL> st;
+    st.X = (float)x;
     int lc[PPL];
     int maxlast = 0;
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
         const size_t o = (size_t)(y0 + 2 * k) * Wp + x;
-        Y[k] = (float)(y0 + 2 * k);
-        T[k] = final_T[(size_t)view * plane + o];
+        st.Y[k] = (float)(y0 + 2 * k);
+        st.T[k] = final_T[(size_t)view * plane + o];
         lc[k] = last[(size_t)view * plane + o];
-        gR[k] = d_img[((size_t)view * 3) * plane + o];
-        gG[k] = d_img[((size_t)view * 3 + 1) * plane + o];
-        gB[k] = d_img[((size_t)view * 3 + 2) * plane + o];
-        gT[k] = TRANS ? T[k] * d_trans[(size_t)view * plane + o] : 0.0f;     // T_final * dL/dT (raster.cu:665)
-        Bd[k] = 0.0f;                    // (colour blended BEHIND the current splat) . dL/dC of the pixel
+        st.gR[k] = d_img[((size_t)view * 3) * plane + o];
+        st.gG[k] = d_img[((size_t)view * 3 + 1) * plane + o];
+        st.gB[k] = d_img[((size_t)view * 3 + 2) * plane + o];
+        st.gT[k] = TRANS ? st.T[k] * d_trans[(size_t)view * plane + o] : 0.0f;     // T_final * dL/dT (raster.cu:665)
+        st.Bd[k] = 0.0f;                 // (colour blended BEHIND the current splat) . dL/dC of the pixel
         maxlast = max(maxlast, lc[k]);
     }
     maxlast = rfl(wave_max_i(maxlast));
-    maxlast = min(maxlast, end - start);
-    const int myslot = wave_slot(lane);
+    const int n = min(maxlast, end - start);        // list positions n-1 .. 0 are walked
     int contributing = 0;
-
-    // Software pipeline over the wave-uniform (scalar-path) loads: the splat id is fetched two iterations ahead and the record one
-    // iteration ahead, so neither dependent s_load (~150 cycles each) sits on the iteration's critical path.
-    int pid = maxlast > 0 ? rfl(sp[maxlast - 1]) : 0;
-    int pid_next = rfl(sp[max(maxlast - 2, 0)]);
-    FwdRec rec = load_fwd(pk, pid);
-    for (int idx = maxlast - 1; idx >= 0; idx--) {
-        const FwdRec rec_next = load_fwd(pk, pid_next);
-        const int pid_next2 = (dbg & 8) ? 0 : rfl(sp[max(idx - 2, 0)]);
-        const float spx = rec.lo[0], spy = rec.lo[1], A2 = rec.lo[2], B2 = rec.lo[3], C2 = rec.lo[4], o = rec.lo[5];
-        const float cr = rec.lo[6], cg = rec.lo[7], cb = rec.cb;
-        const float dx = spx - X;
-        const float t0 = A2 * dx * dx, t1 = B2 * dx;
-        float G[PPL], alpha[PPL], dy[PPL];
-        bool valid[PPL];
-        bool anyv = false;
+    if (n > 0) {
+        const int myslot = wave_slot(lane);
+        const unsigned long long writers = __ballot(myslot >= 0);
+        const unsigned slot_off = (unsigned)max(myslot, 0) * 4u;
+        // An even number of iterations (two per trip over a ping-pong pair of record registers): if n is odd the walk starts one
+        // position early, at `n`, with the record of position n-1 -- no pixel has last_contributor > n, so that splat adds zeros.
+        const int top = (n + 1) & ~1;
+        int c0 = (top - 1) & ~63;                                    // first position of the current 64-chunk
+        // lane l of `prv` holds the id at position c0 + l - 1: the splat to REQUEST while position c0 + l is processed
+        int prv = sp[min(max(c0 + lane - 1, 0), n - 1)];
+        unsigned off_a = (unsigned)rfl(sp[min(top - 1, n - 1)]) << 6, off_b = 0;
+        f32x16 ra, rb;
+        rec_request(ra, pk, off_a);
+        rec_wait(ra);
+        for (; c0 >= 0; c0 -= 64) {
+            const int prv_next = sp[min(max(c0 - 64 + lane - 1, 0), n - 1)];       // next (lower) chunk's ids, in flight during this chunk
 #pragma unroll
-        for (int k = 0; k < PPL; k++) {
-            dy[k] = spy - Y[k];
-            G[k] = __builtin_amdgcn_exp2f(t0 + dy[k] * (t1 + C2 * dy[k]));
-            alpha[k] = fminf(255.0f / 256, o * G[k]);
-            valid[k] = (alpha[k] >= 1.0f / 256) && (idx < lc[k]);
-            anyv |= valid[k];
-        }
-        if (__any(anyv) && !(dbg & 4)) {
-            contributing++;
-            float v_r = 0.f, v_g = 0.f, v_b = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, esq = 0.f;
-            if constexpr (PPL == 2 && !STAT) {
-                // the lane's two pixels as one 2-vector: packed fp32 ops do two pixels per issue slot
-                typedef float v2f __attribute__((ext_vector_type(2)));
-                const v2f am = { valid[0] ? alpha[0] : 0.0f, valid[1] ? alpha[1] : 0.0f };
-                const v2f Gm = { valid[0] ? G[0] : 0.0f, valid[1] ? G[1] : 0.0f };
-                const v2f om = 1.0f - am;
-                const v2f rc = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
-                v2f Tv = { T[0], T[1] };
-                Tv = Tv * rc;
-                Tv.x = fminf(1.0f, Tv.x); Tv.y = fminf(1.0f, Tv.y);
-                T[0] = Tv.x; T[1] = Tv.y;
-                const v2f gRv = { gR[0], gR[1] }, gGv = { gG[0], gG[1] }, gBv = { gB[0], gB[1] }, dyv = { dy[0], dy[1] };
-                const v2f w = am * Tv;
-                const v2f ar = w * gRv, ag = w * gGv, ab = w * gBv;
-                const v2f cdot = cr * gRv + cg * gGv + cb * gBv;
-                v2f Bdv = { Bd[0], Bd[1] };
-                const v2f diff = cdot - Bdv;
-                v2f d_alpha = diff * Tv;
-                Bdv = Bdv + am * diff;
-                Bd[0] = Bdv.x; Bd[1] = Bdv.y;
-                if (TRANS) { const v2f gTv = { gT[0], gT[1] }; d_alpha = d_alpha - gTv * rc; }
-                const v2f m = d_alpha * Gm;
-                const v2f my = m * dyv;
-                const v2f myy = my * dyv;
-                v_r = ar.x + ar.y; v_g = ag.x + ag.y; v_b = ab.x + ab.y;
-                s0 = m.x + m.y; s1 = my.x + my.y; s2 = myy.x + myy.y;
-            } else {
-#pragma unroll
-                for (int k = 0; k < PPL; k++) {
-                    if (STAT && !__any(valid[k])) continue;         // reference's per-row-group gate (raster.cu:753)
-                    const float am = valid[k] ? alpha[k] : 0.0f;
-                    const float Gm = valid[k] ? G[k] : 0.0f;
-                    const float rc = __builtin_amdgcn_rcpf(1.0f - am);
-                    T[k] = fminf(1.0f, T[k] * rc);
-                    const float w = am * T[k];
-                    v_r += w * gR[k]; v_g += w * gG[k]; v_b += w * gB[k];
-                    // reference (raster.cu:757-776) keeps the three blended-behind colours; only their dot product with the pixel's
-                    // colour gradient is ever used, and it obeys the same recurrence: B.g <- B.g + alpha * (c.g - B.g)
-                    const float cdot = cr * gR[k] + cg * gG[k] + cb * gB[k];
-                    const float diff = cdot - Bd[k];
-                    float d_alpha = diff * T[k];
-                    Bd[k] += am * diff;
-                    if (TRANS) d_alpha -= gT[k] * rc;
-                    const float m = d_alpha * Gm;
-                    s0 += m;
-                    if (STAT) esq += s0 * s0;                        // running-sum quirk of d_opacity, raster.cu:781-783
-                    s1 += m * dy[k]; s2 += m * dy[k] * dy[k];
-                }
+            for (int k = 0; k < PPL; k++) st.lcrel[k] = lc[k] - c0;
+            for (int j = min(63, top - 1 - c0); j >= 1; j -= 2) {          // j is odd here: positions c0 + j and c0 + j - 1
+                off_b = (unsigned)__builtin_amdgcn_readlane(prv, j) << 6;
+                rec_request(rb, pk, off_b);
+                bwd_splat<PPL, STAT, TRANS, COUNT>(st, ra, j, off_a, slot_off, writers, pg, err_square_sum, lane, contributing);
+                rec_wait(rb);
+                off_a = (unsigned)__builtin_amdgcn_readlane(prv, j - 1) << 6;
+                rec_request(ra, pk, off_a);
+                bwd_splat<PPL, STAT, TRANS, COUNT>(st, rb, j - 1, off_b, slot_off, writers, pg, err_square_sum, lane, contributing);
+                rec_wait(ra);
             }
-            const float mx = dx * s0;
-            float tot;
-            if (dbg & 2) tot = mx + s1 + dx * mx + dx * s1 + s2 + v_r + v_g + v_b + s0;
-            else tot = reduce9(mx, s1, dx * mx, dx * s1, s2, v_r, v_g, v_b, s0);
-            if (dbg & 16) { if (myslot >= 0) pg[(size_t)pid * GREC + myslot] = tot; }
-            else if (dbg & 32) { if (myslot >= 0) unsafeAtomicAdd(pg + ((size_t)tile * 64 + (idx & 63)) * GREC + myslot, tot); }
-            else if (!(dbg & 1)) { if (myslot >= 0) unsafeAtomicAdd(pg + (size_t)pid * GREC + myslot, tot); }
-            else if (tot == 1.2345f) pg[0] = tot;
-            if (STAT) {
-                esq = wave_sum(esq);
-                if (lane == 0) unsafeAtomicAdd(&err_square_sum[(size_t)view * N + pid], esq);
-            }
+            prv = prv_next;
         }
-        rec = rec_next; pid = pid_next; pid_next = pid_next2;
     }
-    if (tile_counters != nullptr && lane == 0) {          // measurement hook (bench.py roofline): visited / contributing (tile, splat) iterations
-        tile_counters[((size_t)view * (ntiles + 1) + tile) * 2] = maxlast;
+    if (COUNT && lane == 0) {          // measurement hook (bench.py roofline): visited / contributing (tile, splat) iterations
+        tile_counters[((size_t)view * (ntiles + 1) + tile) * 2] = n;
         tile_counters[((size_t)view * (ntiles + 1) + tile) * 2 + 1] = contributing;
     }
 }
@@ -558,11 +645,9 @@ __global__ void __launch_bounds__(64 * WPB) raster_backward_kernel(const int* __
 LG_API int lg_set_tuning(int key, int value)
 {
     switch (key) {
-    case 0: g_bwd_wpb = (value == 1 || value == 2) ? value : 4; return 0;     // waves (tiles) per workgroup of the blend backward
     case 1: g_bwd_map = value; return 0;                                      // workgroup -> tile map of the blend backward (block_remap)
-    case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
-    case 3: g_bwd_dbg = value; return 0;                                      // ablation bits of the blend backward (WRONG results; timing experiments only)
     case 2: g_fwd_map = value; return 0;                                      // ... of the blend forward
+    case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
     default: return (int)hipErrorInvalidValue;
     }
 }
@@ -577,26 +662,28 @@ LG_API int lg_raster_backward(const int* sorted_points, const int* start_index, 
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
     const int nslots = tiles ? K : ntiles;
     if (nslots <= 0) return 0;
+    if (N >= (1 << 26)) return (int)hipErrorInvalidValue;          // 32-bit record offsets
     hipStream_t s = (hipStream_t)stream;
     if (!g_use_order) order = nullptr;
-    const int wpb = g_bwd_wpb;
-    dim3 grid(lg_cdiv(nslots, wpb), V), block(64 * wpb);
-#define LAUNCH_RB(A_, B_, S_, T_, W_) hipLaunchKernelGGL((raster_backward_kernel<A_, B_, S_, T_, W_>), grid, block, 0, s, sorted_points, start_index, \
+    dim3 grid(lg_cdiv(nslots, 4), V), block(256);
+#define LAUNCH_RB(A_, B_, S_, T_, C_) hipLaunchKernelGGL((raster_backward_kernel<A_, B_, S_, T_, C_>), grid, block, 0, s, sorted_points, start_index, \
                                                          packed, tiles, K, final_T, last, d_img, d_trans, packed_grad, err_square_sum, tile_counters, order, \
-                                                         gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_dbg)
-#define LAUNCH_RBW(A_, B_, S_, T_) do { if (wpb == 1) LAUNCH_RB(A_, B_, S_, T_, 1); else if (wpb == 2) LAUNCH_RB(A_, B_, S_, T_, 2); else LAUNCH_RB(A_, B_, S_, T_, 4); } while (0)
+                                                         gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map)
 #define DISPATCH_RB(A_, B_)                                                   \
     do {                                                                      \
-        if (enable_stat) { if (d_trans) LAUNCH_RBW(A_, B_, true, true); else LAUNCH_RBW(A_, B_, true, false); } \
-        else { if (d_trans) LAUNCH_RBW(A_, B_, false, true); else LAUNCH_RBW(A_, B_, false, false); }           \
+        if (enable_stat) { if (d_trans) LAUNCH_RB(A_, B_, true, true, false); else LAUNCH_RB(A_, B_, true, false, false); } \
+        else { if (d_trans) LAUNCH_RB(A_, B_, false, true, false); else LAUNCH_RB(A_, B_, false, false, false); }           \
     } while (0)
-    if (TH == 8 && TW == 16) DISPATCH_RB(8, 16);
+    if (tile_counters != nullptr) {          // measurement variant: the plain 8x16 kernel with the two counters
+        if (TH != 8 || TW != 16 || enable_stat || d_trans) return (int)hipErrorInvalidValue;
+        LAUNCH_RB(8, 16, false, false, true);
+    }
+    else if (TH == 8 && TW == 16) DISPATCH_RB(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RB(16, 16);
     else if (TH == 12 && TW == 16) DISPATCH_RB(12, 16);
     else if (TH == 8 && TW == 8) DISPATCH_RB(8, 8);
     else return (int)hipErrorInvalidValue;
 #undef DISPATCH_RB
-#undef LAUNCH_RBW
 #undef LAUNCH_RB
     LG_RETURN_LAST();
 }

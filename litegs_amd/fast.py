@@ -77,6 +77,16 @@ class FusedRenderer:
         return _RenderFn.apply(self, frame, cluster_origin, cluster_extend, degree, xyz, scale, rot, sh_0, sh_rest, opacity)
 
 
+def _d_opacity(pg, ws1, N):
+    """gradient w.r.t. the ACTIVATED opacity from the blend backward's moment record: slot 8 holds sum(m) = opacity * d_opacity
+    (csrc/raster.hip); the opacity is dword 5 of the packed splat record at the head of workspace 1's `packed` area."""
+    L = lib()
+    off = L.lg_fused_packed_offset(N)
+    rec = ws1[off:off + 4 * N * L.lg_packed_record_floats()].view(torch.float32).view(N, L.lg_packed_record_floats())
+    o = rec[:, 5]
+    return torch.where(o > 0, pg[:, 8] / o, torch.zeros_like(o)).reshape(1, 1, N)
+
+
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, R: FusedRenderer, frame: CameraFrame, origin, extend, degree, xyz, scale, rot, sh_0, sh_rest, opacity):
@@ -193,7 +203,7 @@ class _RenderFn(torch.autograd.Function):
             if stat:
                 fc, fw = ctx.stat_bufs
                 STATS.add_moments("fragment_weight", fw, fw * fw, fc)
-                STATS.add_moments("fragment_err", pg[:, 8].reshape(1, 1, N), esq, fc)
+                STATS.add_moments("fragment_err", _d_opacity(pg, ws1, N), esq, fc)
             R.pending = dict(pg=pg, A=A, S=S, frame=frame, degree=degree, chunks=chunks, Rr=Rr, vis_ids=vis_ids, vis_num=vis_num)
             return (None,) * 11
         d_pos = torch.empty((3, A, S), dtype=torch.float32, device=dev)
@@ -213,7 +223,7 @@ class _RenderFn(torch.autograd.Function):
         if stat:
             fc, fw = ctx.stat_bufs
             # d_opacity of the activated opacity = packed_grad slot 8 (rasterize_backward's 4th output)
-            d_op_act = pg[:, 8].reshape(1, 1, N)
+            d_op_act = _d_opacity(pg, ws1, N)
             STATS.add_moments("fragment_weight", fw, fw * fw, fc)
             STATS.add_moments("fragment_err", d_op_act, esq, fc)
         ids = vis_ids[:A]

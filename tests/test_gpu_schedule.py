@@ -50,7 +50,9 @@ def test_schedule_does_not_change_results(oracle):
     c = case("small")
     H, W = c["H"], c["W"]
     L = lib()
-    sp, ts, pk = _dev(res.sorted_point), _dev(res.tile_start), _dev(res.packed)
+    sp, ts = _dev(res.sorted_point), _dev(res.tile_start)
+    pos, sc, rt, col, op = res.act
+    pk = F.rasterize_forward(sp, ts, _dev(res.ndc), _dev(res.inv_cov), _dev(col), _dev(op), None, H, W, 8, 16, False, False, False)[4]
     outs = []
     for use in (1, 0):
         check(L.lg_set_tuning(4, use), "tuning")

@@ -40,7 +40,3 @@ L.lg_set_tuning(4, 0)
 measure("no schedule (band per XCD)")
 L.lg_set_tuning(4, 1)
 measure("schedule again")
-for d, name in ((4, "no body"), (2, "no reduce")):
-    L.lg_set_tuning(3, d)
-    measure(f"dbg {d}: {name}")
-L.lg_set_tuning(3, 0)
