@@ -213,14 +213,26 @@ int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float
                     int do_cull, uint8_t* visibility, int* vis_num, int64_t* vis_ids, int A,
                     void* ws1, long long ws1_bytes, int* host_feedback_vis, int* host_feedback_total,
                     void* cull_scratch /*nullable: persistent, lg_fused_cull_scratch_bytes(chunks), zeroed once*/, uint32_t cull_epoch /*1,2,3,.. per call*/,
+                    const int* sched_cull /*nullable: the frame's depth-bound block of its previous visit -> depth-bound culling (fused.hip)*/,
+                    int* sched_out /*nullable: the depth-bound block the coming lg_fused_stage2 fills; its head is cleared here*/,
                     void* stream);
 long long lg_fused_cull_scratch_bytes(int chunks);
 int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                     void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
                     float* img, float* trans, short* last, int* frag_count, float* frag_weight,
                     float* packed_grad_clear /*nullable [N,16]: zeroed on the side for the coming lg_fused_backward*/,
-                    const int* order_in /*nullable [T]: tile schedule for the blend forward*/,
-                    int* order_out /*nullable [T]: receives this visit's heaviest-first schedule; may alias order_in*/, void* stream);
+                    const int* order /*nullable int32[T]: the frame's heaviest-first tile schedule (raster.hip)*/,
+                    int* order_out /*nullable int32[T], may alias order: the schedule recomputed from this visit (one more launch)*/,
+                    const int* sched_in /*nullable: the frame's depth-bound block of its previous visit*/,
+                    int* sched_out /*nullable: this visit's depth-bound block, lg_sched_words() words*/,
+                    int cull_active /*stage 1 culled against sched_in: verify, and enqueue the gated fallback*/,
+                    long long L_cull /*table length the culled run is sized for (<= L)*/,
+                    int* host_feedback_full /*nullable pinned int: full table length, written when the fallback ran*/,
+                    const float* view_host, const float* proj_host, int degree, int chunks,
+                    const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa,
+                    const int64_t* vis_ids, const int* vis_num, void* stream);
+long long lg_sched_words(int H, int W, int TH, int TW);   /* 32-bit words of a per-frame depth-bound block (csrc/lg_tilewalk.h) */
+long long lg_fused_flags_offset(long long N);   /* int32[2] in workspace 1: {fallback flag of the last stage 2, full table length if it ran} */
 int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
                       const void* ws2, long long ws2_bytes, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                       const int64_t* vis_ids, const int* vis_num,
@@ -228,7 +240,7 @@ int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, c
                       const int* tiles, int K, const float* final_T, const short* last, const float* d_img, const float* d_trans,
                       const float* grad_inv_scaler, int enable_stat, float* packed_grad, int packed_grad_is_zero, float* err_square_sum,
                       float* d_pos, float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa,
-                      const int* order /*nullable [T]: tile schedule of the blend backward*/, void* stream);
+                      const int* order /*nullable int32[T]: the frame's tile schedule*/, void* stream);
 int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                            const int64_t* vis_ids, const int* vis_num, const float* packed_grad, const float* grad_inv_scaler,
                            float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,

@@ -236,8 +236,10 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
                                                         int* __restrict__ totals /*nullable [passes][256]*/, DigitSpec ds,
                                                         uint32_t* __restrict__ zero_ptr, long long zero_words,
                                                         uint32_t* __restrict__ ones_ptr, long long ones_words,
-                                                        uint32_t* __restrict__ zero2_ptr, long long zero2_words)
+                                                        uint32_t* __restrict__ zero2_ptr, long long zero2_words,
+                                                        const int* __restrict__ gate, int* __restrict__ trunc_flag)
 {
+    if (gate != nullptr && *gate == 0) return;            // fallback launch of the depth-bound culling that is not needed (fused.hip)
     __shared__ LdsKeyT buf[DUP_LDS_ENTRIES];              // 16/32 KiB: compacted keys of the small splats
     __shared__ int t_loff[TPB + 1];                       // per-thread start in buf
     __shared__ int t_goff[TPB];                           // per-thread start in the table
@@ -291,6 +293,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             // the table becomes key 0 = "no tile".  Values too (the table is not pre-cleared on the fused path), and the padding keys
             // are counted into the sort's digit totals (digit 0 of every pass) -- the sort then handles exactly table_len keys.
             for (long long q = off; q < table_len; q++) { kout[q] = 0; vout[q] = 0; }
+            if (trunc_flag) atomicOr(trunc_flag, 1);          // the table was under-predicted: the culled run asks for the fallback
             if (totals)
                 for (int p = 0; p < ds.passes; p++) atomicAdd(&totals[p * 256], (int)(table_len - off));
         }
@@ -427,8 +430,9 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                                                       const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                       long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
                                                       const int* __restrict__ qcount, const uint32_t* __restrict__ qentries,
-                                                      int* __restrict__ totals, DigitSpec ds)
+                                                      int* __restrict__ totals, DigitSpec ds, const int* __restrict__ gate)
 {
+    if (gate != nullptr && *gate == 0) return;
     __shared__ int w_minv[TPB / 64][DUP_MAX_SLICES];      // per-wave slice scratch
     __shared__ int w_off[TPB / 64][DUP_MAX_SLICES + 1];
     __shared__ int c_idx[TPB / 64][DUP_MAX_SLICES];       // r-th non-empty slice
@@ -609,6 +613,17 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
                 int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
                 uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words, void* stream)
 {
+    return lg_dup_emit_gated(ndc, inv_cov, opacity, packed, prefix, sorted_id, sorted_id_is_int64, V, N, H, W, TH, TW, table_len, keys, values,
+                             qcount, qentries, totals, begin_bit, end_bit, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words,
+                             nullptr, nullptr, stream);
+}
+
+int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
+                      int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
+                      int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
+                      uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words,
+                      const int* gate, int* trunc_flag, void* stream)
+{
     if (N <= 0) return 0;
     if (packed && sorted_id_is_int64) return (int)hipErrorInvalidValue;     // packed records: fused executor only (int32 order)
     if (N >= (1 << 24)) return (int)hipErrorInvalidValue;                   // queue entries carry the depth slot in 24 bits
@@ -628,12 +643,12 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
     do {                                                                                                                                   \
         if (gx * gy + 1 <= 0xffff)                                                                                                         \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag); \
         else                                                                                                                               \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,   \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag); \
         hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
-                           N, H, W, gx, gy, table_len, keys, values, (const int*)qcount, (const uint32_t*)qentries, totals, ds);            \
+                           N, H, W, gx, gy, table_len, keys, values, (const int*)qcount, (const uint32_t*)qentries, totals, ds, gate);      \
     } while (0)
 #define DISPATCH_DUP(A_, B_)                                              \
     do {                                                                  \
@@ -900,6 +915,7 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
     int* digit_base = digit_base_[half]; int* global_base = global_base_[half];
     int* wsum = wsum_[half]; int* wsum_g = wsum_g_[half];
     n = bounded_n(n, n_dev);
+    if (n <= 0) return;                              // nothing to sort (a gated fallback pass that is not needed): no ticket traffic
     if (threadIdx.x == 0) bid_s = atomicAdd(ticket, 1);
 #pragma unroll
     for (int w = 0; w < NW; w++) wave_cnt[w][tid] = 0;
@@ -1328,14 +1344,22 @@ __global__ void __launch_bounds__(TPB) scan_apply_kernel(const int32_t* __restri
 // sort; wave 0 inspects 64 predecessors per step), so the gathered values are read once and there is no spine launch.
 // status[ntiles] and ticket[1] must be zero on entry.  host_total (nullable): pinned host int that receives out[n-1]
 // (the GPU-driven sizing feedback, litegs/data.py:238) -- stored by the kernel itself instead of a copy launch.
+// mode: how a source word is read -- 0 as is; 1 "culled view" of an encoded tile count (sign bit = splat removed by the depth-bound
+// culling: counts 0); 2 "full view" (sign bit masked off).  gate (nullable): the launch does nothing unless *gate != 0 (then
+// total_out, if given, receives 0); total_out (nullable): device copy of out[n-1].
 template <typename IdxT>
 __global__ void __launch_bounds__(TPB) scan_lookback_kernel(const int32_t* __restrict__ src, const IdxT* __restrict__ idx, long long n,
                                                             int32_t* __restrict__ out, uint32_t* __restrict__ status,
-                                                            int* __restrict__ ticket, int* __restrict__ host_total)
+                                                            int* __restrict__ ticket, int* __restrict__ host_total,
+                                                            int mode, const int* __restrict__ gate, int* __restrict__ total_out)
 {
     __shared__ int wsum[TPB / 64];
     __shared__ int bid_s, excl_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (gate != nullptr && *gate == 0) {
+        if (total_out != nullptr && blockIdx.x == 0 && tid == 0) *total_out = 0;
+        return;
+    }
     if (tid == 0) bid_s = atomicAdd(ticket, 1);
     __syncthreads();
     const int bid = bid_s;
@@ -1343,7 +1367,12 @@ __global__ void __launch_bounds__(TPB) scan_lookback_kernel(const int32_t* __res
     int v[SORT_ITEMS];
     int s = 0;
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; j++) { v[j] = scan_load(src, idx, base + j, n); s += v[j]; }
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        int x = scan_load(src, idx, base + j, n);
+        if (mode == 1) x = x < 0 ? 0 : x;
+        else if (mode == 2) x &= 0x7fffffff;
+        v[j] = x; s += x;
+    }
     int incl = s;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1387,6 +1416,7 @@ __global__ void __launch_bounds__(TPB) scan_lookback_kernel(const int32_t* __res
         run += v[j];
         if (base + j < n) out[base + j] = run;
         if (host_total && base + j == n - 1) __hip_atomic_store(host_total, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (total_out && base + j == n - 1) *total_out = run;
     }
 }
 
@@ -1395,10 +1425,16 @@ long long lg_scan_status_words(long long n) { return (n + SORT_TILE - 1) / SORT_
 
 int lg_gather_scan_prepared(const int32_t* src, const int32_t* idx, long long n, int32_t* out, uint32_t* status, int* host_total, void* stream)
 {
+    return lg_gather_scan_gated(src, idx, n, out, status, host_total, 0, nullptr, nullptr, stream);
+}
+
+int lg_gather_scan_gated(const int32_t* src, const int32_t* idx, long long n, int32_t* out, uint32_t* status, int* host_total,
+                         int mode, const int* gate, int* total_out, void* stream)
+{
     if (n <= 0) return 0;
     int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
     hipLaunchKernelGGL(scan_lookback_kernel<int32_t>, dim3(ntiles), dim3(TPB), 0, (hipStream_t)stream, src, idx, n, out, status,
-                       (int*)(status + ntiles), host_total);
+                       (int*)(status + ntiles), host_total, mode, gate, total_out);
     LG_RETURN_LAST();
 }
 

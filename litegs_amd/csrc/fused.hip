@@ -42,13 +42,18 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
                                      const float* __restrict__ sh0, const float* __restrict__ shr, const float* __restrict__ opa,
                                      int C, int S, int A,
                                      float* __restrict__ view_z, int* __restrict__ alloc, float4* __restrict__ packed, int gx, int gy,
-                                     uint32_t* __restrict__ zero_ptr, long long zero_words)
+                                     uint32_t* __restrict__ zero_ptr, long long zero_words,
+                                     uint32_t* __restrict__ zero3_ptr, long long zero3_words,
+                                     const float* __restrict__ bound_pyr, const int* __restrict__ gate)
 {
+    if (gate != nullptr && *gate == 0) return;          // fallback launch of the depth-bound culling that is not needed
     const int a = blockIdx.x, t = threadIdx.x;
     const size_t N = (size_t)A * S;
     const size_t i = (size_t)a * S + t;
-    // zero duty: sort headers, look-back table and the big-splat counter of the kernels that follow (no fill launches)
+    // zero duty: sort headers, look-back table and the big-splat counter of the kernels that follow (no fill launches), and the head
+    // (bucket counts, upper bound levels) of the frame's sched block the coming blend forward fills
     for (long long z = (long long)i; z < zero_words; z += (long long)N) zero_ptr[z] = 0u;
+    for (long long z = (long long)i; z < zero3_words; z += (long long)N) zero3_ptr[z] = 0u;
     if (a >= visible_chunks_num[0]) {
         alloc[i] = 0;
         view_z[i] = 3.0e38f;            // sorts last and emits nothing
@@ -71,9 +76,15 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     J6[0] = j4[0]; J6[1] = 0.0f; J6[2] = 0.0f; J6[3] = j4[1]; J6[4] = j4[2]; J6[5] = j4[3];
     lg_cov2d(T9, cam.V, J6, c4);
     lg_inv2x2(c4[0], c4[1], c4[2], c4[3], i4);
-    const int tiles = lg_tile_count<TH, TW>(n[0], n[1], v[2], i4[0], i4[1], i4[3], o, cam.H, cam.W, gx, gy);     // a8, fused
-    // ---- SH -> RGB (+0.5, no clamp).  Only for splats that touch a tile: a third of the Gaussians of the visible CHUNKS fail
-    // the fine test (frustum / opacity / degenerate), and the 48 SH coefficients are 76 % of a Gaussian's bytes
+    int rect[4];
+    int tiles = lg_tile_count<TH, TW>(n[0], n[1], v[2], i4[0], i4[1], i4[3], o, cam.H, cam.W, gx, gy, rect);     // a8, fused
+    // ---- depth-bound culling (see "depth-bound culling" below): deeper than the saturation bound of every tile of its rectangle ->
+    // keeps its count (sign bit set: the culled view of the prefix sum counts it as 0) but emits nothing
+    if (bound_pyr != nullptr && tiles > 0 && v[2] > lg_bound_query(bound_pyr, gx, gy, rect[0], rect[1], rect[2], rect[3]))
+        tiles |= (int)0x80000000u;
+    // ---- SH -> RGB (+0.5, no clamp).  Only for splats that are emitted: a third of the Gaussians of the visible CHUNKS fail
+    // the fine test (frustum / opacity / degenerate), most of the rest are culled by depth, and the 48 SH coefficients are 76 % of
+    // a Gaussian's bytes
     float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
     if (tiles > 0) {
         float cx, cy, cz, dx, dy, dz;
@@ -99,7 +110,7 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     rec[0] = make_float4(ppx, ppy, -0.5f * i4[0] * LOG2E, -i4[1] * LOG2E);       // layout: raster.hip
     rec[1] = make_float4(-0.5f * i4[3] * LOG2E, o, r0, r1);
     rec[2] = make_float4(r2, i4[0], i4[1], i4[3]);
-    rec[3] = make_float4(n[2], n[0], n[1], lg_log2_opacity(o));                 // 13,14: ndc for the tile walk (binning.hip load_splat); 15: blend exponent offset
+    rec[3] = make_float4(v[2], n[0], n[1], lg_log2_opacity(o));                 // 12: VIEW depth (depth bounds); 13,14: ndc for the tile walk (binning.hip load_splat); 15: blend exponent offset
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -293,6 +304,8 @@ struct Layout1 {      // sized by N = A*S (per-Gaussian buffers)
     // [zeroed, zeroed + zero_bytes) must be zero after the projection: depth-sort header | tile-sort header | depth-sort look-back
     // table | scan look-back words | head of dup_queue (the big-splat sub-queue counters).  Cleared on the side by the culling kernel ("zero duty").
     size_t zeroed, zero_bytes, dsort_hdr, tsort_hdr, dsort_table, scan_status, dup_queue;
+    // second set for the gated fallback of the depth-bound culling + its two device flags (fail flag | full total), same zeroed region
+    size_t tsort_hdr2, scan_status2, dup_queue2, flags;
 };
 struct Layout2 {      // sized by the tile-instance table length L
     size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, tile_work, dup_entries, total;
@@ -316,7 +329,11 @@ static Layout1 layout1(long long N)
     f.dsort_hdr = f.zeroed; f.tsort_hdr = f.zeroed + hdr; f.dsort_table = f.zeroed + 2 * hdr;
     f.scan_status = f.dsort_table + 4 * (size_t)lg_radix_table_words(N, 4);
     f.dup_queue = take(4 * 64);                                // the 64 sub-queue counters (the entries live in workspace 2: their number depends on L)
-    f.zero_bytes = f.dup_queue + 4 * 64 - f.zeroed;
+    f.tsort_hdr2 = take(hdr);
+    f.scan_status2 = take(4 * (size_t)lg_scan_status_words(N));
+    f.dup_queue2 = take(4 * 64);
+    f.flags = take(4 * 64);
+    f.zero_bytes = f.flags + 4 * 64 - f.zeroed;
     f.total = o;
     return f;
 }
@@ -363,16 +380,70 @@ static Camera make_camera(const float* view_host, const float* proj_host, int H,
     return c;
 }
 
-// Stage 1: cull (unless vis_ids already computed) -> fused projection -> tile counts -> depth order -> prefix sums.
+// ---------------------------------------------------------------------------------------------
+// Depth-bound culling (no reference counterpart; the reference emits, sorts and range-scans every tile instance).
+//
+// At 3 M Gaussians @1080p a tile's list holds ~720 splats of which the blend walks ~85 before every pixel is saturated: 88 % of the
+// emitted instances are never read.  Each visit of a frame therefore records, per tile, a view depth a safe margin BEHIND the point
+// where the tile saturated (raster.hip, end of the blend forward) and the maxima of these bounds over 2^k x 2^k tile blocks (a
+// pyramid).  The next visit of the same frame drops, in the projection kernel, every splat that lies deeper than the bound of every
+// tile its rectangle touches (one 2 x 2 pyramid lookup): it keeps its depth-sort slot but counts zero instances.  The lists that
+// are built are exact prefixes (in depth) of the full lists up to each tile's bound, so the blend is bit-identical to the unculled
+// one PROVIDED every tile saturates at or before its bound.  The forward checks exactly that per tile; a violated bound (or a table
+// that turned out too short) raises a device flag, and a second, gated copy of the pipeline -- projection without culling, prefix
+// sum, emission, sort, ranges, blend -- that is always enqueued but exits at once while the flag is clear, redoes the frame in
+// full.  No host decision, no synchronisation; the common case pays seven empty launches.
+// ---------------------------------------------------------------------------------------------
+struct Scene {            // what the projection kernel reads (raw parameters + the frame's visible chunks)
+    const float *pos, *scale, *rot, *sh0, *shr, *opa;
+    const int64_t* vis_ids;
+    const int* vis_num;
+    int chunks, S, A, degree;
+};
+
+static int launch_projection(const Scene& sc, const Camera& cam, int TH, int TW, char* w, const Layout1& f, bool zero_duty,
+                             const int* sched_in /*nullable: cull against its depth bounds*/, int* sched_out /*nullable: head cleared*/,
+                             const int* gate, hipStream_t s)
+{
+    const float* bound_pyr = reinterpret_cast<const float*>(sched_in);
+    float* view_z = (float*)(w + f.view_z); float4* packed = (float4*)(w + f.packed);
+    int* alloc = (int*)(w + f.alloc);
+    const int gx = (cam.W + TW - 1) / TW, gy = (cam.H + TH - 1) / TH;
+#define LAUNCH_PF(D, A_, B_) hipLaunchKernelGGL((project_fused_kernel<D, A_, B_>), dim3(sc.A), dim3(sc.S), 0, s, sc.vis_ids, sc.vis_num, cam,   \
+                                                sc.pos, sc.scale, sc.rot, sc.sh0, sc.shr, sc.opa, sc.chunks, sc.S, sc.A, view_z, alloc, packed, \
+                                                gx, gy, (uint32_t*)(w + f.zeroed), zero_duty ? (long long)(f.zero_bytes / 4) : 0LL,             \
+                                                (uint32_t*)sched_out, sched_out ? lg_sched_clear_words(gx, gy) : 0LL, bound_pyr, gate)
+#define DISPATCH_PF(A_, B_)                                                  \
+    switch (sc.degree) {                                                     \
+    case 0: LAUNCH_PF(0, A_, B_); break;                                     \
+    case 1: LAUNCH_PF(1, A_, B_); break;                                     \
+    case 2: LAUNCH_PF(2, A_, B_); break;                                     \
+    case 3: LAUNCH_PF(3, A_, B_); break;                                     \
+    default: return (int)hipErrorInvalidValue;                               \
+    }
+    if (TH == 8 && TW == 16) { DISPATCH_PF(8, 16) }
+    else if (TH == 16 && TW == 16) { DISPATCH_PF(16, 16) }
+    else if (TH == 12 && TW == 16) { DISPATCH_PF(12, 16) }
+    else if (TH == 8 && TW == 8) { DISPATCH_PF(8, 8) }
+    else return (int)hipErrorInvalidValue;
+#undef DISPATCH_PF
+#undef LAUNCH_PF
+    return (int)hipGetLastError();
+}
+
+// Stage 1: cull (unless vis_ids already computed) -> fused projection + tile counts -> depth order -> prefix sums.
 // view_host / proj_host are HOST copies of the 4x4 matrices (passed by value to the kernels: no device reads of them).
-// Afterwards prefix[N-1] (device) is the exact table length; it is copied to host_feedback_total if given.
+// Afterwards prefix[N-1] (device) is the table length; it is copied to host_feedback_total if given.
+// sched_cull (nullable): this frame's sched block of its previous visit -> depth-bound culling against its bounds.
+// sched_out (nullable): the block this visit's blend forward will fill; its head is cleared here.
 LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
                            const float* view_host, const float* proj_host, int H, int W, int TH, int TW, int degree,
                            const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,
                            int do_cull, uint8_t* visibility, int* vis_num, int64_t* vis_ids, int A,
                            void* ws1, long long ws1_bytes,
                            int* host_feedback_vis, int* host_feedback_total,
-                           void* cull_scratch /*nullable: lg_fused_cull_scratch_bytes(chunks), zeroed once*/, unsigned int cull_epoch, void* stream)
+                           void* cull_scratch /*nullable: lg_fused_cull_scratch_bytes(chunks), zeroed once*/, unsigned int cull_epoch,
+                           const int* sched_cull, int* sched_out, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -391,92 +462,139 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
     if ((long long)f.total > ws1_bytes) return (int)hipErrorInvalidValue;
     char* w = (char*)ws1;
     Camera cam = make_camera(view_host, proj_host, H, W);
-    float* view_z = (float*)(w + f.view_z); float4* packed = (float4*)(w + f.packed);
-    const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
-    int* alloc = (int*)(w + f.alloc);
-#define LAUNCH_PF(D, A_, B_) hipLaunchKernelGGL((project_fused_kernel<D, A_, B_>), dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, pos, scale, rot, \
-                                                sh0, shr, opa, chunks, S, A, view_z, alloc, packed, gx, gy,             \
-                                                (uint32_t*)(w + f.zeroed), (long long)(f.zero_bytes / 4))
-#define DISPATCH_PF(A_, B_)                                                  \
-    switch (degree) {                                                        \
-    case 0: LAUNCH_PF(0, A_, B_); break;                                     \
-    case 1: LAUNCH_PF(1, A_, B_); break;                                     \
-    case 2: LAUNCH_PF(2, A_, B_); break;                                     \
-    case 3: LAUNCH_PF(3, A_, B_); break;                                     \
-    default: return (int)hipErrorInvalidValue;                               \
-    }
-    if (TH == 8 && TW == 16) { DISPATCH_PF(8, 16) }
-    else if (TH == 16 && TW == 16) { DISPATCH_PF(16, 16) }
-    else if (TH == 12 && TW == 16) { DISPATCH_PF(12, 16) }
-    else if (TH == 8 && TW == 8) { DISPATCH_PF(8, 8) }
-    else return (int)hipErrorInvalidValue;
-#undef DISPATCH_PF
-#undef LAUNCH_PF
-    rc = (int)hipGetLastError(); if (rc) return rc;
+    Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
+    rc = launch_projection(sc, cam, TH, TW, w, f, true, sched_cull, sched_out, nullptr, s); if (rc) return rc;
+    float* view_z = (float*)(w + f.view_z);
     rc = lg_depth_keys_hist(view_z, N, (uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (int*)(w + f.dsort_hdr), stream); if (rc) return rc;
     // the last pass also gathers the tile counts into depth order (into the prefix buffer, scanned in place below)
     rc = lg_radix_sort_prepared((uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (uint32_t*)(w + f.dk_b), (uint32_t*)(w + f.dv_b), N, nullptr, 0, 32,
                                 (int*)(w + f.dsort_hdr), (uint32_t*)(w + f.dsort_table), (const int32_t*)(w + f.alloc), (int32_t*)(w + f.prefix),
                                 stream);
     if (rc) return rc;
-    const bool odd = lg_radix_sort_num_passes(0, 32) % 2 == 1;
-    const void* order = odd ? (w + f.dv_b) : (w + f.dv_a);
-    // depth-ordered inclusive scan of the tile counts; prefix[N-1] (the exact table length) also goes to the host feedback slot
-    (void)order;
-    rc = lg_gather_scan_prepared((const int32_t*)(w + f.prefix), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
-                                 (uint32_t*)(w + f.scan_status), host_feedback_total, stream);
-    if (rc) return rc;
-    return 0;
+    // depth-ordered inclusive scan of the tile counts (culled splats count 0); prefix[N-1] (the table length) also goes to the host
+    // feedback slot
+    return lg_gather_scan_gated((const int32_t*)(w + f.prefix), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
+                                (uint32_t*)(w + f.scan_status), host_feedback_total, sched_cull ? 1 : 0, nullptr, nullptr, stream);
 }
 
-// Stage 2: key/value emission -> stable tile sort -> tile ranges -> blend forward.  L = table length of the layout.
+static int tile_key_bits(int ntiles)
+{
+    int bits = 0;
+    for (unsigned int mt = (unsigned int)ntiles; mt >>= 1;) bits++;
+    return bits + 1;
+}
+
+// key/value emission -> stable tile sort -> tile ranges -> blend forward over the table described by `prefix`; Ls = table length this
+// run is sized for (<= the capacity L of the layout).  hdr / qcount: the zeroed scratch set to use.
+static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, long long Ls, int H, int W, int TH, int TW,
+                             int* tsort_hdr, int* qcount, const int* tiles, int K, int enable_stat,
+                             float* img, float* trans, short* last, int* frag_count, float* frag_weight, float* packed_grad_clear,
+                             const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag, const int* gate,
+                             const int* total_dev, hipStream_t s)
+{
+    const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
+    const void* depth_order = odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a);
+    const int bits = tile_key_bits(ntiles);
+    // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
+    // clears the sort's look-back table.  No table memset: the bounded sort only reads the first prefix[N-1] entries, and a
+    // truncated table (Ls < total) gets its tail zeroed by the first splat that does not fit.
+    int rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
+                               (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
+                               qcount, (uint32_t*)(w + f.dup_entries), tsort_hdr, 0, bits, (uint32_t*)(w + f.tsort_table),
+                               (long long)lg_radix_table_words(Ls, lg_radix_sort_num_passes(0, bits)),
+                               (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * N : 0, gate, fail_flag, s);
+    if (rc) return rc;
+    // instance count on the device: only that many entries are sorted and range-scanned
+    rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
+                                total_dev, 0, bits, tsort_hdr, (uint32_t*)(w + f.tsort_table), nullptr, nullptr, s);
+    if (rc) return rc;
+    const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
+    const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
+    const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
+    rc = lg_tile_range_prefilled(sorted_keys, 1, Ls, total_dev, ntiles, (int32_t*)(w + f.tile_start), s); if (rc) return rc;
+    return lg_raster_forward_bounds(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
+                                    enable_stat, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order, tiles ? nullptr : tile_work,
+                                    tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, zb_check, fail_flag, gate, s);
+}
+
+static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, int H, int W, int TH, int TW,
+                            float* img, float* trans, short* last, float* packed_grad_clear, const int* order, int* tile_work,
+                            const int* sched_in, int* sched_out, int* host_feedback_full,
+                            const float* view_host, const float* proj_host, int degree, int chunks,
+                            const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa,
+                            const int64_t* vis_ids, const int* vis_num, int A, int S, hipStream_t s);
+
+// Stage 2: key/value emission -> stable tile sort -> tile ranges -> blend forward.  L = table capacity of the layout.
+// order (nullable [T]): heaviest-first tile schedule of the frame (raster.hip); order_out (nullable [T], may alias order): recomputed from
+// this visit's work per tile (one more launch -- callers refresh it every few visits).  sched_in (nullable): the frame's depth-bound
+// block of its previous visit (the bounds stage 1 culled with when cull_active).  sched_out (nullable): receives this visit's bounds.
+// cull_active: stage 1 culled against sched_in -> the bounds are verified and the gated fallback (which needs the projection's inputs
+// again) is enqueued; L_cull <= L then sizes the culled run.  host_feedback_full (nullable, pinned): receives the full table length
+// when the fallback ran.
 LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                            void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
                            float* img, float* trans, short* last, int* frag_count, float* frag_weight,
                            float* packed_grad_clear /*nullable: [N,16] gradient accumulator of the coming backward, zeroed on the side*/,
-                           const int* order_in /*nullable [T]: tile schedule of the blend forward (this frame's previous visit)*/,
-                           int* order_out /*nullable [T]: receives the heaviest-first schedule of THIS visit (may alias order_in)*/,
-                           void* stream)
+                           const int* order, int* order_out, const int* sched_in, int* sched_out, int cull_active, long long L_cull,
+                           int* host_feedback_full, const float* view_host, const float* proj_host, int degree, int chunks,
+                           const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa,
+                           const int64_t* vis_ids, const int* vis_num, void* stream)
 {
     if (A <= 0 || L <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
     const long long N = (long long)A * S;
-    const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH, ntiles = gx * gy;
     Layout1 f1 = layout1(N);
     Layout2 f = layout2(L, ntiles, N);
     if ((long long)f1.total > ws1_bytes || (long long)f.total > ws2_bytes) return (int)hipErrorInvalidValue;
     char* w1 = (char*)ws1;            // stage 2 updates the tile-sort header and the big-splat queue that live in workspace 1
     char* w = (char*)ws2;
-    int rc;
-    const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
-    const void* order = odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a);
-    int bits = 0;
-    for (unsigned int mt = (unsigned int)ntiles; mt >>= 1;) bits++;
-    bits++;
-    // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
-    // clears the sort's look-back table.  No table memset: the bounded sort only reads the first prefix[N-1] entries, and a
-    // truncated table (L < total) gets its tail zeroed by the first splat that does not fit.
-    rc = lg_dup_emit(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
-                     (const int32_t*)(w1 + f1.prefix), order, 0, 1, (int)N, H, W, TH, TW, L, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
-                     (int*)(w1 + f1.dup_queue), (uint32_t*)(w + f.dup_entries), (int*)(w1 + f1.tsort_hdr), 0, bits, (uint32_t*)(w + f.tsort_table),
-                     (long long)lg_radix_table_words(L, lg_radix_sort_num_passes(0, bits)),
-                     (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
-                     (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * N : 0, stream);
-    if (rc) return rc;
-    // exact instance count on the device (prefix[N-1]): only that many entries are sorted and range-scanned
+    if (tiles != nullptr || enable_stat) { sched_in = nullptr; sched_out = nullptr; order_out = nullptr; if (cull_active) return (int)hipErrorInvalidValue; }
+    int* tile_work = order_out ? (int*)(w + f.tile_work) : nullptr;
+    if (cull_active && (sched_in == nullptr || sched_out == nullptr)) return (int)hipErrorInvalidValue;
+    int* fail_flag = (int*)(w1 + f1.flags);
+    const long long Ls = (cull_active && L_cull > 0 && L_cull < L) ? L_cull : L;
     const int* total_dev = (const int*)(w1 + f1.prefix) + (N - 1);
-    rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), L,
-                                total_dev, 0, bits, (int*)(w1 + f1.tsort_hdr), (uint32_t*)(w + f.tsort_table), nullptr, nullptr, stream);
+    int rc = binning_and_blend(w1, f1, w, f, N, L, Ls, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr), (int*)(w1 + f1.dup_queue), tiles, K, enable_stat,
+                               img, trans, last, frag_count, frag_weight, packed_grad_clear, order, tile_work, sched_in, sched_out,
+                               cull_active, cull_active ? fail_flag : nullptr, nullptr, total_dev, s);
     if (rc) return rc;
-    const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
-    const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
-    const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
-    rc = lg_tile_range_prefilled(sorted_keys, 1, L, total_dev, ntiles, (int32_t*)(w + f.tile_start), stream); if (rc) return rc;
-    rc = lg_raster_forward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
-                           enable_stat, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order_in,
-                           (order_out && !tiles) ? (int*)(w + f.tile_work) : nullptr, stream);
-    if (rc || order_out == nullptr || tiles != nullptr) return rc;
-    return lg_tile_order((const int*)(w + f.tile_work), 1, ntiles, order_out, stream);
+    if (cull_active) { rc = culling_fallback(w1, f1, w, f, N, L, H, W, TH, TW, img, trans, last, packed_grad_clear, order, tile_work, sched_in, sched_out,
+                                              host_feedback_full, view_host, proj_host, degree, chunks, pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, A, S, s);
+                       if (rc) return rc; }
+    if (order_out != nullptr) return lg_tile_order(tile_work, 1, ntiles, order_out, s);
+    return 0;
 }
+
+static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, int H, int W, int TH, int TW,
+                            float* img, float* trans, short* last, float* packed_grad_clear, const int* order, int* tile_work,
+                            const int* sched_in, int* sched_out, int* host_feedback_full,
+                            const float* view_host, const float* proj_host, int degree, int chunks,
+                            const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa,
+                            const int64_t* vis_ids, const int* vis_num, int A, int S, hipStream_t s)
+{
+    int* fail_flag = (int*)(w1 + f1.flags);
+    int* full_total = fail_flag + 1;
+    int rc;
+    // the gated fallback: everything below returns at once unless the culled run raised the flag.  The projection is repeated without
+    // culling (records of the culled splats carry no colour yet) and clears the head of sched_out again.
+    Camera cam = make_camera(view_host, proj_host, H, W);
+    Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
+    rc = launch_projection(sc, cam, TH, TW, w1, f1, false, nullptr, sched_out, fail_flag, s); if (rc) return rc;
+    const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
+    const int32_t* depth_order = (const int32_t*)(odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));
+    rc = lg_gather_scan_gated((const int32_t*)(w1 + f1.alloc), depth_order, N, (int32_t*)(w1 + f1.prefix), (uint32_t*)(w1 + f1.scan_status2),
+                              host_feedback_full, 0, fail_flag, full_total, s);
+    if (rc) return rc;
+    return binning_and_blend(w1, f1, w, f, N, L, L, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr2), (int*)(w1 + f1.dup_queue2), nullptr, 0, 0,
+                             img, trans, last, nullptr, nullptr, packed_grad_clear, order, tile_work, sched_in, sched_out, 0, nullptr, fail_flag,
+                             full_total, s);
+}
+
+// 1 if the culled run of the last lg_fused_stage2 on this workspace raised the fail flag (device word; read it after a sync) -- tests
+LG_API long long lg_fused_flags_offset(long long N) { return (long long)layout1(N).flags; }
 
 // Backward: blend backward (atomics into packed_grad) -> fused per-Gaussian backward -> six compact gradients.
 LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
@@ -488,7 +606,7 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
                              float* packed_grad /*[N,16] scratch*/, int packed_grad_is_zero /*cleared by lg_fused_stage2*/, float* err_square_sum,
                              float* d_pos /*NULL: blend backward only (gradients consumed later by lg_fused_backward_adam)*/,
                              float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa,
-                             const int* order /*nullable [T]: tile schedule (lg_fused_stage2's order_out)*/, void* stream)
+                             const int* order /*nullable [T]: the frame's tile schedule*/, void* stream)
 {
     if (A <= 0 || L <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;

@@ -33,9 +33,21 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
                 uint32_t* ones_ptr /*filled with 0xffffffff*/, long long ones_words,
                 uint32_t* zero2_ptr /*16-byte aligned, also cleared on the side (the backward's gradient accumulator)*/, long long zero2_words, void* stream);
 
+// the same with a gate (nullable device int: the launches do nothing unless *gate != 0) and a truncation flag (nullable: set when the
+// table turns out too short for the prefix sums)
+int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
+                      int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
+                      int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
+                      uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words,
+                      const int* gate, int* trunc_flag, void* stream);
+
 // gathered inclusive scan in one launch; status = lg_scan_status_words(n) zero words; host_total (nullable) = pinned host int
 long long lg_scan_status_words(long long n);
 int lg_gather_scan_prepared(const int32_t* src, const int32_t* idx, long long n, int32_t* out, uint32_t* status, int* host_total, void* stream);
+// mode 0: source words as they are; 1 / 2: culled / full view of tile counts whose sign bit marks a culled splat.  gate (nullable):
+// nothing happens unless *gate != 0 (total_out then receives 0).  total_out (nullable): device copy of the last prefix.
+int lg_gather_scan_gated(const int32_t* src, const int32_t* idx, long long n, int32_t* out, uint32_t* status, int* host_total,
+                         int mode, const int* gate, int* total_out, void* stream);
 
 // tileRange on a table whose output was pre-filled with -1
 int lg_tile_range_prefilled(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream);
@@ -48,3 +60,10 @@ int lg_frustum_culling_fb(const float* origin, const float* ext, const float* pl
 long long lg_cull_scratch_bytes(int M);
 int lg_frustum_culling_chain(const float* origin, const float* ext, const float* planes, int V, int M, uint8_t* visibility, int* visible_num,
                              int64_t* visible_chunk_id, void* scratch, unsigned int epoch, int* host_feedback, void* stream);
+
+// blend forward reading / filling the per-frame depth-bound blocks of lg_tilewalk.h (raster.hip; see fused.hip "depth-bound culling")
+int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
+                             int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
+                             float* img, float* trans, short* last, int* frag_count, float* frag_weight,
+                             const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag, const int* gate,
+                             void* stream);

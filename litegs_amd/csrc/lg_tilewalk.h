@@ -118,9 +118,11 @@ __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int
 // slightly negative discriminant (sqrt -> NaN) and the slice then uses the other line's intersection, as in the reference.
 
 
-// visibility test + exact tile count of one splat (reference: GR/binning.cu:310-373)
+// visibility test + exact tile count of one splat (reference: GR/binning.cu:310-373); rect (nullable) receives the tile rectangle
+// [x0, x1) x [y0, y1) the walk stays inside
 template <int TH, int TW>
-__device__ __forceinline__ int lg_tile_count(float nx, float ny, float view_z, float a, float bb, float c, float o, int H, int W, int gx, int gy)
+__device__ __forceinline__ int lg_tile_count(float nx, float ny, float view_z, float a, float bb, float c, float o, int H, int W, int gx, int gy,
+                                             int* rect = nullptr)
 {
     float disc = bb * bb - a * c;
     bool vis = !((nx < -1.3f) || (nx > 1.3f) || (ny < -1.3f) || (ny > 1.3f) || (view_z <= 0.2f) || (o < 1.0f / 255));
@@ -129,5 +131,48 @@ __device__ __forceinline__ int lg_tile_count(float nx, float ny, float view_z, f
     SplatExtent e;
     splat_extent<TH, TW>(nx, ny, a, bb, c, o, H, W, gx, gy, e);
     if ((e.rmaxy - e.rminy) * (e.rmaxx - e.rminx) <= 0) return 0;
+    if (rect) { rect[0] = e.rminx; rect[1] = e.rmaxx; rect[2] = e.rminy; rect[3] = e.rmaxy; }
     return (int)walk_tiles<TH, TW, false>(e, gx, 0, 0, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-frame depth-bound block ("bounds", no reference counterpart; see fused.hip "depth-bound culling").  Written by the blend forward
+// of one visit of a frame (plain stores + atomicMax, no extra launch), read by the next visit of the same frame.  Floats:
+//   [0, U)          pyramid levels 1..3: max of level 0 over 2^k x 2^k tile blocks (positive floats, atomicMax on their bit patterns)
+//   [U, U + T)      level 0: one view-depth bound per tile (T = gx * gy)
+// The first U words must be zero before the forward that fills the block (cleared by the projection kernel's zero duty).
+// ---------------------------------------------------------------------------------------------
+#define LG_PYR_LEVELS 4
+__host__ __device__ static inline int lg_pyr_w(int g, int k) { return (g + (1 << k) - 1) >> k; }
+__host__ __device__ static inline long long lg_sched_upper_words(int gx, int gy)
+{
+    long long o = 0;
+    for (int k = 1; k < LG_PYR_LEVELS; k++) o += (long long)lg_pyr_w(gx, k) * lg_pyr_w(gy, k);
+    return o;
+}
+__host__ __device__ static inline long long lg_sched_level_offset(int gx, int gy, int k)      // word offset of pyramid level k
+{
+    if (k == 0) return lg_sched_upper_words(gx, gy);
+    long long o = 0;
+    for (int j = 1; j < k; j++) o += (long long)lg_pyr_w(gx, j) * lg_pyr_w(gy, j);
+    return o;
+}
+__host__ __device__ static inline long long lg_sched_words_total(int gx, int gy) { return lg_sched_upper_words(gx, gy) + (long long)gx * gy; }
+__host__ __device__ static inline long long lg_sched_clear_words(int gx, int gy) { return lg_sched_upper_words(gx, gy); }
+
+// upper bound of the maximum of the level-0 bounds over the tile rectangle [x0, x1) x [y0, y1): cells of the coarsest stored level
+// that keeps the lookup at <= 16 cells; larger rectangles are not culled (+inf)
+__device__ __forceinline__ float lg_bound_query(const float* __restrict__ sched, int gx, int gy, int x0, int x1, int y0, int y1)
+{
+    const int span = max(x1 - x0, y1 - y0);                       // >= 1
+    int k = span <= 1 ? 0 : 32 - __clz(span - 1);                 // 2^k >= span: at most 2 cells per axis
+    if (k > LG_PYR_LEVELS - 1) k = LG_PYR_LEVELS - 1;
+    const int cx0 = x0 >> k, cx1 = (x1 - 1) >> k, cy0 = y0 >> k, cy1 = (y1 - 1) >> k;
+    if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 16) return __builtin_inff();
+    const int wk = lg_pyr_w(gx, k);
+    const float* __restrict__ lv = sched + lg_sched_level_offset(gx, gy, k);
+    float m = 0.0f;
+    for (int cy = cy0; cy <= cy1; cy++)
+        for (int cx = cx0; cx <= cx1; cx++) m = fmaxf(m, lv[cy * wk + cx]);
+    return m;
 }

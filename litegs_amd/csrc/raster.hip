@@ -29,6 +29,8 @@
 // the statistic-mode err_square running sum (GR/raster.cu:781-783) is defined over.
 #include "lg_common.h"
 #include "lg_chain.h"
+#include "lg_tilewalk.h"
+#include "lg_binning_internal.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #define REC 16                 // floats per packed splat record (64 B, one cache line)
@@ -209,8 +211,11 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
                                                              float* __restrict__ img, float* __restrict__ trans, short* __restrict__ last,
                                                              int* __restrict__ frag_count, float* __restrict__ frag_weight,
                                                              const int* __restrict__ order, int* __restrict__ tile_work,
+                                                             const int* __restrict__ sched_in, int* __restrict__ sched_out, int zb_check,
+                                                             int* __restrict__ fail_flag, const int* __restrict__ gate,
                                                              int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode)
 {
+    if (gate != nullptr && *gate == 0) return;              // fallback launch of the depth-bound culling that is not needed
     constexpr int PPL = TileMap<TH, TW>::PPL;
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
@@ -237,9 +242,10 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     for (int k = 0; k < PPL; k++) { st.Y[k] = (float)(y0 + 2 * k); st.T[k] = 1.0f; st.Cr[k] = st.Cg[k] = st.Cb[k] = 0.0f; st.lc[k] = 0; }
 
     int visited = 0;
-    if (start >= 0 && end > start) {
-        const int n = end - start;
-        const int* __restrict__ sp = sorted_points + (size_t)view * L + start;
+    bool live = true;
+    const int n = (start >= 0 && end > start) ? end - start : 0;
+    const int* __restrict__ sp = sorted_points + (size_t)view * L + (start >= 0 ? start : 0);
+    if (n > 0) {
         // ids of the list, 64 at a time: lane l of `nxt` holds the id at position c0 + l + 1, i.e. the splat to REQUEST while
         // position c0 + l is blended (clamped at the list end: the surplus request is never used)
         unsigned off_a = (unsigned)rfl(sp[0]) << 6, off_b = 0;
@@ -247,7 +253,6 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
         rec_request(ra, pk, off_a);
         int nxt = sp[min(lane + 1, n - 1)];
         rec_wait(ra);
-        bool live = true;
         for (int c0 = 0; c0 < n && live; c0 += 64) {
             const int cnt = min(64, n - c0);                            // positions c0 .. c0 + cnt - 1 in this chunk
             const int nxt_next = sp[min(c0 + 64 + lane + 1, n - 1)];    // next chunk's ids, in flight while this chunk is blended
@@ -271,6 +276,42 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     }
     // work done for this tile (splats walked before every pixel saturated): the schedule key of the backward and of the next visit
     if (tile_work != nullptr && lane == 0) tile_work[(size_t)view * (ntiles + 1) + tile] = visited;
+    // Depth bounds of this visit (single view; "bounds" block of lg_tilewalk.h).
+    // Depth-bound culling (fused.hip): level 0 of sched_in holds, per tile, the view depth beyond which this frame's previous visit
+    // predicted the tile to be saturated; splats deeper than the bound of EVERY tile of their rectangle were not emitted.  The list
+    // walked here is then complete up to the bound, so the result is exact if the tile saturated at or before it (or if nothing was
+    // culled for it); otherwise the fail flag makes the executor's gated fallback re-run the binning without culling.  The new bound
+    // is the depth 50 % (at least 16 splats) further down the list than where the tile saturated.
+    if (sched_out != nullptr) {
+        const int gy = ntiles / gx;
+        const float INF = __builtin_inff();
+        const float zused = (zb_check && sched_in != nullptr) ? reinterpret_cast<const float*>(sched_in)[lg_sched_level_offset(gx, gy, 0) + tile - 1] : INF;
+        bool sat = !live;
+        if (live) {                                          // the list ran out: saturated exactly at its end?
+            bool any_act = false;
+#pragma unroll
+            for (int k = 0; k < PPL; k++) any_act |= (st.T[k] > 1.0f / 8192);
+            sat = !__any(any_act);
+        }
+        float znew = INF;
+        bool ok = !(zused < INF);
+        if (sat && visited > 0) {
+            const float stop_z = pk[(size_t)rfl(sp[visited - 1]) * REC + 12];
+            ok = stop_z <= zused;
+            const int p = visited - 1 + max(16, visited >> 1);
+            if (p <= n - 1) znew = pk[(size_t)rfl(sp[p]) * REC + 12];
+            else if (zused < INF) znew = fmaxf(zused, pk[(size_t)rfl(sp[n - 1]) * REC + 12]) * 1.25f;
+        }
+        if (lane == 0) {
+            reinterpret_cast<float*>(sched_out)[lg_sched_level_offset(gx, gy, 0) + tile - 1] = znew;
+            const int tx0 = (tile - 1) % gx, ty0 = (tile - 1) / gx;
+#pragma unroll
+            for (int k = 1; k < LG_PYR_LEVELS; k++)             // positive floats order like their bit patterns
+                atomicMax(reinterpret_cast<unsigned int*>(sched_out) + lg_sched_level_offset(gx, gy, k) + (ty0 >> k) * lg_pyr_w(gx, k) + (tx0 >> k),
+                          __float_as_uint(znew));
+            if (!ok && fail_flag != nullptr) atomicOr(fail_flag, 1);
+        }
+    }
     const size_t plane = (size_t)Hp * Wp;
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
@@ -288,16 +329,30 @@ LG_API int lg_raster_forward(const int* sorted_points, const int* start_index, c
                              float* img, float* trans, short* last, int* frag_count, float* frag_weight,
                              const int* order /*nullable [V,T]: tile schedule (a permutation of 1..T)*/, int* tile_work /*nullable [V,T+1]*/, void* stream)
 {
+    return lg_raster_forward_bounds(sorted_points, start_index, packed, tiles, K, V, L, N, H, W, TH, TW, enable_stat, img, trans, last,
+                                    frag_count, frag_weight, order, tile_work, nullptr, nullptr, 0, nullptr, nullptr, stream);
+}
+
+// The executor's entry: the same blend, reading / filling the per-frame depth-bound blocks (single view; record dword 12 must hold the
+// VIEW depth, as the fused projection writes it), with an optional gate (device int; nothing runs unless it is non-zero).
+int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
+                             int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
+                             float* img, float* trans, short* last, int* frag_count, float* frag_weight,
+                             const int* order, int* tile_work, const int* sched_in /*nullable: previous visit's block (the bounds used)*/,
+                             int* sched_out /*nullable: this visit's block; its first lg_sched_clear_words() words are zero*/,
+                             int zb_check /*0: nothing was culled, only produce new bounds*/, int* fail_flag, const int* gate, void* stream)
+{
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
     const int nslots = tiles ? K : ntiles;
     if (nslots <= 0) return 0;
     if (N >= (1 << 26)) return (int)hipErrorInvalidValue;          // 32-bit record offsets
+    if ((sched_in != nullptr || sched_out != nullptr) && (V != 1 || tiles != nullptr)) return (int)hipErrorInvalidValue;
     if (!g_use_order) order = nullptr;
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_RF(A_, B_, S_) hipLaunchKernelGGL((raster_forward_kernel<A_, B_, S_>), grid, block, 0, s, sorted_points, start_index, packed, \
-                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map)
+                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map)
 #define DISPATCH_RF(A_, B_) do { if (enable_stat) LAUNCH_RF(A_, B_, true); else LAUNCH_RF(A_, B_, false); } while (0)
     if (TH == 8 && TW == 16) DISPATCH_RF(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RF(16, 16);
@@ -326,7 +381,18 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const int* __restrict_
     int* __restrict__ o = order + (size_t)view * ntiles;
     hist[t] = 0;
     __syncthreads();
-    for (int i = t; i < ntiles; i += 1024) atomicAdd(&hist[1023 - min(max(w[i], 0), 1023)], 1);
+    // 16 tiles per thread and round: the loads of a round are independent (issued together), the bins stay in registers for the
+    // scatter pass.  One round covers 16 384 tiles (1080p at 8x16: 16 200); larger grids take more rounds and re-read the keys.
+    constexpr int R = 16;
+    int bin[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int i = t + k * 1024;
+        bin[k] = i < ntiles ? 1023 - min(max(w[i], 0), 1023) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) if (bin[k] >= 0) atomicAdd(&hist[bin[k]], 1);
+    for (int i = t + R * 1024; i < ntiles; i += 1024) atomicAdd(&hist[1023 - min(max(w[i], 0), 1023)], 1);
     __syncthreads();
     // exclusive scan of the 1024 bins
     const int mine = hist[t];
@@ -340,7 +406,9 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const int* __restrict_
     __syncthreads();
     hist[t] = base + v - mine;
     __syncthreads();
-    for (int i = t; i < ntiles; i += 1024) o[atomicAdd(&hist[1023 - min(max(w[i], 0), 1023)], 1)] = i + 1;
+#pragma unroll
+    for (int k = 0; k < R; k++) if (bin[k] >= 0) o[atomicAdd(&hist[bin[k]], 1)] = t + k * 1024 + 1;
+    for (int i = t + R * 1024; i < ntiles; i += 1024) o[atomicAdd(&hist[1023 - min(max(w[i], 0), 1023)], 1)] = i + 1;
 }
 
 LG_API int lg_tile_order(const int* tile_work /*[V,T+1]*/, int V, int ntiles, int* order /*[V,T]*/, void* stream)
@@ -348,6 +416,11 @@ LG_API int lg_tile_order(const int* tile_work /*[V,T+1]*/, int V, int ntiles, in
     if (V <= 0 || ntiles <= 0) return 0;
     hipLaunchKernelGGL(tile_order_kernel, dim3(V), dim3(1024), 0, (hipStream_t)stream, tile_work, ntiles, order);
     LG_RETURN_LAST();
+}
+
+LG_API long long lg_sched_words(int H, int W, int TH, int TW)
+{
+    return lg_sched_words_total((W + TW - 1) / TW, (H + TH - 1) / TH);
 }
 
 // work per tile from last_contributor (operator path: the forward and the backward are separate calls): one wave per tile

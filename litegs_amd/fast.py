@@ -10,6 +10,7 @@ written by an async 4-byte copy in step k and read in step k+1 give the allocati
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import numpy as np
@@ -43,12 +44,25 @@ class FusedRenderer:
         self.Hp = (height + tile[0] - 1) // tile[0] * tile[0]
         self.Wp = (width + tile[1] - 1) // tile[1] * tile[1]
         self.last_sizes = (0, 0)
-        # per-frame tile schedule (heaviest tiles first), produced by every visit's forward and used by its backward and by the next
-        # visit's forward; a scheduling hint only -- results do not depend on it
+        # Per frame: a heaviest-first tile schedule (csrc/raster.hip; a hint -- results do not depend on it -- recomputed on a frame's
+        # first visit and then every `cull_refresh`-th) and two depth-bound blocks (csrc/lg_tilewalk.h) used alternately: every
+        # visit's blend forward records per-tile saturation depths, and the next visit of the frame skips the splats no tile will
+        # reach (depth-bound culling, csrc/fused.hip); a gated fallback keeps the result exact.  Every `cull_refresh`-th visit of a
+        # frame runs unculled (fresh bounds from the complete lists, fresh full table size, fresh schedule).
         self.ntiles = (self.Hp // tile[0]) * (self.Wp // tile[1])
+        self.n_frames = n_frames
+        self.sched = None
+        self.sched_cur = [0] * n_frames
+        self.sched_valid = [False] * n_frames
         self.tile_order = None
         self.tile_order_valid = [False] * n_frames
-        self.n_frames = n_frames
+        self.cull_enabled = os.environ.get("LITEGS_DEPTH_CULL", "1") != "0"
+        self.cull_refresh = 16
+        self.visits = [0] * n_frames
+        self.full_total = [0] * n_frames                     # host copy of the full table length of a frame's last unculled visit
+        self.last_unculled = [False] * n_frames
+        self.fb_full = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()     # written by the device when a fallback ran
+        self.last_cull = False
         # fuse_optimizer: backward stops after the blend backward; FusedAdam.step() then runs the per-Gaussian backward fused
         # with the Adam update (csrc/fused.hip: project_backward_adam_kernel) -- parameter gradients never go to HBM.
         # Only valid when nothing needs the gradients between backward and the optimizer step (no DP exchange).
@@ -56,6 +70,15 @@ class FusedRenderer:
         self.pending = None
         self.probe_events = None      # measurement hook (bench.py): a list that receives an event pair around every blend backward launch
         self._cull_scratch, self._cull_chunks, self._cull_epoch = None, -1, 0
+
+    def reset_feedback(self):
+        """parameters were replaced / re-sorted: forget everything predicted from earlier visits (sizes, schedules, depth bounds)"""
+        self.fb_vis.zero_(); self.fb_total.zero_(); self.fb_full.zero_()
+        n = self.n_frames
+        self.sched_valid = [False] * n
+        self.tile_order_valid = [False] * n
+        self.full_total = [0] * n
+        self.last_unculled = [False] * n
 
     def cull_scratch(self, chunks: int, device):
         """persistent look-back table of the multi-workgroup culling kernel (epoch-tagged: zeroed once, never cleared again)"""
@@ -106,7 +129,7 @@ class _RenderFn(torch.autograd.Function):
         do_cull = 1
         if pred_vis <= 0:                                    # first visit: blocking count (GR/compact.cu:543-546)
             check(L.lg_fused_stage1(*common, 1, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), 0, None, 0, fb_vis_ptr, None,
-                                    *R.cull_scratch(chunks, dev), s),
+                                    *R.cull_scratch(chunks, dev), None, None, s),
                   "fused cull")
             A = int(vis_num.item())
             do_cull = 0
@@ -116,22 +139,48 @@ class _RenderFn(torch.autograd.Function):
         N = A * S
         ws1_bytes = L.lg_fused_workspace1_bytes(N)
         ws1 = torch.empty((ws1_bytes,), dtype=torch.uint8, device=dev)
-        check(L.lg_fused_stage1(*common, do_cull, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), A, ws1.data_ptr(), ws1_bytes,
-                                fb_vis_ptr if do_cull else None, fb_tot_ptr, *(R.cull_scratch(chunks, dev) if do_cull else (None, 0)), s), "fused stage1")
+        stat = STATS.active
+        tiles = STATS.schedule_for_current_frame()
+        # depth-bound culling: bookkeeping of the sizing feedback (the emitted total of a culled visit is not the full table length)
         pred_total = int(R.fb_total[k])
+        if R.last_unculled[k] and pred_total > 0:
+            R.full_total[k] = pred_total                      # the previous visit of this frame emitted everything
+        if int(R.fb_full[k]) > 0:                             # ... or a fallback re-ran it in full
+            R.full_total[k] = max(R.full_total[k], int(R.fb_full[k]))
+            R.fb_full[k] = 0
+        use_sched = not stat and tiles is None
+        if use_sched and R.sched is None:
+            R.sched = torch.empty((R.n_frames, 2, L.lg_sched_words(R.H, R.W, R.TH, R.TW)), dtype=torch.int32, device=dev)
+            R.tile_order = torch.empty((R.n_frames, R.ntiles), dtype=torch.int32, device=dev)
+        in_ptr = out_ptr = None
+        if use_sched:
+            cur = R.sched_cur[k]
+            if R.sched_valid[k]:
+                in_ptr = R.sched[k, cur].data_ptr()
+            out_ptr = R.sched[k, 1 - cur].data_ptr()
+        refresh = R.visits[k] % R.cull_refresh == 0
+        cull = bool(R.cull_enabled and in_ptr is not None and R.full_total[k] > 0 and pred_total > 0 and not refresh)
+        order_ptr = (R.tile_order.data_ptr() + 4 * R.ntiles * k) if use_sched else None
+        order_in = order_ptr if (use_sched and R.tile_order_valid[k]) else None
+        order_out = order_ptr if (use_sched and (refresh or not R.tile_order_valid[k])) else None
+        R.visits[k] += 1
+        check(L.lg_fused_stage1(*common, do_cull, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), A, ws1.data_ptr(), ws1_bytes,
+                                fb_vis_ptr if do_cull else None, fb_tot_ptr, *(R.cull_scratch(chunks, dev) if do_cull else (None, 0)),
+                                in_ptr if cull else None, out_ptr, s), "fused stage1")
         if pred_total <= 0:                                  # first visit: blocking table size (GR/binning.cu:152-163)
             off = L.lg_fused_total_offset(N)
             table_len = int(ws1[off:off + 4].view(torch.int32).item())
+        elif cull:
+            table_len = int(1.5 * R.full_total[k])           # capacity for the fallback's full table
         else:
-            table_len = int(1.5 * pred_total)
+            table_len = int(1.5 * max(pred_total, R.full_total[k]))
         table_len = max(table_len, 1)
+        len_cull = min(table_len, int(1.5 * pred_total) + 65536) if cull else table_len
         ws2_bytes = L.lg_fused_workspace2_bytes(table_len, N, R.H, R.W, R.TH, R.TW)
         ws2 = torch.empty((ws2_bytes,), dtype=torch.uint8, device=dev)
         img = torch.empty((1, 3, R.Hp, R.Wp), dtype=torch.float32, device=dev)
         trans = torch.empty((1, 1, R.Hp, R.Wp), dtype=torch.float32, device=dev)
         last = torch.empty((1, 1, R.Hp, R.Wp), dtype=torch.int16, device=dev)
-        stat = STATS.active
-        tiles = STATS.schedule_for_current_frame()
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
         fc = fw = None
         if stat:
@@ -144,18 +193,23 @@ class _RenderFn(torch.autograd.Function):
             img.zero_(); trans.fill_(1.0); last.zero_()
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
         pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
-        if R.tile_order is None:
-            R.tile_order = torch.empty((R.n_frames, R.ntiles), dtype=torch.int32, device=dev)
-        order_ptr = R.tile_order.data_ptr() + 4 * R.ntiles * k
-        use_order = tiles is None
         check(L.lg_fused_stage2(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes, tp, K,
                                 1 if stat else 0, img.data_ptr(), trans.data_ptr(), last.data_ptr(),
                                 fc.data_ptr() if stat else None, fw.data_ptr() if stat else None,
                                 pg.data_ptr() if pg is not None else None,
-                                order_ptr if (use_order and R.tile_order_valid[k]) else None, order_ptr if use_order else None, s), "fused stage2")
-        if use_order:
+                                order_in, order_out, in_ptr, out_ptr, 1 if cull else 0, len_cull, R.fb_full.data_ptr() + 4 * k,
+                                frame.view_ptr, frame.proj_ptr, int(degree), chunks,
+                                xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), sh_0.data_ptr(), sh_rest.data_ptr(), opacity.data_ptr(),
+                                vis_ids.data_ptr(), vis_num.data_ptr(), s), "fused stage2")
+        if use_sched:
+            R.sched_cur[k] = 1 - R.sched_cur[k]
+            R.sched_valid[k] = True
+        R.last_unculled[k] = not cull
+        R.last_cull = cull
+        R.last_ws1 = (ws1, N)                              # for tests: the fallback flag lives in workspace 1 (lg_fused_flags_offset)
+        if order_out is not None:
             R.tile_order_valid[k] = True
-        ctx.order_ptr = order_ptr if use_order else None
+        ctx.order_ptr = order_ptr if (use_sched and R.tile_order_valid[k]) else None
         ctx.pg = pg
         if stat:
             STATS.update_tile_schedule(last, R.TH, R.TW)

@@ -119,8 +119,7 @@ class SyntheticTrainer:
         self.fadam._ready = False
         self.renderer.pending = None
         torch.cuda.current_stream().synchronize()               # pinned feedback words may still be in flight
-        self.renderer.fb_vis.zero_()
-        self.renderer.fb_total.zero_()
+        self.renderer.reset_feedback()
         self.feedback_visible_chunks_num.zero_()
         self.feedback_binning_allocate_size.zero_()
 

@@ -1,0 +1,103 @@
+"""Depth-bound culling of the native executor (csrc/fused.hip): a revisited frame emits only the splats its tiles can reach, the image
+stays bit-identical, and a violated bound is repaired by the gated fallback without any host decision."""
+import numpy as np
+import pytest
+import torch
+
+from litegs_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n=150_000, W=640, H=360, f=380.0):
+    from litegs_amd import fast, render as R
+    params = [torch.nn.Parameter(torch.from_numpy(p).cuda()) for p in S.make_scene(n, seed=5)]
+    view, proj, planes = [torch.from_numpy(x).cuda() for x in S.make_camera(W, H, f, f, (1.6, -0.4, 1.1))]
+    with torch.no_grad():
+        origin, extend = R.get_cluster_AABB(params[0], params[1].exp(), torch.nn.functional.normalize(params[2], dim=0))
+    cam = fast.CameraFrame(view, proj, planes, 0)
+    return params, cam, origin, extend, H, W
+
+
+def _render(rd, cam, origin, extend, params, w=None):
+    for p in params:
+        p.grad = None
+    img, vis_id, vis_num = rd.render(cam, origin, extend, *params, 3)
+    if w is not None:
+        (img * w).sum().backward()
+    torch.cuda.synchronize()
+    return img.detach().clone()
+
+
+def _bounds(rd, H, W, th=8, tw=16):
+    """float view of the frame's current depth-bound block (layout: csrc/lg_tilewalk.h)"""
+    gx, gy = -(-W // tw), -(-H // th)
+    upper = sum((-(-gx // (1 << k))) * (-(-gy // (1 << k))) for k in range(1, 4))
+    blk = rd.sched[0, rd.sched_cur[0]]
+    return blk[:upper + gx * gy].view(torch.float32)
+
+
+def _flags(rd):
+    from litegs_amd._lib import lib
+    ws1, N = rd.last_ws1
+    off = lib().lg_fused_flags_offset(N)
+    return ws1[off:off + 8].view(torch.int32).cpu().numpy()
+
+
+def test_culled_visit_is_bit_identical_and_emits_less():
+    from litegs_amd import fast
+    params, cam, origin, extend, H, W = _scene()
+    w = torch.from_numpy(np.random.default_rng(2).standard_normal((1, 3, H, W)).astype(np.float32)).cuda()
+    rd = fast.FusedRenderer(1, H, W)
+    img0 = _render(rd, cam, origin, extend, params, w)
+    nvis = int(rd.fb_vis[0])
+    g0 = [p.grad.compacted_values[..., :nvis, :].clone() for p in params]
+    full = int(rd.fb_total[0])
+    assert not rd.last_cull
+    img1 = _render(rd, cam, origin, extend, params, w)
+    assert rd.last_cull, "the second visit of the frame must run culled"
+    culled = int(rd.fb_total[0])
+    assert _flags(rd)[0] == 0, "no bound was violated: the fallback must not have run"
+    assert torch.equal(img0, img1)
+    assert culled < 0.95 * full, (culled, full)
+    for a, p in zip(g0, params):
+        b = p.grad.compacted_values[..., :nvis, :]
+        assert torch.allclose(a, b, rtol=0, atol=2e-5 * float(a.abs().max()) + 1e-12)
+    # ... and a third visit (bounds produced by a culled visit) again
+    img2 = _render(rd, cam, origin, extend, params, w)
+    assert rd.last_cull and _flags(rd)[0] == 0 and torch.equal(img0, img2)
+
+
+def test_violated_bounds_take_the_gated_fallback():
+    from litegs_amd import fast
+    params, cam, origin, extend, H, W = _scene()
+    rd = fast.FusedRenderer(1, H, W)
+    img0 = _render(rd, cam, origin, extend, params)
+    full = int(rd.fb_total[0])
+    _bounds(rd, H, W).mul_(0.2)                 # bounds far too tight: most tiles cannot saturate inside them
+    img1 = _render(rd, cam, origin, extend, params)
+    assert rd.last_cull
+    assert _flags(rd)[0] == 1, "the culled run must have raised the fallback flag"
+    assert _flags(rd)[1] == full and int(rd.fb_full[0]) == full, "the fallback rebuilds the full table"
+    assert torch.equal(img0, img1)
+    # the fallback left fresh bounds: the next visit is culled and clean again
+    img2 = _render(rd, cam, origin, extend, params)
+    assert rd.last_cull and _flags(rd)[0] == 0 and torch.equal(img0, img2)
+
+
+def test_scene_change_between_visits_stays_exact():
+    """opacities drop between two visits (tiles saturate deeper than predicted): whatever the culled visit decides, the image equals
+    the one a fresh, unculled renderer produces"""
+    from litegs_amd import fast
+    params, cam, origin, extend, H, W = _scene()
+    rd = fast.FusedRenderer(1, H, W)
+    _render(rd, cam, origin, extend, params)
+    for shift in (0.3, 1.0, 3.0):
+        with torch.no_grad():
+            params[5].sub_(shift)              # raw opacity (pre-sigmoid)
+        img_c = _render(rd, cam, origin, extend, params)
+        assert rd.last_cull
+        ref = fast.FusedRenderer(1, H, W)
+        ref.cull_enabled = False
+        img_r = _render(ref, cam, origin, extend, params)
+        assert torch.equal(img_c, img_r), f"shift {shift}: culled visit differs (fallback flag {_flags(rd)[0]})"
