@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-from . import fused
+from .binding import ops as fused
 from ._lib import check, lib
 
 

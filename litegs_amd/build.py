@@ -37,12 +37,47 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+ABI_HEADER = os.path.join(os.path.dirname(HERE), "include", "litegs_hip.h")
+EXT_SRC = os.path.join(CSRC, "ext", "litegs_fused_ext.cpp")
+EXT_LIB = os.path.join(HERE, "_litegs_fused_C.so")
+
+
 def _newer(src: str, dst: str) -> bool:
+    """the ABI header is a dependency of every object: ctypes prototypes are parsed from it, so a stale object would be called with
+    the new argument list"""
     if not os.path.exists(dst):
         return True
     t = os.path.getmtime(dst)
-    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps = [src, ABI_HEADER, os.path.abspath(__file__)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_extension(force: bool = False, verbose: bool = False) -> str:
+    """``litegs_fused`` as a compiled torch extension (csrc/ext/litegs_fused_ext.cpp): host-only C++ over the C ABI, built with g++
+    against the torch headers and linked to liblitegs_hip.so next to it (rpath $ORIGIN).  The reference builds the module of the same
+    name with GR/setup.py."""
+    if not (force or _newer(EXT_SRC, EXT_LIB) or os.path.getmtime(LIB) > os.path.getmtime(EXT_LIB)):
+        return EXT_LIB
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    inc = ce.include_paths("cuda") + [sysconfig.get_paths()["include"], "/opt/rocm/include", os.path.join(os.path.dirname(HERE), "include")]
+    libdirs = ce.library_paths("cuda")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_litegs_fused_C",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations",
+           EXT_SRC, "-o", EXT_LIB]
+    for p in inc:
+        cmd += ["-I", p]
+    for p in libdirs:
+        cmd += ["-L", p, f"-Wl,-rpath,{p}"]
+    cmd += ["-L", HERE, "-l:liblitegs_hip.so", "-Wl,-rpath,$ORIGIN", "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-ltorch_python"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout.decode())
+        raise RuntimeError("g++ failed on the litegs_fused extension")
+    return EXT_LIB
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -75,6 +110,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_extension(force=force, verbose=verbose)
     return LIB
 
 

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 
 import torch
 
-from . import fused
+from .binding import ops as fused
 from .wrapper import CompactedTensor, sparse_adam_update
 
 

@@ -13,7 +13,8 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import fused, wrapper
+from . import wrapper
+from .binding import ops as fused
 from .statistics import STATS
 
 

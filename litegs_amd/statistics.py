@@ -12,7 +12,7 @@ from typing import Callable, Dict, Optional
 
 import torch
 
-from . import fused
+from .binding import ops as fused
 
 
 class _Moments:

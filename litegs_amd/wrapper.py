@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from . import binning as _binning
-from . import fused
+from .binding import ops as fused
 from .statistics import STATS
 
 
