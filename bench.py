@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--config", default="3m_1080p", help="key of litegs_amd.synthetic.CONFIGS")
     ap.add_argument("--frames", type=int, default=8, help="camera frames per rank (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-operator-path", action="store_true", help="skip the extra measurement of the drop-in operator surface")
     ap.add_argument("--operator-path", action="store_true",
                     help="run the iteration operator by operator through the litegs_fused drop-in surface instead of the native executor "
                          "(not the headline configuration; single GPU only)")
@@ -125,6 +126,23 @@ def roofline_probe(tr, frames, steps_per_frame=2):
         "note": "fp32 vector (VALU) roofline binds the blend kernels, not HBM; units averaged over the frames timed; traffic (PMC) is in "
                 "profiles/, not re-measured in this run",
     }
+
+
+def operator_path_ms(n, W, H, focal, scene, frames, steps=16):
+    """ms per training iteration when the SAME iteration is driven operator by operator through the drop-in `litegs_fused` surface
+    (what the reference's unmodified trainer calls; the compiled binding when it is built) instead of the native executor --
+    reported next to the headline, never as the headline."""
+    from litegs_amd.trainer import SyntheticTrainer
+    from litegs_amd.binding import ops
+    tr = SyntheticTrainer(n, W, H, focal, n_frames=frames, scene=scene, fused=False)
+    for i in range(frames + 8):
+        tr.step(i % frames)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(i % frames)
+    torch.cuda.synchronize()
+    return {"ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 4), "binding": ops.binding, "steps": steps}
 
 
 def cpu_baseline(scene, cam, H, W, degree, tile_stride):
@@ -293,6 +311,8 @@ def main():
         }
         if world == 1 and not args.operator_path:
             result["roofline"] = roofline_probe(tr, list(range(len(tr.frames))))    # in situ, after the timed region
+        if world == 1 and not args.operator_path and not args.no_operator_path:
+            result["operator_path_ms"] = operator_path_ms(n, W, H, focal, scene, args.frames)
         if world == 1:
             if not args.no_cpu_baseline:
                 fr = tr.frames[frame_of(0)]
