@@ -252,20 +252,26 @@ def main():
     hook = None
     if world > 1:
         from litegs_amd import dp
-        hook = dp.GradientExchange(tr.params, world).hook
+        # default: the moment exchange of the native executor (csrc/dp.hip); LITEGS_DP_EXCHANGE=sparse|dense selects the gradient hooks
+        mode = os.environ.get("LITEGS_DP_EXCHANGE", "moments")
+        exchange = dp.MomentExchange(tr.params, world) if mode == "moments" else dp.GradientExchange(tr.params, world, mode=mode)
+        hook = exchange if mode == "moments" else exchange.hook
 
-    def frame_of(step):                               # rank r trains frame (step*world + r): disjoint frames per step
-        return (step * world + rank) % len(tr.frames)
+    def frame_of(step, r=rank):                       # rank r trains frame (step*world + r): disjoint frames per step
+        return (step * world + r) % len(tr.frames)
+
+    def peers_of(step):
+        return [frame_of(step, r) for r in range(world)]
 
     # Setup, not warm-up: every frame set is visited once so that the GPU-driven sizing protocol has its per-frame feedback (the first
     # visit of a frame takes the reference's blocking read, GR/compact.cu:543-546); then exactly W warm-up and K timed steps.
     n_slots = max(args.frames, 1)                     # step i trains the frame set {i*world + r}: it recurs every `frames` steps
     step_no = 0
     for i in range(n_slots):
-        tr.step(frame_of(step_no), hook, step_no % n_slots)
+        tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
         step_no += 1
     for i in range(args.warmup):
-        tr.step(frame_of(step_no), hook, step_no % n_slots)
+        tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
         step_no += 1
     torch.cuda.synchronize()
     if dist is not None:
@@ -273,7 +279,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        tr.step(frame_of(step_no), hook, step_no % n_slots)
+        tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
         step_no += 1
     torch.cuda.synchronize()
     if dist is not None:
@@ -304,13 +310,16 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} Gaussians SH3, {W}x{H}, 1 camera frame per GPU per step, full training iteration "
                                    "(render_preprocess+render+L1/SSIM loss+backward+sparse Adam), seed 0 (SURVEY 8d)",
-                       "frames_per_rank": args.frames, "tile": [8, 16], "path": "litegs_fused operator surface" if args.operator_path else "native executor", "parallelism": f"dp{world} (one frame per GPU, RCCL exchange of the non-zero gradient rows, replicated sparse Adam)" if world > 1 else "single GPU"},
+                       "frames_per_rank": args.frames, "tile": [8, 16], "path": "litegs_fused operator surface" if args.operator_path else "native executor", "parallelism": f"dp{world} (one frame per GPU, RCCL all_gather of the blend-backward moment records, fused backward+Adam over the union on every replica)" if world > 1 else "single GPU"},
             "fwd_msplats_per_s": round(n / fwd_s / 1e6, 2), "fwd_ms": round(fwd_s * 1e3, 4),
             "n_vis": stats["n_vis"], "instances": stats["instances"],
             "reference_derived_rtx3090_iters_per_s": 103.0,
         }
         if world == 1 and not args.operator_path:
             result["roofline"] = roofline_probe(tr, list(range(len(tr.frames))))    # in situ, after the timed region
+        if world > 1 and hasattr(hook, "bytes_last"):
+            hook.check()
+            result["dp_exchange"] = {"mode": "moments", "bytes_received_per_rank_per_step": int(hook.bytes_last), "record_capacity": int(hook.last_cap)}
         if world == 1 and not args.operator_path and not args.no_operator_path:
             result["operator_path_ms"] = operator_path_ms(n, W, H, focal, scene, args.frames)
         if world == 1:

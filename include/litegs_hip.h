@@ -251,6 +251,23 @@ int lg_adam_update_multi(int ngroups, void* const* param, const void* const* gra
                          const int* rows, const float* lr, const int64_t* visible_chunk_id, const int* valid_length,
                          int chunks, int A, int S, int grad_dense, float b1, float b2, float eps, void* stream);
 
+/* ---- dp.hip : data-parallel gradient exchange on the device (the reference is single-GPU only).  The ranks exchange the
+ * blend backward's moment records (global Gaussian index + 9 floats per touched Gaussian) instead of parameter gradients; every rank
+ * replays the per-Gaussian chain backward of every rank's records with that rank's camera, averages and applies Adam in one kernel.
+ * A block is float[(1 + cap) * lg_dp_record_floats()]: row 0 = header (word 0 = number of touched Gaussians, int bits), then records. */
+int lg_dp_record_floats(void);
+int lg_dp_compact_moments(const float* packed_grad /*[A*S,16] of lg_fused_backward*/, const int64_t* vis_ids, const int* vis_num, int A, int S,
+                          int cap, float* block, void* stream);
+int lg_dp_build_slotmap(const float* gathered /*[W] blocks*/, int W, int cap, long long total /*chunks*S*/, int* slot /*[W][total], zero*/,
+                        int* host_max_k /*nullable pinned int: largest count of the job*/, int* overflow /*nullable device flag*/, void* stream);
+int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count, int chunks, int S, int H, int W_img,
+                        const float* views_host /*[W][16]*/, const float* projs_host /*[W][16]*/, int world, int degree, int R,
+                        const float* gathered, int cap, int* slot,
+                        float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
+                        float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
+                        float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
+                        const float* lr6 /*host: xyz, sh_0, sh_rest, opacity, scale, rot*/, float b1, float b2, float eps, void* stream);
+
 /* ---- knn.hip : simple_knn._C.distCUDA2 (litegs/submodules/simple-knn/simple_knn.cu:186-222; caller litegs/scene/point.py:8) --------
  * mean squared distance of every point to its 3 nearest neighbours (exact).  points [P,3] fp32, mean_dist2 [P]. */
 long long lg_knn3_temp_bytes(int P);

@@ -25,6 +25,7 @@ SOURCES = {
     "raster.hip": ["-munsafe-fp-atomics"],
     "loss.hip": ["-munsafe-fp-atomics"],
     "fused.hip": ["-ffp-contract=off"],
+    "dp.hip": ["-ffp-contract=off"],
     "knn.hip": [],
     "refine.hip": ["-ffp-contract=off"],
 }

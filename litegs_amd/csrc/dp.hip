@@ -1,0 +1,220 @@
+// Data-parallel gradient exchange on the device (the reference is single-GPU only -- no counterpart).
+//
+// One camera frame per GPU, full replicas.  What a frame contributes to the parameter gradients is fully described by the blend
+// backward's MOMENT records (raster.hip: nine floats per Gaussian that received any gradient) plus that frame's camera: the
+// per-Gaussian chain backward is a cheap function of (raw parameters, camera, moments).  So the ranks exchange the records of the
+// Gaussians they touched -- 40 bytes each instead of the 236-byte parameter gradient (59 floats) -- and every rank replays the
+// chain backward of EVERY rank's records with that rank's camera, sums the parameter gradients in rank order in registers
+// (deterministic: replicas stay bit-identical), scales by 1/W and applies Adam in the same kernel.  The parameter gradients never
+// exist in HBM, on any rank; backward + Adam stay fused exactly as on one GPU.
+//
+//   lg_dp_compact_moments : packed_grad [N,16] -> block [1 + cap][10]: row 0 = header (word 0: number of touched Gaussians K),
+//                           row 1 + k = { global Gaussian index (int bits), 9 moments }.  Unordered (one atomic per wave).
+//   (RCCL all_gather of the W blocks -- torch.distributed, litegs_amd/dp.py)
+//   lg_dp_build_slotmap   : for every rank r and record k: slot[r][gid] = k + 1; also the job's largest K to a pinned host word
+//                           (sizes the next visit's blocks) and an overflow flag if some K exceeded the capacity.
+//   lg_dp_backward_adam   : over the union of the ranks' visible chunks: per Gaussian, for r = 0..W-1 in order, the record (if any)
+//                           through gaussian_backward with camera r; mean; Adam on param / exp_avg / exp_avg_sq; the slot entries
+//                           read are reset to 0 (the map needs no clearing launch).
+// Compiled with -ffp-contract=off (same chain arithmetic as fused.hip).
+#include "lg_common.h"
+#include "lg_chain.h"
+#include "lg_gaussian_bwd.h"
+#include "litegs_hip.h"
+
+#define DP_REC 10              // floats per exchanged record
+#define DP_MAX_WORLD 8
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dp_compact_kernel(const float4* __restrict__ packed_grad, const int64_t* __restrict__ vis_ids,
+                                                         const int* __restrict__ vis_num, int A, int S, int cap, float* __restrict__ block)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long long N = (long long)A * S;
+    bool nz = false;
+    float mom[9];
+    long long gid = 0;
+    if (i < N) {
+        const int a = (int)(i / S), t = (int)(i % S);
+        if (a < vis_num[0]) {
+            load_moments(packed_grad, (size_t)i, mom);
+#pragma unroll
+            for (int k = 0; k < 9; k++) nz |= (__float_as_uint(mom[k]) & 0x7fffffffu) != 0u;     // +-0 adds nothing to a sum; NaN/inf travel
+            gid = vis_ids[a] * S + t;
+        }
+    }
+    const unsigned long long m = __ballot(nz);
+    if (m == 0ull) return;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(reinterpret_cast<int*>(block), __popcll(m));     // header word 0 = K
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (nz) {
+        const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (k < cap) {                                       // beyond the capacity: dropped, the header still counts it (overflow)
+            float* __restrict__ r = block + (size_t)(1 + k) * DP_REC;
+            r[0] = __int_as_float((int)gid);
+#pragma unroll
+            for (int q = 0; q < 9; q++) r[1 + q] = mom[q];
+        }
+    }
+}
+
+LG_API int lg_dp_record_floats(void) { return DP_REC; }
+
+LG_API int lg_dp_compact_moments(const float* packed_grad, const int64_t* vis_ids, const int* vis_num, int A, int S, int cap,
+                                 float* block /*[(1 + cap) * 10]*/, void* stream)
+{
+    if (A <= 0 || cap <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(block, 0, sizeof(float) * DP_REC, s);          // the header row
+    if (e != hipSuccess) return (int)e;
+    const long long N = (long long)A * S;
+    hipLaunchKernelGGL(dp_compact_kernel, dim3(lg_cdiv(N, 256)), dim3(256), 0, s, (const float4*)packed_grad, vis_ids, vis_num, A, S, cap, block);
+    LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dp_slotmap_kernel(const float* __restrict__ gathered, int W, int cap, long long total,
+                                                         int* __restrict__ slot, int* __restrict__ host_max_k, int* __restrict__ overflow)
+{
+    const int r = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const float* __restrict__ blk = gathered + (size_t)r * (1 + cap) * DP_REC;
+    const int ktrue = __float_as_int(blk[0]);
+    const int kr = ktrue < cap ? ktrue : cap;
+    if (k < kr) {
+        const int gid = __float_as_int(blk[(size_t)(1 + k) * DP_REC]);
+        if (gid >= 0 && gid < total) slot[(size_t)r * total + gid] = k + 1;
+    }
+    if (r == 0 && k == 0) {
+        int mx = 0;
+        for (int q = 0; q < W; q++) mx = max(mx, __float_as_int(gathered[(size_t)q * (1 + cap) * DP_REC]));
+        if (host_max_k) __hip_atomic_store(host_max_k, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (mx > cap && overflow) atomicOr(overflow, 1);
+    }
+}
+
+LG_API int lg_dp_build_slotmap(const float* gathered /*[W][(1 + cap) * 10]*/, int W, int cap, long long total /*chunks * S*/,
+                               int* slot /*[W][total], all zero between steps*/, int* host_max_k /*nullable pinned*/,
+                               int* overflow /*nullable device flag, sticky*/, void* stream)
+{
+    if (W <= 0 || W > DP_MAX_WORLD || cap <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(dp_slotmap_kernel, dim3(lg_cdiv(cap, 256), W), dim3(256), 0, (hipStream_t)stream, gathered, W, cap, total, slot,
+                       host_max_k, overflow);
+    LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+struct CameraSet { Camera c[DP_MAX_WORLD]; };
+
+template <int DEG>
+__global__ void dp_backward_adam_kernel(const int64_t* __restrict__ union_ids, const int* __restrict__ union_count, CameraSet cams, int W,
+                                        AdamRates ar, int C, int S, int R, const float* __restrict__ gathered, int cap,
+                                        int* __restrict__ slot,
+                                        float* __restrict__ pos, float* __restrict__ scale, float* __restrict__ rot,
+                                        float* __restrict__ sh0, float* __restrict__ shr, float* __restrict__ opa,
+                                        float* __restrict__ m_pos, float* __restrict__ m_scale, float* __restrict__ m_rot,
+                                        float* __restrict__ m_sh0, float* __restrict__ m_shr, float* __restrict__ m_opa,
+                                        float* __restrict__ v_pos, float* __restrict__ v_scale, float* __restrict__ v_rot,
+                                        float* __restrict__ v_sh0, float* __restrict__ v_shr, float* __restrict__ v_opa)
+{
+    const int a = blockIdx.x, t = threadIdx.x;
+    if (a >= union_count[0]) return;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const size_t CS = (size_t)C * S;
+    const size_t sd = (size_t)union_ids[a] * S + t;
+    const float px = pos[sd], py = pos[CS + sd], pz = pos[2 * CS + sd];
+    const float s0 = scale[sd], s1 = scale[CS + sd], s2 = scale[2 * CS + sd];
+    const float rw = rot[sd], rx = rot[CS + sd], ry = rot[2 * CS + sd], rz = rot[3 * CS + sd];
+    const float oraw = opa[sd];
+    float g_pos[3] = { 0.f, 0.f, 0.f }, g_scale[3] = { 0.f, 0.f, 0.f }, g_rot[4] = { 0.f, 0.f, 0.f, 0.f }, g_opa = 0.f;
+    float g_sh[NB * 3];
+#pragma unroll
+    for (int k = 0; k < NB * 3; k++) g_sh[k] = 0.f;
+    for (int r = 0; r < W; r++) {                           // rank order: the sum is the same on every replica
+        int* __restrict__ sp = slot + (size_t)r * CS + sd;
+        const int k1 = *sp;
+        if (k1 == 0) continue;
+        *sp = 0;                                            // leave the map clean for the next step
+        const float* __restrict__ rec = gathered + ((size_t)r * (1 + cap) + k1) * DP_REC + 1;
+        float mom[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) mom[q] = rec[q];
+        GaussGrads G;
+        gaussian_backward<DEG>(cams.c[r], mom, 1.0f, px, py, pz, s0, s1, s2, rw, rx, ry, rz, oraw, G);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { g_pos[k] += G.pos[k]; g_scale[k] += G.scale[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) g_rot[k] += G.rot[k];
+        g_opa += G.opa;
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) g_sh[k * 3 + ch] += G.basis[k] * G.gc[ch];
+    }
+    const float inv_w = 1.0f / (float)W;                    // MEAN over the ranks' frames
+    {
+        const size_t o3[3] = { sd, CS + sd, 2 * CS + sd };
+        const size_t o4[4] = { sd, CS + sd, 2 * CS + sd, 3 * CS + sd };
+        const size_t o1[1] = { sd };
+        const float gp[3] = { g_pos[0] * inv_w, g_pos[1] * inv_w, g_pos[2] * inv_w };
+        const float gs[3] = { g_scale[0] * inv_w, g_scale[1] * inv_w, g_scale[2] * inv_w };
+        const float gr[4] = { g_rot[0] * inv_w, g_rot[1] * inv_w, g_rot[2] * inv_w, g_rot[3] * inv_w }, go[1] = { g_opa * inv_w };
+        const float g0[3] = { g_sh[0] * inv_w, g_sh[1] * inv_w, g_sh[2] * inv_w };
+        adam_rows<3>(pos, m_pos, v_pos, o3, gp, ar.lr_pos, ar.b1, ar.b2, ar.eps);
+        adam_rows<3>(scale, m_scale, v_scale, o3, gs, ar.lr_scale, ar.b1, ar.b2, ar.eps);
+        adam_rows<4>(rot, m_rot, v_rot, o4, gr, ar.lr_rot, ar.b1, ar.b2, ar.eps);
+        adam_rows<1>(opa, m_opa, v_opa, o1, go, ar.lr_opa, ar.b1, ar.b2, ar.eps);
+        adam_rows<3>(sh0, m_sh0, v_sh0, o3, g0, ar.lr_sh0, ar.b1, ar.b2, ar.eps);
+    }
+    constexpr int KB = (DEG == 2) ? 4 : 3;
+    static_assert(NB == 1 || (NB - 1) % KB == 0, "SH-rest batches must tile the active coefficients");
+#pragma unroll
+    for (int k0 = 1; k0 < NB; k0 += KB) {
+        size_t o9[KB * 3];
+        float g9[KB * 3];
+#pragma unroll
+        for (int kk = 0; kk < KB; kk++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                o9[kk * 3 + ch] = ((size_t)(k0 + kk - 1) * 3 + ch) * CS + sd;
+                g9[kk * 3 + ch] = g_sh[(k0 + kk) * 3 + ch] * inv_w;
+            }
+        adam_rows<KB * 3>(shr, m_shr, v_shr, o9, g9, ar.lr_shr, ar.b1, ar.b2, ar.eps);
+    }
+    for (int k = NB - 1; k < R; k++)                         // inactive SH degrees: zero gradient, moments still decay (as adamUpdate)
+        for (int ch = 0; ch < 3; ch++) adam_row(shr, m_shr, v_shr, ((size_t)k * 3 + ch) * CS + sd, 0.0f, ar.lr_shr, ar.b1, ar.b2, ar.eps);
+}
+
+// views_host / projs_host: HOST float[W][16], the cameras of the W ranks' frames of this step, in rank order
+LG_API int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count, int chunks, int S, int H, int W_img,
+                               const float* views_host, const float* projs_host, int world, int degree, int R,
+                               const float* gathered, int cap, int* slot,
+                               float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
+                               float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
+                               float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
+                               const float* lr6 /*xyz, sh_0, sh_rest, opacity, scale, rot*/, float b1, float b2, float eps, void* stream)
+{
+    if (world <= 0 || world > DP_MAX_WORLD || chunks <= 0 || S <= 0 || S > 1024) return (int)hipErrorInvalidValue;
+    CameraSet cams;
+    for (int r = 0; r < DP_MAX_WORLD; r++) {
+        const int q = r < world ? r : 0;
+        for (int k = 0; k < 16; k++) { cams.c[r].V[k] = views_host[q * 16 + k]; cams.c[r].P[k] = projs_host[q * 16 + k]; }
+        cams.c[r].H = H; cams.c[r].W = W_img;
+    }
+    AdamRates ar = { lr6[0], lr6[1], lr6[2], lr6[3], lr6[4], lr6[5], b1, b2, eps };
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_DP(D) hipLaunchKernelGGL(dp_backward_adam_kernel<D>, dim3(chunks), dim3(S), 0, s, union_ids, union_count, cams, world, ar, chunks, S, R, \
+                                        gathered, cap, slot, pos, scale, rot, sh0, shr, opa, m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa,               \
+                                        v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa)
+    switch (degree) {
+    case 0: LAUNCH_DP(0); break;
+    case 1: LAUNCH_DP(1); break;
+    case 2: LAUNCH_DP(2); break;
+    case 3: LAUNCH_DP(3); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef LAUNCH_DP
+    LG_RETURN_LAST();
+}

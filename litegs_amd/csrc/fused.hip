@@ -134,7 +134,9 @@ __global__ void project_fused_backward_kernel(const int64_t* __restrict__ visibl
     const size_t sd = (size_t)visible_chunk_id[a] * S + t;
     const float sc = grad_inv_scaler ? grad_inv_scaler[0] : 1.0f;
     GaussGrads G;
-    gaussian_backward<DEG>(cam, packed_grad + od * (GREC / 4), sc, pos[sd], pos[CS + sd], pos[2 * CS + sd],
+    float mom[9];
+    load_moments(packed_grad, od, mom);
+    gaussian_backward<DEG>(cam, mom, sc, pos[sd], pos[CS + sd], pos[2 * CS + sd],
                            scale[sd], scale[CS + sd], scale[2 * CS + sd], rot[sd], rot[CS + sd], rot[2 * CS + sd], rot[3 * CS + sd], opa[sd], G);
 #pragma unroll
     for (int k = 0; k < 3; k++) { d_pos[k * AS + od] = G.pos[k]; d_scale[k * AS + od] = G.scale[k]; }
@@ -173,7 +175,9 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
     const size_t sd = (size_t)visible_chunk_id[a] * S + t;
     const float sc = grad_inv_scaler ? grad_inv_scaler[0] : 1.0f;
     GaussGrads G;
-    gaussian_backward<DEG>(cam, packed_grad + od * (GREC / 4), sc, pos[sd], pos[CS + sd], pos[2 * CS + sd],
+    float mom[9];
+    load_moments(packed_grad, od, mom);
+    gaussian_backward<DEG>(cam, mom, sc, pos[sd], pos[CS + sd], pos[2 * CS + sd],
                            scale[sd], scale[CS + sd], scale[2 * CS + sd], rot[sd], rot[CS + sd], rot[2 * CS + sd], rot[3 * CS + sd], opa[sd], G);
     {
         const size_t o3[3] = { sd, CS + sd, 2 * CS + sd };

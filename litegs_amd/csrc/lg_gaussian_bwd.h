@@ -21,7 +21,8 @@ struct GaussGrads {
 };
 
 template <int DEG>
-__device__ __forceinline__ void gaussian_backward(const Camera& cam, const float4* __restrict__ rec, float sc,
+// mom: the nine blend-backward moments of the Gaussian (raster.hip: Mx My Mxx Mxy Myy dr dg db M0)
+__device__ __forceinline__ void gaussian_backward(const Camera& cam, const float (&mom)[9], float sc,
                                                   float px, float py, float pz, float sr0, float sr1, float sr2,
                                                   float rw, float rx, float ry, float rz, float opa_raw, GaussGrads& G)
 {
@@ -36,12 +37,11 @@ __device__ __forceinline__ void gaussian_backward(const Camera& cam, const float
     lg_cov2d(T9, cam.V, J6, c4);
     lg_inv2x2(c4[0], c4[1], c4[2], c4[3], i4);
     // ---- unpack: blend-backward moments -> d_pixel, d_conic, d_opacity (raster.hip), then GR/raster.cu:866-884
-    const float4 m0 = rec[0], m1 = rec[1];
     float gm[9];
-    lg_moments_to_grads(m0.x, m0.y, m0.z, m0.w, m1.x, rec[2].x, i4[0], i4[1], i4[3], lg_act_opacity(opa_raw), gm);
+    lg_moments_to_grads(mom[0], mom[1], mom[2], mom[3], mom[4], mom[8], i4[0], i4[1], i4[3], lg_act_opacity(opa_raw), gm);
     float gn[4] = { gm[0] * 0.5f * cam.W * sc, gm[1] * 0.5f * cam.H * sc, 0.0f, 0.0f };
     float ginv[4] = { gm[2] * sc, gm[3] * sc, gm[3] * sc, gm[4] * sc };
-    G.gc[0] = m1.y * sc; G.gc[1] = m1.z * sc; G.gc[2] = m1.w * sc;
+    G.gc[0] = mom[5] * sc; G.gc[1] = mom[6] * sc; G.gc[2] = mom[7] * sc;
     const float gop = gm[8] * sc;
     // ---- chain backward
     float gcov[4], gT[9], gq[4], gs[3];
@@ -64,6 +64,14 @@ __device__ __forceinline__ void gaussian_backward(const Camera& cam, const float
     lg_camera_center(cam.V, cx, cy, cz);
     lg_view_dir(px, py, pz, cx, cy, cz, dx, dy, dz);
     lg_sh_basis<DEG>(dx, dy, dz, G.basis);
+}
+
+// the nine moments of compacted Gaussian `od` from the blend backward's 64-byte gradient records
+__device__ __forceinline__ void load_moments(const float4* __restrict__ packed_grad, size_t od, float (&mom)[9])
+{
+    const float4* __restrict__ rec = packed_grad + od * (LG_GREC / 4);
+    const float4 a = rec[0], b = rec[1];
+    mom[0] = a.x; mom[1] = a.y; mom[2] = a.z; mom[3] = a.w; mom[4] = b.x; mom[5] = b.y; mom[6] = b.z; mom[7] = b.w; mom[8] = rec[2].x;
 }
 
 struct AdamRates { float lr_pos, lr_sh0, lr_shr, lr_opa, lr_scale, lr_rot, b1, b2, eps; };

@@ -227,3 +227,109 @@ def frame_for(step: int, rank: int, world: int, n_frames: int, perm=None) -> int
     """Rank r trains frame perm[(step*world + r) mod n_frames]: disjoint frames within a step, same permutation everywhere."""
     k = (step * world + rank) % n_frames
     return int(perm[k]) if perm is not None else k
+
+
+# ==================================================================================================================================
+# mode "moments": the exchange of the native executor (csrc/dp.hip)
+# ==================================================================================================================================
+class HipMomentOps:
+    """Device primitives of the moment exchange on the HIP kernels (no CPU path)."""
+
+    @staticmethod
+    def compact_moments(pg, vis_ids, vis_num, A, S, cap, block):
+        from ._lib import check, lib
+        check(lib().lg_dp_compact_moments(pg.data_ptr(), vis_ids.data_ptr(), vis_num.data_ptr(), A, S, cap, block.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "dp_compact_moments")
+
+    @staticmethod
+    def build_slotmap(gathered, W, cap, total, slot, host_max_k_ptr, overflow):
+        from ._lib import check, lib
+        check(lib().lg_dp_build_slotmap(gathered.data_ptr(), W, cap, total, slot.data_ptr(), host_max_k_ptr, overflow.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "dp_build_slotmap")
+
+    @staticmethod
+    def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps):
+        import ctypes
+        from ._lib import check, lib
+        va = (ctypes.c_float * (16 * W))(*[float(x) for v in views for x in v])
+        pa = (ctypes.c_float * (16 * W))(*[float(x) for v in projs for x in v])
+        la = (ctypes.c_float * 6)(*lr6)
+        check(lib().lg_dp_backward_adam(union_ids.data_ptr(), union_count.data_ptr(), chunks, S, H, Wimg, va, pa, W, degree, R,
+                                        gathered.data_ptr(), cap, slot.data_ptr(), *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms],
+                                        *[v.data_ptr() for v in vs], la, 0.9, 0.999, eps, torch.cuda.current_stream().cuda_stream),
+              "dp_backward_adam")
+
+
+class MomentExchange:
+    """Data-parallel step of the native executor: what travels is the blend backward's moment records (csrc/dp.hip header), the
+    parameter gradients are rebuilt from them on every rank inside the fused backward + Adam kernel.
+
+    Per step: one small ``all_reduce(MAX)`` (union of the ranks' visible chunks; the chunks some rank saw are the chunks Adam touches)
+    and one ``all_gather`` of fixed-size record blocks.  The block capacity follows the GPU-driven sizing protocol
+    (litegs/data.py:236-241): the job's largest record count of a slot's previous visit (every rank reads the same value out of the
+    gathered headers; the device stores it into a pinned word) x1.5; only a slot's first visit blocks on a count.  A count that
+    outgrows the capacity sets a sticky device flag -- ``check()`` raises: gradients were dropped, unlike a short table this must
+    not pass silently.  No ``nonzero()``, no ``.item()`` in the steady state.
+    """
+
+    def __init__(self, params, world: int, ops=HipMomentOps, union_ops=HipOps, group=None, n_slots: int = 64):
+        self.world, self.ops, self.union_ops, self.group = world, ops, union_ops, group
+        self.n_slots = n_slots
+        self.cap_factor, self.cap_margin = 1.5, 64       # block capacity = factor x (largest count of the slot's last visit) + margin
+        self.rebind(params)
+
+    def rebind(self, params) -> None:
+        p0 = params[0]
+        self.chunks, self.S = p0.shape[-2], p0.shape[-1]
+        dev = p0.device
+        if p0.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        self.mask = torch.zeros((self.chunks,), dtype=torch.int32, device=dev)
+        self.slot = torch.zeros((self.world, self.chunks * self.S), dtype=torch.int32, device=dev)
+        self.overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.fb_k = torch.zeros((self.n_slots,), dtype=torch.int32)
+        if p0.is_cuda:
+            self.fb_k = self.fb_k.pin_memory()
+        self.last_cap = 0
+        self.bytes_last = 0
+
+    def check(self) -> None:
+        """raises if any step since the last call dropped records (capacity outgrown); synchronises -- call at epoch boundaries"""
+        if int(self.overflow.item()) != 0:
+            self.overflow.zero_()
+            raise RuntimeError("litegs_amd.dp: a record block overflowed its predicted capacity; gradients of that step were truncated")
+
+    @torch.no_grad()
+    def step(self, pending: dict, cams, ps, ms, vs, lr6, eps: float, H: int, Wimg: int, slot: int = 0):
+        """pending: what the blend backward left (litegs_amd/fast.py: pg, A, S, vis_ids, vis_num, degree, chunks, Rr); cams: the W
+        ranks' (view_host16, proj_host16) of this step in rank order; ps / ms / vs: parameters and Adam moments in the order
+        xyz, scale, rot, sh_0, sh_rest, opacity.  -> (union_ids, union_count)"""
+        W, S, chunks = self.world, self.S, self.chunks
+        A, vis_ids, vis_num, pg = pending["A"], pending["vis_ids"], pending["vis_num"], pending["pg"]
+        slot %= self.n_slots
+        dev = pg.device
+        nrec = self.ops.record_floats() if hasattr(self.ops, "record_floats") else 10
+        # union of visibility (device-side list + count)
+        self.mask.zero_()
+        self.union_ops.mark(self.mask, vis_ids, vis_num)
+        dist.all_reduce(self.mask, op=dist.ReduceOp.MAX, group=self.group)
+        union_ids, union_count, _ = self.union_ops.compact(self.mask)
+        # capacity of the record blocks
+        pred = int(self.fb_k[slot])
+        if pred <= 0:                                    # first visit of the slot: blocking count
+            probe = torch.empty(((1 + A * S) * nrec,), dtype=torch.float32, device=dev)
+            self.ops.compact_moments(pg, vis_ids, vis_num, A, S, A * S, probe)
+            k = probe[:1].view(torch.int32).clone()
+            dist.all_reduce(k, op=dist.ReduceOp.MAX, group=self.group)
+            pred = max(int(k.item()), 1)
+        cap = int(self.cap_factor * pred) + self.cap_margin
+        self.last_cap = cap
+        block = torch.empty(((1 + cap) * nrec,), dtype=torch.float32, device=dev)
+        self.ops.compact_moments(pg, vis_ids, vis_num, A, S, cap, block)
+        gathered = torch.empty((W * (1 + cap) * nrec,), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(gathered, block, group=self.group)
+        self.bytes_last = (W - 1) * block.numel() * 4
+        self.ops.build_slotmap(gathered, W, cap, chunks * S, self.slot, self.fb_k.data_ptr() + 4 * slot, self.overflow)
+        self.ops.backward_adam(union_ids, union_count, chunks, S, H, Wimg, [c[0] for c in cams], [c[1] for c in cams], W, pending["degree"],
+                               pending["Rr"], gathered, cap, self.slot, ps, ms, vs, lr6, eps)
+        return union_ids, union_count

@@ -330,6 +330,23 @@ class FusedAdam:
                                            lr6, 0.9, 0.999, float(self.groups[0]["eps"]), _s()), "fused backward+adam")
 
     @torch.no_grad()
+    def step_exchange(self, exchange, cams, slot: int = 0):
+        """data-parallel step (litegs_amd/dp.py: MomentExchange): the pending blend-backward moments of this rank are exchanged and the
+        per-Gaussian backward + Adam runs over the union of the ranks' visible chunks -> (union_ids, union_count)"""
+        if not self._ready:
+            self._init_state()
+        pend, self.renderer.pending = self.renderer.pending, None
+        if pend is None:
+            raise RuntimeError("step_exchange: no pending blend backward (FusedRenderer.fuse_optimizer must be on)")
+        order = ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]
+        ps = [self._by_name[n]["params"][0] for n in order]
+        ms = [self.opt.state[p]["exp_avg"] for p in ps]
+        vs = [self.opt.state[p]["exp_avg_sq"] for p in ps]
+        lr6 = [float(self._by_name[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]]
+        R = self.renderer
+        return exchange.step(pend, cams, ps, ms, vs, lr6, float(self.groups[0]["eps"]), R.H, R.W, slot)
+
+    @torch.no_grad()
     def step(self, visible_chunk: torch.Tensor, visible_chunks_num: Optional[torch.Tensor]):
         if not self._ready:
             self._init_state()

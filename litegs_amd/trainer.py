@@ -79,10 +79,16 @@ class SyntheticTrainer:
                                                        (self.H, self.W), self.pp)
         return img, vis_id, vis_num, prim_vis
 
-    def step(self, frame_index: int, grad_hook=None, hook_slot: int = 0):
+    def step(self, frame_index: int, grad_hook=None, hook_slot: int = 0, peer_frames=None):
+        """grad_hook: None, a gradient hook (dp.GradientExchange.hook: parameter gradients are materialised and exchanged) or a
+        dp.MomentExchange (native executor only: the blend backward's moment records are exchanged, backward + Adam stay fused;
+        peer_frames = the frame indices of ranks 0..W-1 of this step)."""
         frame = self.frames[frame_index % len(self.frames)]
-        # gradients are only materialised when something consumes them between backward and the optimizer (DP exchange)
-        self.renderer.fuse_optimizer = self.fused and self.fuse_adam and grad_hook is None
+        moments = grad_hook is not None and hasattr(grad_hook, "step") and not callable(grad_hook)
+        if moments and not (self.fused and self.fuse_adam):
+            raise RuntimeError("MomentExchange needs the native executor (fused=True)")
+        # gradients are only materialised when something consumes them between backward and the optimizer (gradient-hook DP exchange)
+        self.renderer.fuse_optimizer = self.fused and self.fuse_adam and (grad_hook is None or moments)
         img, vis_id, vis_num, prim_vis = self.forward(frame, raw=self.raw_loss)
         if self.raw_loss:
             from . import loss_hip
@@ -90,9 +96,15 @@ class SyntheticTrainer:
         else:
             loss = self.loss_fn(img, frame.gt)
         loss.backward(self._unit)
-        if grad_hook is not None:            # data-parallel gradient exchange (litegs_amd/dp.py)
+        if moments:                          # data-parallel moment exchange + fused backward/Adam over the union (csrc/dp.hip)
+            peers = peer_frames if peer_frames is not None else [frame_index]
+            cams = [(self.frames[f % len(self.frames)].cam.view_host, self.frames[f % len(self.frames)].cam.proj_host) for f in peers]
+            vis_id, vis_num = self.fadam.step_exchange(grad_hook, cams, hook_slot)
+        elif grad_hook is not None:          # data-parallel gradient exchange (litegs_amd/dp.py)
             vis_id, vis_num = grad_hook(self.params, vis_id, vis_num, hook_slot)
-        if self.fused:
+        if moments:
+            pass
+        elif self.fused:
             self.fadam.step(vis_id, vis_num)
         else:
             self.opt.step(vis_id, vis_num, prim_vis)
@@ -120,6 +132,8 @@ class SyntheticTrainer:
         self.renderer.pending = None
         torch.cuda.current_stream().synchronize()               # pinned feedback words may still be in flight
         self.renderer.reset_feedback()
+        if getattr(self, "exchange", None) is not None:
+            self.exchange.rebind(self.params)
         self.feedback_visible_chunks_num.zero_()
         self.feedback_binning_allocate_size.zero_()
 
@@ -157,22 +171,27 @@ class SyntheticTrainer:
 
 
 def train(trainer: SyntheticTrainer, epochs: int, exchange=None, rank: int = 0, world: int = 1, start_epoch: int = 0, on_epoch=None):
-    """The reference's epoch loop (trainer.py:108-195) around the hot path, data-parallel when ``exchange`` (dp.GradientExchange) is
-    given: each step trains ``world`` different frames (one per rank), gradients are averaged over the union of the ranks' visible
-    chunks, and at the epoch boundaries every rank performs the same Morton re-sort and the same density-control decisions
-    (statistics summed across ranks, shared random draws) -- replicas stay bit-identical without ever broadcasting parameters."""
+    """The reference's epoch loop (trainer.py:108-195) around the hot path, data-parallel when ``exchange`` (dp.MomentExchange or
+    dp.GradientExchange) is given: each step trains ``world`` different frames (one per rank), gradients are averaged over the union
+    of the ranks' visible chunks, and at the epoch boundaries every rank performs the same Morton re-sort and the same density-control
+    decisions (statistics summed across ranks, shared random draws) -- replicas stay bit-identical without ever broadcasting
+    parameters.  The exchange is re-bound only when the parameters were replaced (density control, re-sort), not every epoch."""
     from . import dp
     n_frames = len(trainer.frames)
     steps_per_epoch = (n_frames + world - 1) // world
     step = start_epoch * steps_per_epoch
+    trainer.exchange = exchange
+    moments = exchange is not None and not hasattr(exchange, "hook")
     for epoch in range(start_epoch, epochs):
         with trainer.begin_epoch(epoch):
-            if exchange is not None:
-                exchange.rebind(trainer.params)
             for k in range(steps_per_epoch):
-                trainer.step(dp.frame_for(step, rank, world, n_frames), exchange.hook if exchange is not None else None, k)
+                peers = [dp.frame_for(step, r, world, n_frames) for r in range(world)]
+                hook = None if exchange is None else (exchange if moments else exchange.hook)
+                trainer.step(peers[rank], hook, k, peers)
                 step += 1
         trainer.end_epoch(epoch)
+        if moments:
+            exchange.check()
         if on_epoch is not None:
             on_epoch(epoch, trainer)
     return trainer

@@ -253,3 +253,115 @@ def test_sparse_gradient_exchange_world2():
     out = mgr.dict()
     mp.spawn(_sparse_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# mode "moments" (litegs_amd/dp.py: MomentExchange): the collective / sizing / slot-map logic on CPU with plain-torch primitives.
+# The stand-in for the fused backward + Adam kernel just accumulates the records it is handed, in rank order, into ps[0].
+# ------------------------------------------------------------------------------------------------------------------------------
+class TorchMomentOps:
+    NREC = 10
+
+    @staticmethod
+    def compact_moments(pg, vis_ids, vis_num, A, S, cap, block):
+        n = int(vis_num) * S
+        rows = pg[:n, :9]
+        nz = (rows != 0).any(dim=1).nonzero()[:, 0]
+        blk = block.view(-1, TorchMomentOps.NREC)
+        blk[0].zero_()
+        blk[0, :1].view(torch.int32)[0] = len(nz)
+        keep = nz[:cap]
+        gid = (vis_ids[keep // S] * S + keep % S).to(torch.int32)
+        blk[1:1 + len(keep), 0] = gid.view(torch.float32)
+        blk[1:1 + len(keep), 1:] = rows[keep]
+
+    @staticmethod
+    def build_slotmap(gathered, W, cap, total, slot, host_max_k_ptr, overflow):
+        g = gathered.view(W, 1 + cap, TorchMomentOps.NREC)
+        ks = [int(g[r, 0, :1].view(torch.int32)[0]) for r in range(W)]
+        for r in range(W):
+            k = min(ks[r], cap)
+            gid = g[r, 1:1 + k, 0].contiguous().view(torch.int32).long()
+            slot[r, gid] = torch.arange(1, k + 1, dtype=torch.int32)
+        TorchMomentOps.fb_target[0] = max(ks)
+        if max(ks) > cap:
+            overflow[0] = 1
+
+    @staticmethod
+    def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps):
+        g = gathered.view(W, 1 + cap, TorchMomentOps.NREC)
+        acc = ps[0].view(9, chunks * S)
+        acc.zero_()
+        for c in union_ids[: int(union_count)].tolist():
+            for t in range(S):
+                gid = c * S + t
+                for r in range(W):                     # rank order
+                    k1 = int(slot[r, gid])
+                    if k1:
+                        slot[r, gid] = 0
+                        acc[:, gid] += g[r, k1, 1:] * float(views[r][0])        # "camera" r scales rank r's records
+        acc /= W
+
+
+def _moment_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from litegs_amd import dp
+    chunks, S = 10, 4
+    params = [torch.zeros((9, chunks, S))]
+    ex = dp.MomentExchange(params, world, ops=TorchMomentOps, union_ops=TorchOps)
+    ex.cap_margin = 1
+    vis = [torch.tensor([1, 4, 5, 9, 0, 0]), torch.tensor([4, 5, 6, 8, 2, 0])][rank]
+    cnt = torch.tensor([4 if rank == 0 else 5], dtype=torch.int32)
+    A = len(vis)
+    ok = True
+    cams = [([2.0] + [0.0] * 15, [0.0] * 16), ([3.0] + [0.0] * 15, [0.0] * 16)]
+    for visit in range(3):
+        g = torch.Generator().manual_seed(10 * visit + rank)
+        pg = torch.zeros((A * S, 16))
+        touched = torch.rand((A * S,), generator=g) < (0.5 if visit < 2 else 0.95)          # visit 2: many more records than predicted
+        if rank == 1 and visit == 1:
+            touched[:] = False                                                               # a rank that touched nothing
+        pg[touched, :9] = torch.randn((int(touched.sum()), 9), generator=g)
+        pg[int(cnt) * S:] = 7.0                                                              # slots beyond vis_num are dirty by design
+        dense = torch.zeros((9, chunks * S))
+        n = int(cnt) * S
+        gid = (vis[torch.arange(n) // S] * S + torch.arange(n) % S)
+        dense[:, gid] = pg[:n, :9].t() * cams[rank][0][0]
+        both = [torch.zeros_like(dense) for _ in range(world)]
+        dist.all_gather(both, dense)
+        expect = (both[0] + both[1]) / world
+        TorchMomentOps.fb_target = ex.fb_k[3:4]
+        pend = dict(pg=pg, A=A, S=S, vis_ids=vis, vis_num=cnt, degree=3, Rr=15)
+        uid, ucnt = ex.step(pend, cams, params, [None], [None], [0.0] * 6, 1e-15, 8, 8, slot=3)
+        why = []
+        if uid[: int(ucnt)].tolist() != [1, 2, 4, 5, 6, 8, 9]:
+            why.append(("union", uid[: int(ucnt)].tolist()))
+        got = params[0].view(9, chunks * S)
+        if visit < 2:
+            if not torch.allclose(got, expect, atol=1e-6):
+                why.append(("values", visit, float((got - expect).abs().max())))
+            if int(ex.overflow[0]) != 0:
+                why.append(("overflow", visit, ex.last_cap))
+            ok &= not why
+            if why:
+                out[f"why{rank}"] = str(why)
+        else:                                            # capacity predicted from visit 1 is outgrown: loud failure, not silence
+            try:
+                ex.check()
+                ok = False
+            except RuntimeError:
+                pass
+        ok &= int(ex.slot.abs().sum()) == 0              # the map is left clean
+        ok &= int(ex.fb_k[3]) > 0
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_moment_exchange_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_moment_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)

@@ -63,6 +63,88 @@ def test_single_rank_exchange_is_identity():
         dist.destroy_process_group()
 
 
+def test_single_rank_moment_exchange_equals_the_fused_step():
+    """world 1: the moment exchange (compaction -> gather of one block -> slot map -> fused backward + Adam over the union) must
+    reproduce the single-GPU fused step -- same chain arithmetic, same Adam, same chunks; the two runs differ only by the order of the
+    blend backward's float atomics (last-bit differences in the moments)"""
+    import torch.distributed as dist
+    from litegs_amd import dp, synthetic as S
+    from litegs_amd.trainer import SyntheticTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        scene = S.make_scene(6000, seed=4)
+        ta = SyntheticTrainer(6000, 320, 200, 300.0, n_frames=2, scene=scene)
+        tb = SyntheticTrainer(6000, 320, 200, 300.0, n_frames=2, scene=scene)
+        ex = dp.MomentExchange(tb.params, 1)
+        for i in range(6):
+            la = ta.step(i)
+            lb = tb.step(i, ex, i % 2, [i])
+            assert abs(la.item() - lb.item()) < 1e-6
+        ex.check()
+        assert ex.last_cap > 0 and int(ex.slot.abs().sum().item()) == 0, "the slot map must be left clean"
+        for pa, pb in zip(ta.params, tb.params):
+            assert (pa - pb).abs().max().item() < 2e-5
+            ma, mb = ta.opt.state[pa], tb.opt.state[pb]
+            assert torch.allclose(ma["exp_avg"], mb["exp_avg"], rtol=1e-4, atol=1e-7 * float(ma["exp_avg"].abs().max()) + 1e-12)
+            assert torch.allclose(ma["exp_avg_sq"], mb["exp_avg_sq"], rtol=1e-3, atol=1e-7 * float(ma["exp_avg_sq"].abs().max()) + 1e-20)
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_rank_moments_worker(rank, world, port, out):
+    """two ranks on cuda:0 over gloo: the moment exchange against the gradient exchange (dense mode) on identical replicas"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from litegs_amd import dp, synthetic as S
+        from litegs_amd.trainer import SyntheticTrainer
+        scene = S.make_scene(20000, seed=4)
+        ta = SyntheticTrainer(20000, 320, 200, 700.0, n_frames=2 * world, scene=scene)
+        tb = SyntheticTrainer(20000, 320, 200, 700.0, n_frames=2 * world, scene=scene)
+        ex_m = dp.MomentExchange(ta.params, world)
+        ex_g = dp.GradientExchange(tb.params, world, mode="dense")
+        checks = {}
+        nframes = len(ta.frames)
+        for i in range(4):
+            peers = [dp.frame_for(i, r, world, nframes) for r in range(world)]
+            ta.step(peers[rank], ex_m, i % 2, peers)
+            tb.step(peers[rank], ex_g.hook, i % 2)
+        ex_m.check()
+        torch.cuda.synchronize()
+        checks["slot_clean"] = int(ex_m.slot.abs().sum().item()) == 0
+        checks["bytes"] = ex_m.bytes_last > 0
+        worst = 0.0
+        for pa, pb, nm in zip(ta.params, tb.params, ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]):
+            worst = max(worst, float((pa - pb).abs().max()))
+        checks["matches_gradient_exchange"] = worst < 5e-4
+        checks["worst"] = worst
+        flat = torch.cat([p.detach().reshape(-1) for p in ta.params]).cpu()
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        checks["replicas_identical"] = torch.equal(both[0], both[1])
+        checks["moved"] = not torch.equal(flat, torch.cat([torch.from_numpy(a).reshape(-1) for a in scene]))
+        out[rank] = checks
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_moment_exchange_over_gloo():
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_rank_moments_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        c = dict(out.get(r) or {})
+        assert c and all(v for k, v in c.items() if k != "worst"), (r, c)
+
+
 def _dense_grad(p, n_valid, chunks, S):
     g = p.grad
     return (g.to_dense(n_valid) if hasattr(g, "compacted_values") else g).reshape(-1, chunks, S)
@@ -131,7 +213,7 @@ def test_two_ranks_share_one_gpu_over_gloo(mode):
         assert c and all(v for k, v in c.items() if k != "max_err"), (r, c)
 
 
-def _two_rank_epochs_worker(rank, world, port, out):
+def _two_rank_epochs_worker(rank, world, port, mode, out):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -145,7 +227,7 @@ def _two_rank_epochs_worker(rank, world, port, out):
         n0 = tr.n_chunks
         tr.enable_densify(D.DensifyParams(densify_from=1, densification_interval=2, opacity_reset_interval=4, target_primitives=20000,
                                           prune_mode="threshold"), total_epochs=10, seed=1)
-        ex = dp.GradientExchange(tr.params, world)
+        ex = dp.MomentExchange(tr.params, world) if mode == "moments" else dp.GradientExchange(tr.params, world)
         sizes = []
         train(tr, 6, ex, rank, world, on_epoch=lambda e, t: sizes.append(t.n_chunks))
         torch.cuda.synchronize()
@@ -163,14 +245,15 @@ def _two_rank_epochs_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_epochs_with_density_control_stay_identical():
+@pytest.mark.parametrize("mode", ["moments", "sparse"])
+def test_two_ranks_epochs_with_density_control_stay_identical(mode):
     """six epochs of the data-parallel loop on two ranks (one GPU, gloo transport): statistic epochs, density control (append + prune +
     opacity reset), Morton re-sort, exchange buffers re-bound to the new chunk count -- and the replicas never diverge"""
     import torch.multiprocessing as mp
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_two_rank_epochs_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_two_rank_epochs_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
     for r in range(world):
         c = dict(out.get(r) or {})
         assert c and all(c.values()), (r, c)

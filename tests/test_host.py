@@ -67,7 +67,8 @@ def test_oracle_binning_invariants(oracle):
 
 def test_train_loop_schedule_with_a_fake_trainer():
     """litegs_amd.trainer.train(): the reference's epoch shape (trainer.py:108-195) -- begin_epoch guard, ceil(frames / world) steps of
-    disjoint frames per rank, end_epoch hook, the exchange re-bound at every epoch start, slots recurring with the same frame set."""
+    disjoint frames per rank, end_epoch hook, the exchange attached to the trainer (re-bound by the trainer only when the parameters
+    are replaced, not per epoch), slots recurring with the same frame set, every rank knowing its peers' frames."""
     import contextlib
     from litegs_amd import trainer as T
 
@@ -81,8 +82,8 @@ def test_train_loop_schedule_with_a_fake_trainer():
             log.append(("begin", epoch))
             return contextlib.nullcontext()
 
-        def step(self, frame, hook, slot):
-            log.append(("step", frame, hook is not None, slot))
+        def step(self, frame, hook, slot, peers=None):
+            log.append(("step", frame, hook is not None, slot, peers))
 
         def end_epoch(self, epoch):
             log.append(("end", epoch))
@@ -102,10 +103,11 @@ def test_train_loop_schedule_with_a_fake_trainer():
     T.train(FakeTrainer(), 3, ex, rank=1, world=4, start_epoch=1, on_epoch=lambda e, t: seen.append(e))
     steps = [x for x in log if x[0] == "step"]
     assert [x for x in log if x[0] in ("begin", "end")] == [("begin", 1), ("end", 1), ("begin", 2), ("end", 2)]
-    assert len(steps) == 2 * 2 and ex.rebinds == 2 and seen == [1, 2]            # ceil(6 / 4) = 2 steps per epoch, epochs 1 and 2
+    assert len(steps) == 2 * 2 and ex.rebinds == 0 and seen == [1, 2]            # ceil(6 / 4) = 2 steps per epoch, epochs 1 and 2
     # global step counter continues from start_epoch: steps 2,3 | 4,5 -> frames (step * 4 + 1) % 6
     assert [s[1] for s in steps] == [(k * 4 + 1) % 6 for k in (2, 3, 4, 5)]
     assert [s[3] for s in steps] == [0, 1, 0, 1] and all(s[2] for s in steps)
+    assert [s[4] for s in steps] == [[(k * 4 + r) % 6 for r in range(4)] for k in (2, 3, 4, 5)]
     log.clear()
     T.train(FakeTrainer(), 1)                                                      # single process: no hook, every frame once
-    assert [s[1:] for s in log if s[0] == "step"] == [(k, False, k) for k in range(6)]
+    assert [s[1:4] for s in log if s[0] == "step"] == [(k, False, k) for k in range(6)]

@@ -1,5 +1,5 @@
 """Developer tool: cost of the data-parallel exchange glue on ONE GPU (single-rank RCCL group: the collectives degenerate to copies, what
-remains is the compaction / accumulation work every rank does per step)."""
+remains is the compaction / map / accumulation work every rank does per step).  Frozen parameters (lr 0): the workload does not drift."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,17 +9,30 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from litegs_amd import dp, synthetic as S
 from litegs_amd.trainer import SyntheticTrainer
-n, W, H, f = S.CONFIGS["3m_1080p"]
-tr = SyntheticTrainer(n, W, H, f, n_frames=4)
-out = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "dp_glue.log"), "w")
-for mode in (sys.argv[1:] or ["sparse"]):
-    ex = dp.GradientExchange(tr.params, 1, mode=mode)
+cfg = "3m_1080p"
+n, W, H, f = S.CONFIGS[cfg]
+outside = "--outside" in sys.argv                      # camera outside the cloud: a frame touches ~10x more Gaussians
+tr = SyntheticTrainer(n, W, H, f, n_frames=4, cam_radius_frac=(1.6 if outside else 0.5))
+for g in tr.opt.param_groups:
+    g["lr"] = 0.0
+tr.sched.step = lambda: None
+out = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "dp_glue.log"), "a")
+modes = [a for a in sys.argv[1:] if not a.startswith("--")] or ["none", "moments", "sparse"]
+for mode in modes:
+    ex = None if mode == "none" else (dp.MomentExchange(tr.params, 1) if mode == "moments" else dp.GradientExchange(tr.params, 1, mode=mode))
+    hook = None if ex is None else (ex if mode == "moments" else ex.hook)
     for i in range(8):
-        tr.step(i, ex.hook, i % 4)
+        tr.step(i, hook, i % 4, [i % 4])
     torch.cuda.synchronize(); t = time.perf_counter()
     K = 24
     for i in range(K):
-        tr.step(i, ex.hook, i % 4)
+        tr.step(i, hook, i % 4, [i % 4])
     torch.cuda.synchronize()
-    print(f"{mode}: {(time.perf_counter() - t) / K * 1e3:.3f} ms/step with the exchange hook (world 1), last K = {ex.last_k}", file=out, flush=True)
+    extra = ""
+    if mode == "moments":
+        ex.check()
+        extra = f", record capacity {ex.last_cap}, block bytes {(1 + ex.last_cap) * 40}"
+    elif ex is not None:
+        extra = f", last K = {ex.last_k}"
+    print(f"{'outside ' if outside else ''}{mode}: {(time.perf_counter() - t) / K * 1e3:.3f} ms/step (world 1){extra}", file=out, flush=True)
 dist.destroy_process_group()
