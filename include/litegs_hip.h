@@ -133,6 +133,10 @@ int lg_create_table(const float* ndc, const float* inv_cov2d, const float* opaci
                     int32_t* keys_a, int32_t* vals_a, int32_t* keys_b, int32_t* vals_b, void* temp, long long temp_bytes, void* stream);
 /* create_table, second half: stable LSD radix sort replacing cub::DeviceRadixSort::SortPairs (binning.cu:204-221).
  * Ping-pongs a->b->a...; result is in the b pair when lg_radix_sort_num_passes() is odd, else in the a pair. */
+/* 0: the radix passes rank keys with lane-ordered returning LDS adds, verified by a device self-test on first use; 1: ballot ranking
+ * (stability by construction; also forced by LITEGS_RADIX_RANK=ballot).  The first call runs the self-test (synchronous). */
+int lg_radix_rank_mode(void);
+int lg_radix_set_rank_mode(int mode);   /* test hook: 0 / 1 force, -1 re-run the self-test */
 long long lg_radix_sort_temp_bytes(long long n);
 int lg_radix_sort_num_passes(int begin_bit, int end_bit);
 int lg_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n,

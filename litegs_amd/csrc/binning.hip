@@ -6,6 +6,7 @@
 // HBM traffic per tile instance (I of them): 8 B written by duplicate_with_keys, then per radix pass 8 B read + 8 B
 // written; 13 tile-id bits at 1080p = 2 passes of 8 bits.  No MFMA: this is byte shuffling.
 #include "lg_common.h"
+#include <stdlib.h>
 #include "lg_tilewalk.h"
 #include "lg_binning_internal.h"
 
@@ -890,7 +891,7 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
 
 // TILES key tiles per workgroup (256 threads each, processed side by side) share ONE ticket: the ticket is a returning atomic on a
 // single address (~8 ns each, serialised in L2); at 2865 tiles per pass it delayed workgroup starts by ~16 us per pass.
-template <int TILES>
+template <int TILES, bool BALLOT_RANK>
 __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              const int* __restrict__ totals /*[RADIX] of this pass*/,
@@ -934,17 +935,39 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
         key[j] = ok ? keys_in[base + e] : 0u;
         val[j] = ok ? vals_in[base + e] : 0u;
     }
-    // Rank of a key among the wave's earlier keys with the same digit = the value a returning LDS add hands back: rounds are
-    // sequential, and inside one ds_add_rtn instruction the LDS serves the lanes that hit the same address in increasing lane
-    // order, so equal digits keep their input order.  That order is a property of the CDNA LDS pipeline rather than of the
-    // programming model; tests/test_gpu_ops.py::test_radix_sort_is_stable_and_exact (duplicate-heavy keys) and the bit-exact
-    // full-size binning test pin it.  It replaces a "match-any" built from 8 ballots per key (~65 VALU per key).
+    // Rank of a key among the wave's earlier keys with the same digit.
+    // Fast path: the value a returning LDS add hands back -- rounds are sequential, and inside one ds_add_rtn instruction the LDS
+    // serves the lanes that hit the same address in increasing lane order, so equal digits keep their input order.  That order is a
+    // property of the CDNA LDS pipeline, not of the programming model, so it is never ASSUMED: lg_radix_rank_selftest() (below) runs
+    // once per process before the first sort and checks it on this very device; if a single rank comes back out of lane order the
+    // sorts use BALLOT_RANK instead, where stability follows from the code alone: the lanes that share a digit are found with eight
+    // ballots (one per digit bit), a key's rank is the number of LOWER lanes in that set, and the set's lowest lane advances the
+    // wave-private counter (+~10 us per pass of the 11.7 M-key tile sort; measured when it replaced the first version).
     int* my_cnt = wave_cnt[wave];
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
         const bool ok = (wave * WAVE_KEYS + j * 64 + lane) < cnt_tile;
         const uint32_t d = (key[j] >> shift) & mask;
-        lrank[j] = ok ? atomicAdd(&my_cnt[d], 1) : 0;
+        if constexpr (!BALLOT_RANK) {
+            lrank[j] = ok ? atomicAdd(&my_cnt[d], 1) : 0;
+        } else {
+            unsigned long long same = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < RADIX_BITS; b++) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                same &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            int r = 0;
+            if (ok) {
+                const int leader = __ffsll((long long)same) - 1;
+                const int below = __popcll(same & ((1ull << lane) - 1ull));
+                int base = 0;
+                if (lane == leader) { base = my_cnt[d]; my_cnt[d] = base + __popcll(same); }
+                base = __shfl(base, leader);
+                r = base + below;
+            }
+            lrank[j] = r;
+        }
     }
     __syncthreads();
     // thread d: counts of digit d per wave -> wave offsets inside the digit, tile count of the digit
@@ -1030,18 +1053,89 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-off self-test of the LDS property the fast ranking relies on (see radix_onesweep_kernel): for several digit patterns, 64 lanes
+// of a wave issue a returning LDS add on counters chosen by the pattern, repeatedly; every returned value must equal the counter's
+// previous total plus the number of LOWER lanes that hit the same counter.  Runs on 64 workgroups x 4 waves so that several CUs and
+// all SIMDs of a CU are exercised, with neighbouring waves hammering the same LDS at the same time.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) radix_rank_selftest_kernel(int* __restrict__ bad)
+{
+    __shared__ int cnt[TPB / 64][RADIX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = lane; k < RADIX; k += 64) cnt[wave][k] = 0;
+    __syncthreads();
+    int expect[RADIX / 64 + 1];
+    uint32_t seed = 0x9e3779b9u * (blockIdx.x * 4 + wave + 1);
+    int errors = 0;
+    for (int round = 0; round < 512; round++) {
+        uint32_t d;
+        const int kind = round & 7;
+        if (kind == 0) d = 0;                                   // all lanes on one counter
+        else if (kind == 1) d = lane & 1;
+        else if (kind == 2) d = (lane >> 3) & 7;
+        else if (kind == 3) d = lane % 3;
+        else if (kind == 4) d = (uint32_t)lane;                  // all different
+        else {                                                  // pseudo-random, few distinct values
+            seed = seed * 1664525u + 1013904223u + (uint32_t)lane * 2654435761u;
+            d = (seed >> 24) & (kind == 5 ? 3u : (kind == 6 ? 15u : 255u));
+            seed = __shfl((int)seed, 0) ^ (uint32_t)round;
+        }
+        (void)expect;
+        const int before = cnt[wave][d];                        // plain read: nothing else touches this wave's counters
+        unsigned long long same = ~0ull;
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; b++) {
+            const unsigned long long bal = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const int want = before + __popcll(same & ((1ull << lane) - 1ull));
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // the read above completes before the atomics are issued
+        const int got = atomicAdd(&cnt[wave][d], 1);
+        if (got != want) errors++;
+    }
+    if (errors) atomicAdd(bad, errors);
+}
+
+static int g_rank_mode = -1;          // -1 unknown, 0 lane-ordered LDS returns verified on this device, 1 ballot ranking
+
+LG_API int lg_radix_rank_mode(void)
+{
+    if (g_rank_mode >= 0) return g_rank_mode;
+    const char* force = getenv("LITEGS_RADIX_RANK");
+    if (force && force[0] == 'b') { g_rank_mode = 1; return 1; }
+    int* bad = nullptr;
+    int host = -1;
+    if (hipMalloc(&bad, sizeof(int)) != hipSuccess) { g_rank_mode = 1; return 1; }
+    (void)hipMemset(bad, 0, sizeof(int));
+    hipLaunchKernelGGL(radix_rank_selftest_kernel, dim3(64), dim3(TPB), 0, 0, bad);
+    if (hipMemcpy(&host, bad, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) host = -1;
+    (void)hipFree(bad);
+    g_rank_mode = (host == 0) ? 0 : 1;
+    return g_rank_mode;
+}
+
+LG_API int lg_radix_set_rank_mode(int mode)          // test hook: 0 / 1 force a ranking, -1 = decide again by the self-test
+{
+    g_rank_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    return 0;
+}
+
 // Two tiles per workgroup once there are more tiles than fit on the chip at once (the tile sort); small sorts keep one tile per
 // workgroup so that every CU gets work.
 static void launch_onesweep(int ntiles, hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, const int* totals,
                             uint32_t* status, int* ticket, long long n, const int* n_dev, int shift, uint32_t mask, const int32_t* aux_in,
                             int32_t* aux_out)
 {
-    if (ntiles >= 1024)                               // (4 tiles per workgroup measured slower: 97 vs 88 us per pass)
-        hipLaunchKernelGGL(radix_onesweep_kernel<2>, dim3((ntiles + 1) / 2), dim3(TPB * 2), 0, s, kin, vin, kout, vout, totals, status, ticket, n,
-                           n_dev, shift, mask, aux_in, aux_out);
-    else
-        hipLaunchKernelGGL(radix_onesweep_kernel<1>, dim3(ntiles), dim3(TPB), 0, s, kin, vin, kout, vout, totals, status, ticket, n, n_dev,
-                           shift, mask, aux_in, aux_out);
+    const bool ballot = lg_radix_rank_mode() != 0;
+#define LAUNCH_OS(T_, B_, G_) hipLaunchKernelGGL((radix_onesweep_kernel<T_, B_>), dim3(G_), dim3(TPB * T_), 0, s, kin, vin, kout, vout, totals, status, \
+                                                 ticket, n, n_dev, shift, mask, aux_in, aux_out)
+    if (ntiles >= 1024) {                             // (4 tiles per workgroup measured slower: 97 vs 88 us per pass)
+        if (ballot) LAUNCH_OS(2, true, (ntiles + 1) / 2); else LAUNCH_OS(2, false, (ntiles + 1) / 2);
+    } else {
+        if (ballot) LAUNCH_OS(1, true, ntiles); else LAUNCH_OS(1, false, ntiles);
+    }
+#undef LAUNCH_OS
 }
 
 LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,

@@ -10,6 +10,8 @@
 // Loss partial sums are written per workgroup and reduced in a fixed order (deterministic scalar).
 #include "lg_common.h"
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 #define TS 32                   // output tile edge
 #define HALO 5
 #define TIN (TS + 2 * HALO)     // 42
@@ -75,46 +77,51 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
     if (hwork) {
         // Four blurred maps instead of five: SSIM needs E[x^2]+E[y^2] and E[xy] only, and both follow from P = blur((x+y)^2) and
         // Q = blur((x-y)^2):  E[x^2]+E[y^2] = (P+Q)/2,  E[xy] = (P-Q)/4  (the blur is linear).  -20 % of the FMAs and LDS traffic.
-        float a[4][HSEG];
+        // The kernel is bound by VALU issue (25 M wave instructions, 4 cycles each): the four maps are accumulated as two packed
+        // 2-vectors (v_pk_fma_f32), which halves the multiply-add instructions.
+        v2f a01[HSEG], a23[HSEG];
 #pragma unroll
-        for (int j = 0; j < HSEG; j++) { a[0][j] = a[1][j] = a[2][j] = a[3][j] = 0.0f; }
+        for (int j = 0; j < HSEG; j++) { a01[j] = v2f{ 0.0f, 0.0f }; a23[j] = v2f{ 0.0f, 0.0f }; }
 #pragma unroll
         for (int u = 0; u < HSEG + 10; u++) {
-            float xv = xin[u], yv = yin[u];
-            float sp = xv + yv, sm = xv - yv;
-            float pp = sp * sp, qq = sm * sm;
+            const float xv = xin[u], yv = yin[u];
+            const float sp = xv + yv, sm = xv - yv;
+            const v2f xy = { xv, yv }, pq = { sp * sp, sm * sm };
 #pragma unroll
             for (int j = 0; j < HSEG; j++) {
                 const int t = u - j;
                 if (t >= 0 && t <= 10) {
-                    float w = c_gauss[t];
-                    a[0][j] += w * xv; a[1][j] += w * yv; a[2][j] += w * pp; a[3][j] += w * qq;
+                    const float w = c_gauss[t];
+                    a01[j] += w * xy; a23[j] += w * pq;
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < HSEG; j++) {
-            sh[0][hr][hc0 + j] = a[0][j]; sh[1][hr][hc0 + j] = a[1][j]; sh[2][hr][hc0 + j] = a[2][j];
-            sh[3][hr][hc0 + j] = a[3][j];
+            sh[0][hr][hc0 + j] = a01[j].x; sh[1][hr][hc0 + j] = a01[j].y; sh[2][hr][hc0 + j] = a23[j].x;
+            sh[3][hr][hc0 + j] = a23[j].y;
         }
     }
     __syncthreads();
     const int tx = tid % TS, r0 = (tid / TS) * VSEG;
-    float m[4][VSEG];
+    v2f m01[VSEG], m23[VSEG];
 #pragma unroll
-    for (int j = 0; j < VSEG; j++) { m[0][j] = m[1][j] = m[2][j] = m[3][j] = 0.0f; }
+    for (int j = 0; j < VSEG; j++) { m01[j] = v2f{ 0.0f, 0.0f }; m23[j] = v2f{ 0.0f, 0.0f }; }
 #pragma unroll
     for (int u = 0; u < VSEG + 10; u++) {
-        float v0 = sh[0][r0 + u][tx], v1 = sh[1][r0 + u][tx], v2 = sh[2][r0 + u][tx], v3 = sh[3][r0 + u][tx];
+        const v2f v01 = { sh[0][r0 + u][tx], sh[1][r0 + u][tx] }, v23 = { sh[2][r0 + u][tx], sh[3][r0 + u][tx] };
 #pragma unroll
         for (int j = 0; j < VSEG; j++) {
             const int t = u - j;
             if (t >= 0 && t <= 10) {
-                float w = c_gauss[t];
-                m[0][j] += w * v0; m[1][j] += w * v1; m[2][j] += w * v2; m[3][j] += w * v3;
+                const float w = c_gauss[t];
+                m01[j] += w * v01; m23[j] += w * v23;
             }
         }
     }
+    float m[4][VSEG];
+#pragma unroll
+    for (int j = 0; j < VSEG; j++) { m[0][j] = m01[j].x; m[1][j] = m01[j].y; m[2][j] = m23[j].x; m[3][j] = m23[j].y; }
     const int gx = bx + tx;
     float s_sum = 0.0f;
     const size_t stride = (size_t)gridDim.z * plane;
@@ -240,35 +247,42 @@ __global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __re
     }
     __syncthreads();                                     // inputs are in registers: the buffer may be overwritten
     if (hwork) {
-        float a[3][HSEG];
+        v2f a01[HSEG];
+        float a2[HSEG];
 #pragma unroll
-        for (int j = 0; j < HSEG; j++) { a[0][j] = a[1][j] = a[2][j] = 0.0f; }
+        for (int j = 0; j < HSEG; j++) { a01[j] = v2f{ 0.0f, 0.0f }; a2[j] = 0.0f; }
 #pragma unroll
         for (int u = 0; u < HSEG + 10; u++) {
-            float v0 = vin[0][u], v1 = vin[1][u], v2 = vin[2][u];
+            const v2f v01 = { vin[0][u], vin[1][u] };
+            const float v2 = vin[2][u];
 #pragma unroll
             for (int j = 0; j < HSEG; j++) {
                 const int t = u - j;
-                if (t >= 0 && t <= 10) { float w = c_gauss[t]; a[0][j] += w * v0; a[1][j] += w * v1; a[2][j] += w * v2; }
+                if (t >= 0 && t <= 10) { const float w = c_gauss[t]; a01[j] += w * v01; a2[j] += w * v2; }
             }
         }
 #pragma unroll
-        for (int j = 0; j < HSEG; j++) { sh[0][hr][hc0 + j] = a[0][j]; sh[1][hr][hc0 + j] = a[1][j]; sh[2][hr][hc0 + j] = a[2][j]; }
+        for (int j = 0; j < HSEG; j++) { sh[0][hr][hc0 + j] = a01[j].x; sh[1][hr][hc0 + j] = a01[j].y; sh[2][hr][hc0 + j] = a2[j]; }
     }
     __syncthreads();
     const int tx = tid % TS, r0 = (tid / TS) * VSEG;
-    float b[3][VSEG];
+    v2f b01[VSEG];
+    float b2[VSEG];
 #pragma unroll
-    for (int j = 0; j < VSEG; j++) { b[0][j] = b[1][j] = b[2][j] = 0.0f; }
+    for (int j = 0; j < VSEG; j++) { b01[j] = v2f{ 0.0f, 0.0f }; b2[j] = 0.0f; }
 #pragma unroll
     for (int u = 0; u < VSEG + 10; u++) {
-        float v0 = sh[0][r0 + u][tx], v1 = sh[1][r0 + u][tx], v2 = sh[2][r0 + u][tx];
+        const v2f v01 = { sh[0][r0 + u][tx], sh[1][r0 + u][tx] };
+        const float v2 = sh[2][r0 + u][tx];
 #pragma unroll
         for (int j = 0; j < VSEG; j++) {
             const int t = u - j;
-            if (t >= 0 && t <= 10) { float w = c_gauss[t]; b[0][j] += w * v0; b[1][j] += w * v1; b[2][j] += w * v2; }
+            if (t >= 0 && t <= 10) { const float w = c_gauss[t]; b01[j] += w * v01; b2[j] += w * v2; }
         }
     }
+    float b[3][VSEG];
+#pragma unroll
+    for (int j = 0; j < VSEG; j++) { b[0][j] = b01[j].x; b[1][j] = b01[j].y; b[2][j] = b2[j]; }
     const int gx = bx + tx;
     const float g = grad_out ? grad_out[0] : 1.0f;
 #pragma unroll

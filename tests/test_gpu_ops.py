@@ -18,10 +18,34 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(scope="module")
-def F():
-    from litegs_amd import fused
-    return fused
+@pytest.fixture(scope="module", params=["ctypes", "ext"])
+def F(request):
+    """the litegs_fused surface through both bindings of the C ABI: ctypes (litegs_amd/fused.py) and the compiled torch extension"""
+    from litegs_amd import binding, fused
+    if request.param == "ctypes":
+        return fused
+    if binding.compiled is None:
+        pytest.skip("compiled litegs_fused extension not built")
+    return binding.ops
+
+
+@pytest.fixture(params=["lds", "ballot"])
+def rank_mode(request):
+    """both rankings of the radix passes: lane-ordered returning LDS adds (self-tested fast path) and the ballot ranking"""
+    from litegs_amd._lib import lib
+    L = lib()
+    L.lg_radix_set_rank_mode(0 if request.param == "lds" else 1)
+    yield request.param
+    L.lg_radix_set_rank_mode(-1)
+
+
+def test_radix_rank_selftest_runs():
+    from litegs_amd._lib import lib
+    L = lib()
+    L.lg_radix_set_rank_mode(-1)
+    mode = L.lg_radix_rank_mode()
+    assert mode in (0, 1)
+    print(f"[radix] rank self-test: {'lane-ordered LDS returns verified' if mode == 0 else 'VIOLATED -> ballot ranking'}")
 
 
 def test_frustum_culling_bit_exact(F, oracle):
@@ -194,7 +218,7 @@ def test_create_table_overallocated_and_truncated(F, oracle):
 
 
 @pytest.mark.parametrize("n,bits", [(1, 8), (255, 8), (4096, 8), (4097, 14), (100_003, 14), (1_000_000, 11), (300_000, 32)])
-def test_radix_sort_is_stable_and_exact(F, oracle, n, bits):
+def test_radix_sort_is_stable_and_exact(F, oracle, rank_mode, n, bits):
     rng = np.random.default_rng(n)
     hi = (1 << bits) - 1 if bits < 32 else 0xFFFFFFFF
     keys = rng.integers(0, hi, size=n, dtype=np.uint64, endpoint=True).astype(np.uint32)
@@ -208,7 +232,7 @@ def test_radix_sort_is_stable_and_exact(F, oracle, n, bits):
 
 
 @pytest.mark.parametrize("pattern", ["all_equal", "two_values", "three_bit", "runs_of_64", "tile_like"])
-def test_radix_sort_stability_under_heavy_duplicates(F, pattern):
+def test_radix_sort_stability_under_heavy_duplicates(F, rank_mode, pattern):
     """Equal digits inside one 64-key wave instruction must keep their input order (the ranking relies on the LDS serving
     same-address returning adds in lane order): patterns where every instruction has many collisions, 1.2 M keys so that the
     look-back chain spans ~300 workgroups."""
