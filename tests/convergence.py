@@ -1,0 +1,226 @@
+"""Convergence evidence for the hot path: teacher -> student on synthetic data, three ways.
+
+A seeded "teacher" cloud is rendered from 8 orbit cameras (targets); a perturbed copy (the "student") is then trained to reproduce
+the targets by
+  executor  -- the native executor (litegs_amd/fast.py: fused forward, fused backward + sparse Adam),
+  operator  -- the operator-by-operator path through the litegs_fused surface (what the reference's Python drives),
+  torch     -- tests/torch_reference.py: dense torch + autograd formulation (pinned against the oracle on CPU), torch L1+SSIM loss,
+               plain no-bias-correction Adam,
+all with the reference's learning rates and schedule, visiting the frames in the same order.  PSNR over all frames is recorded
+every epoch.  Phase 2 continues executor and operator through density control (statistics, clone/split, prune, opacity decay,
+Morton re-sort); the torch formulation has no density control and stops after phase 1.
+
+    python tests/convergence.py --out gpurun_out/convergence.md           (GPU box; also imported by tests/test_gpu_convergence.py)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch_reference as TR                      # noqa: E402
+from litegs_amd import loss as loss_mod           # noqa: E402
+from litegs_amd import synthetic as S             # noqa: E402
+from litegs_amd.trainer import SyntheticTrainer   # noqa: E402
+
+
+def perturb(scene, seed, amount=1.0):
+    """student = teacher + seeded noise in raw parameter space (positions 2 % of the radius, 25 % axis lengths, colours, opacity)."""
+    rng = np.random.default_rng(seed)
+    xyz, scale, rot, sh0, shr, opa = [np.array(a, copy=True) for a in scene]
+    xyz += amount * 0.08 * rng.standard_normal(xyz.shape).astype(np.float32)
+    scale += amount * 0.25 * rng.standard_normal(scale.shape).astype(np.float32)
+    rot += amount * 0.2 * rng.standard_normal(rot.shape).astype(np.float32)
+    sh0 += amount * 0.4 * rng.standard_normal(sh0.shape).astype(np.float32)
+    shr = shr * 0.0
+    opa += amount * 0.7 * rng.standard_normal(opa.shape).astype(np.float32)
+    return xyz, scale, rot, sh0, shr.astype(np.float32), opa
+
+
+def make_trainer(scene, cfg, fused):
+    return SyntheticTrainer(cfg["n"], cfg["W"], cfg["H"], cfg["focal"], n_frames=cfg["frames"], seed=cfg["seed"], radius=cfg["radius"],
+                            cam_radius_frac=cfg["cam_frac"], scene=scene, fused=fused)
+
+
+def evaluate(tr, targets):
+    """mean PSNR over all frames (forward only, no state of the executor is consumed: render + discard)."""
+    vals = [TR.psnr(tr.forward_only(k)[0], targets[k][0]) for k in range(len(targets))]
+    return float(np.mean(vals))
+
+
+def train_native(student, targets, cfg, fused, epochs, densify=None):
+    from litegs_amd.statistics import STATS
+    tr = make_trainer(student, cfg, fused)
+    for k, t in enumerate(targets):
+        tr.frames[k].gt = t
+    assert int(tr.params[0].shape[-2]) == tr.n_chunks
+    curve, sizes = [evaluate(tr, targets)], [tr.n_chunks * tr.S]
+    ctl = None
+    if densify is not None:
+        from litegs_amd import densify as D
+        ctl = tr.enable_densify(D.DensifyParams(**densify), total_epochs=epochs, seed=cfg["seed"])
+    losses = []
+    for epoch in range(epochs):
+        if ctl is not None:
+            with tr.begin_epoch(epoch):
+                for k in range(cfg["frames"]):
+                    losses.append(tr.step(k))
+            tr.end_epoch(epoch)
+        else:
+            for k in range(cfg["frames"]):
+                losses.append(tr.step(k))
+        curve.append(evaluate(tr, targets))
+        sizes.append(tr.n_chunks * tr.S)
+    torch.cuda.synchronize()
+    if ctl is not None:
+        STATS.reset(1, 1, enabled_for_epoch=lambda e: False, device="cuda")
+        STATS.tile_schedule.clear(); STATS.tile_blend_count.clear()
+    vis = int(tr.last["vis_num"].reshape(-1)[0]) if torch.is_tensor(tr.last.get("vis_num")) else -1
+    return dict(psnr=curve, size=sizes, loss=[float(l.detach()) for l in losses[:: cfg["frames"]]], last_visible_chunks=vis)
+
+
+def train_torch(student, targets, cams, cfg, epochs):
+    from litegs_amd import optimizer as opt_mod
+    dev = targets[0].device
+    params = [torch.tensor(p, device=dev, requires_grad=True) for p in student]
+    o = opt_mod.OptimizationParams()
+    # group order of get_optimizer: xyz sh_0 sh_rest opacity scale rot; params order: xyz scale rot sh_0 sh_rest opacity
+    lrs = [o.position_lr_init, o.scaling_lr, o.rotation_lr, o.feature_lr, o.feature_lr / 10.0, o.opacity_lr]
+    adam = TR.PlainAdam(params, lrs)
+    dummies = [torch.nn.Parameter(torch.zeros(1)) for _ in range(6)]
+    sched_opt, sched = opt_mod.get_optimizer(*dummies, 1.0, o)                    # only its position-lr schedule is used
+
+    def frame(k):
+        view, proj = cams[k]
+        return TR.render(params, view, proj, cfg["H"], cfg["W"], 3)
+
+    def evaluate_t():
+        with torch.no_grad():
+            return float(np.mean([TR.psnr(frame(k), targets[k][0]) for k in range(len(targets))]))
+
+    curve, losses = [evaluate_t()], []
+    for epoch in range(epochs):
+        for k in range(cfg["frames"]):
+            adam.lrs[0] = [g["lr"] for g in sched_opt.param_groups if g["name"] == "xyz"][0]
+            img = frame(k)
+            loss = loss_mod.l1_ssim_loss_torch(img[None].clamp(0, 1), targets[k])
+            loss.backward()
+            adam.step()
+            sched.step()
+            if k == 0:
+                losses.append(float(loss.detach()))
+        curve.append(evaluate_t())
+    return dict(psnr=curve, loss=losses)
+
+
+def run(n=4096, W=128, H=96, focal=110.0, frames=8, seed=11, radius=4.0, cam_frac=2.2, epochs=60, densify_epochs=48, densify_until=17, with_torch=True,
+        log=print):
+    cfg = dict(n=n, W=W, H=H, focal=focal, frames=frames, seed=seed, radius=radius, cam_frac=cam_frac)
+    teacher = S.make_scene(n, seed=seed, radius=radius, scale_mult=0.9)
+    student = perturb(teacher, seed + 1)
+    t0 = time.time()
+    teach = make_trainer(teacher, cfg, True)
+    targets = [teach.forward_only(k).clamp(0, 1).clone() for k in range(frames)]
+    cams = [(f.view[0].clone(), f.proj[0].clone()) for f in teach.frames]
+    # the dense formulation sees every Gaussian: make sure chunk culling drops nothing for these cameras
+    with torch.no_grad():
+        t_imgs = [TR.render([p.detach() for p in teach.params], *cams[k], H, W, 3) for k in range(frames)]
+    teacher_agree = float(np.mean([TR.psnr(t_imgs[k], targets[k][0]) for k in range(frames)]))
+    del teach
+    out = dict(config=cfg, epochs=epochs, densify_epochs=densify_epochs, teacher_render_agreement_db=teacher_agree)
+    log(f"teacher targets rendered; dense-torch vs executor teacher render PSNR {teacher_agree:.1f} dB")
+    out["executor"] = train_native(student, targets, cfg, True, epochs)
+    log(f"executor   {out['executor']['psnr'][0]:.3f} -> {out['executor']['psnr'][-1]:.3f} dB   ({time.time() - t0:.0f}s)")
+    out["executor_again"] = train_native(student, targets, cfg, True, epochs)          # same path, second run: the noise floor
+    out["operator"] = train_native(student, targets, cfg, False, epochs)
+    log(f"operator   {out['operator']['psnr'][0]:.3f} -> {out['operator']['psnr'][-1]:.3f} dB   ({time.time() - t0:.0f}s)")
+    if with_torch:
+        out["torch"] = train_torch(student, targets, cams, cfg, epochs)
+        log(f"torch      {out['torch']['psnr'][0]:.3f} -> {out['torch']['psnr'][-1]:.3f} dB   ({time.time() - t0:.0f}s)")
+    if densify_epochs:
+        # four densifications (epochs 4, 8, 12, 16; opacity decay at 8 and 16), then both paths settle on the final topology
+        dn = dict(densify_from=1, densification_interval=4, opacity_reset_interval=8, target_primitives=2 * n, prune_mode="threshold",
+                  densify_until=min(densify_until, densify_epochs))
+        out["executor_densify"] = train_native(student, targets, cfg, True, densify_epochs, dn)
+        out["operator_densify"] = train_native(student, targets, cfg, False, densify_epochs, dn)
+        log(f"densify    executor {out['executor_densify']['psnr'][-1]:.3f} dB ({out['executor_densify']['size'][-1]} pts)   "
+            f"operator {out['operator_densify']['psnr'][-1]:.3f} dB ({out['operator_densify']['size'][-1]} pts)")
+    out["seconds"] = time.time() - t0
+    return out
+
+
+def _smooth(x, w=5):
+    x = np.asarray(x, dtype=np.float64)
+    return np.convolve(x, np.ones(w) / w, mode="valid") if len(x) >= w else x
+
+
+def deltas(out):
+    """per pair of paths: max |dPSNR| over the raw per-epoch curve, over the 5-epoch moving average (the per-epoch value carries
+    the step-to-step oscillation of a constant-lr Adam, which is uncorrelated between paths), the mean |dPSNR| and the final."""
+    pairs = [("executor", "executor_again"), ("executor", "operator")] + ([("executor", "torch"), ("operator", "torch")] if "torch" in out else [])
+    if "executor_densify" in out:
+        pairs.append(("executor_densify", "operator_densify"))
+    res = {}
+    for a, b in pairs:
+        pa, pb = np.array(out[a]["psnr"]), np.array(out[b]["psnr"])
+        res[f"{a}~{b}"] = dict(max=float(np.abs(pa - pb).max()), smoothed=float(np.abs(_smooth(pa) - _smooth(pb)).max()),
+                               mean=float(np.abs(pa - pb).mean()), final=float(abs(pa[-1] - pb[-1])),
+                               final5=float(abs(pa[-5:].mean() - pb[-5:].mean())))
+    return res
+
+
+def to_markdown(out):
+    d = deltas(out)
+    cfg = out["config"]
+    L = ["# Convergence: teacher -> student, executor vs operator path vs dense torch autograd", "",
+         f"Scene: {cfg['n']} Gaussians (seed {cfg['seed']}), {cfg['frames']} orbit cameras {cfg['W']}x{cfg['H']}, SH degree 3; student = teacher + noise "
+         f"(tests/convergence.py `perturb`).  Reference learning rates and position-lr schedule, L1 + 0.2 D-SSIM, Adam without bias "
+         f"correction.  PSNR = mean over all frames against the teacher renders.  Generated by `python tests/convergence.py` on MI355X "
+         f"in {out['seconds']:.0f} s.", "",
+         f"Teacher render, dense torch formulation vs executor: {out['teacher_render_agreement_db']:.1f} dB.", "",
+         "## Phase 1: fixed topology", "",
+         "`executor (2nd run)` is the same path run again from the same start: float atomics make the blend backward's summation order, "
+         "and with it the trajectory, differ from run to run -- that difference is the noise floor the other pairs are to be read against.", "",
+         "| epoch | executor | executor (2nd run) | operator | torch autograd |", "|---:|---:|---:|---:|---:|"]
+    E = out["epochs"]
+    rows = sorted(set(list(range(0, E + 1, max(1, E // 12))) + [E]))
+    for e in rows:
+        t = f"{out['torch']['psnr'][e]:.3f}" if "torch" in out else "-"
+        L.append(f"| {e} | {out['executor']['psnr'][e]:.3f} | {out['executor_again']['psnr'][e]:.3f} | {out['operator']['psnr'][e]:.3f} | {t} |")
+    L += ["", "| pair | max abs dPSNR, per epoch (dB) | max abs dPSNR, 5-epoch moving average | mean abs dPSNR | final epoch | mean of last 5 epochs |",
+          "|---|---:|---:|---:|---:|---:|"]
+    for k, v in d.items():
+        L.append(f"| {k} | {v['max']:.4f} | {v['smoothed']:.4f} | {v['mean']:.4f} | {v['final']:.4f} | {v['final5']:.4f} |")
+    if "executor_densify" in out:
+        L += ["", "## Phase 2: with density control (clone/split, prune, opacity decay, Morton re-sort)", "",
+              "| epoch | executor dB | executor points | operator dB | operator points |", "|---:|---:|---:|---:|---:|"]
+        a, b = out["executor_densify"], out["operator_densify"]
+        E2 = out["densify_epochs"]
+        for e in sorted(set(list(range(0, E2 + 1, max(1, E2 // 15))) + [E2])):
+            L.append(f"| {e} | {a['psnr'][e]:.3f} | {a['size'][e]} | {b['psnr'][e]:.3f} | {b['size'][e]} |")
+    return "\n".join(L) + "\n"
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/convergence.md")
+    ap.add_argument("--epochs", type=int, default=60)
+    ap.add_argument("--densify-epochs", type=int, default=48)
+    ap.add_argument("--n", type=int, default=4096)
+    a = ap.parse_args()
+    res = run(n=a.n, epochs=a.epochs, densify_epochs=a.densify_epochs)
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    with open(a.out, "w") as f:
+        f.write(to_markdown(res))
+    with open(os.path.splitext(a.out)[0] + ".json", "w") as f:
+        json.dump(res, f)
+    print(json.dumps(deltas(res)))
