@@ -7,6 +7,11 @@
 // (horizontal, 8-output register sliding window) then LDS->registers (vertical, 4-output sliding window).  The forward also emits the three partial-derivative maps
 // (dS/dmu1, dS/dE[x^2], dS/dE[xy]) so the backward is a second separable blur of three maps.
 // HBM traffic: forward 8 B in + 12 B out, backward 20 B in + 4 B out per pixel-channel -- bandwidth bound.
+// Measured split of the backward at 1080p (launches with parts switched off, 53 us in total): the halo fetch of the three derivative
+// maps 25 us (12 us for the same number of perfectly coalesced loads; the rest is the 168-byte halo row that straddles three 128-byte
+// lines), the pixel's own x / y 7 us, the store 4 us; both blur passes hide behind them.  Occupancy (4, 6 or 7 workgroups per CU) and the
+// order of the loads do not move it: the L1 miss path is the limit, not latency.  Forward: all 14 halo loads of a thread are issued
+// before the first LDS store and the two divisions are v_rcp_f32 (57 -> 48 us).
 // Loss partial sums are written per workgroup and reduced in a fixed order (deterministic scalar).
 #include "lg_common.h"
 
@@ -47,14 +52,29 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
     const float* y = gt + plane_id * plane;
     const int bx = blockIdx.x * TS, by = blockIdx.y * TS;
     const int tid = threadIdx.x;
-    for (int k = tid; k < TIN * TIN; k += 256) {
-        int r = k / TIN, c = k % TIN;
-        int gy = by + r - HALO, gx = bx + c - HALO;
-        bool in = (gy >= 0 && gy < H && gx >= 0 && gx < W);
-        float xv = in ? x[(size_t)gy * img_rs + gx] : 0.0f;
-        if (clamp01) xv = fminf(fmaxf(xv, 0.0f), 1.0f);
-        sx[r][c] = xv;
-        sy[r][c] = in ? y[(size_t)gy * W + gx] : 0.0f;
+    // halo load: all 7 x 2 loads of a thread are issued before the first LDS store (a rolled loop waits for each pair in turn and the
+    // kernel's time is this latency times the number of workgroup rounds per CU)
+    {
+        constexpr int NLD = (TIN * TIN + 255) / 256;
+        float xv[NLD], yv[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; it++) {
+            const int k = tid + it * 256;
+            const int r = k / TIN, c = k - r * TIN;
+            const int gy = by + r - HALO, gx = bx + c - HALO;
+            const bool in = (k < TIN * TIN) && (gy >= 0 && gy < H && gx >= 0 && gx < W);
+            xv[it] = in ? x[(size_t)gy * img_rs + gx] : 0.0f;
+            yv[it] = in ? y[(size_t)gy * W + gx] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; it++) {
+            const int k = tid + it * 256;
+            const int r = k / TIN, c = k - r * TIN;
+            if (k < TIN * TIN) {
+                sx[r][c] = clamp01 ? fminf(fmaxf(xv[it], 0.0f), 1.0f) : xv[it];
+                sy[r][c] = yv[it];
+            }
+        }
     }
     __syncthreads();
     const bool hwork = tid < TIN * (TS / HSEG);          // 168 row segments
@@ -135,13 +155,14 @@ __global__ void __launch_bounds__(256) l1_ssim_forward_kernel(const float* __res
             float s12 = exy - mu1 * mu2;
             float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * s12 + C2;
             float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = (e2sum - mu1 * mu1 - mu2 * mu2) + C2;
-            float inv = 1.0f / (B1 * B2);
+            const float rB2 = __builtin_amdgcn_rcpf(B2);               // B1, B2 >= C1, C2 > 0: v_rcp_f32 (1 ulp) instead of two IEEE divisions
+            float inv = __builtin_amdgcn_rcpf(B1) * rB2;
             float s_val = A1 * A2 * inv;
             // partial derivatives of S wrt the three blurred moments that depend on x
             float dA = 2.0f * mu2 * A2 - 2.0f * mu2 * A1;                 // d(A1*A2)/dmu1
             float dB = 2.0f * mu1 * B2 - 2.0f * mu1 * B1;                 // d(B1*B2)/dmu1
             float dmu1 = (dA - s_val * dB) * inv;
-            float dex2 = -s_val / B2;                                      // d/dE[x^2] : only B2
+            float dex2 = -s_val * rB2;                                     // d/dE[x^2] : only B2
             float dexy = 2.0f * A1 * inv;                                  // d/dE[xy]  : only A2
             size_t o = plane_id * plane + (size_t)gy * W + gx;
             dmaps[o] = dmu1;
@@ -213,7 +234,7 @@ LG_API long long lg_l1_ssim_partial_floats(int planes, int H, int W)
 // backward: d_img = g * [ lam*(-1/n) * ( blur(M1) + 2x*blur(M2) + y*blur(M3) ) + (1-lam)/n * sign(x-y) ]
 // With clamp01 the gradient is taken through clamp(img, 0, 1) (zero where the raw value lies outside [0,1], as torch's clamp backward)
 // and d_img has the padded raster layout [planes][Hp][Wp], padding written as 0 -- directly consumable by the blend backward.
-__global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __restrict__ img, long long img_ps, int img_rs, int clamp01,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) l1_ssim_backward_kernel(const float* __restrict__ img, long long img_ps, int img_rs, int clamp01,
                                                                const float* __restrict__ gt,
                                                                const float* __restrict__ dmaps, const float* __restrict__ grad_out,
                                                                int H, int W, int Hp, int Wp, float lam, float inv_n, float* __restrict__ d_img)
@@ -228,14 +249,29 @@ __global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __re
     const size_t stride = (size_t)gridDim.z * plane;
     const int bx = blockIdx.x * TS, by = blockIdx.y * TS;
     const int tid = threadIdx.x;
-    for (int k = tid; k < TIN * TIN; k += 256) {
-        int r = k / TIN, c = k % TIN;
-        int gy = by + r - HALO, gx = bx + c - HALO;
-        bool in = (gy >= 0 && gy < H && gx >= 0 && gx < W);
-        size_t o = plane_id * plane + (size_t)gy * W + gx;
-        sm[0][r][c] = in ? dmaps[o] : 0.0f;
-        sm[1][r][c] = in ? dmaps[stride + o] : 0.0f;
-        sm[2][r][c] = in ? dmaps[2 * stride + o] : 0.0f;
+    // the 7 x 3 halo loads are all in flight before the first LDS store
+    const int tx = tid % TS, r0 = (tid / TS) * VSEG;
+    const int gx = bx + tx;
+    {
+        constexpr int NLD = (TIN * TIN + 255) / 256;
+        float v0[NLD], v1[NLD], v2[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; it++) {
+            const int k = tid + it * 256;
+            const int r = k / TIN, c = k - r * TIN;
+            const int gy = by + r - HALO, gxx = bx + c - HALO;
+            const bool in = (k < TIN * TIN) && (gy >= 0 && gy < H && gxx >= 0 && gxx < W);
+            const size_t o = plane_id * plane + (size_t)gy * W + gxx;
+            v0[it] = in ? dmaps[o] : 0.0f;
+            v1[it] = in ? dmaps[stride + o] : 0.0f;
+            v2[it] = in ? dmaps[2 * stride + o] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; it++) {
+            const int k = tid + it * 256;
+            const int r = k / TIN, c = k - r * TIN;
+            if (k < TIN * TIN) { sm[0][r][c] = v0[it]; sm[1][r][c] = v1[it]; sm[2][r][c] = v2[it]; }
+        }
     }
     __syncthreads();
     const bool hwork = tid < TIN * (TS / HSEG);
@@ -264,8 +300,16 @@ __global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < HSEG; j++) { sh[0][hr][hc0 + j] = a01[j].x; sh[1][hr][hc0 + j] = a01[j].y; sh[2][hr][hc0 + j] = a2[j]; }
     }
+    // the pixel's own x / y are needed last: issued here (the row-segment registers are dead), they land during the vertical pass
+    float xraw[VSEG], yown[VSEG];
+#pragma unroll
+    for (int j = 0; j < VSEG; j++) {
+        const int gy = by + r0 + j;
+        const bool in = gx < W && gy < H;
+        xraw[j] = in ? img[plane_id * img_ps + (size_t)gy * img_rs + gx] : 0.0f;
+        yown[j] = in ? gt[plane_id * plane + (size_t)gy * W + gx] : 0.0f;
+    }
     __syncthreads();
-    const int tx = tid % TS, r0 = (tid / TS) * VSEG;
     v2f b01[VSEG];
     float b2[VSEG];
 #pragma unroll
@@ -283,14 +327,13 @@ __global__ void __launch_bounds__(256) l1_ssim_backward_kernel(const float* __re
     float b[3][VSEG];
 #pragma unroll
     for (int j = 0; j < VSEG; j++) { b[0][j] = b01[j].x; b[1][j] = b01[j].y; b[2][j] = b2[j]; }
-    const int gx = bx + tx;
     const float g = grad_out ? grad_out[0] : 1.0f;
 #pragma unroll
     for (int j = 0; j < VSEG; j++) {
         const int gy = by + r0 + j;
         if (gx < W && gy < H) {
             const size_t oi = plane_id * img_ps + (size_t)gy * img_rs + gx;
-            float xr = img[oi], yv = gt[plane_id * plane + (size_t)gy * W + gx];
+            float xr = xraw[j], yv = yown[j];
             float xv = clamp01 ? fminf(fmaxf(xr, 0.0f), 1.0f) : xr;
             float d = xv - yv;
             float sgn = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);
