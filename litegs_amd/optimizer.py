@@ -27,7 +27,9 @@ class OptimizationParams:
     opacity_lr: float = 0.025
     scaling_lr: float = 0.005
     rotation_lr: float = 0.001
+    lambda_dssim: float = 0.2            # unused by the reference as well (the fused loss fixes 0.8 L1 + 0.2 D-SSIM)
     reg_weight: float = 0.0
+    learnable_viewproj: bool = False
 
 
 class SparseGaussianAdam(torch.optim.Adam):

@@ -1,9 +1,10 @@
-"""One training iteration of the LiteGS hot loop on synthetic data (litegs/training/trainer.py:111-163):
+"""One training iteration of the LiteGS hot loop (litegs/training/trainer.py:111-163):
 render_preprocess -> render -> L1+SSIM loss -> backward -> sparse Adam -> zero_grad -> lr schedule.
 
-``SyntheticTrainer`` owns a seeded Gaussian cloud, a set of camera frames with per-frame targets and the
-pinned feedback buffers of the GPU-driven protocol (litegs/data.py:236-241), so steady-state iterations run
-without any host<->device synchronisation.  Used by bench.py, the smoke test and the DP tests.
+``FrameTrainer`` owns the parameters, a set of camera frames with per-frame targets and the pinned feedback buffers of the
+GPU-driven protocol (litegs/data.py:236-241), so steady-state iterations run without any host<->device synchronisation.
+``SyntheticTrainer`` (bench.py, the smoke test, the DP tests) fills it with a seeded cloud; ``litegs_amd.training.start`` with a COLMAP
+scene.
 """
 from __future__ import annotations
 
@@ -27,28 +28,27 @@ class Frame:
         self.cam = fast.CameraFrame(view, proj, planes, idx)
 
 
-class SyntheticTrainer:
-    def __init__(self, n_gaussians: int, width: int, height: int, focal: float, n_frames: int = 8, seed: int = 0, sh_degree: int = 3,
-                 device: Optional[torch.device] = None, radius: float = 4.0, cam_radius_frac: float = 0.5, use_torch_loss: bool = False,
-                 scene=None, fused: bool = True, fuse_adam: bool = True):
-        """fused=True: native executor (litegs_amd/fast.py); fused=False: operator-by-operator path through the litegs_fused surface."""
-        self.device = device or torch.device("cuda", torch.cuda.current_device())
+class FrameTrainer:
+    """The hot loop over a given set of posed frames and a given parameter set (the reference's per-iteration body,
+    trainer.py:121-163).  ``SyntheticTrainer`` (seeded cloud + orbit cameras, bench / tests) and ``litegs_amd.training.start`` (COLMAP
+    scenes) are its two callers."""
+
+    def __init__(self, params: List[torch.nn.Parameter], frames: List[Frame], height: int, width: int, opt, sched, pp=None,
+                 sh_degree: int = 3, device: Optional[torch.device] = None, use_torch_loss: bool = False, fused: bool = True,
+                 fuse_adam: bool = True, extra_slots: int = 0):
+        """fused=True: native executor (litegs_amd/fast.py); fused=False: operator-by-operator path through the litegs_fused surface.
+        extra_slots: additional per-frame feedback slots behind the training frames' (evaluation frames, indices len(frames)...)."""
+        self.device = device or params[0].device
         self.H, self.W, self.degree = height, width, sh_degree
-        self.pp = R.PipelineParams()
-        if scene is None:
-            scene = S.make_scene(n_gaussians, seed=seed, sh_degree=sh_degree, radius=radius)
-        self.params = [torch.nn.Parameter(torch.from_numpy(p).to(self.device)) for p in scene]
+        self.pp = pp or R.PipelineParams()
+        self.params = list(params)
         self.n_chunks, self.S = self.params[0].shape[-2], self.params[0].shape[-1]
-        cams = S.orbit_cameras(n_frames, width, height, focal, focal, cam_radius_frac * radius)
-        rng = np.random.default_rng(seed + 1)
-        self.frames: List[Frame] = []
-        for k, (view, proj, planes) in enumerate(cams):
-            gt = torch.from_numpy(rng.random((1, 3, height, width), dtype=np.float32)).to(self.device)
-            self.frames.append(Frame(*[torch.from_numpy(x).to(self.device) for x in (view, proj, planes)], gt, k))
+        self.frames = frames
+        n_frames = len(frames) + extra_slots
         # Implicit synchronisation buffers: written in epoch N, read in epoch N+1 (litegs/data.py:238)
         self.feedback_visible_chunks_num = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
         self.feedback_binning_allocate_size = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
-        self.opt, self.sched = opt_mod.get_optimizer(*self.params, 1.0, opt_mod.OptimizationParams())
+        self.opt, self.sched = opt, sched
         with torch.no_grad():
             xyz, scale, rot = self.params[0], self.params[1], self.params[2]
             self.cluster_origin, self.cluster_extend = R.get_cluster_AABB(xyz, scale.exp(), torch.nn.functional.normalize(rot, dim=0))
@@ -137,11 +137,12 @@ class SyntheticTrainer:
         self.feedback_visible_chunks_num.zero_()
         self.feedback_binning_allocate_size.zero_()
 
-    def enable_densify(self, params=None, total_epochs: int = 100, screen_extent: float = 1.0, seed: int = 0, group=None):
+    def enable_densify(self, params=None, total_epochs: int = 100, screen_extent: float = 1.0, seed: int = 0, group=None,
+                       init_points_num: Optional[int] = None):
         from . import densify as D
         dp = params or D.DensifyParams()
         dp.resolve_until(total_epochs)
-        self.controller = D.DensityController(screen_extent, dp, self.S, self.n_chunks * self.S, STATS, D.Sampler(seed), group)
+        self.controller = D.DensityController(screen_extent, dp, self.S, init_points_num or self.n_chunks * self.S, STATS, D.Sampler(seed), group)
         self.controller.on_change = self._rebind
         STATS.reset(self.n_chunks, self.S, self.controller.is_densify_actived, device=self.device)
         return self.controller
@@ -170,7 +171,27 @@ class SyntheticTrainer:
         return dict(n_vis=int(self.feedback_visible_chunks_num[k]) * self.S, instances=int(self.feedback_binning_allocate_size[k]))
 
 
-def train(trainer: SyntheticTrainer, epochs: int, exchange=None, rank: int = 0, world: int = 1, start_epoch: int = 0, on_epoch=None):
+class SyntheticTrainer(FrameTrainer):
+    """A seeded Gaussian cloud (SURVEY.md 8d distribution), orbit cameras and per-frame noise targets: the bench / test workload."""
+
+    def __init__(self, n_gaussians: int, width: int, height: int, focal: float, n_frames: int = 8, seed: int = 0, sh_degree: int = 3,
+                 device: Optional[torch.device] = None, radius: float = 4.0, cam_radius_frac: float = 0.5, use_torch_loss: bool = False,
+                 scene=None, fused: bool = True, fuse_adam: bool = True):
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        if scene is None:
+            scene = S.make_scene(n_gaussians, seed=seed, sh_degree=sh_degree, radius=radius)
+        params = [torch.nn.Parameter(torch.from_numpy(p).to(device)) for p in scene]
+        cams = S.orbit_cameras(n_frames, width, height, focal, focal, cam_radius_frac * radius)
+        rng = np.random.default_rng(seed + 1)
+        frames: List[Frame] = []
+        for k, (view, proj, planes) in enumerate(cams):
+            gt = torch.from_numpy(rng.random((1, 3, height, width), dtype=np.float32)).to(device)
+            frames.append(Frame(*[torch.from_numpy(x).to(device) for x in (view, proj, planes)], gt, k))
+        opt, sched = opt_mod.get_optimizer(*params, 1.0, opt_mod.OptimizationParams())
+        super().__init__(params, frames, height, width, opt, sched, None, sh_degree, device, use_torch_loss, fused, fuse_adam)
+
+
+def train(trainer: FrameTrainer, epochs: int, exchange=None, rank: int = 0, world: int = 1, start_epoch: int = 0, on_epoch=None):
     """The reference's epoch loop (trainer.py:108-195) around the hot path, data-parallel when ``exchange`` (dp.MomentExchange or
     dp.GradientExchange) is given: each step trains ``world`` different frames (one per rank), gradients are averaged over the union
     of the ranks' visible chunks, and at the epoch boundaries every rank performs the same Morton re-sort and the same density-control
