@@ -25,6 +25,12 @@ from litegs_amd import synthetic as S            # noqa: E402
 from litegs_amd.io import colmap as C            # noqa: E402
 
 
+def make(out, points=20000, frames=32, width=480, height=320, focal=420.0, radius=4.0, cam_radius=2.6, sfm_fraction=0.5, seed=7, text=False):
+    a = argparse.Namespace(out=out, points=points, frames=frames, width=width, height=height, focal=focal, radius=radius,
+                           cam_radius=cam_radius, sfm_fraction=sfm_fraction, seed=seed, text=text)
+    return _make(a)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
@@ -38,7 +44,10 @@ def main():
     ap.add_argument("--sfm_fraction", type=float, default=0.5, help="fraction of the teacher's Gaussians that appear as SfM points")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--text", action="store_true", help="write the .txt model instead of .bin")
-    a = ap.parse_args()
+    print(_make(ap.parse_args()))
+
+
+def _make(a):
     import PIL.Image
     dev = torch.device("cuda", 0)
     scene = S.make_scene(a.points, seed=a.seed, radius=a.radius)
@@ -85,7 +94,7 @@ def main():
         C.write_cameras_binary(os.path.join(sp, "cameras.bin"), cameras)
         C.write_images_binary(os.path.join(sp, "images.bin"), images)
         C.write_points3d_binary(os.path.join(sp, "points3D.bin"), pts, rgb)
-    print(f"wrote {a.out}: {a.frames} frames {a.width}x{a.height}, {len(pick)} SfM points of {n} teacher Gaussians")
+    return f"wrote {a.out}: {a.frames} frames {a.width}x{a.height}, {len(pick)} SfM points of {n} teacher Gaussians"
 
 
 if __name__ == "__main__":

@@ -6,4 +6,5 @@ DST="$PWD/_refstage"
 if [ "$1" == "clean" ]; then rm -rf "$DST"; exit 0; fi
 rm -rf "$DST" && mkdir -p "$DST"
 (cd /root/reference && find litegs -name "*.py" -not -path "*/submodules/*" -exec cp --parents {} "$DST" \;)
+cp /root/reference/example_train.py /root/reference/example_metrics.py /root/reference/full_eval.py "$DST"/
 find "$DST" -name "*.py" | wc -l
