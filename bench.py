@@ -315,6 +315,11 @@ def main():
             "n_vis": stats["n_vis"], "instances": stats["instances"],
             "reference_derived_rtx3090_iters_per_s": 103.0,
         }
+        if not args.operator_path:
+            rd = tr.renderer
+            result["depth_bound_culling"] = {"enabled": bool(rd.cull_enabled), "margin_pct": sorted(set(int(m) for m in rd.margin)),
+                                             "unculled_reruns_observed": int(rd.fallbacks), "visits": int(sum(rd.visits)),
+                                             "full_instances": int(rd.full_total[frame_of(0)])}
         if world == 1 and not args.operator_path:
             result["roofline"] = roofline_probe(tr, list(range(len(tr.frames))))    # in situ, after the timed region
         if world > 1 and hasattr(hook, "bytes_last"):

@@ -152,6 +152,12 @@ long long lg_scan_temp_bytes(long long n);
 int lg_gather_inclusive_scan(const int32_t* src, const void* idx, int idx_is_int64, long long n, int32_t* out,
                              void* temp, long long temp_bytes, void* stream);
 int lg_tile_range(const int32_t* sorted_keys, int V, long long L, int max_tile, int32_t* out /*[V,max_tile+2]*/, void* stream); /* binning.cu:228-287 */
+/* tilesort.hip -- replaces the depth half of wrapper.py:739-745 (torch.sort over all visible splats) + the reliance on the stable
+ * tile sort (binning.cu:205-220) to carry that order into the tiles: every tile's list in vals [V,L] (splat ids grouped by tile,
+ * ascending id inside a tile; tile_start from lg_tile_range) is sorted in place by (view depth = word 12 of the splat's packed record,
+ * id).  scratch [V,L] uint32: only touched for lists longer than 2048. */
+int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const float* packed, int V, long long L, int N, int ntiles,
+                       uint32_t* scratch, void* stream);
 int lg_memset_async(void* ptr, int value, long long bytes, void* stream);
 
 /* ---- raster.hip : GR/raster.h --------------------------------------------------------------- */
@@ -206,6 +212,12 @@ int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt
  * There is no counterpart in the reference (its executor is the Python in litegs/render/__init__.py:11-94 + wrapper.py); these
  * entry points are what litegs_amd/fast.py binds.  view_host/proj_host are HOST float[16] (row-vector 4x4, passed to kernels by value).
  * Workspace 1 holds per-Gaussian buffers for N = A*S, workspace 2 the tile-instance table of length L. */
+/* process-wide executor options.  key 0 = depth order of the tile lists: 0 (default) the reference's structure (depth sort of all
+ * visible splats before the emission, wrapper.py:739-745), 1 per-tile depth sort after the tile sort (tilesort.hip; no sort over the
+ * splats).  Identical tables either way.  key 1 = margin of the depth-bound culling in percent (default 100): how far beyond
+ * a tile's saturation point its bound for the frame's next visit lies.  Returns 0, or hipErrorInvalidValue for an unknown key / value. */
+int lg_fused_set_option(int key, int value);
+int lg_fused_get_option(int key);
 long long lg_fused_workspace1_bytes(long long N);
 long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW);
 long long lg_fused_total_offset(long long N);

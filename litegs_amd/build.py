@@ -22,6 +22,7 @@ SOURCES = {
     "transform.hip": ["-ffp-contract=off"],
     "compact.hip": ["-ffp-contract=off"],
     "binning.hip": ["-ffp-contract=off"],
+    "tilesort.hip": [],
     "raster.hip": ["-munsafe-fp-atomics"],
     "loss.hip": ["-munsafe-fp-atomics"],
     "fused.hip": ["-ffp-contract=off"],

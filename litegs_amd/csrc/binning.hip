@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     // 3. geometry of the small splats
     SplatExtent e;
     if (small) {
-        idx = (int)sorted_id[(size_t)b * N + j];
+        idx = sorted_id ? (int)sorted_id[(size_t)b * N + j] : j;          // no order given: slots are the splats themselves
         float nx, ny, a, bb, cc, o;
         load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
         splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             const int j = (int)(ent >> 8);
             my_part = (int)(ent & 255u);
             my_off = (j == 0) ? 0 : pf[j - 1];
-            my_idx = (int)sorted_id[(size_t)b * N + j];
+            my_idx = sorted_id ? (int)sorted_id[(size_t)b * N + j] : j;
             float nx, ny, a, bb, cc, o;
             load_splat<PACKED>(src, b, N, my_idx, nx, ny, a, bb, cc, o);
             splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);

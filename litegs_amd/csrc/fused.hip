@@ -23,6 +23,30 @@
 
 #define REC 16
 #define GREC 16
+
+// How each tile's list gets its depth order.  GLOBAL (default): the reference's structure (wrapper.py:739-745): stable
+// depth sort of all visible splats first (4 radix passes), emission in that order, stable tile sort.  TILE: no sort over the splats --
+// instances are emitted in splat-id order, the stable tile sort groups them and tilesort.hip sorts every tile's list by (depth, id).
+// Both give the same table bit for bit (tests/test_gpu_tilesort.py).  Measured at 3 M @1080p (gpurun_out/margin_ab.log, DESIGN.md
+// section 9): TILE removes 93 us of splat sort per frame but pays 54-65 us for the per-tile sort (LDS-bandwidth bound bitonic network)
+// and 25-30 us in the emission, whose adaptive small/big split and output locality were tuned for depth order (Morton neighbours are
+// all large or all small) -- 1.017 vs 0.986 ms per step, so GLOBAL stays the default.
+#define LG_DEPTH_ORDER_GLOBAL 0
+#define LG_DEPTH_ORDER_TILE 1
+static int g_depth_order_mode = LG_DEPTH_ORDER_GLOBAL;
+// depth-bound culling: how far (percent of the splats walked, at least 16 splats) beyond a tile's saturation point its next bound lies.
+// A wider margin emits more instances but survives more drift of the scene between two visits of a frame before the gated fallback
+// has to re-run the frame unculled (key 1 of lg_fused_set_option; litegs_amd/fast.py adapts it per frame).
+static int g_bound_margin_pct = 100;
+
+LG_API int lg_fused_set_option(int key, int value)
+{
+    if (key == 0 && (value == LG_DEPTH_ORDER_GLOBAL || value == LG_DEPTH_ORDER_TILE)) { g_depth_order_mode = value; return 0; }
+    if (key == 1 && value >= 1 && value <= 100000) { g_bound_margin_pct = value; return 0; }
+    return (int)hipErrorInvalidValue;
+}
+
+LG_API int lg_fused_get_option(int key) { return key == 0 ? g_depth_order_mode : (key == 1 ? g_bound_margin_pct : -1); }
 #define LOG2E 1.4426950408889634f
 
 
@@ -380,6 +404,12 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
     Camera cam = make_camera(view_host, proj_host, H, W);
     Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
     rc = launch_projection(sc, cam, TH, TW, w, f, true, sched_cull, sched_out, nullptr, s); if (rc) return rc;
+    if (g_depth_order_mode == LG_DEPTH_ORDER_TILE) {
+        // no splat sort: instances are emitted in splat-id order and every tile's list is depth-sorted after the tile sort
+        // (tilesort.hip).  Inclusive scan of the tile counts in id order; prefix[N-1] (the table length) also goes to the host feedback slot
+        return lg_gather_scan_gated((const int32_t*)(w + f.alloc), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
+                                    (uint32_t*)(w + f.scan_status), host_feedback_total, sched_cull ? 1 : 0, nullptr, nullptr, stream);
+    }
     float* view_z = (float*)(w + f.view_z);
     rc = lg_depth_keys_hist(view_z, N, (uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (int*)(w + f.dsort_hdr), stream); if (rc) return rc;
     // the last pass also gathers the tile counts into depth order (into the prefix buffer, scanned in place below)
@@ -410,7 +440,8 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
 {
     const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
-    const void* depth_order = odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a);
+    const bool tile_mode = g_depth_order_mode == LG_DEPTH_ORDER_TILE;
+    const void* depth_order = tile_mode ? nullptr : (odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));     // nullptr: emission in splat-id order
     const int bits = tile_key_bits(ntiles);
     // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
     // clears the sort's look-back table.  No table memset: the bounded sort only reads the first prefix[N-1] entries, and a
@@ -430,9 +461,14 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
     const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
     rc = lg_tile_range_prefilled(sorted_keys, 1, Ls, total_dev, ntiles, (int32_t*)(w + f.tile_start), s); if (rc) return rc;
+    if (tile_mode) {      // depth order inside every tile; scratch for lists beyond 2048: the key buffer the tile sort did not end in
+        rc = lg_tile_depth_sort_gated((int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.packed), 1, L,
+                                      (int)N, ntiles, (uint32_t*)(w + (odd ? f.tk_a : f.tk_b)), gate, s);
+        if (rc) return rc;
+    }
     return lg_raster_forward_bounds(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
                                     enable_stat, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order, tiles ? nullptr : tile_work,
-                                    tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, zb_check, fail_flag, gate, s);
+                                    tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, (zb_check & 1) | (g_bound_margin_pct << 8), fail_flag, gate, s);
 }
 
 static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, int H, int W, int TH, int TW,
@@ -500,7 +536,7 @@ static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2&
     Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
     rc = launch_projection(sc, cam, TH, TW, w1, f1, false, nullptr, sched_out, fail_flag, s); if (rc) return rc;
     const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
-    const int32_t* depth_order = (const int32_t*)(odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));
+    const int32_t* depth_order = g_depth_order_mode == LG_DEPTH_ORDER_TILE ? nullptr : (const int32_t*)(odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));
     rc = lg_gather_scan_gated((const int32_t*)(w1 + f1.alloc), depth_order, N, (int32_t*)(w1 + f1.prefix), (uint32_t*)(w1 + f1.scan_status2),
                               host_feedback_full, 0, fail_flag, full_total, s);
     if (rc) return rc;

@@ -49,6 +49,10 @@ int lg_gather_scan_prepared(const int32_t* src, const int32_t* idx, long long n,
 int lg_gather_scan_gated(const int32_t* src, const int32_t* idx, long long n, int32_t* out, uint32_t* status, int* host_total,
                          int mode, const int* gate, int* total_out, void* stream);
 
+// per-tile depth sort of the tile-sorted value table (tilesort.hip); gate as above
+int lg_tile_depth_sort_gated(int32_t* vals, const int32_t* tile_start, const float* packed, int V, long long L, int N, int ntiles,
+                             uint32_t* scratch, const int* gate, void* stream);
+
 // tileRange on a table whose output was pre-filled with -1
 int lg_tile_range_prefilled(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream);
 

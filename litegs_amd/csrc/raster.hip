@@ -281,10 +281,12 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     // predicted the tile to be saturated; splats deeper than the bound of EVERY tile of their rectangle were not emitted.  The list
     // walked here is then complete up to the bound, so the result is exact if the tile saturated at or before it (or if nothing was
     // culled for it); otherwise the fail flag makes the executor's gated fallback re-run the binning without culling.  The new bound
-    // is the depth 50 % (at least 16 splats) further down the list than where the tile saturated.
+    // is the depth `margin` % (default 50, at least 16 splats) further down the list than where the tile saturated.
     if (sched_out != nullptr) {
         const int gy = ntiles / gx;
         const float INF = __builtin_inff();
+        const int margin_pct = (zb_check >> 8) > 0 ? (zb_check >> 8) : 50;        // bits 8..: how far beyond the saturation point the new bound lies
+        zb_check &= 1;
         const float zused = (zb_check && sched_in != nullptr) ? reinterpret_cast<const float*>(sched_in)[lg_sched_level_offset(gx, gy, 0) + tile - 1] : INF;
         bool sat = !live;
         if (live) {                                          // the list ran out: saturated exactly at its end?
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
         if (sat && visited > 0) {
             const float stop_z = pk[(size_t)rfl(sp[visited - 1]) * REC + 12];
             ok = stop_z <= zused;
-            const int p = visited - 1 + max(16, visited >> 1);
+            const int p = visited - 1 + max(16, (int)(((long long)visited * margin_pct) / 100));
             if (p <= n - 1) znew = pk[(size_t)rfl(sp[p]) * REC + 12];
             else if (zused < INF) znew = fmaxf(zused, pk[(size_t)rfl(sp[n - 1]) * REC + 12]) * 1.25f;
         }
@@ -340,7 +342,8 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
                              float* img, float* trans, short* last, int* frag_count, float* frag_weight,
                              const int* order, int* tile_work, const int* sched_in /*nullable: previous visit's block (the bounds used)*/,
                              int* sched_out /*nullable: this visit's block; its first lg_sched_clear_words() words are zero*/,
-                             int zb_check /*0: nothing was culled, only produce new bounds*/, int* fail_flag, const int* gate, void* stream)
+                             int zb_check /*bit 0 clear: nothing was culled, only produce new bounds; bits 8..: bound margin in percent (0 = 50)*/,
+                             int* fail_flag, const int* gate, void* stream)
 {
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;

@@ -36,8 +36,19 @@ class CameraFrame:
         self.proj_ptr = self.proj_host.ctypes.data
 
 
+def _apply_env_options() -> None:
+    """LITEGS_DEPTH_ORDER=tile selects the per-tile depth sort (csrc/tilesort.hip: no sort over the splats) instead of the default
+    depth sort of all visible splats before the emission; same results bit for bit, measured slightly slower (csrc/fused.hip)"""
+    mode = os.environ.get("LITEGS_DEPTH_ORDER")
+    if mode is not None:
+        if mode not in ("tile", "global"):
+            raise ValueError("LITEGS_DEPTH_ORDER must be 'tile' or 'global'")
+        check(lib().lg_fused_set_option(0, 1 if mode == "tile" else 0), "set_option")
+
+
 class FusedRenderer:
     def __init__(self, n_frames: int, height: int, width: int, tile=(8, 16), cluster_size: int = 128):
+        _apply_env_options()
         self.H, self.W, self.TH, self.TW, self.S = height, width, tile[0], tile[1], cluster_size
         self.fb_vis = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
         self.fb_total = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
@@ -58,6 +69,19 @@ class FusedRenderer:
         self.tile_order_valid = [False] * n_frames
         self.cull_enabled = os.environ.get("LITEGS_DEPTH_CULL", "1") != "0"
         self.cull_refresh = 16
+        # margin of the depth bounds (csrc/raster.hip: percent of the splats walked beyond a tile's saturation point), per frame.  A
+        # fallback costs a whole second binning + blend (~0.4 ms at 3 M @1080p), a wider margin only a few more instances (~35 us per
+        # million): measured over 40 training steps of the bench scene, margin 50 % -> 12 fallbacks, 1.093 ms/step; 100 % -> 1 fallback,
+        # 0.986 ms; 200 % -> none, 1.026 ms (gpurun_out/margin_ab.log).  Base 100 %; the margin of a frame doubles when its previous
+        # visit fell back and decays back after clean visits.  LITEGS_CULL_MARGIN=<percent> pins it.
+        pin = os.environ.get("LITEGS_CULL_MARGIN")
+        self.margin_fixed = int(pin) if pin else 0
+        self.margin_lo, self.margin_hi = 100, 400
+        self.margin = [self.margin_fixed or self.margin_lo] * n_frames
+        self.clean_visits = [0] * n_frames
+        self.margin_written = [self.margin[0]] * n_frames    # margin of the bounds a frame's next visit will cull with
+        self.margin_emitted = [self.margin[0]] * n_frames    # margin of the bounds behind the frame's last emitted total (fb_total)
+        self.fallbacks = 0                                   # visits that were re-run unculled (observed one visit later)
         self.visits = [0] * n_frames
         self.full_total = [0] * n_frames                     # host copy of the full table length of a frame's last unculled visit
         self.last_unculled = [False] * n_frames
@@ -79,6 +103,10 @@ class FusedRenderer:
         self.tile_order_valid = [False] * n
         self.full_total = [0] * n
         self.last_unculled = [False] * n
+        self.margin = [self.margin_fixed or self.margin_lo] * n
+        self.clean_visits = [0] * n
+        self.margin_written = [self.margin[0]] * n
+        self.margin_emitted = [self.margin[0]] * n
 
     def cull_scratch(self, chunks: int, device):
         """persistent look-back table of the multi-workgroup culling kernel (epoch-tagged: zeroed once, never cleared again)"""
@@ -148,6 +176,15 @@ class _RenderFn(torch.autograd.Function):
         if int(R.fb_full[k]) > 0:                             # ... or a fallback re-ran it in full
             R.full_total[k] = max(R.full_total[k], int(R.fb_full[k]))
             R.fb_full[k] = 0
+            R.fallbacks += 1
+            R.clean_visits[k] = 0
+            if not R.margin_fixed:
+                R.margin[k] = min(R.margin[k] * 2, R.margin_hi)
+        elif not R.margin_fixed:
+            R.clean_visits[k] += 1
+            if R.clean_visits[k] >= 6 and R.margin[k] > R.margin_lo:
+                R.margin[k] = max(R.margin_lo, (R.margin[k] * 3) // 4)
+                R.clean_visits[k] = 0
         use_sched = not stat and tiles is None
         if use_sched and R.sched is None:
             R.sched = torch.empty((R.n_frames, 2, L.lg_sched_words(R.H, R.W, R.TH, R.TW)), dtype=torch.int32, device=dev)
@@ -175,7 +212,9 @@ class _RenderFn(torch.autograd.Function):
         else:
             table_len = int(1.5 * max(pred_total, R.full_total[k]))
         table_len = max(table_len, 1)
-        len_cull = min(table_len, int(1.5 * pred_total) + 65536) if cull else table_len
+        # the emitted total was predicted under the margin of the visit before last: scale the culled table when the bounds got wider
+        grow = max(1.0, R.margin_written[k] / max(R.margin_emitted[k], 1))
+        len_cull = min(table_len, int(1.5 * grow * pred_total) + 65536) if cull else table_len
         ws2_bytes = L.lg_fused_workspace2_bytes(table_len, N, R.H, R.W, R.TH, R.TW)
         ws2 = torch.empty((ws2_bytes,), dtype=torch.uint8, device=dev)
         img = torch.empty((1, 3, R.Hp, R.Wp), dtype=torch.float32, device=dev)
@@ -193,6 +232,7 @@ class _RenderFn(torch.autograd.Function):
             img.zero_(); trans.fill_(1.0); last.zero_()
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
         pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
+        L.lg_fused_set_option(1, int(R.margin[k]))
         check(L.lg_fused_stage2(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes, tp, K,
                                 1 if stat else 0, img.data_ptr(), trans.data_ptr(), last.data_ptr(),
                                 fc.data_ptr() if stat else None, fw.data_ptr() if stat else None,
@@ -206,6 +246,9 @@ class _RenderFn(torch.autograd.Function):
             R.sched_valid[k] = True
         R.last_unculled[k] = not cull
         R.last_cull = cull
+        if cull:
+            R.margin_emitted[k] = R.margin_written[k]
+        R.margin_written[k] = R.margin[k]
         R.last_ws1 = (ws1, N)                              # for tests: the fallback flag lives in workspace 1 (lg_fused_flags_offset)
         if order_out is not None:
             R.tile_order_valid[k] = True

@@ -1,0 +1,121 @@
+"""Per-tile depth sort (csrc/tilesort.hip): the table it leaves is the one a stable depth sort of the splats followed
+by a stable tile sort produces -- checked (a) on synthetic tables with every list-length regime against numpy, (b) end to end: the
+executor renders bit-identical images with the per-tile sort and with the global depth sort it replaces, on first visits, culled
+visits and forced fallbacks."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _depth_key(d):
+    u = d.view(np.uint32).astype(np.uint64)
+    neg = (u & 0x80000000) != 0
+    return np.where(neg, (~u) & 0xFFFFFFFF, u | 0x80000000)
+
+
+@pytest.mark.parametrize("case", ["mixed", "ties", "long"])
+def test_tile_depth_sort_matches_stable_sorts(case):
+    from litegs_amd import fused
+    from litegs_amd._lib import check, lib
+    rng = np.random.default_rng({"mixed": 1, "ties": 2, "long": 3}[case])
+    if case == "long":
+        lengths = [2049, 0, 4096, 5000, 1, 9001, 2048, 16385, 1]          # the table's LAST run has no closing entry (tileRange): keep it trivial
+    else:
+        lengths = [0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 190, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 2047, 2048, 0, 0, 5, 2100]
+        lengths += list(rng.integers(0, 600, size=120)) + [1]
+    ntiles = len(lengths) + 3                                        # the last tiles stay empty
+    N = 40000
+    depth = rng.uniform(0.01, 50.0, size=N).astype(np.float32)
+    if case == "ties":
+        depth = rng.choice(np.array([0.5, 1.0, 1.0000001, 7.25], dtype=np.float32), size=N)
+    depth[:8] = np.array([-1.0, -0.0, 0.0, 1e-30, 3e38, -3e38, 2.5, 2.5], dtype=np.float32)
+    packed = rng.standard_normal((1, N, 16)).astype(np.float32)
+    packed[0, :, 12] = depth
+    keys, vals = [], []
+    for t, n in enumerate(lengths):
+        ids = np.sort(rng.choice(N, size=int(n), replace=False)) if n else np.zeros((0,), np.int64)
+        if n >= 8 and t % 3 == 0:
+            ids[:8] = np.arange(8)                                   # the special depths take part
+            ids = np.unique(ids)
+        keys.append(np.full((len(ids),), t + 1, np.int32)); vals.append(ids.astype(np.int32))
+    keys, vals = np.concatenate(keys), np.concatenate(vals)
+    L = len(keys)
+    dev = torch.device("cuda", 0)
+    tk, tv, pk = torch.from_numpy(keys[None]).to(dev), torch.from_numpy(vals[None].copy()).to(dev), torch.from_numpy(packed).to(dev)
+    start = fused.tileRange(tk, ntiles)
+    scratch = torch.full((1, L), 0x7fffffff, dtype=torch.int32, device=dev)
+    check(lib().lg_tile_depth_sort(tv.data_ptr(), start.data_ptr(), pk.data_ptr(), 1, L, N, ntiles, scratch.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream), "tile_depth_sort")
+    got = tv.cpu().numpy()[0]
+    st = start.cpu().numpy()[0]
+    off = 0
+    for t, n in enumerate(lengths):
+        n = int((keys == t + 1).sum())
+        ids = vals[off:off + n]
+        a, b = st[t + 1], st[t + 2]
+        seen = (a >= 0 and b > a)
+        if n == 0:
+            off += n
+            continue
+        if not seen:                                                 # tileRange's convention: the last run has no closing entry -> not a list
+            np.testing.assert_array_equal(got[off:off + n], ids)
+            off += n
+            continue
+        assert (a, b) == (off, off + n)
+        order = np.lexsort((ids, _depth_key(depth[ids])))            # primary: depth key, ties: id  == stable sort of ascending ids
+        np.testing.assert_array_equal(got[off:off + n], ids[order], err_msg=f"tile {t + 1} n={n}")
+        off += n
+
+
+def _render_all(tr, frames, visits):
+    out = []
+    for v in range(visits):
+        for k in frames:
+            with torch.no_grad():
+                img = tr.forward_only(k)
+            out.append(img.clone())
+    torch.cuda.synchronize()
+    return out
+
+
+def test_executor_is_bit_identical_with_and_without_the_splat_sort():
+    """first visits (unculled, blocking sizes), culled revisits and the 16th-visit refresh: same images bit for bit in both modes"""
+    from litegs_amd._lib import lib
+    from litegs_amd.trainer import SyntheticTrainer
+    L = lib()
+    imgs = {}
+    try:
+        for mode in (1, 0):
+            assert L.lg_fused_set_option(0, mode) == 0
+            tr = SyntheticTrainer(60000, 640, 360, 500.0, n_frames=3, seed=5)
+            imgs[mode] = _render_all(tr, range(3), 18)
+            if mode == 1:
+                assert tr.renderer.last_cull                          # the revisits really ran culled
+    finally:
+        L.lg_fused_set_option(0, 1)
+    assert len(imgs[0]) == len(imgs[1]) == 54
+    for a, b in zip(imgs[0], imgs[1]):
+        assert torch.equal(a, b)
+
+
+def test_training_steps_agree_between_the_two_modes():
+    """a few optimisation steps (forward, loss, blend backward, fused backward + Adam) with both orders: the blend backward's float
+    atomics make parameters differ in the last bits run to run, so this is a tolerance check on top of the bit-exact forward test"""
+    from litegs_amd._lib import lib
+    from litegs_amd.trainer import SyntheticTrainer
+    L = lib()
+    res = {}
+    try:
+        for mode in (1, 0):
+            L.lg_fused_set_option(0, mode)
+            tr = SyntheticTrainer(30000, 480, 270, 400.0, n_frames=2, seed=9)
+            losses = [float(tr.step(i % 2).detach()) for i in range(12)]
+            torch.cuda.synchronize()
+            res[mode] = (losses, [p.detach().clone() for p in tr.params])
+    finally:
+        L.lg_fused_set_option(0, 1)
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-4)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 2e-2 * max(float(a.abs().max()), 1.0)       # 12 Adam steps amplify last-bit differences of the atomics
