@@ -320,6 +320,14 @@ def main():
             result["depth_bound_culling"] = {"enabled": bool(rd.cull_enabled), "margin_pct": sorted(set(int(m) for m in rd.margin)),
                                              "unculled_reruns_observed": int(rd.fallbacks), "visits": int(sum(rd.visits)),
                                              "full_instances": int(rd.full_total[frame_of(0)])}
+            fa = tr.fadam
+            if fa.skip_untouched and fa.touched is not None:
+                # exact skip of no-op Adam updates (csrc/fused.hip): Gaussians of the visible chunks that never received a gradient
+                result["adam_noop_skip"] = {"enabled": True, "gaussians_with_history": int(fa.touched.sum().item()),
+                                            "gaussians_total": int(fa.touched.numel()),
+                                            "note": "bit-exact: zero moments + zero gradient = unchanged parameter; LITEGS_ADAM_SKIP_UNTOUCHED=0 disables"}
+            else:
+                result["adam_noop_skip"] = {"enabled": False}
         if world == 1 and not args.operator_path:
             result["roofline"] = roofline_probe(tr, list(range(len(tr.frames))))    # in situ, after the timed region
         if world > 1 and hasattr(hook, "bytes_last"):

@@ -262,7 +262,10 @@ int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_host, c
                            float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
                            float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
                            float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
-                           const float* lr6, float b1, float b2, float eps, void* stream);
+                           const float* lr6, float b1, float b2, float eps,
+                           unsigned char* touched /* nullable uint8[chunks*S] owned by the optimizer: 0 = all Adam moments of that Gaussian are
+                                                     zero; such Gaussians are skipped (exactly a no-op) while their blend moments are zero, and
+                                                     flagged on their first non-zero record */, void* stream);
 int lg_adam_update_multi(int ngroups, void* const* param, const void* const* grad, void* const* exp_avg, void* const* exp_avg_sq,
                          const int* rows, const float* lr, const int64_t* visible_chunk_id, const int* valid_length,
                          int chunks, int A, int S, int grad_dense, float b1, float b2, float eps, void* stream);

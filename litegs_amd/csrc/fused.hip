@@ -189,7 +189,8 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
                                              float* __restrict__ m_pos, float* __restrict__ m_scale, float* __restrict__ m_rot,
                                              float* __restrict__ m_sh0, float* __restrict__ m_shr, float* __restrict__ m_opa,
                                              float* __restrict__ v_pos, float* __restrict__ v_scale, float* __restrict__ v_rot,
-                                             float* __restrict__ v_sh0, float* __restrict__ v_shr, float* __restrict__ v_opa)
+                                             float* __restrict__ v_sh0, float* __restrict__ v_shr, float* __restrict__ v_opa,
+                                             unsigned char* __restrict__ touched)
 {
     const int a = blockIdx.x, t = threadIdx.x;
     if (a >= visible_chunks_num[0]) return;
@@ -201,6 +202,21 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
     GaussGrads G;
     float mom[9];
     load_moments(packed_grad, od, mom);
+    // Exact skip of no-op updates.  touched[g] == 0 asserts that both Adam moments of every row of Gaussian g are (+-)0 -- it has never
+    // received a gradient.  If this frame's nine blend moments are all zero as well, every parameter gradient is 0 and the update is
+    // m' = b1*0 + (1-b1)*0 = 0, v' = 0, p' = p - lr*0/(sqrt(0)+eps) = p: bit for bit what is already in memory, so the 708 B of
+    // parameters/moments are neither read nor written (1480 -> 65 B for such a Gaussian).  The first non-zero record sets the flag for
+    // good.  The reference's semantics (Adam over all Gaussians of the visible chunks, GR/compact.cu:333-342) are untouched: Gaussians
+    // with a history keep decaying their moments on zero gradients.
+    if (touched != nullptr) {
+        unsigned int any = 0u;
+#pragma unroll
+        for (int k = 0; k < 9; k++) any |= __float_as_uint(mom[k]) << 1;          // +-0 -> 0; NaN / inf count as a gradient
+        if (touched[sd] == 0) {
+            if (any == 0u) return;
+            touched[sd] = 1;
+        }
+    }
     gaussian_backward<DEG>(cam, mom, sc, pos[sd], pos[CS + sd], pos[2 * CS + sd],
                            scale[sd], scale[CS + sd], scale[2 * CS + sd], rot[sd], rot[CS + sd], rot[2 * CS + sd], rot[3 * CS + sd], opa[sd], G);
     {
@@ -602,7 +618,8 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
                                   float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
                                   float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
                                   float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
-                                  const float* lr6, float b1, float b2, float eps, void* stream)
+                                  const float* lr6, float b1, float b2, float eps,
+                                  unsigned char* touched /*nullable [chunks*S]: 0 = both moments of every row of that Gaussian are zero*/, void* stream)
 {
     if (A <= 0) return 0;
     if (S > 1024 || S <= 0) return (int)hipErrorInvalidValue;
@@ -611,7 +628,7 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
     AdamRates ar = { lr6[0], lr6[1], lr6[2], lr6[3], lr6[4], lr6[5], b1, b2, eps };
 #define LAUNCH_PA(D) hipLaunchKernelGGL(project_backward_adam_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, ar, chunks, S, A, R, \
                                         (const float4*)packed_grad, grad_inv_scaler, pos, scale, rot, sh0, shr, opa,                          \
-                                        m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa, v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa)
+                                        m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa, v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched)
     switch (degree) {
     case 0: LAUNCH_PA(0); break;
     case 1: LAUNCH_PA(1); break;

@@ -341,6 +341,8 @@ class FusedAdam:
         self._iarr = ctypes.c_int * G
         self._farr = ctypes.c_float * G
         self._ready = False
+        self.touched = None
+        self.skip_untouched = os.environ.get("LITEGS_ADAM_SKIP_UNTOUCHED", "1") != "0"
 
     def _init_state(self):
         for g in self.groups:
@@ -357,7 +359,24 @@ class FusedAdam:
         self._v = self._arr(*[self.opt.state[p]["exp_avg_sq"].data_ptr() for p in ps])
         self._rows = self._iarr(*[int(p.numel() // (self.chunks * self.S)) for p in ps])
         self._by_name = {g.get("name"): g for g in self.groups}
+        self.touched = None                  # rebuilt from the moments before the next fused backward + Adam
         self._ready = True
+
+    def _touched_flags(self) -> torch.Tensor:
+        """uint8 [chunks*S]: 0 where BOTH Adam moments of EVERY row of a Gaussian are zero (it never received a gradient): the fused
+        backward + Adam skips such Gaussians while their gradient is zero too -- exactly a no-op (csrc/fused.hip).  Maintained by that
+        kernel; every other writer of the moments (the other optimizer paths, density control, re-sort, checkpoints) drops the array
+        and it is rebuilt from the moments here (one pass over the optimizer state, only on such transitions)."""
+        if self.touched is None or self.touched.numel() != self.chunks * self.S:
+            flags = None
+            for g in self.groups:
+                p = g["params"][0]
+                st = self.opt.state[p]
+                for key in ("exp_avg", "exp_avg_sq"):
+                    nz = (st[key].reshape(-1, self.chunks * self.S) != 0).any(dim=0)
+                    flags = nz if flags is None else (flags | nz)
+            self.touched = flags.to(torch.uint8).contiguous()
+        return self.touched
 
     def _step_fused_backward(self, pend):
         """per-Gaussian backward + Adam in one kernel, from the packed gradients left by the blend backward."""
@@ -370,7 +389,8 @@ class FusedAdam:
         check(lib().lg_fused_backward_adam(pend["A"], pend["S"], R.H, R.W, fr.view_ptr, fr.proj_ptr, pend["degree"], pend["chunks"], pend["Rr"],
                                            pend["vis_ids"].data_ptr(), pend["vis_num"].data_ptr(), pend["pg"].data_ptr(), None,
                                            *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms], *[v.data_ptr() for v in vs],
-                                           lr6, 0.9, 0.999, float(self.groups[0]["eps"]), _s()), "fused backward+adam")
+                                           lr6, 0.9, 0.999, float(self.groups[0]["eps"]),
+                                           self._touched_flags().data_ptr() if self.skip_untouched else None, _s()), "fused backward+adam")
 
     @torch.no_grad()
     def step_exchange(self, exchange, cams, slot: int = 0):
@@ -387,6 +407,7 @@ class FusedAdam:
         vs = [self.opt.state[p]["exp_avg_sq"] for p in ps]
         lr6 = [float(self._by_name[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]]
         R = self.renderer
+        self.touched = None                  # the exchange's kernel updates the moments without maintaining the flags
         return exchange.step(pend, cams, ps, ms, vs, lr6, float(self.groups[0]["eps"]), R.H, R.W, slot)
 
     @torch.no_grad()
@@ -396,6 +417,7 @@ class FusedAdam:
         if self.renderer is not None and self.renderer.pending is not None:
             pend, self.renderer.pending = self.renderer.pending, None
             return self._step_fused_backward(pend)
+        self.touched = None                  # the paths below update the moments without maintaining the flags
         ps = [g["params"][0] for g in self.groups]
         grads = [p.grad for p in ps]
         if any(g is None for g in grads):
