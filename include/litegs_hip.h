@@ -285,7 +285,8 @@ int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count, int ch
                         float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
                         float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
                         float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
-                        const float* lr6 /*host: xyz, sh_0, sh_rest, opacity, scale, rot*/, float b1, float b2, float eps, void* stream);
+                        const float* lr6 /*host: xyz, sh_0, sh_rest, opacity, scale, rot*/, float b1, float b2, float eps,
+                        unsigned char* touched /*nullable uint8[chunks*S], as in lg_fused_backward_adam*/, void* stream);
 
 /* ---- knn.hip : simple_knn._C.distCUDA2 (litegs/submodules/simple-knn/simple_knn.cu:186-222; caller litegs/scene/point.py:8) --------
  * mean squared distance of every point to its 3 nearest neighbours (exact).  points [P,3] fp32, mean_dist2 [P]. */

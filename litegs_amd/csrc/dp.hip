@@ -117,13 +117,22 @@ __global__ void dp_backward_adam_kernel(const int64_t* __restrict__ union_ids, c
                                         float* __restrict__ m_pos, float* __restrict__ m_scale, float* __restrict__ m_rot,
                                         float* __restrict__ m_sh0, float* __restrict__ m_shr, float* __restrict__ m_opa,
                                         float* __restrict__ v_pos, float* __restrict__ v_scale, float* __restrict__ v_rot,
-                                        float* __restrict__ v_sh0, float* __restrict__ v_shr, float* __restrict__ v_opa)
+                                        float* __restrict__ v_sh0, float* __restrict__ v_shr, float* __restrict__ v_opa,
+                                        unsigned char* __restrict__ touched)
 {
     const int a = blockIdx.x, t = threadIdx.x;
     if (a >= union_count[0]) return;
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const size_t CS = (size_t)C * S;
     const size_t sd = (size_t)union_ids[a] * S + t;
+    // exact skip of no-op updates (see project_backward_adam_kernel, fused.hip): no rank sent a record for this Gaussian and it has no
+    // Adam history -> gradient 0 on zero moments leaves parameter and moments bit for bit as they are
+    if (touched != nullptr && touched[sd] == 0) {
+        int any = 0;
+        for (int r = 0; r < W; r++) any |= slot[(size_t)r * CS + sd];
+        if (any == 0) return;
+        touched[sd] = 1;
+    }
     const float px = pos[sd], py = pos[CS + sd], pz = pos[2 * CS + sd];
     const float s0 = scale[sd], s1 = scale[CS + sd], s2 = scale[2 * CS + sd];
     const float rw = rot[sd], rx = rot[CS + sd], ry = rot[2 * CS + sd], rz = rot[3 * CS + sd];
@@ -194,7 +203,8 @@ LG_API int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count,
                                float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
                                float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
                                float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
-                               const float* lr6 /*xyz, sh_0, sh_rest, opacity, scale, rot*/, float b1, float b2, float eps, void* stream)
+                               const float* lr6 /*xyz, sh_0, sh_rest, opacity, scale, rot*/, float b1, float b2, float eps,
+                               unsigned char* touched /*nullable, as in lg_fused_backward_adam*/, void* stream)
 {
     if (world <= 0 || world > DP_MAX_WORLD || chunks <= 0 || S <= 0 || S > 1024) return (int)hipErrorInvalidValue;
     CameraSet cams;
@@ -207,7 +217,7 @@ LG_API int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count,
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_DP(D) hipLaunchKernelGGL(dp_backward_adam_kernel<D>, dim3(chunks), dim3(S), 0, s, union_ids, union_count, cams, world, ar, chunks, S, R, \
                                         gathered, cap, slot, pos, scale, rot, sh0, shr, opa, m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa,               \
-                                        v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa)
+                                        v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched)
     switch (degree) {
     case 0: LAUNCH_DP(0); break;
     case 1: LAUNCH_DP(1); break;

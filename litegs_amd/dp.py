@@ -248,7 +248,7 @@ class HipMomentOps:
                                         torch.cuda.current_stream().cuda_stream), "dp_build_slotmap")
 
     @staticmethod
-    def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps):
+    def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps, touched=None):
         import ctypes
         from ._lib import check, lib
         va = (ctypes.c_float * (16 * W))(*[float(x) for v in views for x in v])
@@ -256,7 +256,8 @@ class HipMomentOps:
         la = (ctypes.c_float * 6)(*lr6)
         check(lib().lg_dp_backward_adam(union_ids.data_ptr(), union_count.data_ptr(), chunks, S, H, Wimg, va, pa, W, degree, R,
                                         gathered.data_ptr(), cap, slot.data_ptr(), *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms],
-                                        *[v.data_ptr() for v in vs], la, 0.9, 0.999, eps, torch.cuda.current_stream().cuda_stream),
+                                        *[v.data_ptr() for v in vs], la, 0.9, 0.999, eps, touched.data_ptr() if touched is not None else None,
+                                        torch.cuda.current_stream().cuda_stream),
               "dp_backward_adam")
 
 
@@ -300,10 +301,11 @@ class MomentExchange:
             raise RuntimeError("litegs_amd.dp: a record block overflowed its predicted capacity; gradients of that step were truncated")
 
     @torch.no_grad()
-    def step(self, pending: dict, cams, ps, ms, vs, lr6, eps: float, H: int, Wimg: int, slot: int = 0):
+    def step(self, pending: dict, cams, ps, ms, vs, lr6, eps: float, H: int, Wimg: int, slot: int = 0, touched=None):
         """pending: what the blend backward left (litegs_amd/fast.py: pg, A, S, vis_ids, vis_num, degree, chunks, Rr); cams: the W
         ranks' (view_host16, proj_host16) of this step in rank order; ps / ms / vs: parameters and Adam moments in the order
-        xyz, scale, rot, sh_0, sh_rest, opacity.  -> (union_ids, union_count)"""
+        xyz, scale, rot, sh_0, sh_rest, opacity; touched (nullable uint8[chunks*S]): the optimizer's "has Adam history" flags -- Gaussians
+        without history that no rank sent a record for are skipped (an exact no-op).  -> (union_ids, union_count)"""
         W, S, chunks = self.world, self.S, self.chunks
         A, vis_ids, vis_num, pg = pending["A"], pending["vis_ids"], pending["vis_num"], pending["pg"]
         slot %= self.n_slots
@@ -331,5 +333,5 @@ class MomentExchange:
         self.bytes_last = (W - 1) * block.numel() * 4
         self.ops.build_slotmap(gathered, W, cap, chunks * S, self.slot, self.fb_k.data_ptr() + 4 * slot, self.overflow)
         self.ops.backward_adam(union_ids, union_count, chunks, S, H, Wimg, [c[0] for c in cams], [c[1] for c in cams], W, pending["degree"],
-                               pending["Rr"], gathered, cap, self.slot, ps, ms, vs, lr6, eps)
+                               pending["Rr"], gathered, cap, self.slot, ps, ms, vs, lr6, eps, touched)
         return union_ids, union_count

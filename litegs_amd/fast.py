@@ -407,8 +407,8 @@ class FusedAdam:
         vs = [self.opt.state[p]["exp_avg_sq"] for p in ps]
         lr6 = [float(self._by_name[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]]
         R = self.renderer
-        self.touched = None                  # the exchange's kernel updates the moments without maintaining the flags
-        return exchange.step(pend, cams, ps, ms, vs, lr6, float(self.groups[0]["eps"]), R.H, R.W, slot)
+        return exchange.step(pend, cams, ps, ms, vs, lr6, float(self.groups[0]["eps"]), R.H, R.W, slot,
+                             self._touched_flags() if self.skip_untouched else None)
 
     @torch.no_grad()
     def step(self, visible_chunk: torch.Tensor, visible_chunks_num: Optional[torch.Tensor]):

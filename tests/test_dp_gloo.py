@@ -288,7 +288,7 @@ class TorchMomentOps:
             overflow[0] = 1
 
     @staticmethod
-    def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps):
+    def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps, touched=None):
         g = gathered.view(W, 1 + cap, TorchMomentOps.NREC)
         acc = ps[0].view(9, chunks * S)
         acc.zero_()
