@@ -4,6 +4,7 @@
 // GR/{binning,compact,raster,transform}.h; litegs_amd/fused.py is the same binding through ctypes (kept for environments without a
 // C++ toolchain) and the two are tested against each other.  No computation happens here and there is no CPU path.
 #include <torch/extension.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <optional>
 #include <string>
@@ -51,6 +52,7 @@ inline TileShape tiles_shape(int64_t h, int64_t w, int64_t th, int64_t tw)
 // ------------------------------------------------------------------------------------------------ compact.h
 std::vector<Tensor> frustum_culling_aabb(Tensor aabb_origin, Tensor aabb_ext, Tensor frustumplane, OptTensor feedback_buffer_arg, OptTensor data_idx_arg)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(aabb_origin));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor o = f32(aabb_origin, "aabb_origin"), e = f32(aabb_ext, "aabb_ext"), p = f32(frustumplane, "frustumplane");
     const int V = (int)p.size(0), M = (int)o.size(1);
     Tensor visibility = at::empty({M}, like(p, at::kBool)), num = at::empty({1}, like(p, at::kInt)), ids = at::empty({M}, like(p, at::kLong));
@@ -74,6 +76,7 @@ std::vector<Tensor> frustum_culling_aabb(Tensor aabb_origin, Tensor aabb_ext, Te
 std::vector<Tensor> cull_compact_activate(int sh_degree, Tensor visible_chunk_id, Tensor visible_chunks_num, Tensor view_matrix,
                                           Tensor position, Tensor scale, Tensor rotation, Tensor sh_base, Tensor sh_rest, Tensor opacity)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(visible_chunk_id));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor pos = f32(position, "position"), sc = f32(scale, "scale"), rot = f32(rotation, "rotation");
     Tensor s0 = f32(sh_base, "sh_base"), sr = f32(sh_rest, "sh_rest"), op = f32(opacity, "opacity"), vm = f32(view_matrix, "view_matrix");
     Tensor ids = dev(visible_chunk_id, "visible_chunk_id");
@@ -92,6 +95,7 @@ std::vector<Tensor> activate_backward(int sh_degree, Tensor visible_chunk_id, Te
                                       Tensor activated_position_grad, Tensor activated_scale_grad, Tensor activated_rotation_grad,
                                       Tensor color_grad, Tensor activated_opacity_grad)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(visible_chunk_id));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor pos = f32(position, "position"), sc = f32(scale, "scale"), rot = f32(rotation, "rotation"), op = f32(opacity, "opacity");
     Tensor vm = f32(view_matrix, "view_matrix"), ids = dev(visible_chunk_id, "visible_chunk_id");
     Tensor gp = f32(activated_position_grad, "g_pos"), gs = f32(activated_scale_grad, "g_scale"), gr = f32(activated_rotation_grad, "g_rot");
@@ -111,6 +115,7 @@ std::vector<Tensor> activate_backward(int sh_degree, Tensor visible_chunk_id, Te
 void adamUpdate(Tensor param, Tensor param_grad, Tensor exp_avg, Tensor exp_avg_sq, Tensor visible_index, OptTensor valid_length,
                 double lr, double b1, double b2, double eps)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(param));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     for (const Tensor* t : { &param, &param_grad, &exp_avg, &exp_avg_sq })
         TORCH_CHECK(t->is_cuda() && t->is_contiguous() && t->scalar_type() == at::kFloat, "adamUpdate: tensors must be contiguous float32 device tensors");
     Tensor vi = dev(visible_index, "visible_index");
@@ -137,6 +142,7 @@ int dtype_code(at::ScalarType t)
 
 void gpu_driven_pipeline_sparse_op(Tensor A, Tensor B, Tensor visible_chunk_ids, Tensor visible_count, std::string op_name)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(A));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     TORCH_CHECK(A.is_cuda() && B.is_cuda() && visible_chunk_ids.is_cuda() && visible_count.is_cuda(), "inputs must be CUDA tensors");
     int op;
     if (op_name == "add" || op_name == "sum") op = 0;
@@ -153,6 +159,7 @@ void gpu_driven_pipeline_sparse_op(Tensor A, Tensor B, Tensor visible_chunk_ids,
 
 std::vector<Tensor> create_viewproj_forward(Tensor view_params, Tensor recp_tan_half_fov_x, int img_h, int img_w, float z_near, float z_far)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(view_params));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor vp = f32(view_params, "view_params"), fov = f32(recp_tan_half_fov_x, "recp_tan_half_fov_x");
     TORCH_CHECK(vp.dim() == 2 && vp.size(1) == 7, "create_viewproj_forward: view_params must be [views,7]");
     const int V = (int)vp.size(0);
@@ -166,6 +173,7 @@ std::vector<Tensor> create_viewproj_forward(Tensor view_params, Tensor recp_tan_
 std::vector<Tensor> create_viewproj_backward(Tensor view_matrix_grad, Tensor proj_matrix_grad, Tensor viewproj_matrix_grad, Tensor view_params,
                                              Tensor recp_tan_half_fov_x, int img_h, int img_w, float z_near, float z_far)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(view_matrix_grad));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor vp = f32(view_params, "view_params"), fov = f32(recp_tan_half_fov_x, "recp_tan_half_fov_x");
     const int V = (int)vp.size(0);
     Tensor g0 = f32(view_matrix_grad, "view_matrix_grad"), g1 = f32(proj_matrix_grad, "proj_matrix_grad"), g2 = f32(viewproj_matrix_grad, "viewproj_matrix_grad");
@@ -180,6 +188,7 @@ std::vector<Tensor> create_viewproj_backward(Tensor view_matrix_grad, Tensor pro
 // ---------------------------------------------------------------------------------------------- transform.h
 std::vector<Tensor> mvp_transform_forward(Tensor world_position, Tensor view_matrix, Tensor proj_matrix, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(world_position));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor w = f32(world_position, "world_position"), vm = f32(view_matrix, "view_matrix"), pm = f32(proj_matrix, "proj_matrix");
     const int V = (int)vm.size(0), N = (int)w.size(1);
     Tensor view_pos = at::empty({V, 4, N}, w.options()), ndc_pos = at::empty({V, 4, N}, w.options());
@@ -190,6 +199,7 @@ std::vector<Tensor> mvp_transform_forward(Tensor world_position, Tensor view_mat
 
 Tensor mvp_transform_backward(Tensor grad_ndc_pos, Tensor grad_view_pos, Tensor view_matrix, Tensor proj_matrix, Tensor view_pos, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(grad_ndc_pos));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor gn = f32(grad_ndc_pos, "grad_ndc_pos"), gv = f32(grad_view_pos, "grad_view_pos"), vp = f32(view_pos, "view_pos");
     Tensor vm = f32(view_matrix, "view_matrix"), pm = f32(proj_matrix, "proj_matrix");
     const int V = (int)gn.size(0), N = (int)gn.size(2);
@@ -201,6 +211,7 @@ Tensor mvp_transform_backward(Tensor grad_ndc_pos, Tensor grad_view_pos, Tensor 
 
 Tensor createTransformMatrix_forward(Tensor quaternion, Tensor scale, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(quaternion));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor q = f32(quaternion, "quaternion"), sc = f32(scale, "scale");
     const int N = (int)q.size(1);
     Tensor T = at::empty({3, 3, N}, sc.options());
@@ -210,6 +221,7 @@ Tensor createTransformMatrix_forward(Tensor quaternion, Tensor scale, OptTensor 
 
 std::vector<Tensor> createTransformMatrix_backward(Tensor transform_matrix_grad, Tensor quaternion, Tensor scale, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(transform_matrix_grad));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor g = f32(transform_matrix_grad, "transform_matrix_grad"), q = f32(quaternion, "quaternion"), sc = f32(scale, "scale");
     const int N = (int)q.size(1);
     Tensor gq = at::empty({4, N}, g.options()), gs = at::empty({3, N}, g.options());
@@ -220,6 +232,7 @@ std::vector<Tensor> createTransformMatrix_backward(Tensor transform_matrix_grad,
 
 Tensor jacobianRayspace(Tensor translate_position, Tensor proj_matrix, int64_t output_h, int64_t output_w, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(translate_position));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor tp = f32(translate_position, "translate_position"), pm = f32(proj_matrix, "proj_matrix");
     const int V = (int)tp.size(0), N = (int)tp.size(2);
     Tensor J = at::empty({V, 3, 3, N}, tp.options());
@@ -229,6 +242,7 @@ Tensor jacobianRayspace(Tensor translate_position, Tensor proj_matrix, int64_t o
 
 Tensor createCov2dDirectly_forward(Tensor J, Tensor view_matrix, Tensor transform_matrix, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(J));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor j = f32(J, "J"), vm = f32(view_matrix, "view_matrix"), T = f32(transform_matrix, "transform_matrix");
     const int V = (int)vm.size(0), N = (int)T.size(2);
     Tensor cov = at::empty({V, 2, 2, N}, T.options());
@@ -238,6 +252,7 @@ Tensor createCov2dDirectly_forward(Tensor J, Tensor view_matrix, Tensor transfor
 
 Tensor createCov2dDirectly_backward(Tensor cov2d_grad, Tensor J, Tensor view_matrix, Tensor transform_matrix, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(cov2d_grad));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor g = f32(cov2d_grad, "cov2d_grad"), j = f32(J, "J"), vm = f32(view_matrix, "view_matrix"), T = f32(transform_matrix, "transform_matrix");
     const int V = (int)vm.size(0), N = (int)T.size(2);
     Tensor gT = at::empty({3, 3, N}, g.options());
@@ -247,6 +262,7 @@ Tensor createCov2dDirectly_backward(Tensor cov2d_grad, Tensor J, Tensor view_mat
 
 std::vector<Tensor> eigh_and_inv_2x2matrix_forward(Tensor input, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(input));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor x = f32(input, "input");
     const int V = (int)x.size(0), N = (int)x.size(3);
     Tensor val = at::empty({V, 2, N}, x.options()), vec = at::empty({V, 2, 2, N}, x.options()), inv = at::empty({V, 2, 2, N}, x.options());
@@ -257,6 +273,7 @@ std::vector<Tensor> eigh_and_inv_2x2matrix_forward(Tensor input, OptTensor valid
 
 Tensor inv_2x2matrix_backward(Tensor inv_matrix, Tensor dL_dInvMatrix, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(inv_matrix));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor inv = f32(inv_matrix, "inv_matrix"), g = f32(dL_dInvMatrix, "dL_dInvMatrix");
     const int V = (int)inv.size(0), N = (int)inv.size(3);
     Tensor out = at::empty_like(g);
@@ -266,6 +283,7 @@ Tensor inv_2x2matrix_backward(Tensor inv_matrix, Tensor dL_dInvMatrix, OptTensor
 
 Tensor sh2rgb_forward(int64_t degree, Tensor sh_base, Tensor sh_rest, Tensor dir)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(sh_base));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor s0 = f32(sh_base, "sh_base"), sr = f32(sh_rest, "sh_rest"), d = f32(dir, "dir");
     const int V = (int)d.size(0), N = (int)d.size(2);
     Tensor rgb = at::empty({V, 3, N}, d.options());
@@ -275,6 +293,7 @@ Tensor sh2rgb_forward(int64_t degree, Tensor sh_base, Tensor sh_rest, Tensor dir
 
 std::vector<Tensor> sh2rgb_backward(int64_t degree, Tensor rgb_grad, int64_t sh_rest_dim, Tensor dir, Tensor SH_base, Tensor SH_rest)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(rgb_grad));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor g = f32(rgb_grad, "rgb_grad"), d = f32(dir, "dir");
     const int V = (int)d.size(0), N = (int)d.size(2);
     Tensor d0 = at::empty({1, 3, N}, g.options()), dr = at::empty({sh_rest_dim, 3, N}, g.options()), dd = at::empty({V, 3, N}, g.options());
@@ -285,6 +304,7 @@ std::vector<Tensor> sh2rgb_backward(int64_t degree, Tensor rgb_grad, int64_t sh_
 
 std::vector<Tensor> world2ndc_forward(Tensor world_position, Tensor view_project_matrix)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(world_position));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor w = f32(world_position, "world_position"), m = f32(view_project_matrix, "view_project_matrix");
     const int V = (int)m.size(0), N = (int)w.size(1);
     Tensor ndc = at::empty({V, 4, N}, w.options()), rw = at::empty({V, 1, N}, w.options());
@@ -294,6 +314,7 @@ std::vector<Tensor> world2ndc_forward(Tensor world_position, Tensor view_project
 
 Tensor world2ndc_backword(Tensor view_project_matrix, Tensor position, Tensor repc_hom_w, Tensor grad_ndcpos)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(view_project_matrix));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor m = f32(view_project_matrix, "vp"), ndc = f32(position, "ndc_position"), rw = f32(repc_hom_w, "repc_hom_w"), g = f32(grad_ndcpos, "grad_ndcpos");
     const int V = (int)g.size(0), N = (int)g.size(2);
     Tensor out = at::empty({4, N}, g.options());
@@ -305,6 +326,7 @@ Tensor world2ndc_backword(Tensor view_project_matrix, Tensor position, Tensor re
 std::vector<Tensor> get_allocate_size(Tensor ndc, Tensor view_space_z, Tensor inv_cov2d, Tensor opacity, int64_t height, int64_t width,
                                       int64_t tilesize_h, int64_t tilesize_w, OptTensor valid_length)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(ndc));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor n = f32(ndc, "ndc"), vz = f32(view_space_z, "view_space_z"), ic = f32(inv_cov2d, "inv_cov2d"), op = f32(opacity, "opacity");
     const int V = (int)n.size(0), N = (int)n.size(2);
     Tensor left_up = at::empty({V, 2, N}, like(n, at::kInt)), right_down = at::empty({V, 2, N}, like(n, at::kInt)), alloc = at::empty({V, N}, like(n, at::kInt));
@@ -324,6 +346,7 @@ int sort_bits(int64_t height, int64_t width, int64_t th, int64_t tw)       // GR
 std::vector<Tensor> create_table(Tensor ndc, Tensor inv_cov2d, Tensor opacity, Tensor offset, Tensor depth_sorted_pointid,
                                  OptTensor feedback_buffer_cpu, OptTensor idx_tensor_cpu, int64_t height, int64_t width, int64_t tile_size_h, int64_t tile_size_w)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(ndc));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor n = f32(ndc, "ndc"), ic = f32(inv_cov2d, "inv_cov2d"), op = f32(opacity, "opacity"), off = dev(offset, "offset");
     TORCH_CHECK(off.scalar_type() == at::kInt, "create_table: offset must be int32 (cumsum dtype=torch.int32)");
     Tensor ids = dev(depth_sorted_pointid, "depth_sorted_pointid");
@@ -371,6 +394,7 @@ std::vector<Tensor> create_table(Tensor ndc, Tensor inv_cov2d, Tensor opacity, T
 
 Tensor tileRange(Tensor table_tileId, int64_t max_tileId)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(table_tileId));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor t = dev(table_tileId, "table_tileId");
     const int V = (int)t.size(0);
     Tensor out = at::empty({V, max_tileId + 2}, like(t, at::kInt));
@@ -413,6 +437,7 @@ std::vector<Tensor> rasterize_forward(Tensor sorted_points, Tensor start_index, 
                                       OptTensor specific_tiles, int64_t img_h, int64_t img_w, int64_t tilesize_h, int64_t tilesize_w,
                                       bool enable_statistic, bool enable_trans, bool enable_depth)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(sorted_points));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor n = f32(ndc, "ndc"), ic = f32(cov2d_inv, "cov2d_inv"), c = f32(color, "color"), op = f32(opacity, "opacity");
     const int V = (int)n.size(0), N = (int)n.size(2);
     Tensor packed = at::empty({V, N, lg_packed_record_floats()}, n.options());
@@ -426,6 +451,7 @@ std::vector<Tensor> rasterize_forward_packed(Tensor sorted_points, Tensor start_
                                              int64_t img_h, int64_t img_w, int64_t tile_h, int64_t tile_w, bool enable_statistic, bool enable_trans,
                                              bool enable_depth)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(sorted_points));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     RasterOut r = raster_forward_impl(sorted_points, start_index, f32(packed_params, "packed_params"), specific_tiles_arg, img_h, img_w, tile_h, tile_w,
                                       enable_statistic, enable_depth);
     return { r.img, r.trans, r.depth, r.last, r.fc, r.fw };
@@ -436,6 +462,7 @@ std::vector<Tensor> rasterize_backward(Tensor sorted_points, Tensor start_index,
                                        OptTensor d_depth_img_arg, OptTensor grad_inv_sacler_arg, int64_t img_h, int64_t img_w, int64_t tilesize_h,
                                        int64_t tilesize_w, bool enable_statistic)
 {
+    const c10::OptionalDeviceGuard device_guard(at::device_of(sorted_points));      // launches go to the tensors' device (one process per GPU: LOCAL_RANK != 0)
     Tensor sp = dev(sorted_points, "sorted_points"), si = dev(start_index, "start_index"), packed = f32(packed_params, "packed_params");
     Tensor fT = f32(final_transmitance, "final_transmitance"), dimg = f32(d_img, "d_img"), last = dev(last_contributor, "last_contributor");
     const int V = (int)sp.size(0), N = (int)packed.size(1);
