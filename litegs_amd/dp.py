@@ -195,16 +195,18 @@ class GradientExchange:
         union_ids, union_count, _ = self.ops.compact(self.mask[:chunks])
         kmax = max(int(self.mask[chunks].item()), 1)
         self.last_k = (K, kmax)
-        # c. fixed-size block [nrows + 1, kmax + 1]: values | global Gaussian index (int32 bits); padding = index 0, value 0
-        block = torch.zeros((self.nrows + 1, kmax), dtype=torch.float32, device=dev)
-        gidx = (vis_id[idx // S] * S + idx % S).to(torch.int32)
-        block[self.nrows, :K] = gidx.view(torch.float32)
+        # c. fixed-size block [nrows + 1, kmax]: the wire container is INT32 (value rows are float bit patterns, the last row the global
+        #    Gaussian indices): an integer collective can only copy, whereas float transport of small integers (subnormal patterns)
+        #    would be at the mercy of any flush-to-zero on the way.  padding = index 0, value 0
+        block = torch.zeros((self.nrows + 1, kmax), dtype=torch.int32, device=dev)
+        values = block[: self.nrows].view(torch.float32)
+        block[self.nrows, :K] = (vis_id[idx // S] * S + idx % S).to(torch.int32)
         row = 0
         for v, r in zip(comp, self.rows):
             if v is not None:
-                block[row:row + r, :K] = v.reshape(r, -1)[:, idx]
+                values[row:row + r, :K] = v.reshape(r, -1)[:, idx]
             row += r
-        gathered = torch.empty((W * (self.nrows + 1), kmax), dtype=torch.float32, device=dev)       # concatenation along dim 0
+        gathered = torch.empty((W * (self.nrows + 1), kmax), dtype=torch.int32, device=dev)         # concatenation along dim 0
         dist.all_gather_into_tensor(gathered, block, group=self.group)
         gathered = gathered.view(W, self.nrows + 1, kmax)
         # d. rank-ordered accumulation into the dense gradient (deterministic: replicas stay bit-identical).  The buffer is all zeros
@@ -212,9 +214,11 @@ class GradientExchange:
         dense = self.flat.view(self.nrows, chunks * S)
         if self._touched is not None:
             dense[:, self._touched] = 0.0
-        index = gathered[:, self.nrows].contiguous().view(torch.int32).long()                  # [W, kmax]
+        index = gathered[:, self.nrows].long()                                                      # [W, kmax]
+        if int(index.max()) >= chunks * S or int(index.min()) < 0:
+            raise RuntimeError("litegs_amd.dp: gathered Gaussian index out of range (corrupted exchange block)")
         for w in range(W):
-            dense.index_add_(1, index[w], gathered[w, : self.nrows], alpha=1.0 / W)
+            dense.index_add_(1, index[w], gathered[w, : self.nrows].view(torch.float32), alpha=1.0 / W)
         self._touched = index.reshape(-1)
         row = 0
         for p, r in zip(params, self.rows):
@@ -319,16 +323,17 @@ class MomentExchange:
         # capacity of the record blocks
         pred = int(self.fb_k[slot])
         if pred <= 0:                                    # first visit of the slot: blocking count
-            probe = torch.empty(((1 + A * S) * nrec,), dtype=torch.float32, device=dev)
+            probe = torch.empty(((1 + A * S) * nrec,), dtype=torch.int32, device=dev)
             self.ops.compact_moments(pg, vis_ids, vis_num, A, S, A * S, probe)
-            k = probe[:1].view(torch.int32).clone()
+            k = probe[:1].clone()
             dist.all_reduce(k, op=dist.ReduceOp.MAX, group=self.group)
             pred = max(int(k.item()), 1)
         cap = int(self.cap_factor * pred) + self.cap_margin
         self.last_cap = cap
-        block = torch.empty(((1 + cap) * nrec,), dtype=torch.float32, device=dev)
+        # wire container: int32 words (record = index word + nine float bit patterns) -- an integer collective can only copy
+        block = torch.empty(((1 + cap) * nrec,), dtype=torch.int32, device=dev)
         self.ops.compact_moments(pg, vis_ids, vis_num, A, S, cap, block)
-        gathered = torch.empty((W * (1 + cap) * nrec,), dtype=torch.float32, device=dev)
+        gathered = torch.empty((W * (1 + cap) * nrec,), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(gathered, block, group=self.group)
         self.bytes_last = (W - 1) * block.numel() * 4
         self.ops.build_slotmap(gathered, W, cap, chunks * S, self.slot, self.fb_k.data_ptr() + 4 * slot, self.overflow)

@@ -267,7 +267,7 @@ class TorchMomentOps:
         n = int(vis_num) * S
         rows = pg[:n, :9]
         nz = (rows != 0).any(dim=1).nonzero()[:, 0]
-        blk = block.view(-1, TorchMomentOps.NREC)
+        blk = block.view(torch.float32).view(-1, TorchMomentOps.NREC)          # the wire container is int32 (litegs_amd/dp.py)
         blk[0].zero_()
         blk[0, :1].view(torch.int32)[0] = len(nz)
         keep = nz[:cap]
@@ -277,7 +277,7 @@ class TorchMomentOps:
 
     @staticmethod
     def build_slotmap(gathered, W, cap, total, slot, host_max_k_ptr, overflow):
-        g = gathered.view(W, 1 + cap, TorchMomentOps.NREC)
+        g = gathered.view(torch.float32).view(W, 1 + cap, TorchMomentOps.NREC)
         ks = [int(g[r, 0, :1].view(torch.int32)[0]) for r in range(W)]
         for r in range(W):
             k = min(ks[r], cap)
@@ -289,7 +289,7 @@ class TorchMomentOps:
 
     @staticmethod
     def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps, touched=None):
-        g = gathered.view(W, 1 + cap, TorchMomentOps.NREC)
+        g = gathered.view(torch.float32).view(W, 1 + cap, TorchMomentOps.NREC)
         acc = ps[0].view(9, chunks * S)
         acc.zero_()
         for c in union_ids[: int(union_count)].tolist():
