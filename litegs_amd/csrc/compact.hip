@@ -489,6 +489,15 @@ __global__ void __launch_bounds__(ADAM_TPB) adam_chunk_kernel_v4(float* __restri
     float4 g = reinterpret_cast<const float4*>(grad)[go];
     float4 mm = reinterpret_cast<float4*>(m)[po];
     float4 vv = reinterpret_cast<float4*>(v)[po];
+    // exact no-op: zero gradient on zero moments gives m' = v' = 0 and p' = p - lr*0/(0+eps) = p, i.e. what memory already holds --
+    // the parameter is not read and nothing is written (28 -> 12 B per element; most Gaussians of the visible chunks of a frame
+    // receive no gradient, and until one does their moments are zero).  NaN / inf gradients are not "zero" and take the update.
+    {
+        const unsigned int any = (__float_as_uint(g.x) | __float_as_uint(g.y) | __float_as_uint(g.z) | __float_as_uint(g.w) |
+                                  __float_as_uint(mm.x) | __float_as_uint(mm.y) | __float_as_uint(mm.z) | __float_as_uint(mm.w) |
+                                  __float_as_uint(vv.x) | __float_as_uint(vv.y) | __float_as_uint(vv.z) | __float_as_uint(vv.w)) << 1;
+        if (any == 0u) return;
+    }
     float4 p = reinterpret_cast<float4*>(param)[po];
 #define ADAM1(c)                                                      \
     mm.c = b1 * mm.c + (1.0f - b1) * g.c;                             \

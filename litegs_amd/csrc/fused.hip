@@ -676,6 +676,12 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(AdamGroups G, const int
     float4 gr = reinterpret_cast<const float4*>(G.grad[g])[go];
     float4 mm = reinterpret_cast<float4*>(G.m[g])[po];
     float4 vv = reinterpret_cast<float4*>(G.v[g])[po];
+    {   // exact no-op (zero gradient on zero moments): see adam_chunk_kernel_v4, compact.hip
+        const unsigned int any = (__float_as_uint(gr.x) | __float_as_uint(gr.y) | __float_as_uint(gr.z) | __float_as_uint(gr.w) |
+                                  __float_as_uint(mm.x) | __float_as_uint(mm.y) | __float_as_uint(mm.z) | __float_as_uint(mm.w) |
+                                  __float_as_uint(vv.x) | __float_as_uint(vv.y) | __float_as_uint(vv.z) | __float_as_uint(vv.w)) << 1;
+        if (any == 0u) return;
+    }
     float4 p = reinterpret_cast<float4*>(G.param[g])[po];
 #define ADAM1(c)                                  \
     mm.c = b1 * mm.c + (1.0f - b1) * gr.c;        \

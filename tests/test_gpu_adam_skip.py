@@ -85,3 +85,54 @@ def test_flags_are_rebuilt_after_other_optimizer_paths():
         st = tr.opt.state[g["params"][0]]
         nz |= (st["exp_avg"].reshape(-1, n) != 0).any(dim=0) | (st["exp_avg_sq"].reshape(-1, n) != 0).any(dim=0)
     assert int((nz & (f == 0)).sum()) == 0
+
+
+@pytest.mark.parametrize("binding", ["ctypes", "ext"])
+def test_operator_adam_noop_skip_is_exact(binding):
+    """`adamUpdate` (the drop-in operator, stateless): quads whose gradient and both moments are all zero are left untouched -- the
+    result equals the plain update bit for bit, including quads where only ONE of the twelve words is non-zero, a -0.0 and a NaN"""
+    import numpy as np
+    from litegs_amd import fused
+    if binding == "ext":
+        from litegs_amd.binding import compiled
+        if compiled is None:
+            pytest.skip("compiled litegs_fused extension not built")
+        F = compiled
+    else:
+        F = fused
+    rng = np.random.default_rng(21)
+    E, chunks, S, A, nvis = 7, 20, 128, 12, 9
+    p = rng.standard_normal((E, chunks, S)).astype(np.float32)
+    m = np.zeros((E, chunks, S), np.float32)
+    v = np.zeros((E, chunks, S), np.float32)
+    g = np.zeros((E, A, S), np.float32)
+    ids = rng.permutation(chunks)[:A].astype(np.int64)
+    # sprinkle history / gradients over ~10 % of the quads, one word at a time
+    for arr in (m, v):
+        k = rng.random(arr.shape) < 0.03
+        arr[k] = rng.standard_normal(int(k.sum())).astype(np.float32) ** 2 * 1e-3
+    k = rng.random(g.shape) < 0.03
+    g[k] = rng.standard_normal(int(k.sum())).astype(np.float32)
+    g[0, 0, 0] = -0.0                                   # signed zero is still zero
+    g[1, 1, 5] = np.nan                                 # NaN is a gradient
+    t = lambda a: torch.from_numpy(a.copy()).cuda()    # noqa: E731
+    pd, md, vd, gd = t(p), t(m), t(v), t(g)
+    F.adamUpdate(pd, gd, md, vd, t(ids), torch.tensor([nvis], dtype=torch.int32).cuda(), 1e-2, 0.9, 0.999, 1e-15)
+    # plain update in torch, same operation order as the kernel (fp32): m' = b1*m + (1-b1)*g ; v' = b2*v + (1-b2)*g*g ; p' = p + -lr*m'/(sqrt(v')+eps)
+    pt, mt, vt, gt = t(p), t(m), t(v), t(g)
+    sel = t(ids)[:nvis]
+    b1, b2, lr, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-2), np.float32(1e-15)
+    mm = float(b1) * mt[:, sel] + float(np.float32(1.0) - b1) * gt[:, :nvis]
+    vv = float(b2) * vt[:, sel] + float(np.float32(1.0) - b2) * gt[:, :nvis] * gt[:, :nvis]
+    pt[:, sel] = pt[:, sel] + (-float(lr)) * mm / (vv.sqrt() + float(eps))
+    mt[:, sel], vt[:, sel] = mm, vv
+    noop = ((gt[:, :nvis] == 0) & (mt[:, sel] == 0) & (vt[:, sel] == 0))
+    assert float(noop.float().mean()) > 0.8
+    for got, want, name in ((pd, pt, "param"), (md, mt, "m"), (vd, vt, "v")):
+        assert torch.equal(got[:, sel][noop], want[:, sel][noop]), name                      # untouched where it is a no-op
+        a, b = got[:, sel][~noop], want[:, sel][~noop]
+        fin = torch.isfinite(b)
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), name
+        assert torch.allclose(a[fin], b[fin], rtol=2e-6, atol=1e-7), name
+    rest = torch.ones(chunks, dtype=torch.bool, device="cuda"); rest[sel] = False
+    assert torch.equal(pd[:, rest], t(p)[:, rest]) and torch.equal(md[:, rest], t(m)[:, rest])      # invisible chunks untouched
