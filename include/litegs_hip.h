@@ -154,9 +154,9 @@ int lg_gather_inclusive_scan(const int32_t* src, const void* idx, int idx_is_int
 int lg_tile_range(const int32_t* sorted_keys, int V, long long L, int max_tile, int32_t* out /*[V,max_tile+2]*/, void* stream); /* binning.cu:228-287 */
 /* tilesort.hip -- replaces the depth half of wrapper.py:739-745 (torch.sort over all visible splats) + the reliance on the stable
  * tile sort (binning.cu:205-220) to carry that order into the tiles: every tile's list in vals [V,L] (splat ids grouped by tile,
- * ascending id inside a tile; tile_start from lg_tile_range) is sorted in place by (view depth = word 12 of the splat's packed record,
- * id).  scratch [V,L] uint32: only touched for lists longer than 2048. */
-int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const float* packed, int V, long long L, int N, int ntiles,
+ * ascending id inside a tile; tile_start from lg_tile_range) is sorted in place by (depth[V,N] of the splat, id).
+ * scratch [V,L] uint32: only touched for lists longer than 1024. */
+int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
                        uint32_t* scratch, void* stream);
 int lg_memset_async(void* ptr, int value, long long bytes, void* stream);
 
@@ -221,6 +221,7 @@ int lg_fused_get_option(int key);
 long long lg_fused_workspace1_bytes(long long N);
 long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW);
 long long lg_fused_total_offset(long long N);
+long long lg_fused_tile_start_offset(long long L, long long N, int H, int W, int TH, int TW);   /* int32[ntiles+2] tile ranges in workspace 2 (valid after stage 2) */
 long long lg_fused_alloc_offset(long long N);   /* int32[N] tile counts per compacted Gaussian (valid after stage 1) */
 long long lg_fused_packed_offset(long long N);  /* float[N,16] packed splat records (valid after stage 1) */
 int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,

@@ -301,14 +301,23 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     }
     // Threshold between the in-workgroup path and the queue: DUP_SMALL_HI when this group's entries still fit the LDS buffer
     // (the usual case: ~8 tiles per splat on average), DUP_SMALL otherwise (then 256 x 32 entries fit by construction).
+    // The largest of DUP_SMALL_HI, /2, /4 ... for which the group still fits (groups of spatial neighbours -- emission in splat-id
+    // order -- are all large or all small: halving step by step keeps most of such a group in the in-workgroup path instead of
+    // demoting it wholesale to DUP_SMALL).
     int thr = DUP_SMALL_HI;
     {
-        int c64 = (cnt <= DUP_SMALL_HI) ? cnt : 0;
+        int c_hi = (cnt <= DUP_SMALL_HI) ? cnt : 0, c_h2 = (cnt <= DUP_SMALL_HI / 2) ? cnt : 0, c_h4 = (cnt <= DUP_SMALL_HI / 4) ? cnt : 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
-        if (lane == 0) wbig[wave] = c64;
+        for (int o = 32; o > 0; o >>= 1) { c_hi += __shfl_xor(c_hi, o); c_h2 += __shfl_xor(c_h2, o); c_h4 += __shfl_xor(c_h4, o); }
+        if (lane == 0) { wbig[wave] = c_hi; wnz[wave] = c_h2; wsum[wave] = c_h4; }
         __syncthreads();
-        if (wbig[0] + wbig[1] + wbig[2] + wbig[3] > DUP_LDS_ENTRIES) thr = DUP_SMALL;
+        if (wbig[0] + wbig[1] + wbig[2] + wbig[3] > DUP_LDS_ENTRIES) {
+            thr = DUP_SMALL_HI / 2;
+            if (wnz[0] + wnz[1] + wnz[2] + wnz[3] > DUP_LDS_ENTRIES) {
+                thr = DUP_SMALL_HI / 4;
+                if (wsum[0] + wsum[1] + wsum[2] + wsum[3] > DUP_LDS_ENTRIES) thr = DUP_SMALL;
+            }
+        }
         __syncthreads();
     }
     const bool small = cnt > 0 && cnt <= thr;

@@ -27,10 +27,12 @@
 // How each tile's list gets its depth order.  GLOBAL (default): the reference's structure (wrapper.py:739-745): stable
 // depth sort of all visible splats first (4 radix passes), emission in that order, stable tile sort.  TILE: no sort over the splats --
 // instances are emitted in splat-id order, the stable tile sort groups them and tilesort.hip sorts every tile's list by (depth, id).
-// Both give the same table bit for bit (tests/test_gpu_tilesort.py).  Measured at 3 M @1080p (gpurun_out/margin_ab.log, DESIGN.md
-// section 9): TILE removes 93 us of splat sort per frame but pays 54-65 us for the per-tile sort (LDS-bandwidth bound bitonic network)
-// and 25-30 us in the emission, whose adaptive small/big split and output locality were tuned for depth order (Morton neighbours are
-// all large or all small) -- 1.017 vs 0.986 ms per step, so GLOBAL stays the default.
+// Both give the same table bit for bit (tests/test_gpu_tilesort.py) -- except when a table was under-predicted: the truncation of
+// GR/binning.cu:63 then drops the splats that come last in EMISSION order, the deepest ones in GLOBAL mode (the reference's behaviour),
+// the highest ids in TILE mode.  Measured at 3 M @1080p (profiles/r02_margin_ab.log): TILE removes 93 us of
+// splat sort per frame and pays 42 us for the per-tile sort (latency: ~10 us per wave-tile at 4 waves per SIMD) plus 32 us in the
+// emission, whose adaptive small/big split and output locality were tuned for depth order (Morton neighbours are all large or all
+// small) -- 0.787 vs 0.793 ms per step: no difference worth a change of the truncation semantics, so GLOBAL stays the default.
 #define LG_DEPTH_ORDER_GLOBAL 0
 #define LG_DEPTH_ORDER_TILE 1
 static int g_depth_order_mode = LG_DEPTH_ORDER_GLOBAL;
@@ -319,6 +321,13 @@ LG_API long long lg_fused_workspace2_bytes(long long L, long long N, int H, int 
 
 LG_API long long lg_fused_cull_scratch_bytes(int chunks) { return lg_cull_scratch_bytes(chunks); }
 
+// byte offset in workspace 2 of the tile range table int32[ntiles + 2] (valid after stage 2) -- measurement tools
+LG_API long long lg_fused_tile_start_offset(long long L, long long N, int H, int W, int TH, int TW)
+{
+    int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    return (long long)layout2(L > 0 ? L : 1, ntiles, N).tile_start;
+}
+
 // byte offset in workspace 1 of the exact instance total (prefix[N-1]) -- for the blocking first-visit path
 LG_API long long lg_fused_total_offset(long long N) { return (long long)(layout1(N).prefix + 4 * (size_t)(N - 1)); }
 
@@ -478,7 +487,7 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
     const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
     rc = lg_tile_range_prefilled(sorted_keys, 1, Ls, total_dev, ntiles, (int32_t*)(w + f.tile_start), s); if (rc) return rc;
     if (tile_mode) {      // depth order inside every tile; scratch for lists beyond 2048: the key buffer the tile sort did not end in
-        rc = lg_tile_depth_sort_gated((int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.packed), 1, L,
+        rc = lg_tile_depth_sort_gated((int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L,
                                       (int)N, ntiles, (uint32_t*)(w + (odd ? f.tk_a : f.tk_b)), gate, s);
         if (rc) return rc;
     }

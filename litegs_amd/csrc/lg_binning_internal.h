@@ -50,7 +50,7 @@ int lg_gather_scan_gated(const int32_t* src, const int32_t* idx, long long n, in
                          int mode, const int* gate, int* total_out, void* stream);
 
 // per-tile depth sort of the tile-sorted value table (tilesort.hip); gate as above
-int lg_tile_depth_sort_gated(int32_t* vals, const int32_t* tile_start, const float* packed, int V, long long L, int N, int ntiles,
+int lg_tile_depth_sort_gated(int32_t* vals, const int32_t* tile_start, const float* depth /*[V,N] view depths*/, int V, long long L, int N, int ntiles,
                              uint32_t* scratch, const int* gate, void* stream);
 
 // tileRange on a table whose output was pre-filled with -1

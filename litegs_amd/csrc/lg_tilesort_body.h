@@ -163,3 +163,175 @@ TS_FN void ts_sort_tile(int* v, int n, uint64_t* sk, uint32_t* dk, DepthBits dep
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Regime R: one wave sorts a list of up to TS_RADIX_MAX entries with a stable LSD radix sort on the 32-bit depth key, 8 bits per pass,
+// the elements held in registers (element e = c * 64 + lane, c < TS_RCHUNKS) and LDS used for the 256 digit counters and a 4-byte
+// exchange buffer.  The list arrives in ascending id order and every pass is stable, so ties in depth keep ascending ids: the same
+// order as the 64-bit bitonic key, with ~6x less LDS traffic (per pass and element: one returning add, one 4-byte store and load for
+// the key and for the id; the bitonic network moves 16 B per element in each of its ~36 steps).  Passes whose digit is the same for
+// every key of the list (typically the sign/exponent byte) are skipped.
+// The rank of an element inside its digit is what a returning LDS add hands back: rounds (chunks) are sequential, and inside one
+// instruction the LDS serves same-address lanes in lane order -- the property lg_radix_rank_mode() verifies on the device (binning.hip);
+// when it does not hold, the kernel is instantiated with BALLOT ranking, where the order follows from the code alone.
+// ---------------------------------------------------------------------------------------------
+#define TS_RADIX_MAX 1024
+#define TS_RCHUNKS (TS_RADIX_MAX / 64)
+
+#ifdef LG_TILESORT_HOST
+#define TS_LOCAL(type, name, n) type name[64][n]
+#define TS_L(name, c) name[tid][c]
+#else
+#define TS_LOCAL(type, name, n) type name[n]
+#define TS_L(name, c) name[c]
+#endif
+
+// RCH: chunks of 64 the instantiation holds in registers (n <= 64 * RCH); the loops below are unrolled RCH times
+template <bool BALLOT, int RCH, class DepthBits>
+TS_FN void ts_radix_sort_tile_n(int* v, int n, uint32_t* exch /*[64 * RCH]*/, int* cnt /*[256]*/, DepthBits depth_bits TS_TID_ARG)
+{
+    const int C = (n + 63) >> 6;
+    TS_LOCAL(uint32_t, key, RCH);
+    TS_LOCAL(int, id, RCH);
+    TS_LOCAL(int, pos, RCH);
+    uint32_t or_all = 0u, and_all = 0xffffffffu;
+#ifdef LG_TILESORT_HOST
+    uint32_t or_t[64], and_t[64];
+    int s_t[64];
+#endif
+    TS_PHASE(tid, 64) {
+        uint32_t o = 0u, a = 0xffffffffu;
+        // two batches of independent loads (ids, then their depths), no branches in between: a guarded load per chunk would serialise
+        // 2 * C dependent global round trips.  Positions beyond the list re-read its last element (same address: one cache line).
+#pragma unroll
+        for (int c = 0; c < RCH; c++) {
+            const int e = c * 64 + tid;
+            TS_L(id, c) = v[e < n ? e : n - 1];
+        }
+#pragma unroll
+        for (int c = 0; c < RCH; c++) TS_L(key, c) = ts_depth_key(depth_bits(TS_L(id, c)));
+#pragma unroll
+        for (int c = 0; c < RCH; c++)
+            if (c * 64 + tid < n) { o |= TS_L(key, c); a &= TS_L(key, c); }
+#ifdef LG_TILESORT_HOST
+        or_t[tid] = o; and_t[tid] = a;
+#else
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { o |= (uint32_t)__shfl_xor((int)o, off); a &= (uint32_t)__shfl_xor((int)a, off); }
+        or_all = o; and_all = a;
+#endif
+    }
+#ifdef LG_TILESORT_HOST
+    for (int t = 0; t < 64; t++) { or_all |= or_t[t]; and_all &= and_t[t]; }
+#endif
+    const uint32_t varies = or_all ^ and_all;                // bits that differ somewhere in the list (wave-uniform)
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        if (((varies >> shift) & 255u) == 0u) continue;      // every key has the same digit here: the pass would be the identity
+        TS_PHASE(tid, 64) {
+            cnt[4 * tid] = 0; cnt[4 * tid + 1] = 0; cnt[4 * tid + 2] = 0; cnt[4 * tid + 3] = 0;
+        }
+        TS_SYNC(true);
+        // rank inside the digit (stable): chunks in order (the loop), lanes in order (inside one returning add / the ballot ranking)
+#pragma unroll
+        for (int c = 0; c < RCH; c++) {
+            if (c < C) {
+                TS_PHASE(tid, 64) {
+                    const bool ok = c * 64 + tid < n;
+                    const uint32_t d = ok ? ((TS_L(key, c) >> shift) & 255u) : 0u;
+#ifdef LG_TILESORT_HOST
+                    if (ok) { TS_L(pos, c) = cnt[d]; cnt[d] += 1; }
+#else
+                    if constexpr (!BALLOT) {
+                        if (ok) TS_L(pos, c) = atomicAdd(&cnt[d], 1);
+                    } else {
+                        unsigned long long same = __ballot(ok);
+#pragma unroll
+                        for (int b = 0; b < 8; b++) {
+                            const unsigned long long bal = __ballot((d >> b) & 1u);
+                            same &= ((d >> b) & 1u) ? bal : ~bal;
+                        }
+                        if (ok) {
+                            const int leader = __ffsll((long long)same) - 1;
+                            int base = 0;
+                            if (tid == leader) { base = cnt[d]; cnt[d] = base + __popcll(same); }
+                            base = __shfl(base, leader);
+                            TS_L(pos, c) = base + __popcll(same & ((1ull << tid) - 1ull));
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+#endif
+                }
+            }
+        }
+        TS_SYNC(true);
+        // exclusive scan of the 256 counters (4 per lane)
+#ifdef LG_TILESORT_HOST
+        TS_PHASE(tid, 64) { s_t[tid] = cnt[4 * tid] + cnt[4 * tid + 1] + cnt[4 * tid + 2] + cnt[4 * tid + 3]; }
+        TS_PHASE(tid, 64) {
+            int base = 0;
+            for (int t = 0; t < tid; t++) base += s_t[t];
+            const int c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2];
+            cnt[4 * tid] = base; cnt[4 * tid + 1] = base + c0; cnt[4 * tid + 2] = base + c0 + c1; cnt[4 * tid + 3] = base + c0 + c1 + c2;
+        }
+#else
+        TS_PHASE(tid, 64) {
+            const int c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
+            const int s = c0 + c1 + c2 + c3;
+            int incl = s;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int nb = __shfl_up(incl, off);
+                if (tid >= off) incl += nb;
+            }
+            const int base = incl - s;
+            cnt[4 * tid] = base; cnt[4 * tid + 1] = base + c0; cnt[4 * tid + 2] = base + c0 + c1; cnt[4 * tid + 3] = base + c0 + c1 + c2;
+        }
+#endif
+        TS_SYNC(true);
+        // destination of every element, then keys and ids through the exchange buffer
+        TS_PHASE(tid, 64) {
+#pragma unroll
+            for (int c = 0; c < RCH; c++)
+                if (c < C && c * 64 + tid < n) {
+                    TS_L(pos, c) += cnt[(TS_L(key, c) >> shift) & 255u];
+                    exch[TS_L(pos, c)] = TS_L(key, c);
+                }
+        }
+        TS_SYNC(true);
+        TS_PHASE(tid, 64) {
+#pragma unroll
+            for (int c = 0; c < RCH; c++)
+                if (c < C && c * 64 + tid < n) TS_L(key, c) = exch[c * 64 + tid];
+        }
+        TS_SYNC(true);
+        TS_PHASE(tid, 64) {
+#pragma unroll
+            for (int c = 0; c < RCH; c++)
+                if (c < C && c * 64 + tid < n) exch[TS_L(pos, c)] = (uint32_t)TS_L(id, c);
+        }
+        TS_SYNC(true);
+        TS_PHASE(tid, 64) {
+#pragma unroll
+            for (int c = 0; c < RCH; c++)
+                if (c < C && c * 64 + tid < n) TS_L(id, c) = (int)exch[c * 64 + tid];
+        }
+        TS_SYNC(true);
+    }
+    TS_PHASE(tid, 64) {
+#pragma unroll
+        for (int c = 0; c < RCH; c++)
+            if (c < C && c * 64 + tid < n) v[c * 64 + tid] = TS_L(id, c);
+    }
+}
+
+// picks the smallest instantiation that holds the list
+template <bool BALLOT, class DepthBits>
+TS_FN void ts_radix_sort_tile(int* v, int n, uint32_t* exch /*[TS_RADIX_MAX]*/, int* cnt /*[256]*/, DepthBits depth_bits TS_TID_ARG)
+{
+    if (n <= 256) ts_radix_sort_tile_n<BALLOT, 4>(v, n, exch, cnt, depth_bits TS_TID_PASS);
+    else if (n <= 512) ts_radix_sort_tile_n<BALLOT, 8>(v, n, exch, cnt, depth_bits TS_TID_PASS);
+    else ts_radix_sort_tile_n<BALLOT, TS_RCHUNKS>(v, n, exch, cnt, depth_bits TS_TID_PASS);
+}

@@ -250,6 +250,7 @@ class _RenderFn(torch.autograd.Function):
             R.margin_emitted[k] = R.margin_written[k]
         R.margin_written[k] = R.margin[k]
         R.last_ws1 = (ws1, N)                              # for tests: the fallback flag lives in workspace 1 (lg_fused_flags_offset)
+        R.last_ws2 = (ws2, table_len, N)                   # for tools: the tile range table lives in workspace 2 (lg_fused_tile_start_offset)
         if order_out is not None:
             R.tile_order_valid[k] = True
         ctx.order_ptr = order_ptr if (use_sched and R.tile_order_valid[k]) else None

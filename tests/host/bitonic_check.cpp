@@ -10,7 +10,7 @@
 #include <vector>
 #include "lg_tilesort_body.h"
 
-static int check(int n, int n_splats, int distinct_depths, std::mt19937& rng)
+static int check(int n, int n_splats, int distinct_depths, std::mt19937& rng, bool radix = false)
 {
     std::vector<float> depth(n_splats);
     std::uniform_real_distribution<float> ud(0.01f, 40.0f);
@@ -30,7 +30,13 @@ static int check(int n, int n_splats, int distinct_depths, std::mt19937& rng)
     std::vector<uint64_t> sk(TS_CHUNK);
     std::vector<uint32_t> dk(n);
     const bool small = n <= TS_SMALL;
-    ts_sort_tile(v.data(), n, sk.data(), dk.data(), bits, small ? 64 : 256, small);
+    if (radix) {
+        std::vector<uint32_t> exch(TS_RADIX_MAX);
+        std::vector<int> cnt(256);
+        ts_radix_sort_tile<false>(v.data(), n, exch.data(), cnt.data(), bits);
+    } else {
+        ts_sort_tile(v.data(), n, sk.data(), dk.data(), bits, small ? 64 : 256, small);
+    }
     for (int i = 0; i < n; i++)
         if (v[i] != want[i]) { std::printf("MISMATCH n=%d at %d: got %d want %d\n", n, i, v[i], want[i]); return 1; }
     return 0;
@@ -47,6 +53,14 @@ int main()
         if (bad) break;
         bad |= check(n, n + 5, 3, rng); cases++;
         bad |= check(n, n + 5, 1, rng); cases++;
+    }
+    // regime R (wave-private LSD radix sort, lists up to TS_RADIX_MAX): every length, few distinct depths (ties), one depth (all passes skipped)
+    for (int n = 2; n <= TS_RADIX_MAX && !bad; n++) { bad |= check(n, n + 9, 0, rng, true); cases++; }
+    for (int n : {2, 63, 64, 65, 128, 500, 1000, 1023, 1024}) {
+        if (bad) break;
+        bad |= check(n, n + 5, 3, rng, true); cases++;
+        bad |= check(n, n + 5, 1, rng, true); cases++;
+        bad |= check(n, n + 5, 200, rng, true); cases++;
     }
     // the flip/step pair generators enumerate disjoint pairs covering [0, P)
     for (int lp = 1; lp <= 12 && !bad; lp++) {
