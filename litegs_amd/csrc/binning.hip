@@ -53,6 +53,7 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
                                 int32_t* left_up, int32_t* right_down, int32_t* alloc, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(ndc, view_z, inv_cov, opacity, alloc);
     int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     dim3 grid(lg_cdiv(N, TPB), V);
     hipStream_t s = (hipStream_t)stream;
@@ -689,6 +690,7 @@ LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const 
                                   long long table_len, int32_t* keys, int32_t* values, void* temp, long long temp_bytes, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(ndc, inv_cov, opacity, prefix, sorted_id, keys, values);
     if (temp == nullptr || temp_bytes < lg_duplicate_with_keys_temp_bytes(V, N, table_len)) return (int)hipErrorInvalidValue;
     int* qcount = (int*)temp;                                                                        // [V][DUP_NQ]
     uint32_t* qentries = (uint32_t*)(qcount + (size_t)V * DUP_NQ);
@@ -1181,6 +1183,7 @@ LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint3
 {
     int passes = lg_radix_sort_num_passes(begin_bit, end_bit);
     if (n <= 0 || passes == 0) return 0;
+    LG_REQUIRE(keys_a, vals_a, keys_b, vals_b);
     if (passes > SORT_MAX_PASSES || n > 0x3fffffffLL) return (int)hipErrorInvalidValue;   // look-back status words carry 30-bit counts
     if (temp_bytes < lg_radix_sort_temp_bytes(n)) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
@@ -1288,6 +1291,7 @@ LG_API int lg_create_table(const float* ndc, const float* inv_cov, const float* 
                            int sorted_id_is_int64, int N, int H, int W, int TH, int TW, long long table_len, int end_bit,
                            int32_t* keys_a, int32_t* vals_a, int32_t* keys_b, int32_t* vals_b, void* temp, long long temp_bytes, void* stream)
 {
+    LG_REQUIRE(ndc, inv_cov, opacity, prefix, sorted_id, keys_a, vals_a, keys_b, vals_b);
     const int passes = lg_radix_sort_num_passes(0, end_bit);
     if (N <= 0 || table_len <= 0 || passes < 1 || passes > SORT_MAX_PASSES_DUP) return (int)hipErrorInvalidValue;
     const TableLayout f = table_layout(N, table_len, passes);
@@ -1356,6 +1360,7 @@ int lg_depth_keys_hist(const float* depth, long long n, uint32_t* keys, uint32_t
 LG_API int lg_depth_sort_keys(const float* depth, long long n, uint32_t* keys, uint32_t* vals, void* stream)
 {
     if (n <= 0) return 0;
+    LG_REQUIRE(depth, keys, vals);
     hipLaunchKernelGGL(depth_keys_kernel, dim3(lg_cdiv(n, TPB)), dim3(TPB), 0, (hipStream_t)stream, depth, n, keys, vals);
     LG_RETURN_LAST();
 }
@@ -1551,6 +1556,7 @@ LG_API int lg_gather_inclusive_scan(const int32_t* src, const void* idx, int idx
                                     void* temp, long long temp_bytes, void* stream)
 {
     if (n <= 0) return 0;
+    LG_REQUIRE(src, out);
     if (temp_bytes < lg_scan_temp_bytes(n)) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
@@ -1623,6 +1629,8 @@ LG_API int lg_tile_range(const int32_t* sorted_keys, int V, long long L, int max
 // n_dev (nullable): only the first min(L, *n_dev) sorted entries are a valid table (see lg_radix_sort_pairs_bounded)
 LG_API int lg_tile_range_bounded(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream)
 {
+    LG_REQUIRE(out);
+    if (L > 0) LG_REQUIRE(sorted_keys);
     hipStream_t s = (hipStream_t)stream;
     hipError_t err = hipMemsetAsync(out, 0xFF, sizeof(int32_t) * (size_t)V * (max_tile + 2), s);
     if (err != hipSuccess) return (int)err;

@@ -116,6 +116,7 @@ LG_API int lg_frustum_culling_aabb(const float* origin, const float* ext, const 
                                    uint8_t* visibility, int* visible_num, int64_t* visible_chunk_id, void* stream)
 {
     if (M <= 0) return 0;
+    LG_REQUIRE(origin, ext, planes, visible_num, visible_chunk_id);
     int passes = (M + CULL_TPB - 1) / CULL_TPB;
     size_t lds = ((V * 24 * 4 + 15) & ~15) + (size_t)passes * CULL_WAVES * (8 + 4) + 16;
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
@@ -341,6 +342,7 @@ LG_API int lg_cull_compact_activate(int degree, const int64_t* visible_chunk_id,
                                     float* o_pos, float* o_scale, float* o_rot, float* o_color, float* o_opa, void* stream)
 {
     if (A <= 0) return 0;
+    LG_REQUIRE(visible_chunk_id, visible_chunks_num, view, pos, scale, rot, sh0, opa, o_pos, o_scale, o_rot, o_color, o_opa);
     if (S > 1024 || S <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_ACT(D) hipLaunchKernelGGL(activate_forward_kernel<D>, dim3(A), dim3(S), 0, s, visible_chunk_id, visible_chunks_num, view, V, \
@@ -447,6 +449,7 @@ LG_API int lg_activate_backward(int degree, const int64_t* visible_chunk_id, con
                                 float* d_pos, float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa, void* stream)
 {
     if (A <= 0) return 0;
+    LG_REQUIRE(visible_chunk_id, visible_chunks_num, view, pos, scale, rot, opa, d_pos, d_scale, d_rot, d_sh0, d_opa);
     if (S > 1024 || S <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_ACTB(D) hipLaunchKernelGGL(activate_backward_kernel<D>, dim3(A), dim3(S), 0, s, visible_chunk_id, visible_chunks_num, view, V, \
@@ -531,6 +534,7 @@ LG_API int lg_adam_update_chunk(float* param, const float* grad, float* m, float
                                 float lr, float b1, float b2, float eps, void* stream)
 {
     if (A <= 0 || E <= 0) return 0;
+    LG_REQUIRE(param, grad, m, v, visible_chunk_id);
     hipStream_t s = (hipStream_t)stream;
     if (S % 4 == 0 && (S / 4) <= ADAM_TPB && ADAM_TPB % (S / 4) == 0) {
         int rows = ADAM_TPB / (S / 4);
@@ -565,6 +569,7 @@ LG_API int lg_adam_update_primitive(float* param, const float* grad, float* m, f
                                     float lr, float b1, float b2, float eps, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(param, grad, m, v, mask);
     hipLaunchKernelGGL(adam_primitive_kernel, dim3(lg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, mask, E, N, lr, b1, b2, eps);
     LG_RETURN_LAST();
 }
@@ -607,6 +612,7 @@ LG_API int lg_sparse_scatter(void* A, const void* B, const int64_t* chunk_ids, c
                              int E, int chunks, int alloc, int S, int dtype, int op, void* stream)
 {
     if (alloc <= 0 || E <= 0 || S <= 0) return 0;
+    LG_REQUIRE(A, B, chunk_ids, valid_count);
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
     case 0: return launch_scatter<float>(A, B, chunk_ids, valid_count, E, chunks, alloc, S, op, s);

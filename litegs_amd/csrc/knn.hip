@@ -170,6 +170,7 @@ LG_API long long lg_knn3_temp_bytes(int P) { return P <= 0 ? 0 : (long long)knn_
 LG_API int lg_knn3_mean_dist2(const float* points /*[P,3]*/, int P, float* mean_dist2 /*[P]*/, void* temp, long long temp_bytes, void* stream)
 {
     if (P <= 0) return 0;
+    LG_REQUIRE(points, mean_dist2);
     const KnnLayout f = knn_layout(P);
     if (temp == nullptr || temp_bytes < (long long)f.total) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;

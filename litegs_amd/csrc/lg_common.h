@@ -11,6 +11,13 @@
 
 static inline int lg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Argument validation of the C ABI: a binding that is not this repository's Python / ATen layer gets an error code for a missing
+// required buffer instead of a fault inside a kernel (sizes are checked by each launcher; nullable arguments are documented in
+// include/litegs_hip.h and not listed).
+template <typename... P>
+static inline bool lg_nonnull(P... p) { return (... && (p != nullptr)); }
+#define LG_REQUIRE(...) do { if (!lg_nonnull(__VA_ARGS__)) return (int)hipErrorInvalidValue; } while (0)
+
 // float -> int with v_cvt_i32_f32 semantics made explicit (NaN -> 0, saturating); the oracle's f2i twin.
 __device__ __forceinline__ int lg_f2i(float v)
 {

@@ -215,6 +215,7 @@ static int l1_ssim_forward_launch(const float* img, long long img_ps, int img_rs
 LG_API int lg_l1_ssim_forward(const float* img, const float* gt, int planes, int H, int W, float lam,
                               float* dmaps, float* partial, float* loss, void* stream)
 {
+    LG_REQUIRE(img, gt, dmaps, partial, loss);
     return l1_ssim_forward_launch(img, (long long)H * W, W, 0, gt, planes, H, W, lam, dmaps, partial, loss, stream);
 }
 
@@ -222,6 +223,7 @@ LG_API int lg_l1_ssim_forward(const float* img, const float* gt, int planes, int
 LG_API int lg_l1_ssim_forward_raster(const float* img, int Hp, int Wp, const float* gt, int planes, int H, int W, float lam,
                                      float* dmaps, float* partial, float* loss, void* stream)
 {
+    LG_REQUIRE(img, gt, dmaps, partial, loss);
     if (Hp < H || Wp < W) return (int)hipErrorInvalidValue;
     return l1_ssim_forward_launch(img, (long long)Hp * Wp, Wp, 1, gt, planes, H, W, lam, dmaps, partial, loss, stream);
 }
@@ -349,6 +351,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
 LG_API int lg_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, const float* grad_out, int planes, int H, int W,
                                float lam, float* d_img, void* stream)
 {
+    LG_REQUIRE(img, gt, dmaps, grad_out, d_img);
     dim3 grid(lg_cdiv(W, TS), lg_cdiv(H, TS), planes);
     hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, (long long)H * W, W, 0, gt, dmaps, grad_out,
                        H, W, H, W, lam, 1.0f / ((float)planes * H * W), d_img);
@@ -359,6 +362,7 @@ LG_API int lg_l1_ssim_backward(const float* img, const float* gt, const float* d
 LG_API int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt, const float* dmaps, const float* grad_out,
                                       int planes, int H, int W, float lam, float* d_img, void* stream)
 {
+    LG_REQUIRE(img, gt, dmaps, grad_out, d_img);
     if (Hp < H || Wp < W) return (int)hipErrorInvalidValue;
     dim3 grid(lg_cdiv(Wp, TS), lg_cdiv(Hp, TS), planes);
     hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, (long long)Hp * Wp, Wp, 1, gt, dmaps, grad_out,

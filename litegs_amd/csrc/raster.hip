@@ -81,6 +81,7 @@ LG_API int lg_pack_forward_params(const float* ndc, const float* inv_cov, const 
                                   const int* valid_length, int V, int N, int H, int W, float* packed, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(ndc, inv_cov, color, opacity, packed);
     hipLaunchKernelGGL(pack_params_kernel, dim3(lg_cdiv(N, 256), V), dim3(256), 0, (hipStream_t)stream,
                        ndc, inv_cov, color, opacity, valid_length, N, H, W, (float4*)packed);
     LG_RETURN_LAST();
@@ -734,6 +735,7 @@ LG_API int lg_raster_backward(const int* sorted_points, const int* start_index, 
                               float* packed_grad /*[V,N,16] zeroed*/, float* err_square_sum /*[V,1,N] zeroed*/,
                               int* tile_counters /*nullable [V,T+1,2]*/, const int* order /*nullable [V,T]*/, void* stream)
 {
+    LG_REQUIRE(sorted_points, start_index, packed, final_T, last, d_img, packed_grad);
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
     const int nslots = tiles ? K : ntiles;
@@ -811,6 +813,7 @@ LG_API int lg_unpack_gradient(const float* packed_grad, const float* packed, con
                               float* d_ndc, float* d_inv_cov, float* d_color, float* d_opacity, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(packed_grad, packed, d_ndc, d_inv_cov, d_color, d_opacity);
     hipLaunchKernelGGL(unpack_gradient_kernel, dim3(lg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)packed_grad, (const float4*)packed, grad_inv_scaler, valid_length, V, N, H, W, d_ndc, d_inv_cov, d_color, d_opacity);
     LG_RETURN_LAST();

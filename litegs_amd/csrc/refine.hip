@@ -169,6 +169,7 @@ LG_API int lg_permute_columns(const float* src /*[rows,n_src]*/, const int32_t* 
                               long long n_src, long long n_dst, float* dst /*[rows,n_dst]*/, void* stream)
 {
     if (rows <= 0 || n_dst <= 0) return 0;
+    LG_REQUIRE(src, dst);
     if (src == (const float*)dst) return (int)hipErrorInvalidValue;         // out of place only
     dim3 grid(lg_cdiv(n_dst, RF_TPB), lg_cdiv(rows, RF_ROWS));
     if (grid.y > 65535) return (int)hipErrorInvalidValue;

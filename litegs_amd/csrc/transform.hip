@@ -32,6 +32,7 @@ LG_API int lg_mvp_transform_forward(const float* world, const float* view, const
                                     int V, int N, float* view_pos, float* ndc_pos, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(world, view, proj, view_pos, ndc_pos);
     dim3 grid(lg_cdiv(N, TPB), V);
     hipLaunchKernelGGL(mvp_forward_kernel, grid, dim3(TPB), 0, (hipStream_t)stream, world, view, proj, valid_length, N, view_pos, ndc_pos);
     LG_RETURN_LAST();
@@ -61,6 +62,7 @@ LG_API int lg_mvp_transform_backward(const float* g_ndc, const float* g_view, co
                                      const float* view_pos, const int* valid_length, int V, int N, float* g_world, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(g_ndc, view, proj, view_pos, g_world);
     hipLaunchKernelGGL(mvp_backward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream,
                        g_ndc, g_view, view, proj, view_pos, valid_length, V, N, g_world);
     LG_RETURN_LAST();
@@ -85,6 +87,7 @@ __global__ void __launch_bounds__(TPB) transform_matrix_forward_kernel(const flo
 LG_API int lg_create_transform_matrix_forward(const float* quat, const float* scale, const int* valid_length, int N, float* T, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(quat, scale, T);
     hipLaunchKernelGGL(transform_matrix_forward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, quat, scale, valid_length, N, T);
     LG_RETURN_LAST();
 }
@@ -112,6 +115,7 @@ LG_API int lg_create_transform_matrix_backward(const float* gT, const float* qua
                                                int N, float* g_quat, float* g_scale, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(gT, quat, scale, g_quat, g_scale);
     hipLaunchKernelGGL(transform_matrix_backward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream,
                        gT, quat, scale, valid_length, N, g_quat, g_scale);
     LG_RETURN_LAST();
@@ -152,6 +156,7 @@ LG_API int lg_jacobian_rayspace(const float* view_pos, const float* proj, const 
                                 float* J, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(view_pos, proj, J);
     hipLaunchKernelGGL(jacobian_rayspace_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream,
                        view_pos, proj, valid_length, N, H, W, J);
     LG_RETURN_LAST();
@@ -185,6 +190,7 @@ LG_API int lg_create_cov2d_forward(const float* J, const float* view, const floa
                                    float* cov, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(J, view, T, cov);
     hipLaunchKernelGGL(cov2d_forward_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream, J, view, T, valid_length, N, cov);
     LG_RETURN_LAST();
 }
@@ -224,6 +230,7 @@ LG_API int lg_create_cov2d_backward(const float* g_cov, const float* J, const fl
                                     int V, int N, float* gT, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(g_cov, J, view, T, gT);
     hipLaunchKernelGGL(cov2d_backward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, g_cov, J, view, T, valid_length, V, N, gT);
     LG_RETURN_LAST();
 }
@@ -267,6 +274,7 @@ __global__ void __launch_bounds__(TPB) eigh_inv_forward_kernel(const float* __re
 LG_API int lg_eigh_inv_2x2_forward(const float* in, const int* valid_length, int V, int N, float* val, float* vec, float* inv, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(in, inv);
     hipLaunchKernelGGL(eigh_inv_forward_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream, in, valid_length, N, val, vec, inv);
     LG_RETURN_LAST();
 }
@@ -293,6 +301,7 @@ LG_API int lg_inv_2x2_backward(const float* inv, const float* g_inv, const int* 
                                float* g_in, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(inv, g_inv, g_in);
     hipLaunchKernelGGL(inv2x2_backward_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream, inv, g_inv, valid_length, N, zero_nonfinite, g_in);
     LG_RETURN_LAST();
 }
@@ -324,6 +333,7 @@ __global__ void __launch_bounds__(TPB) sh2rgb_forward_kernel(const float* __rest
 LG_API int lg_sh2rgb_forward(int degree, const float* sh0, const float* shr, const float* dirs, int V, int N, float* rgb, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(sh0, dirs, rgb);
     dim3 grid(lg_cdiv(N, TPB), V);
     hipStream_t s = (hipStream_t)stream;
     switch (degree) {
@@ -373,6 +383,7 @@ LG_API int lg_sh2rgb_backward(int degree, const float* g_rgb, const float* dirs,
                               float* d_sh0, float* d_shr, float* d_dirs, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(g_rgb, dirs, d_sh0);
     dim3 grid(lg_cdiv(N, TPB));
     hipStream_t s = (hipStream_t)stream;
     switch (degree) {
@@ -410,6 +421,7 @@ __global__ void __launch_bounds__(TPB) world2ndc_forward_kernel(const float* __r
 LG_API int lg_world2ndc_forward(const float* world, const float* viewproj, int V, int N, float* ndc, float* recp_w, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(world, viewproj, ndc, recp_w);
     hipLaunchKernelGGL(world2ndc_forward_kernel, dim3(lg_cdiv(N, TPB), V), dim3(TPB), 0, (hipStream_t)stream, world, viewproj, N, ndc, recp_w);
     LG_RETURN_LAST();
 }
@@ -438,6 +450,7 @@ LG_API int lg_world2ndc_backward(const float* viewproj, const float* ndc, const 
                                  float* g_pos, void* stream)
 {
     if (N <= 0) return 0;
+    LG_REQUIRE(viewproj, ndc, recp_w, g_ndc, g_pos);
     hipLaunchKernelGGL(world2ndc_backward_kernel, dim3(lg_cdiv(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, viewproj, ndc, recp_w, g_ndc, V, N, g_pos);
     LG_RETURN_LAST();
 }
@@ -508,6 +521,7 @@ LG_API int lg_create_viewproj_forward(const float* view_params, const float* rec
                                       float* view_matrix, float* proj_matrix, float* viewproj_matrix, float* frustumplane, void* stream)
 {
     if (V <= 0) return 0;
+    LG_REQUIRE(view_params, recp_tan_half_fov_x, view_matrix, proj_matrix);
     hipLaunchKernelGGL(create_viewproj_forward_kernel, dim3(lg_cdiv(V, 64)), dim3(64), 0, (hipStream_t)stream, view_params, recp_tan_half_fov_x,
                        V, H, W, z_near, z_far, view_matrix, proj_matrix, viewproj_matrix, frustumplane);
     LG_RETURN_LAST();

@@ -65,3 +65,17 @@ def test_product_does_not_import_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "litegs_oracle" in txt:
                     bad.append(f)
     assert not bad, f"product files reference the oracle: {bad}"
+
+
+def test_c_abi_rejects_missing_required_buffers():
+    """argument validation lives in the C ABI itself (a binder that is not this repository's Python / ATen layer gets an error code,
+    not a fault inside a kernel): hipErrorInvalidValue (1) for a null required buffer, 0 for an empty input; no launch happens either way"""
+    from litegs_amd._lib import lib
+    L = lib()
+    assert L.lg_mvp_transform_forward(None, None, None, None, 1, 128, None, None, None) == 1
+    assert L.lg_mvp_transform_forward(None, None, None, None, 1, 0, None, None, None) == 0          # empty input: nothing to do
+    assert L.lg_pack_forward_params(None, None, None, None, None, 1, 64, 32, 32, None, None) == 1
+    assert L.lg_depth_sort_keys(None, 16, None, None, None) == 1
+    assert L.lg_depth_sort_keys(None, 0, None, None, None) == 0
+    assert L.lg_tile_range(None, 1, 0, 8, None, None) == 1                                          # the range table itself is always required
+    assert L.lg_fused_set_option(99, 0) != 0
