@@ -217,6 +217,9 @@ int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt
  * splats).  Identical tables either way.  key 1 = margin of the depth-bound culling in percent (default 100): how far beyond
  * a tile's saturation point its bound for the frame's next visit lies.  Returns 0, or hipErrorInvalidValue for an unknown key / value. */
 int lg_fused_set_option(int key, int value);
+/* depth-order mode 1 only: emission order of the frames whose N = A*S equals n (a device permutation of 0..n-1 owned by the caller;
+ * NULL = ascending ids).  Shapes the emission's workload, never the table (the per-tile sort orders by depth and id). */
+int lg_fused_set_emission_order(const int32_t* order, long long n);
 int lg_fused_get_option(int key);
 long long lg_fused_workspace1_bytes(long long N);
 long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW);

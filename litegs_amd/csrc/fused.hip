@@ -41,6 +41,19 @@ static int g_depth_order_mode = LG_DEPTH_ORDER_GLOBAL;
 // has to re-run the frame unculled (key 1 of lg_fused_set_option; litegs_amd/fast.py adapts it per frame).
 static int g_bound_margin_pct = 100;
 
+// TILE mode only: the order in which the splats' instances are emitted (slot j -> splat order[j], a permutation of 0..n-1 on the
+// device, owned by the caller; nullptr or a length that does not match the frame's N = A*S: ascending ids).  The per-tile sort makes
+// the table independent of this order; it only shapes the emission's workload: consecutive ids are spatial neighbours -- all large
+// or all small -- while an interleaved order gives every 256-slot group the mix of sizes the emission kernels were tuned for.
+static const int32_t* g_emit_order = nullptr;
+static long long g_emit_order_n = 0;
+LG_API int lg_fused_set_emission_order(const int32_t* order, long long n)
+{
+    g_emit_order = order; g_emit_order_n = order ? n : 0;
+    return 0;
+}
+static const int32_t* emission_order(long long N) { return (g_emit_order != nullptr && g_emit_order_n == N) ? g_emit_order : nullptr; }
+
 LG_API int lg_fused_set_option(int key, int value)
 {
     if (key == 0 && (value == LG_DEPTH_ORDER_GLOBAL || value == LG_DEPTH_ORDER_TILE)) { g_depth_order_mode = value; return 0; }
@@ -432,7 +445,7 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
     if (g_depth_order_mode == LG_DEPTH_ORDER_TILE) {
         // no splat sort: instances are emitted in splat-id order and every tile's list is depth-sorted after the tile sort
         // (tilesort.hip).  Inclusive scan of the tile counts in id order; prefix[N-1] (the table length) also goes to the host feedback slot
-        return lg_gather_scan_gated((const int32_t*)(w + f.alloc), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
+        return lg_gather_scan_gated((const int32_t*)(w + f.alloc), emission_order(N), N, (int32_t*)(w + f.prefix),
                                     (uint32_t*)(w + f.scan_status), host_feedback_total, sched_cull ? 1 : 0, nullptr, nullptr, stream);
     }
     float* view_z = (float*)(w + f.view_z);
@@ -466,7 +479,7 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
     const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
     const bool tile_mode = g_depth_order_mode == LG_DEPTH_ORDER_TILE;
-    const void* depth_order = tile_mode ? nullptr : (odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));     // nullptr: emission in splat-id order
+    const void* depth_order = tile_mode ? (const void*)emission_order(N) : (odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));     // nullptr: emission in splat-id order
     const int bits = tile_key_bits(ntiles);
     // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
     // clears the sort's look-back table.  No table memset: the bounded sort only reads the first prefix[N-1] entries, and a
@@ -561,7 +574,7 @@ static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2&
     Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
     rc = launch_projection(sc, cam, TH, TW, w1, f1, false, nullptr, sched_out, fail_flag, s); if (rc) return rc;
     const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
-    const int32_t* depth_order = g_depth_order_mode == LG_DEPTH_ORDER_TILE ? nullptr : (const int32_t*)(odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));
+    const int32_t* depth_order = g_depth_order_mode == LG_DEPTH_ORDER_TILE ? emission_order(N) : (const int32_t*)(odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));
     rc = lg_gather_scan_gated((const int32_t*)(w1 + f1.alloc), depth_order, N, (int32_t*)(w1 + f1.prefix), (uint32_t*)(w1 + f1.scan_status2),
                               host_feedback_full, 0, fail_flag, full_total, s);
     if (rc) return rc;

@@ -69,6 +69,9 @@ class FusedRenderer:
         self.tile_order_valid = [False] * n_frames
         self.cull_enabled = os.environ.get("LITEGS_DEPTH_CULL", "1") != "0"
         self.cull_refresh = 16
+        # depth-order mode 'tile' only.  Measured (3 M @1080p): interleaving brings the queue kernel back to its depth-order time
+        # (35 -> 18 us) but slows the in-workgroup kernel (66 -> 72 us) and the now gathered scan (16 -> 26 us): no gain, off by default
+        self.interleave_emission = os.environ.get("LITEGS_EMISSION_ORDER", "ids") == "interleaved"
         # margin of the depth bounds (csrc/raster.hip: percent of the splats walked beyond a tile's saturation point), per frame.  A
         # fallback costs a whole second binning + blend (~0.4 ms at 3 M @1080p), a wider margin only a few more instances (~35 us per
         # million): measured over 40 training steps of the bench scene, margin 50 % -> 12 fallbacks, 1.093 ms/step; 100 % -> 1 fallback,
@@ -107,6 +110,23 @@ class FusedRenderer:
         self.clean_visits = [0] * n
         self.margin_written = [self.margin[0]] * n
         self.margin_emitted = [self.margin[0]] * n
+
+    def emission_order(self, A: int, S: int, device):
+        """depth-order mode 'tile' only: slot j -> splat ((j mod A) * P mod A) * S + j div A with P coprime to A -- every group of 256
+        consecutive slots draws one splat from each of 256 chunks that lie far apart in the (Morton-ordered) cloud.  Cached per A."""
+        import math
+        cache = self.__dict__.setdefault("_emit_cache", {})
+        key = (A, S)
+        if key not in cache:
+            if len(cache) >= 16:
+                cache.pop(next(iter(cache)))
+            P = max(int(A * 0.6180339887) | 1, 1)
+            while math.gcd(P, A) != 1:
+                P += 2
+            j = np.arange(A * S, dtype=np.int64)
+            order = ((j % A) * P % A) * S + j // A
+            cache[key] = torch.from_numpy(order.astype(np.int32)).to(device)
+        return cache[key]
 
     def cull_scratch(self, chunks: int, device):
         """persistent look-back table of the multi-workgroup culling kernel (epoch-tagged: zeroed once, never cleared again)"""
@@ -165,6 +185,8 @@ class _RenderFn(torch.autograd.Function):
             A = min(int(1.2 * pred_vis), chunks)
         A = max(A, 1)
         N = A * S
+        if R.interleave_emission and L.lg_fused_get_option(0) == 1:
+            L.lg_fused_set_emission_order(R.emission_order(A, S, dev).data_ptr(), N)
         ws1_bytes = L.lg_fused_workspace1_bytes(N)
         ws1 = torch.empty((ws1_bytes,), dtype=torch.uint8, device=dev)
         stat = STATS.active
