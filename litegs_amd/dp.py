@@ -297,6 +297,16 @@ class MomentExchange:
             self.fb_k = self.fb_k.pin_memory()
         self.last_cap = 0
         self.bytes_last = 0
+        self._mask_work = None
+
+    def begin(self, vis_ids, vis_num) -> None:
+        """start of a step, as early as the rank's visibility is known (litegs_amd/fast.py calls it right after the culling is
+        enqueued): the union-of-visibility all_reduce is launched asynchronously and completes on the collective's stream while the
+        forward, the loss and the blend backward run; step() only waits for it.  Optional: without it step() does the same
+        collective synchronously."""
+        self.mask.zero_()
+        self.union_ops.mark(self.mask, vis_ids, vis_num)
+        self._mask_work = dist.all_reduce(self.mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
 
     def check(self) -> None:
         """raises if any step since the last call dropped records (capacity outgrown); synchronises -- call at epoch boundaries"""
@@ -315,10 +325,15 @@ class MomentExchange:
         slot %= self.n_slots
         dev = pg.device
         nrec = self.ops.record_floats() if hasattr(self.ops, "record_floats") else 10
-        # union of visibility (device-side list + count)
-        self.mask.zero_()
-        self.union_ops.mark(self.mask, vis_ids, vis_num)
-        dist.all_reduce(self.mask, op=dist.ReduceOp.MAX, group=self.group)
+        # union of visibility (device-side list + count): already in flight if begin() was called for this step
+        work = getattr(self, "_mask_work", None)
+        if work is not None:
+            work.wait()
+            self._mask_work = None
+        else:
+            self.mask.zero_()
+            self.union_ops.mark(self.mask, vis_ids, vis_num)
+            dist.all_reduce(self.mask, op=dist.ReduceOp.MAX, group=self.group)
         union_ids, union_count, _ = self.union_ops.compact(self.mask)
         # capacity of the record blocks
         pred = int(self.fb_k[slot])

@@ -96,6 +96,9 @@ class FusedRenderer:
         self.fuse_optimizer = False
         self.pending = None
         self.probe_events = None      # measurement hook (bench.py): a list that receives an event pair around every blend backward launch
+        # data-parallel hook (dp.MomentExchange.begin): called with (visible_chunkid, visible_chunks_num) as soon as the culling is
+        # enqueued, so that the union-of-visibility collective runs on RCCL's stream underneath the whole forward + blend backward
+        self.after_cull = None
         self._cull_scratch, self._cull_chunks, self._cull_epoch = None, -1, 0
 
     def reset_feedback(self):
@@ -226,6 +229,8 @@ class _RenderFn(torch.autograd.Function):
         check(L.lg_fused_stage1(*common, do_cull, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), A, ws1.data_ptr(), ws1_bytes,
                                 fb_vis_ptr if do_cull else None, fb_tot_ptr, *(R.cull_scratch(chunks, dev) if do_cull else (None, 0)),
                                 in_ptr if cull else None, out_ptr, s), "fused stage1")
+        if R.after_cull is not None and any(ctx.needs_input_grad):
+            R.after_cull(vis_ids, vis_num)
         if pred_total <= 0:                                  # first visit: blocking table size (GR/binning.cu:152-163)
             off = L.lg_fused_total_offset(N)
             table_len = int(ws1[off:off + 4].view(torch.int32).item())

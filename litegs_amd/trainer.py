@@ -89,6 +89,7 @@ class FrameTrainer:
             raise RuntimeError("MomentExchange needs the native executor (fused=True)")
         # gradients are only materialised when something consumes them between backward and the optimizer (gradient-hook DP exchange)
         self.renderer.fuse_optimizer = self.fused and self.fuse_adam and (grad_hook is None or moments)
+        self.renderer.after_cull = grad_hook.begin if (moments and hasattr(grad_hook, "begin")) else None
         img, vis_id, vis_num, prim_vis = self.forward(frame, raw=self.raw_loss)
         if self.raw_loss:
             from . import loss_hip
