@@ -13,7 +13,6 @@ torch is used for device memory and streams only; every computation is a HIP ker
 """
 from __future__ import annotations
 
-import math
 from typing import Optional
 
 import torch

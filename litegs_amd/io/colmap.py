@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import os
 import struct
-from typing import Dict, List, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 

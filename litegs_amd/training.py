@@ -23,7 +23,6 @@ Differences from the reference, all deliberate:
 from __future__ import annotations
 
 import json
-import math
 import os
 import time
 from typing import List, Optional, Sequence

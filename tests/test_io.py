@@ -215,3 +215,29 @@ def test_epoch_schedule_properties():
         assert set(seen) == set(range(n)) if n >= w else set(seen) <= set(range(n))
     many = [tuple(s for s, _ in epoch_schedule(13, 1, e)) for e in range(6)]
     assert len(set(many)) > 1                                                         # the order is re-drawn per epoch
+
+
+def test_compat_torchmetrics_stand_ins():
+    """PSNR / SSIM stand-ins used when the reference's own scripts run on this image (compat/README.md)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "compat"))
+    try:
+        for m in [k for k in sys.modules if k == "torchmetrics" or k.startswith("torchmetrics.")]:
+            del sys.modules[m]
+        from torchmetrics.image import lpip, psnr, ssim
+        g = torch.Generator().manual_seed(0)
+        a = torch.rand((1, 3, 40, 48), generator=g)
+        b = (a + 0.05 * torch.randn((1, 3, 40, 48), generator=g)).clamp(0, 1)
+        p = psnr.PeakSignalNoiseRatio(data_range=(0.0, 1.0))(a, b)
+        assert abs(float(p) - float(10 * torch.log10(1.0 / (a - b).square().mean()))) < 1e-5
+        s_same = ssim.StructuralSimilarityIndexMeasure(data_range=(0.0, 1.0))(a, a)
+        s_diff = ssim.StructuralSimilarityIndexMeasure(data_range=(0.0, 1.0))(a, b)
+        assert abs(float(s_same) - 1.0) < 1e-6 and 0.0 < float(s_diff) < 1.0
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert torch.isnan(lpip.LearnedPerceptualImagePatchSimilarity(net_type="vgg")(a, b))
+    finally:
+        sys.path.pop(0)
+        for m in [k for k in sys.modules if k == "torchmetrics" or k.startswith("torchmetrics.")]:
+            del sys.modules[m]
