@@ -32,10 +32,19 @@
 // the highest ids in TILE mode.  Measured at 3 M @1080p (profiles/r02_margin_ab.log): TILE removes 93 us of
 // splat sort per frame and pays 42 us for the per-tile sort (latency: ~10 us per wave-tile at 4 waves per SIMD) plus 32 us in the
 // emission, whose adaptive small/big split and output locality were tuned for depth order (Morton neighbours are all large or all
-// small) -- 0.787 vs 0.793 ms per step: no difference worth a change of the truncation semantics, so GLOBAL stays the default.
+// small) -- 0.787 vs 0.793 ms per step: a tie at this size, so GLOBAL is kept there (reference truncation semantics).
+// AUTO (default): TILE for frames with at least LG_AUTO_TILE_N compacted Gaussians (N = A*S), GLOBAL below -- the splat sort grows
+// with N (hist + 4 passes + gather: 93 us at 0.9 M, 215 us at 3 M) while what the tile mode pays is bounded by the emitted instances:
+// at 10 M Gaussians @1600x1200 (N = 3.0 M) TILE is 1.07 ms per step against 1.16 ms, forward only 0.70 against 0.88 ms.
 #define LG_DEPTH_ORDER_GLOBAL 0
 #define LG_DEPTH_ORDER_TILE 1
-static int g_depth_order_mode = LG_DEPTH_ORDER_GLOBAL;
+#define LG_DEPTH_ORDER_AUTO 2
+#define LG_AUTO_TILE_N 1500000
+static int g_depth_order_mode = LG_DEPTH_ORDER_AUTO;
+static bool use_tile_order(long long N)
+{
+    return g_depth_order_mode == LG_DEPTH_ORDER_TILE || (g_depth_order_mode == LG_DEPTH_ORDER_AUTO && N >= LG_AUTO_TILE_N);
+}
 // depth-bound culling: how far (percent of the splats walked, at least 16 splats) beyond a tile's saturation point its next bound lies.
 // A wider margin emits more instances but survives more drift of the scene between two visits of a frame before the gated fallback
 // has to re-run the frame unculled (key 1 of lg_fused_set_option; litegs_amd/fast.py adapts it per frame).
@@ -56,7 +65,7 @@ static const int32_t* emission_order(long long N) { return (g_emit_order != null
 
 LG_API int lg_fused_set_option(int key, int value)
 {
-    if (key == 0 && (value == LG_DEPTH_ORDER_GLOBAL || value == LG_DEPTH_ORDER_TILE)) { g_depth_order_mode = value; return 0; }
+    if (key == 0 && (value == LG_DEPTH_ORDER_GLOBAL || value == LG_DEPTH_ORDER_TILE || value == LG_DEPTH_ORDER_AUTO)) { g_depth_order_mode = value; return 0; }
     if (key == 1 && value >= 1 && value <= 100000) { g_bound_margin_pct = value; return 0; }
     return (int)hipErrorInvalidValue;
 }
@@ -442,7 +451,7 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
     Camera cam = make_camera(view_host, proj_host, H, W);
     Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
     rc = launch_projection(sc, cam, TH, TW, w, f, true, sched_cull, sched_out, nullptr, s); if (rc) return rc;
-    if (g_depth_order_mode == LG_DEPTH_ORDER_TILE) {
+    if (use_tile_order(N)) {
         // no splat sort: instances are emitted in splat-id order and every tile's list is depth-sorted after the tile sort
         // (tilesort.hip).  Inclusive scan of the tile counts in id order; prefix[N-1] (the table length) also goes to the host feedback slot
         return lg_gather_scan_gated((const int32_t*)(w + f.alloc), emission_order(N), N, (int32_t*)(w + f.prefix),
@@ -478,7 +487,7 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
 {
     const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
-    const bool tile_mode = g_depth_order_mode == LG_DEPTH_ORDER_TILE;
+    const bool tile_mode = use_tile_order(N);
     const void* depth_order = tile_mode ? (const void*)emission_order(N) : (odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));     // nullptr: emission in splat-id order
     const int bits = tile_key_bits(ntiles);
     // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
@@ -574,7 +583,7 @@ static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2&
     Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
     rc = launch_projection(sc, cam, TH, TW, w1, f1, false, nullptr, sched_out, fail_flag, s); if (rc) return rc;
     const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
-    const int32_t* depth_order = g_depth_order_mode == LG_DEPTH_ORDER_TILE ? emission_order(N) : (const int32_t*)(odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));
+    const int32_t* depth_order = use_tile_order(N) ? emission_order(N) : (const int32_t*)(odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));
     rc = lg_gather_scan_gated((const int32_t*)(w1 + f1.alloc), depth_order, N, (int32_t*)(w1 + f1.prefix), (uint32_t*)(w1 + f1.scan_status2),
                               host_feedback_full, 0, fail_flag, full_total, s);
     if (rc) return rc;

@@ -37,13 +37,14 @@ class CameraFrame:
 
 
 def _apply_env_options() -> None:
-    """LITEGS_DEPTH_ORDER=tile selects the per-tile depth sort (csrc/tilesort.hip: no sort over the splats) instead of the default
-    depth sort of all visible splats before the emission; same results bit for bit, measured slightly slower (csrc/fused.hip)"""
+    """LITEGS_DEPTH_ORDER=global|tile|auto: depth sort of all visible splats before the emission (the reference's structure), per-tile
+    depth sort after the tile sort (csrc/tilesort.hip: no sort over the splats), or (default) per frame by its size; same tables bit
+    for bit (csrc/fused.hip)"""
     mode = os.environ.get("LITEGS_DEPTH_ORDER")
     if mode is not None:
-        if mode not in ("tile", "global"):
-            raise ValueError("LITEGS_DEPTH_ORDER must be 'tile' or 'global'")
-        check(lib().lg_fused_set_option(0, 1 if mode == "tile" else 0), "set_option")
+        if mode not in ("tile", "global", "auto"):
+            raise ValueError("LITEGS_DEPTH_ORDER must be 'global', 'tile' or 'auto'")
+        check(lib().lg_fused_set_option(0, {"global": 0, "tile": 1, "auto": 2}[mode]), "set_option")
 
 
 class FusedRenderer:
@@ -188,7 +189,7 @@ class _RenderFn(torch.autograd.Function):
             A = min(int(1.2 * pred_vis), chunks)
         A = max(A, 1)
         N = A * S
-        if R.interleave_emission and L.lg_fused_get_option(0) == 1:
+        if R.interleave_emission and L.lg_fused_get_option(0) != 0:
             L.lg_fused_set_emission_order(R.emission_order(A, S, dev).data_ptr(), N)
         ws1_bytes = L.lg_fused_workspace1_bytes(N)
         ws1 = torch.empty((ws1_bytes,), dtype=torch.uint8, device=dev)

@@ -37,4 +37,4 @@ for mode in modes:
         print(f"{mode:6s} margin {('adaptive' if margin == 0 else str(margin)):8s} step {dt:7.4f} ms  fallbacks in window ~{R.fallbacks - fb0 - (R.fallbacks - fb1) + 0:3d} (+{R.fallbacks - fb1} late)  "
               f"emitted {int(R.fb_total[0])} full {R.full_total[0]}  margins {R.margin}", flush=True)
         del tr
-L.lg_fused_set_option(0, 0)
+L.lg_fused_set_option(0, 2)
