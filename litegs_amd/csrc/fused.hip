@@ -150,6 +150,9 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     alloc[i] = tiles;
     const float ppx = (n[0] + 1.0f) * 0.5f * cam.W - 0.5f;
     const float ppy = (n[1] + 1.0f) * 0.5f * cam.H - 0.5f;
+    // the 64-byte record is only ever read for splats that are emitted (key emission, blend, depth bounds): two thirds of the
+    // Gaussians of the visible chunks fail the fine test or are culled by depth and skip the store
+    if (tiles <= 0) return;
     float4* rec = packed + i * (REC / 4);
     rec[0] = make_float4(ppx, ppy, -0.5f * i4[0] * LOG2E, -i4[1] * LOG2E);       // layout: raster.hip
     rec[1] = make_float4(-0.5f * i4[3] * LOG2E, o, r0, r1);
