@@ -269,7 +269,9 @@ int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_host, c
                            const float* lr6, float b1, float b2, float eps,
                            unsigned char* touched /* nullable uint8[chunks*S] owned by the optimizer: 0 = all Adam moments of that Gaussian are
                                                      zero; such Gaussians are skipped (exactly a no-op) while their blend moments are zero, and
-                                                     flagged on their first non-zero record */, void* stream);
+                                                     flagged on their first non-zero record */,
+                           const int* emitted /* nullable int32[A*S]: this frame's tile counts (workspace 1, lg_fused_alloc_offset): a splat that
+                                                 was not emitted has an all-zero record, which then need not be read */, void* stream);
 int lg_adam_update_multi(int ngroups, void* const* param, const void* const* grad, void* const* exp_avg, void* const* exp_avg_sq,
                          const int* rows, const float* lr, const int64_t* visible_chunk_id, const int* valid_length,
                          int chunks, int A, int S, int grad_dense, float b1, float b2, float eps, void* stream);

@@ -217,7 +217,7 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
                                              float* __restrict__ m_sh0, float* __restrict__ m_shr, float* __restrict__ m_opa,
                                              float* __restrict__ v_pos, float* __restrict__ v_scale, float* __restrict__ v_rot,
                                              float* __restrict__ v_sh0, float* __restrict__ v_shr, float* __restrict__ v_opa,
-                                             unsigned char* __restrict__ touched)
+                                             unsigned char* __restrict__ touched, const int* __restrict__ emitted)
 {
     const int a = blockIdx.x, t = threadIdx.x;
     if (a >= visible_chunks_num[0]) return;
@@ -228,6 +228,10 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
     const float sc = grad_inv_scaler ? grad_inv_scaler[0] : 1.0f;
     GaussGrads G;
     float mom[9];
+    // emitted (nullable): the projection's tile counts of this frame (> 0: the splat was emitted; <= 0: failed the fine test or culled
+    // by depth).  A splat that was not emitted was never blended: its gradient record is the zeros it was cleared to, and for the
+    // no-op test below 4 bytes tell as much as the 64-byte record (two thirds of the Gaussians of the visible chunks)
+    if (emitted != nullptr && touched != nullptr && emitted[od] <= 0 && touched[sd] == 0) return;
     load_moments(packed_grad, od, mom);
     // Exact skip of no-op updates.  touched[g] == 0 asserts that both Adam moments of every row of Gaussian g are (+-)0 -- it has never
     // received a gradient.  If this frame's nine blend moments are all zero as well, every parameter gradient is 0 and the update is
@@ -653,7 +657,8 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
                                   float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
                                   float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
                                   const float* lr6, float b1, float b2, float eps,
-                                  unsigned char* touched /*nullable [chunks*S]: 0 = both moments of every row of that Gaussian are zero*/, void* stream)
+                                  unsigned char* touched /*nullable [chunks*S]: 0 = both moments of every row of that Gaussian are zero*/,
+                                  const int* emitted /*nullable [A*S]: the tile counts stage 1 left in workspace 1 (lg_fused_alloc_offset)*/, void* stream)
 {
     if (A <= 0) return 0;
     if (S > 1024 || S <= 0) return (int)hipErrorInvalidValue;
@@ -662,7 +667,7 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
     AdamRates ar = { lr6[0], lr6[1], lr6[2], lr6[3], lr6[4], lr6[5], b1, b2, eps };
 #define LAUNCH_PA(D) hipLaunchKernelGGL(project_backward_adam_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, ar, chunks, S, A, R, \
                                         (const float4*)packed_grad, grad_inv_scaler, pos, scale, rot, sh0, shr, opa,                          \
-                                        m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa, v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched)
+                                        m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa, v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched, emitted)
     switch (degree) {
     case 0: LAUNCH_PA(0); break;
     case 1: LAUNCH_PA(1); break;

@@ -330,7 +330,8 @@ class _RenderFn(torch.autograd.Function):
                 fc, fw = ctx.stat_bufs
                 STATS.add_moments("fragment_weight", fw, fw * fw, fc)
                 STATS.add_moments("fragment_err", _d_opacity(pg, ws1, N), esq, fc)
-            R.pending = dict(pg=pg, A=A, S=S, frame=frame, degree=degree, chunks=chunks, Rr=Rr, vis_ids=vis_ids, vis_num=vis_num)
+            # ws1 rides along: its tile counts tell the fused backward + Adam which gradient records can only be zero
+            R.pending = dict(pg=pg, A=A, S=S, frame=frame, degree=degree, chunks=chunks, Rr=Rr, vis_ids=vis_ids, vis_num=vis_num, ws1=ws1)
             return (None,) * 11
         d_pos = torch.empty((3, A, S), dtype=torch.float32, device=dev)
         d_scale = torch.empty((3, A, S), dtype=torch.float32, device=dev)
@@ -419,7 +420,9 @@ class FusedAdam:
                                            pend["vis_ids"].data_ptr(), pend["vis_num"].data_ptr(), pend["pg"].data_ptr(), None,
                                            *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms], *[v.data_ptr() for v in vs],
                                            lr6, 0.9, 0.999, float(self.groups[0]["eps"]),
-                                           self._touched_flags().data_ptr() if self.skip_untouched else None, _s()), "fused backward+adam")
+                                           self._touched_flags().data_ptr() if self.skip_untouched else None,
+                                           (pend["ws1"].data_ptr() + lib().lg_fused_alloc_offset(pend["A"] * pend["S"])) if "ws1" in pend else None,
+                                           _s()), "fused backward+adam")
 
     @torch.no_grad()
     def step_exchange(self, exchange, cams, slot: int = 0):

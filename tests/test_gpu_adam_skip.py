@@ -20,7 +20,9 @@ def _apply(tr, pend, ps, ms, vs, touched):
                                        pend["vis_ids"].data_ptr(), pend["vis_num"].data_ptr(), pend["pg"].data_ptr(), None,
                                        *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms], *[v.data_ptr() for v in vs],
                                        lr6, 0.9, 0.999, float(tr.opt.param_groups[0]["eps"]),
-                                       touched.data_ptr() if touched is not None else None, torch.cuda.current_stream().cuda_stream), "backward+adam")
+                                       touched.data_ptr() if touched is not None else None,
+                                       (pend["ws1"].data_ptr() + lib().lg_fused_alloc_offset(pend["A"] * pend["S"])) if touched is not None else None,
+                                       torch.cuda.current_stream().cuda_stream), "backward+adam")
     torch.cuda.synchronize()
 
 
