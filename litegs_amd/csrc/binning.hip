@@ -1474,9 +1474,23 @@ __global__ void __launch_bounds__(TPB) scan_lookback_kernel(const int32_t* __res
     const long long base = (long long)bid * SORT_TILE + (long long)tid * SORT_ITEMS;
     int v[SORT_ITEMS];
     int s = 0;
+    // a thread owns SORT_ITEMS consecutive words: four 16-byte loads instead of sixteen 4-byte ones whose lanes sit 64 bytes apart
+    // (the scalar form re-touches every cache line of the wave sixteen times: 45 us for 3 M words, latency of the L1 miss path)
+    const bool vec = (idx == nullptr) && (base + SORT_ITEMS <= n) && ((reinterpret_cast<uintptr_t>(src + base) & 15) == 0);
+    if (vec) {
+        const int4* __restrict__ s4 = reinterpret_cast<const int4*>(src + base);
+#pragma unroll
+        for (int q = 0; q < SORT_ITEMS / 4; q++) {
+            const int4 x4 = s4[q];
+            v[4 * q] = x4.x; v[4 * q + 1] = x4.y; v[4 * q + 2] = x4.z; v[4 * q + 3] = x4.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; j++) v[j] = scan_load(src, idx, base + j, n);
+    }
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
-        int x = scan_load(src, idx, base + j, n);
+        int x = v[j];
         if (mode == 1) x = x < 0 ? 0 : x;
         else if (mode == 2) x &= 0x7fffffff;
         v[j] = x; s += x;
@@ -1519,12 +1533,19 @@ __global__ void __launch_bounds__(TPB) scan_lookback_kernel(const int32_t* __res
     __syncthreads();
     int run = excl_s + incl - s;
     for (int w = 0; w < wave; w++) run += wsum[w];
+    const bool vec_out = (base + SORT_ITEMS <= n) && ((reinterpret_cast<uintptr_t>(out + base) & 15) == 0);
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
         run += v[j];
-        if (base + j < n) out[base + j] = run;
+        v[j] = run;
+        if (!vec_out && base + j < n) out[base + j] = run;
         if (host_total && base + j == n - 1) __hip_atomic_store(host_total, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (total_out && base + j == n - 1) *total_out = run;
+    }
+    if (vec_out) {
+        int4* __restrict__ o4 = reinterpret_cast<int4*>(out + base);
+#pragma unroll
+        for (int q = 0; q < SORT_ITEMS / 4; q++) o4[q] = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
 }
 
