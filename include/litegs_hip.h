@@ -214,7 +214,7 @@ int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt
  * Workspace 1 holds per-Gaussian buffers for N = A*S, workspace 2 the tile-instance table of length L. */
 /* process-wide executor options.  key 0 = depth order of the tile lists: 0 the reference's structure (depth sort of all
  * visible splats before the emission, wrapper.py:739-745), 1 per-tile depth sort after the tile sort (tilesort.hip; no sort over the
- * splats), 2 (default) choose per frame: 1 from 1.5 M compacted Gaussians on, 0 below.  Identical tables either way.  key 1 = margin of the depth-bound culling in percent (default 100): how far beyond
+ * splats), 2 (default) choose per frame: 1 from 1 M compacted Gaussians on, 0 below.  Identical tables either way.  key 1 = margin of the depth-bound culling in percent (default 100): how far beyond
  * a tile's saturation point its bound for the frame's next visit lies.  Returns 0, or hipErrorInvalidValue for an unknown key / value. */
 int lg_fused_set_option(int key, int value);
 /* depth-order mode 1 only: emission order of the frames whose N = A*S equals n (a device permutation of 0..n-1 owned by the caller;

@@ -35,11 +35,12 @@
 // small) -- 0.787 vs 0.793 ms per step: a tie at this size, so GLOBAL is kept there (reference truncation semantics).
 // AUTO (default): TILE for frames with at least LG_AUTO_TILE_N compacted Gaussians (N = A*S), GLOBAL below -- the splat sort grows
 // with N (hist + 4 passes + gather: 93 us at 0.9 M, 215 us at 3 M) while what the tile mode pays is bounded by the emitted instances:
-// at 10 M Gaussians @1600x1200 (N = 3.0 M) TILE is 1.07 ms per step against 1.16 ms, forward only 0.70 against 0.88 ms.
+// at 6 M Gaussians @1080p (N = 1.75 M) TILE is 0.81 ms per step against 0.92 ms, at 10 M @1600x1200 (N = 3.0 M) 1.07 against 1.16 ms
+// (forward only 0.70 against 0.88 ms); at the 3 M bench frame (N = 0.9 M) the two tie.
 #define LG_DEPTH_ORDER_GLOBAL 0
 #define LG_DEPTH_ORDER_TILE 1
 #define LG_DEPTH_ORDER_AUTO 2
-#define LG_AUTO_TILE_N 1500000
+#define LG_AUTO_TILE_N 1000000
 static int g_depth_order_mode = LG_DEPTH_ORDER_AUTO;
 static bool use_tile_order(long long N)
 {

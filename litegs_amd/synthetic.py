@@ -131,3 +131,5 @@ CONFIGS = {
     "3m_1080p": (3_000_000, 1920, 1080, 1200.0),
     "10m_1600x1200": (10_000_000, 1600, 1200, 1100.0),
 }
+# not in BASELINE.json: an intermediate size used to place the switch between the two depth-order modes (tools/margin_ab.py)
+CONFIGS["6m_1080p"] = (6_000_000, 1920, 1080, 1200.0)
