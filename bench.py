@@ -318,7 +318,8 @@ def main():
         if not args.operator_path:
             rd = tr.renderer
             result["depth_bound_culling"] = {"enabled": bool(rd.cull_enabled), "margin_pct": sorted(set(int(m) for m in rd.margin)),
-                                             "unculled_reruns_observed": int(rd.fallbacks), "visits": int(sum(rd.visits)),
+                                             "unculled_reruns_observed": int(rd.fallbacks), "truncated_tables_observed": int(rd.truncated_visits),
+                                             "visits": int(sum(rd.visits)),
                                              "full_instances": int(rd.full_total[frame_of(0)])}
             fa = tr.fadam
             if fa.skip_untouched and fa.touched is not None:

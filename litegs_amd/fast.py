@@ -86,6 +86,8 @@ class FusedRenderer:
         self.margin_written = [self.margin[0]] * n_frames    # margin of the bounds a frame's next visit will cull with
         self.margin_emitted = [self.margin[0]] * n_frames    # margin of the bounds behind the frame's last emitted total (fb_total)
         self.fallbacks = 0                                   # visits that were re-run unculled (observed one visit later)
+        self.last_capacity = [0] * n_frames                  # table capacity a frame's last unculled visit ran with
+        self.truncated_visits = 0                            # unculled visits whose table turned out too short (observed one visit later)
         self.visits = [0] * n_frames
         self.full_total = [0] * n_frames                     # host copy of the full table length of a frame's last unculled visit
         self.last_unculled = [False] * n_frames
@@ -110,6 +112,7 @@ class FusedRenderer:
         self.tile_order_valid = [False] * n
         self.full_total = [0] * n
         self.last_unculled = [False] * n
+        self.last_capacity = [0] * n
         self.margin = [self.margin_fixed or self.margin_lo] * n
         self.clean_visits = [0] * n
         self.margin_written = [self.margin[0]] * n
@@ -197,9 +200,19 @@ class _RenderFn(torch.autograd.Function):
         tiles = STATS.schedule_for_current_frame()
         # depth-bound culling: bookkeeping of the sizing feedback (the emitted total of a culled visit is not the full table length)
         pred_total = int(R.fb_total[k])
+        if R.last_unculled[k] and pred_total > R.last_capacity[k] > 0:
+            # the previous (unculled) visit needed more entries than its predicted table held: its tail was dropped, as in the reference
+            # (GR/binning.cu:63, silent there).  Counted here, and this visit sizes its table exactly (the blocking first-visit path).
+            R.truncated_visits += 1
+            pred_total = 0
+            R.fb_total[k] = 0
         if R.last_unculled[k] and pred_total > 0:
             R.full_total[k] = pred_total                      # the previous visit of this frame emitted everything
         if int(R.fb_full[k]) > 0:                             # ... or a fallback re-ran it in full
+            if int(R.fb_full[k]) > R.last_capacity[k] > 0:    # ... into a table that was too short for it: same treatment
+                R.truncated_visits += 1
+                pred_total = 0
+                R.fb_total[k] = 0
             R.full_total[k] = max(R.full_total[k], int(R.fb_full[k]))
             R.fb_full[k] = 0
             R.fallbacks += 1
@@ -273,6 +286,7 @@ class _RenderFn(torch.autograd.Function):
             R.sched_cur[k] = 1 - R.sched_cur[k]
             R.sched_valid[k] = True
         R.last_unculled[k] = not cull
+        R.last_capacity[k] = table_len
         R.last_cull = cull
         if cull:
             R.margin_emitted[k] = R.margin_written[k]

@@ -165,3 +165,10 @@ def test_fused_render_with_underpredicted_table(oracle):
     full_img = np.clip(res.img[..., :H, :W], 0, 1)
     assert np.abs(ref_img - full_img).max() > 0.05, "the truncation must be visible in this case"
     assert_close(img.cpu().numpy(), ref_img, flip_frac=5e-5, name="truncated img")
+    # the truncation is silent in the reference; here the next visit notices (the true total came back through the feedback slot),
+    # counts it and sizes its table exactly again
+    with torch.no_grad():
+        img3, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
+        torch.cuda.synchronize()
+    assert rd.truncated_visits == 1 and rd.last_sizes[1] == total
+    assert_close(img3.cpu().numpy(), full_img, flip_frac=5e-5, name="healed img")
