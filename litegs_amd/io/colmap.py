@@ -47,7 +47,8 @@ class Image:
 
 # -- binary -------------------------------------------------------------------------------------------------------------------------
 def read_cameras_binary(path: str) -> Dict[int, Camera]:
-    buf = memoryview(open(path, "rb").read())
+    with open(path, "rb") as f:
+        buf = memoryview(f.read())
     (count,), off = struct.unpack_from("<Q", buf, 0), 8
     cams = {}
     for _ in range(count):
@@ -62,7 +63,8 @@ def read_cameras_binary(path: str) -> Dict[int, Camera]:
 
 
 def read_images_binary(path: str) -> Dict[int, Image]:
-    buf = memoryview(open(path, "rb").read())
+    with open(path, "rb") as f:
+        buf = memoryview(f.read())
     raw = buf.tobytes()
     (count,), off = struct.unpack_from("<Q", buf, 0), 8
     images = {}
@@ -80,7 +82,8 @@ def read_images_binary(path: str) -> Dict[int, Image]:
 
 def read_points3d_binary(path: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """-> xyz [P,3] f64, rgb [P,3] (0..255 as f64, like the reference), error [P,1]"""
-    buf = memoryview(open(path, "rb").read())
+    with open(path, "rb") as f:
+        buf = memoryview(f.read())
     (count,), off = struct.unpack_from("<Q", buf, 0), 8
     xyz, rgb, err = np.empty((count, 3)), np.empty((count, 3)), np.empty((count, 1))
     for p in range(count):
