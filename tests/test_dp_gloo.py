@@ -334,7 +334,11 @@ def _moment_worker(rank, world, port, out):
         expect = (both[0] + both[1]) / world
         TorchMomentOps.fb_target = ex.fb_k[3:4]
         pend = dict(pg=pg, A=A, S=S, vis_ids=vis, vis_num=cnt, degree=3, Rr=15)
+        if visit == 1:                                   # the asynchronous form: the union collective is started early (the renderer does
+            ex.begin(vis, cnt)                           # this right after the culling), step() only waits for it
+            ok &= ex._mask_work is not None
         uid, ucnt = ex.step(pend, cams, params, [None], [None], [0.0] * 6, 1e-15, 8, 8, slot=3)
+        ok &= ex._mask_work is None
         why = []
         if uid[: int(ucnt)].tolist() != [1, 2, 4, 5, 6, 8, 9]:
             why.append(("union", uid[: int(ucnt)].tolist()))
