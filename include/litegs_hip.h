@@ -284,7 +284,7 @@ int lg_dp_record_floats(void);
 int lg_dp_compact_moments(const float* packed_grad /*[A*S,16] of lg_fused_backward*/, const int64_t* vis_ids, const int* vis_num, int A, int S,
                           int cap, float* block, void* stream);
 int lg_dp_build_slotmap(const float* gathered /*[W] blocks*/, int W, int cap, long long total /*chunks*S*/, int* slot /*[W][total], zero*/,
-                        int* host_max_k /*nullable pinned int: largest count of the job*/, int* overflow /*nullable device flag*/, void* stream);
+                        int* host_max_k /*nullable pinned int[2]: {largest count of the job, the same count if it exceeded cap (records were dropped) else 0}*/, int* overflow /*nullable device flag*/, void* stream);
 int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count, int chunks, int S, int H, int W_img,
                         const float* views_host /*[W][16]*/, const float* projs_host /*[W][16]*/, int world, int degree, int R,
                         const float* gathered, int cap, int* slot,

@@ -90,13 +90,16 @@ __global__ void __launch_bounds__(256) dp_slotmap_kernel(const float* __restrict
     if (r == 0 && k == 0) {
         int mx = 0;
         for (int q = 0; q < W; q++) mx = max(mx, __float_as_int(gathered[(size_t)q * (1 + cap) * DP_REC]));
-        if (host_max_k) __hip_atomic_store(host_max_k, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (host_max_k) {         // word 0: the job's largest count (sizes the slot's next visit); word 1: that count when it outgrew THIS step's capacity
+            __hip_atomic_store(host_max_k, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_max_k + 1, mx > cap ? mx : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (mx > cap && overflow) atomicOr(overflow, 1);
     }
 }
 
 LG_API int lg_dp_build_slotmap(const float* gathered /*[W][(1 + cap) * 10]*/, int W, int cap, long long total /*chunks * S*/,
-                               int* slot /*[W][total], all zero between steps*/, int* host_max_k /*nullable pinned*/,
+                               int* slot /*[W][total], all zero between steps*/, int* host_max_k /*nullable pinned int[2]: {largest count, overflow marker}*/,
                                int* overflow /*nullable device flag, sticky*/, void* stream)
 {
     if (W <= 0 || W > DP_MAX_WORLD || cap <= 0) return (int)hipErrorInvalidValue;

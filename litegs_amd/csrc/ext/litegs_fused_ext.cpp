@@ -61,9 +61,14 @@ std::vector<Tensor> frustum_culling_aabb(Tensor aabb_origin, Tensor aabb_ext, Te
           "frustum_culling_aabb");
     int64_t pred = 0;
     if (feedback_buffer_arg.has_value() && data_idx_arg.has_value()) {
+        // the reference reads `(*data_idx_arg)[i].item()` (GR/compact.cu:527): any device, any integer dtype
+        TORCH_CHECK(!feedback_buffer_arg->is_cuda() && feedback_buffer_arg->scalar_type() == at::kInt && feedback_buffer_arg->is_contiguous(),
+                    "frustum_culling_aabb: feedback_buffer must be a contiguous (pinned) CPU int32 tensor");
+        const Tensor idx_host = data_idx_arg->to(at::kCPU, at::kLong).contiguous();
         int* base = feedback_buffer_arg->data_ptr<int>();
-        const int64_t* idx = data_idx_arg->data_ptr<int64_t>();
-        for (int64_t i = 0; i < data_idx_arg->size(0); i++) {
+        const int64_t* idx = idx_host.data_ptr<int64_t>();
+        for (int64_t i = 0; i < idx_host.size(0); i++) {
+            TORCH_CHECK(idx[i] >= 0 && idx[i] < feedback_buffer_arg->numel(), "frustum_culling_aabb: data index outside the feedback buffer");
             pred = std::max<int64_t>(pred, base[idx[i]]);
             check(lg_feedback_d2h(base + idx[i], num.data_ptr<int>(), s), "feedback copy");
         }
@@ -355,8 +360,11 @@ std::vector<Tensor> create_table(Tensor ndc, Tensor inv_cov2d, Tensor opacity, T
     void* s = cur_stream();
     int64_t pred = 0;
     if (feedback_buffer_cpu.has_value() && idx_tensor_cpu.has_value()) {
+        TORCH_CHECK(!feedback_buffer_cpu->is_cuda() && feedback_buffer_cpu->scalar_type() == at::kInt && feedback_buffer_cpu->is_contiguous(),
+                    "create_table: feedback_buffer must be a contiguous (pinned) CPU int32 tensor");
+        const Tensor idx_host = idx_tensor_cpu->to(at::kCPU, at::kLong).contiguous();       // any device / integer dtype, as GR/binning.cu:139-150 reads it
         int* base = feedback_buffer_cpu->data_ptr<int>();
-        const int64_t* idx = idx_tensor_cpu->data_ptr<int64_t>();
+        const int64_t* idx = idx_host.data_ptr<int64_t>();
         for (int i = 0; i < V; i++) {
             pred = std::max<int64_t>(pred, base[idx[i]]);
             check(lg_feedback_d2h(base + idx[i], off.data_ptr<int>() + ((int64_t)i * N + N - 1), s), "feedback copy");

@@ -14,7 +14,7 @@
 // for the large strides and one pass over LDS-resident chunks for the small ones (tilesort.hip, regime L).
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define LG_HD __host__ __device__ __forceinline__
 #else
 #define LG_HD inline

@@ -271,33 +271,58 @@ class MomentExchange:
 
     Per step: one small ``all_reduce(MAX)`` (union of the ranks' visible chunks; the chunks some rank saw are the chunks Adam touches)
     and one ``all_gather`` of fixed-size record blocks.  The block capacity follows the GPU-driven sizing protocol
-    (litegs/data.py:236-241): the job's largest record count of a slot's previous visit (every rank reads the same value out of the
-    gathered headers; the device stores it into a pinned word) x1.5; only a slot's first visit blocks on a count.  A count that
-    outgrows the capacity sets a sticky device flag -- ``check()`` raises: gradients were dropped, unlike a short table this must
-    not pass silently.  No ``nonzero()``, no ``.item()`` in the steady state.
+    (litegs/data.py:236-241): the job's largest record count of a slot's previous visit x1.5; only a slot's first visit blocks on a
+    count.  Every rank computes that count from the same gathered headers and its device stores it into a pinned word of ITS host;
+    the host reads the word only after the event recorded behind the kernel that wrote it (free when the slot recurs an epoch later,
+    a wait when two frame sets share a slot back to back) -- so every rank sizes its collective from the same number, whatever the
+    relative progress of the hosts.  A slot index beyond ``n_slots`` raises (no silent aliasing of frame sets).
+    A count that outgrows the capacity means records were DROPPED: the device marks it in the slot's second pinned word and the
+    host raises at the start of the next step but one (the step is named), ``check()`` at the latest -- never silently.
+    No ``nonzero()``, no ``.item()`` in the steady state.
+
+    ``profile = True`` brackets the phases of every step with events (``timing()``): wait for the union-of-visibility collective,
+    record compaction, all_gather, slot map, backward + Adam over the union.
     """
 
     def __init__(self, params, world: int, ops=HipMomentOps, union_ops=HipOps, group=None, n_slots: int = 64):
         self.world, self.ops, self.union_ops, self.group = world, ops, union_ops, group
-        self.n_slots = n_slots
+        self.n_slots = max(int(n_slots), 1)
         self.cap_factor, self.cap_margin = 1.5, 64       # block capacity = factor x (largest count of the slot's last visit) + margin
+        self.profile = False
         self.rebind(params)
 
     def rebind(self, params) -> None:
         p0 = params[0]
         self.chunks, self.S = p0.shape[-2], p0.shape[-1]
         dev = p0.device
-        if p0.is_cuda:
+        self.cuda = bool(p0.is_cuda)
+        if self.cuda:
             torch.cuda.current_stream().synchronize()
         self.mask = torch.zeros((self.chunks,), dtype=torch.int32, device=dev)
         self.slot = torch.zeros((self.world, self.chunks * self.S), dtype=torch.int32, device=dev)
         self.overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
-        self.fb_k = torch.zeros((self.n_slots,), dtype=torch.int32)
-        if p0.is_cuda:
+        # per slot: {largest count of the job, overflow marker}, written by the device (csrc/dp.hip: dp_slotmap_kernel)
+        self.fb_k = torch.zeros((self.n_slots, 2), dtype=torch.int32)
+        if self.cuda:
             self.fb_k = self.fb_k.pin_memory()
+        self.fb_event = [None] * self.n_slots            # recorded behind the kernel that writes fb_k[slot]
+        self.in_flight = []                              # (step number, slot) of steps whose overflow word has not been read yet
+        self.steps = 0
         self.last_cap = 0
         self.bytes_last = 0
         self._mask_work = None
+        self._marks = []
+
+    def ensure_slots(self, n_slots: int) -> None:
+        """grow the per-slot feedback (call before a loop whose epochs have more steps than the constructor was told)"""
+        if n_slots > self.n_slots:
+            if self.cuda:
+                torch.cuda.current_stream().synchronize()
+            grown = torch.zeros((n_slots, 2), dtype=torch.int32)
+            grown[: self.n_slots] = self.fb_k
+            self.fb_k = grown.pin_memory() if self.cuda else grown
+            self.fb_event += [None] * (n_slots - self.n_slots)
+            self.n_slots = n_slots
 
     def begin(self, vis_ids, vis_num) -> None:
         """start of a step, as early as the rank's visibility is known (litegs_amd/fast.py calls it right after the culling is
@@ -308,11 +333,58 @@ class MomentExchange:
         self.union_ops.mark(self.mask, vis_ids, vis_num)
         self._mask_work = dist.all_reduce(self.mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
 
+    def _wait_slot(self, slot: int) -> None:
+        ev = self.fb_event[slot]
+        if ev is not None:
+            ev.synchronize()
+            self.fb_event[slot] = None
+
+    def _raise_if_dropped(self, upto_step: int, only_slot: int = -1) -> None:
+        """reads the overflow words of the steps numbered <= upto_step (their events have normally long completed), or of the step
+        that last used `only_slot` (its word is about to be overwritten)"""
+        keep = []
+        for (no, slot) in self.in_flight:
+            if no > upto_step and slot != only_slot:
+                keep.append((no, slot))
+                continue
+            self._wait_slot(slot)
+            k = int(self.fb_k[slot, 1])
+            if k > 0:
+                self.fb_k[slot, 1] = 0
+                self.in_flight = [x for x in self.in_flight if x[0] > no]
+                raise RuntimeError(f"litegs_amd.dp: step {no} (slot {slot}): {k} moment records exceeded the predicted block capacity; "
+                                   "the gradients of that step were truncated")
+        self.in_flight = keep
+
     def check(self) -> None:
         """raises if any step since the last call dropped records (capacity outgrown); synchronises -- call at epoch boundaries"""
+        self._raise_if_dropped(self.steps)
         if int(self.overflow.item()) != 0:
             self.overflow.zero_()
             raise RuntimeError("litegs_amd.dp: a record block overflowed its predicted capacity; gradients of that step were truncated")
+
+    def _mark(self, tag: str) -> None:
+        if self.profile and self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append((self.steps, tag, ev))
+
+    def timing(self) -> dict:
+        """mean milliseconds per phase over the profiled steps (synchronises); clears the marks"""
+        if self.cuda:
+            torch.cuda.current_stream().synchronize()
+        by_step = {}
+        for no, tag, ev in self._marks:
+            by_step.setdefault(no, []).append((tag, ev))
+        acc, n = {}, 0
+        for no, marks in by_step.items():
+            if len(marks) < 2:
+                continue
+            n += 1
+            for (t0, e0), (t1, e1) in zip(marks[:-1], marks[1:]):
+                acc[t1] = acc.get(t1, 0.0) + e0.elapsed_time(e1)
+        self._marks = []
+        return {"steps": n, **{k: round(v / max(n, 1), 4) for k, v in acc.items()}}
 
     @torch.no_grad()
     def step(self, pending: dict, cams, ps, ms, vs, lr6, eps: float, H: int, Wimg: int, slot: int = 0, touched=None):
@@ -322,9 +394,13 @@ class MomentExchange:
         without history that no rank sent a record for are skipped (an exact no-op).  -> (union_ids, union_count)"""
         W, S, chunks = self.world, self.S, self.chunks
         A, vis_ids, vis_num, pg = pending["A"], pending["vis_ids"], pending["vis_num"], pending["pg"]
-        slot %= self.n_slots
+        if not 0 <= slot < self.n_slots:
+            raise ValueError(f"MomentExchange: slot {slot} outside [0, {self.n_slots}) -- construct it with n_slots = steps per epoch")
+        self.steps += 1
+        self._raise_if_dropped(self.steps - 2)           # steps older than the previous one: their words have landed
         dev = pg.device
         nrec = self.ops.record_floats() if hasattr(self.ops, "record_floats") else 10
+        self._mark("start")
         # union of visibility (device-side list + count): already in flight if begin() was called for this step
         work = getattr(self, "_mask_work", None)
         if work is not None:
@@ -334,9 +410,12 @@ class MomentExchange:
             self.mask.zero_()
             self.union_ops.mark(self.mask, vis_ids, vis_num)
             dist.all_reduce(self.mask, op=dist.ReduceOp.MAX, group=self.group)
+        self._mark("union_wait_ms")
         union_ids, union_count, _ = self.union_ops.compact(self.mask)
-        # capacity of the record blocks
-        pred = int(self.fb_k[slot])
+        # capacity of the record blocks: the count every rank's device derived from the gathered headers of the slot's last visit
+        self._raise_if_dropped(0, only_slot=slot)
+        self._wait_slot(slot)
+        pred = int(self.fb_k[slot, 0])
         if pred <= 0:                                    # first visit of the slot: blocking count
             probe = torch.empty(((1 + A * S) * nrec,), dtype=torch.int32, device=dev)
             self.ops.compact_moments(pg, vis_ids, vis_num, A, S, A * S, probe)
@@ -348,10 +427,19 @@ class MomentExchange:
         # wire container: int32 words (record = index word + nine float bit patterns) -- an integer collective can only copy
         block = torch.empty(((1 + cap) * nrec,), dtype=torch.int32, device=dev)
         self.ops.compact_moments(pg, vis_ids, vis_num, A, S, cap, block)
+        self._mark("compact_ms")
         gathered = torch.empty((W * (1 + cap) * nrec,), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(gathered, block, group=self.group)
+        self._mark("all_gather_ms")
         self.bytes_last = (W - 1) * block.numel() * 4
-        self.ops.build_slotmap(gathered, W, cap, chunks * S, self.slot, self.fb_k.data_ptr() + 4 * slot, self.overflow)
+        self.ops.build_slotmap(gathered, W, cap, chunks * S, self.slot, self.fb_k.data_ptr() + 8 * slot, self.overflow)
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.fb_event[slot] = ev
+        self.in_flight.append((self.steps, slot))
+        self._mark("slotmap_ms")
         self.ops.backward_adam(union_ids, union_count, chunks, S, H, Wimg, [c[0] for c in cams], [c[1] for c in cams], W, pending["degree"],
                                pending["Rr"], gathered, cap, self.slot, ps, ms, vs, lr6, eps, touched)
+        self._mark("backward_adam_ms")
         return union_ids, union_count

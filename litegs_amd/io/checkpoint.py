@@ -17,7 +17,11 @@ def save_checkpoint(model_path: str, epoch: int, optimizer, schedular) -> str:
 
 
 def load_checkpoint(file_path: str):
-    """-> xyz, scale, rot, sh_0, sh_rest, opacity, start_epoch, optimizer, schedular"""
+    """-> xyz, scale, rot, sh_0, sh_rest, opacity, start_epoch, optimizer, schedular.
+
+    TRUSTED INPUT ONLY: the reference's checkpoints pickle the optimizer and scheduler OBJECTS (litegs/io_manager/__init__.py),
+    so this has to unpickle arbitrary classes (``weights_only=False``) -- loading a checkpoint executes whatever its pickle
+    says.  Load only files you wrote."""
     d = torch.load(file_path, weights_only=False)
     opt = d["optimizer"]
     by_name = {g["name"]: g["params"][0] for g in opt.param_groups}

@@ -209,7 +209,23 @@ def load_pointcloud(path: str) -> Tuple[np.ndarray, np.ndarray]:
             xyz, rgb, _ = read_points3d_binary(os.path.join(sparse, "points3D.bin"))
         else:
             xyz, rgb, _ = read_points3d_text(os.path.join(sparse, "points3D.txt"))
-        ply_io.store_points_ply(ply_path, xyz, rgb)
+        # Several ranks may get here at once on a fresh scene: each writes its own temporary file and publishes it with an atomic
+        # rename (identical bytes whichever rank wins), so no reader ever sees a truncated cache; and this call returns what the
+        # cache holds without re-reading a file another rank may be replacing.
+        tmp = f"{ply_path}.tmp.{os.getpid()}"
+        try:
+            ply_io.store_points_ply(tmp, xyz, rgb)
+            out = ply_io.fetch_points_ply(tmp)
+            os.replace(tmp, ply_path)
+        except OSError:                                  # read-only dataset directory: serve the arrays without the cache
+            out = None
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
+        if out is not None:
+            return out
+        return np.asarray(xyz, dtype=np.float32), np.asarray(rgb, dtype=np.float32) / 255.0
     return ply_io.fetch_points_ply(ply_path)
 
 

@@ -34,9 +34,10 @@ class FrameTrainer:
     scenes) are its two callers."""
 
     def __init__(self, params: List[torch.nn.Parameter], frames: List[Frame], height: int, width: int, opt, sched, pp=None,
-                 sh_degree: int = 3, device: Optional[torch.device] = None, use_torch_loss: bool = False, fused: bool = True,
+                 sh_degree: int = 3, device: Optional[torch.device] = None, loss_fn=None, fused: bool = True,
                  fuse_adam: bool = True, extra_slots: int = 0):
         """fused=True: native executor (litegs_amd/fast.py); fused=False: operator-by-operator path through the litegs_fused surface.
+        loss_fn: None = the HIP L1+SSIM loss (csrc/loss.hip); a callable (img[1,3,H,W] in [0,1], gt) -> scalar replaces it (tests).
         extra_slots: additional per-frame feedback slots behind the training frames' (evaluation frames, indices len(frames)...)."""
         self.device = device or params[0].device
         self.H, self.W, self.degree = height, width, sh_degree
@@ -52,14 +53,18 @@ class FrameTrainer:
         with torch.no_grad():
             xyz, scale, rot = self.params[0], self.params[1], self.params[2]
             self.cluster_origin, self.cluster_extend = R.get_cluster_AABB(xyz, scale.exp(), torch.nn.functional.normalize(rot, dim=0))
-        self.loss_fn = loss_mod.l1_ssim_loss_torch if use_torch_loss else loss_mod.fused_l1_ssim_loss
+        self.loss_fn = loss_fn if loss_fn is not None else loss_mod.fused_l1_ssim_loss
         self.fused = fused
         # the native executor hands the raw raster image to the loss kernels (crop + clamp fused in); only with the HIP loss
-        self.raw_loss = fused and not use_torch_loss
+        self.raw_loss = fused and loss_fn is None
         self._unit = torch.ones((), dtype=torch.float32, device=self.device)      # d(loss)/d(loss): reused, no fill launch per step
         self.renderer = fast.FusedRenderer(n_frames, height, width, self.pp.tile_size, self.pp.cluster_size)
         self.fadam = fast.FusedAdam(self.opt, self.renderer)
         self.fuse_adam = fuse_adam
+        # lr-schedule ticks per step: a data-parallel step consumes `world` frames of the reference's iteration budget
+        # (litegs/training/trainer.py:108: total_epoch = iterations / frames), so training.start sets this to the world size and the
+        # position learning rate reaches its final value after the same number of FRAMES as on one GPU
+        self.sched_ticks = 1
         self.last = {}
 
     # -------------------------------------------------------------------------------------------
@@ -110,7 +115,8 @@ class FrameTrainer:
         else:
             self.opt.step(vis_id, vis_num, prim_vis)
         self.opt.zero_grad(set_to_none=True)
-        self.sched.step()
+        for _ in range(self.sched_ticks):
+            self.sched.step()
         self.last = dict(loss=loss.detach(), vis_num=vis_num)
         return loss
 
@@ -176,7 +182,7 @@ class SyntheticTrainer(FrameTrainer):
     """A seeded Gaussian cloud (SURVEY.md 8d distribution), orbit cameras and per-frame noise targets: the bench / test workload."""
 
     def __init__(self, n_gaussians: int, width: int, height: int, focal: float, n_frames: int = 8, seed: int = 0, sh_degree: int = 3,
-                 device: Optional[torch.device] = None, radius: float = 4.0, cam_radius_frac: float = 0.5, use_torch_loss: bool = False,
+                 device: Optional[torch.device] = None, radius: float = 4.0, cam_radius_frac: float = 0.5, loss_fn=None,
                  scene=None, fused: bool = True, fuse_adam: bool = True):
         device = device or torch.device("cuda", torch.cuda.current_device())
         if scene is None:
@@ -189,7 +195,7 @@ class SyntheticTrainer(FrameTrainer):
             gt = torch.from_numpy(rng.random((1, 3, height, width), dtype=np.float32)).to(device)
             frames.append(Frame(*[torch.from_numpy(x).to(device) for x in (view, proj, planes)], gt, k))
         opt, sched = opt_mod.get_optimizer(*params, 1.0, opt_mod.OptimizationParams())
-        super().__init__(params, frames, height, width, opt, sched, None, sh_degree, device, use_torch_loss, fused, fuse_adam)
+        super().__init__(params, frames, height, width, opt, sched, None, sh_degree, device, loss_fn, fused, fuse_adam)
 
 
 def train(trainer: FrameTrainer, epochs: int, exchange=None, rank: int = 0, world: int = 1, start_epoch: int = 0, on_epoch=None):
@@ -204,6 +210,8 @@ def train(trainer: FrameTrainer, epochs: int, exchange=None, rank: int = 0, worl
     step = start_epoch * steps_per_epoch
     trainer.exchange = exchange
     moments = exchange is not None and not hasattr(exchange, "hook")
+    if moments and hasattr(exchange, "ensure_slots"):
+        exchange.ensure_slots(steps_per_epoch)           # one feedback slot per frame set of an epoch, never shared (litegs_amd/dp.py)
     for epoch in range(start_epoch, epochs):
         with trainer.begin_epoch(epoch):
             for k in range(steps_per_epoch):

@@ -105,6 +105,11 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
     say = log if rank == 0 else (lambda *a, **k: None)
     if getattr(op, "learnable_viewproj", False):
         raise ValueError("learnable_viewproj is not available in litegs_amd.training.start (see the module docstring)")
+    # loss terms of the reference's trainer (litegs/training/trainer.py:141-150) that this loop does not compute: refuse, never ignore
+    if float(getattr(op, "reg_weight", 0.0) or 0.0) > 0.0:
+        raise ValueError("op.reg_weight > 0 (scale regularisation) is not implemented in litegs_amd.training.start")
+    if getattr(pp, "enable_transmitance", False):
+        raise ValueError("pp.enable_transmitance (transmittance loss term) is not implemented in litegs_amd.training.start")
 
     cameras_info, camera_frames, init_xyz, init_color = io_manager.load_colmap_result(lp.source_path, lp.images)
     training_frames, test_frames = split_frames(lp, camera_frames)
@@ -145,8 +150,11 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
     exchange = None
     if world > 1:
         from . import dp as dp_mod
-        exchange = dp_mod.MomentExchange(trainer.params, world)
+        # one feedback slot per frame set of an epoch: a slot must never be shared by two sets (its capacity prediction and the
+        # rank-consistent sizing of the collectives are per set, litegs_amd/dp.py)
+        exchange = dp_mod.MomentExchange(trainer.params, world, n_slots=(len(frames) + world - 1) // world)
     trainer.exchange = exchange
+    trainer.sched_ticks = world                           # the lr schedule counts frames, not optimizer steps (FrameTrainer.sched_ticks)
     say(f"[litegs_amd] {len(frames)} training frames {W}x{H}, {len(test_frames_dev)} test frames, {init_points_num} initial points, "
         f"{total_epoch} epochs, world {world}, scene radius {norm_radius:.3f}")
 

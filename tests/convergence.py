@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import torch_reference as TR                      # noqa: E402
-from litegs_amd import loss as loss_mod           # noqa: E402
+from torch_loss import l1_ssim_loss_torch         # noqa: E402
 from litegs_amd import synthetic as S             # noqa: E402
 from litegs_amd.trainer import SyntheticTrainer   # noqa: E402
 
@@ -112,7 +112,7 @@ def train_torch(student, targets, cams, cfg, epochs):
         for k in range(cfg["frames"]):
             adam.lrs[0] = [g["lr"] for g in sched_opt.param_groups if g["name"] == "xyz"][0]
             img = frame(k)
-            loss = loss_mod.l1_ssim_loss_torch(img[None].clamp(0, 1), targets[k])
+            loss = l1_ssim_loss_torch(img[None].clamp(0, 1), targets[k])
             loss.backward()
             adam.step()
             sched.step()

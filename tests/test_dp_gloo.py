@@ -283,7 +283,8 @@ class TorchMomentOps:
             k = min(ks[r], cap)
             gid = g[r, 1:1 + k, 0].contiguous().view(torch.int32).long()
             slot[r, gid] = torch.arange(1, k + 1, dtype=torch.int32)
-        TorchMomentOps.fb_target[0] = max(ks)
+        TorchMomentOps.fb_target[0] = max(ks)                 # the two pinned words of csrc/dp.hip: {largest count, overflow marker}
+        TorchMomentOps.fb_target[1] = max(ks) if max(ks) > cap else 0
         if max(ks) > cap:
             overflow[0] = 1
 
@@ -332,7 +333,7 @@ def _moment_worker(rank, world, port, out):
         both = [torch.zeros_like(dense) for _ in range(world)]
         dist.all_gather(both, dense)
         expect = (both[0] + both[1]) / world
-        TorchMomentOps.fb_target = ex.fb_k[3:4]
+        TorchMomentOps.fb_target = ex.fb_k[3]
         pend = dict(pg=pg, A=A, S=S, vis_ids=vis, vis_num=cnt, degree=3, Rr=15)
         if visit == 1:                                   # the asynchronous form: the union collective is started early (the renderer does
             ex.begin(vis, cnt)                           # this right after the culling), step() only waits for it
@@ -355,10 +356,17 @@ def _moment_worker(rank, world, port, out):
             try:
                 ex.check()
                 ok = False
-            except RuntimeError:
-                pass
+            except RuntimeError as e:
+                ok &= "step 3" in str(e)                 # the step that dropped records is named
         ok &= int(ex.slot.abs().sum()) == 0              # the map is left clean
-        ok &= int(ex.fb_k[3]) > 0
+        ok &= int(ex.fb_k[3, 0]) > 0
+    try:                                                 # a slot beyond n_slots must not alias another frame set's prediction
+        ex.step(pend, cams, params, [None], [None], [0.0] * 6, 1e-15, 8, 8, slot=ex.n_slots)
+        ok = False
+    except ValueError:
+        pass
+    ex.ensure_slots(ex.n_slots + 3)
+    ok &= ex.fb_k.shape[0] == ex.n_slots and int(ex.fb_k[3, 0]) > 0
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -3,6 +3,8 @@ un-vendored submodule: parity unpinned, formula stated in litegs_amd/loss.py).""
 import pytest
 import torch
 
+from tests.torch_loss import l1_ssim_loss_torch
+
 pytestmark = pytest.mark.gpu
 
 
@@ -17,7 +19,7 @@ def test_l1_ssim_loss_matches_torch(shape):
     (l_hip * 3.0).backward()
     g_hip = img.grad.clone()
     img.grad = None
-    l_ref = Lm.l1_ssim_loss_torch(img.double(), gt.double())
+    l_ref = l1_ssim_loss_torch(img.double(), gt.double())
     (l_ref * 3.0).backward()
     g_ref = img.grad
     assert abs(l_hip.item() - l_ref.item()) < 2e-6 * max(1.0, abs(l_ref.item()))
@@ -37,7 +39,7 @@ def test_raster_loss_equals_clamp_crop_then_loss(H, W, Hp, Wp):
     l_hip.backward()
     g_hip = raw.grad.clone()
     raw64 = raw.detach().double().requires_grad_(True)
-    l_ref = Lm.l1_ssim_loss_torch(raw64[..., :H, :W].clamp(0, 1), gt.double())
+    l_ref = l1_ssim_loss_torch(raw64[..., :H, :W].clamp(0, 1), gt.double())
     l_ref.backward()
     assert abs(l_hip.item() - l_ref.item()) < 1e-5
     assert (g_hip.double() - raw64.grad).abs().max().item() < 1e-4 * raw64.grad.abs().max().item() + 1e-9

@@ -9,7 +9,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "500k_1080p"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 n, W, H, f = S.CONFIGS[cfg]
 t0 = time.time()
-tr = SyntheticTrainer(n, W, H, f, n_frames=8, use_torch_loss=True)
+tr = SyntheticTrainer(n, W, H, f, n_frames=8, loss_fn=None)
 print("setup s", time.time() - t0, flush=True)
 for i in range(16):
     tr.step(i)
