@@ -41,6 +41,10 @@ def parse_args():
     ap.add_argument("--operator-path", action="store_true",
                     help="run the iteration operator by operator through the litegs_fused drop-in surface instead of the native executor "
                          "(not the headline configuration; single GPU only)")
+    ap.add_argument("--soak-steps", type=int, default=1000,
+                    help="training steps between the timed region and the steady_state measurement (0 = skip steady_state)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the process rocprofv3 wraps: a few training steps, no report
     ap.add_argument("--cpu-tile-stride", type=int, default=0,
                     help="CPU baseline rasterises every n-th tile (x n extrapolated); 0 = auto: the whole frame on >= 32 host threads, every 24th tile otherwise")
     return ap.parse_args()
@@ -89,6 +93,57 @@ def frame_units(tr, frame_index):
                     n_vis=int(vl.item()))
 
 
+def percentiles(ms):
+    ms = sorted(ms)
+    pick = lambda q: ms[min(len(ms) - 1, max(0, int(round(q * (len(ms) - 1)))))]
+    return {"ms_p10": round(pick(0.10), 4), "ms_p50": round(pick(0.50), 4), "ms_p90": round(pick(0.90), 4), "samples": len(ms)}
+
+
+def timed_steps(step_fn, n):
+    """n steps, one event on the launch stream behind each: -> per-step milliseconds (start of the list = first step's duration)"""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    evs[0].record()
+    for i in range(n):
+        step_fn(i)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    return [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+
+
+def pmc_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one
+    pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") over a child process that runs a few training steps of the same workload.
+    Correction as the guide's HBM section prescribes for gfx950: FETCH_SIZE (KiB) reports half of a wide coalesced read -> 2F + W;
+    the raw F + W is given beside it (the kernel's reads are 64-byte scalar record loads and 4-byte pixel loads: uncalibrated widths)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="litegs_pmc_")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", args.config, "--frames", str(args.frames), "--steps", "8", "--warmup", "0"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            vals = []
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and "raster_backward" in row["Kernel_Name"]:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no {counter} rows for the blend backward"
+            got[counter] = sum(vals) / len(vals)
+        except (subprocess.SubprocessError, OSError, KeyError, ValueError) as e:
+            return None, f"{counter} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    f, w = got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
+    return {"bytes": int(2 * f + w), "raw_fetch_plus_write_bytes": int(f + w), "fetch_kib": round(got["FETCH_SIZE"], 1),
+            "write_kib": round(got["WRITE_SIZE"], 1)}, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, 8 working launches of the fresh cloud; 2F+W"
+
+
 def roofline_probe(tr, frames, steps_per_frame=2):
     """Roofline of the dominant kernel (the blend backward), measured IN SITU: extra training steps after the timed region with a
     pair of events (on the launch stream) around the blend backward launch of every step, so the kernel runs in the cache state it
@@ -123,9 +178,42 @@ def roofline_probe(tr, frames, steps_per_frame=2):
         "hbm_frac": round(hbm_frac, 4), "hbm_achieved_gbs": round(hbm, 1), "algorithmic_bytes_per_launch": int(b_bwd),
         "valu_frac": round(valu_frac, 4), "valu_achieved_tflops": round(valu, 3), "algorithmic_flop_per_launch": int(flop),
         "units_per_launch": {k: int(round(v)) for k, v in mean.items()},
-        "note": "fp32 vector (VALU) roofline binds the blend kernels, not HBM; units averaged over the frames timed; traffic (PMC) is in "
-                "profiles/, not re-measured in this run",
+        "note": "fp32 vector (VALU) roofline binds the blend kernels, not HBM; units averaged over the frames timed",
     }
+
+
+def steady_state(tr, args, n_frames):
+    """The same workload after `--soak-steps` more training steps: the targets are noise images, so training reshapes the cloud
+    (opacities fall, tiles stop saturating, lists are walked to their ends, most visible Gaussians acquire Adam history) and a step
+    settles at a different cost (profiles/r02_soak.log).  Measured here: 100 per-step event intervals, forward-only time, the state
+    of the two exact elisions, and the dominant kernel's roofline in that state."""
+    rd, fa = tr.renderer, tr.fadam
+    fb0 = rd.fallbacks
+    t0 = time.perf_counter()
+    for i in range(args.soak_steps):
+        tr.step(i % n_frames)
+    torch.cuda.synchronize()
+    soak_s = time.perf_counter() - t0
+    reruns_soak = rd.fallbacks - fb0
+    fb1 = rd.fallbacks
+    ms = timed_steps(lambda i: tr.step(i % n_frames), 100)
+    reruns = rd.fallbacks - fb1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(16):
+        tr.forward_only(i % n_frames)
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - t0) / 16 * 1e3
+    out = {"after_steps": args.soak_steps, "soak_ms_per_step": round(soak_s / max(args.soak_steps, 1) * 1e3, 4),
+           "ms_per_step": round(sum(ms) / len(ms), 4), **percentiles(ms), "frames_per_s": round(1e3 / (sum(ms) / len(ms)), 2),
+           "fwd_ms": round(fwd_ms, 4),
+           "gaussians_with_adam_history": int(fa.touched.sum().item()) if fa.touched is not None else None,
+           "instances_emitted": int(rd.fb_total[0]), "instances_full": int(rd.full_total[0]),
+           "unculled_reruns_in_soak": int(reruns_soak), "unculled_reruns_in_100_timed_steps": int(reruns),
+           "margin_pct": sorted(set(int(m) for m in rd.margin))}
+    out["roofline"] = roofline_probe(tr, list(range(n_frames)))
+    out["finite"] = all(bool(torch.isfinite(p).all()) for p in tr.params)
+    return out
 
 
 def operator_path_ms(n, W, H, focal, scene, frames, steps=16):
@@ -274,13 +362,22 @@ def main():
         tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
         step_no += 1
     torch.cuda.synchronize()
+    if args.pmc_child:                                # wrapped by rocprofv3 --pmc (pmc_traffic): a few more training steps, nothing else
+        for i in range(args.steps):
+            tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
+            step_no += 1
+        torch.cuda.synchronize()
+        return
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step event pairs
     t0 = time.perf_counter()
+    step_events[0].record()
     for i in range(args.steps):
         tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
         step_no += 1
+        step_events[i + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -291,6 +388,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    step_ms = [step_events[i].elapsed_time(step_events[i + 1]) for i in range(args.steps)]
 
     # forward-only throughput (render_preprocess + render), same frames
     torch.cuda.synchronize()
@@ -300,13 +398,35 @@ def main():
     torch.cuda.synchronize()
     fwd_s = (time.perf_counter() - t0) / args.steps
 
+    dp_diag = {}
+    if world > 1 and hasattr(hook, "bytes_last"):
+        # Diagnosis of the multi-GPU step (every rank takes part: collectives inside).  (1) a dropped record raises here, naming the
+        # step; (2) phase split of the exchange from events on the launch stream over 16 more steps; (3) the replicas must still be
+        # bit-identical after everything above -- the exchange's whole design rests on it (litegs_amd/dp.py).
+        hook.check()
+        hook.profile = True
+        for i in range(16):
+            tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
+            step_no += 1
+        dp_diag["phase_ms"] = hook.timing()
+        hook.profile = False
+        hook.check()
+        sums = torch.stack([p.detach().view(torch.int32).to(torch.int64).sum() for p in tr.params])
+        if one_gpu:
+            sums = sums.cpu()                         # gloo (the one-GPU test hook) gathers host tensors
+        gathered = [torch.zeros_like(sums) for _ in range(world)]
+        dist.all_gather(gathered, sums)
+        same = all(bool((g == gathered[0]).all()) for g in gathered)
+        dp_diag["replicas_bit_identical"] = bool(same)
+        if not same:
+            raise SystemExit("bench.py: parameter replicas differ across ranks after the data-parallel steps")
     if rank == 0:
         stats = tr.workload_stats(frame_of(0))
         result = {
             "metric": "train iters/s (camera frames trained per second, whole job) + fwd Msplats/s, "
                       + ("3M Gaussians @1080p" if args.config == "3m_1080p" else f"{args.config} (not the BASELINE headline config)"),
             "value": round(world * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), **{k: v for k, v in percentiles(step_ms).items() if k != "samples"}, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} Gaussians SH3, {W}x{H}, 1 camera frame per GPU per step, full training iteration "
                                    "(render_preprocess+render+L1/SSIM loss+backward+sparse Adam), seed 0 (SURVEY 8d)",
@@ -332,10 +452,20 @@ def main():
         if world == 1 and not args.operator_path:
             result["roofline"] = roofline_probe(tr, list(range(len(tr.frames))))    # in situ, after the timed region
         if world > 1 and hasattr(hook, "bytes_last"):
-            hook.check()
-            result["dp_exchange"] = {"mode": "moments", "bytes_received_per_rank_per_step": int(hook.bytes_last), "record_capacity": int(hook.last_cap)}
+            result["dp_exchange"] = {"mode": "moments", "bytes_received_per_rank_per_step": int(hook.bytes_last), "record_capacity": int(hook.last_cap),
+                                     **dp_diag}
         if world == 1 and not args.operator_path and not args.no_operator_path:
             result["operator_path_ms"] = operator_path_ms(n, W, H, focal, scene, args.frames)
+        if world == 1 and not args.operator_path and args.soak_steps > 0:
+            result["steady_state"] = steady_state(tr, args, len(tr.frames))
+        if world == 1 and not args.operator_path:
+            if args.no_pmc:
+                result["roofline"]["traffic_note"] = "PMC passes skipped (--no-pmc)"
+            else:
+                traffic, note = pmc_traffic(args)
+                result["roofline"]["traffic"] = None if traffic is None else traffic["bytes"]
+                result["roofline"]["traffic_detail"] = traffic
+                result["roofline"]["traffic_note"] = note
         if world == 1:
             if not args.no_cpu_baseline:
                 fr = tr.frames[frame_of(0)]

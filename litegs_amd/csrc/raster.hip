@@ -149,7 +149,7 @@ __device__ __forceinline__ void rec_request(f32x16& rec, const float* __restrict
 }
 __device__ __forceinline__ void rec_wait(f32x16& rec) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rec)); }
 
-static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1;       // launch variants (lg_set_tuning)
+static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1;       // launch variants (lg_set_tuning)
 
 // ---------------------------------------------------------------------------------------------
 // a13 rasterize_forward (reference: GR/raster.cu:162-332)
@@ -719,12 +719,198 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// a14, the default 8x16 tile without statistics: the same reverse traversal with fewer VALU issue slots per (tile, splat)
+// (the kernel is bound by VALU issue; profiles/r03_sq_counters.md):
+//  * splat ids come through the scalar path as well (one s_load_dword two splats ahead of its use) -- no vector load of the
+//    list, no v_readlane per splat;
+//  * a splat that no pixel of the tile takes (alpha < 1/256 everywhere, or every pixel stopped before it) is dropped after the
+//    alpha evaluation by one ballot: nothing changes for such a splat (alpha = 0: T, the blended-behind dot product and all nine
+//    sums keep their values) -- the reference gates the same way (GR/raster.cu:752, 795);
+//  * list positions below the tile's smallest last_contributor need no per-pixel "j < last_contributor" compare: the walk is split
+//    at that position into a checked and an unchecked phase;
+//  * the three colour sums use colour-packed copies of the pixel gradients ({dR, dG} of each pixel as one 2-vector): 4 instead of 6
+//    instructions; the adds behind the permlane swaps of the transposing reduction are issued as packed adds (two totals per slot);
+//  * the atomic's address is a scalar base (record of the splat) + a constant per-lane offset.
+// Results: the same nine sums (the additions inside a lane associate differently: fp32 rounding only).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void id_request(int& id, const int* __restrict__ sp, unsigned byte_off)
+{
+    asm volatile("s_load_dword %0, %1, %2" : "=s"(id) : "s"(sp), "s"(byte_off));
+}
+__device__ __forceinline__ void rec_id_wait(f32x16& rec, int& id) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rec), "+s"(id)); }
+
+// Nine totals; the adds behind the permlane32 swaps are packed (two totals per issue slot).  Input order chosen so that every packed
+// operand is a pair the producer leaves in adjacent registers: (v0, v2), (v1, v3), (v4, v6) and (v5, v7) -- v5 / v7 being the
+// two halves of one packed result.  Totals land as in reduce9: value k in the lane with wave_slot(lane) == k.
+__device__ __forceinline__ float reduce9_pk(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8)
+{
+    v8 += xor_32(v8);
+    swap32(v0, v1); swap32(v2, v3);
+    v2f a = { v0, v2 }, b = { v1, v3 };
+    a += b;                                           // {v0', v2'}
+    swap32(v4, v5); swap32(v6, v7);
+    v2f c = { v4, v6 }, d = { v5, v7 };
+    c += d;                                           // {v4', v6'}
+    v8 += xor_swz16(v8);
+    float a0 = a.x, a1 = a.y, c0 = c.x, c1 = c.y;
+    swap16(a0, a1); swap16(c0, c1);
+    a0 += a1; c0 += c1;
+    float r = bfly_mirror8(a0, c0);
+    v8 += mirror16(v8);
+    r = bfly_hmirror4(r, v8);
+    r += xor_dpp2(r);
+    r += xor_dpp1(r);
+    return r;
+}
+// v_min_f32 without the canonicalising v_max the compiler puts in front of fminf when it cannot prove its operand quiet
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+struct BwdFast {
+    float X;
+    v2f Y, T, Bd, gR, gG, gB, gT;      // the lane's two pixels
+    v2f G0, G1;                        // {dL/dR, dL/dG} of pixel 0 / pixel 1 (colour-packed copies)
+    int lc0, lc1;
+};
+
+template <bool TRANS, bool CHECK>
+__device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, int pos, unsigned pid_off, unsigned slot_off,
+                                               unsigned long long writers, float* __restrict__ pg)
+{
+    const float dx = rec[R_PX] - st.X;
+    const float t1 = rec[R_B2] * dx;
+    const float t0 = __builtin_fmaf(rec[R_A2] * dx, dx, rec[R_LO]);
+    const v2f dyv = rec[R_PY] - st.Y;
+    const v2f qv = dyv * (rec[R_C2] * dyv + t1) + t0;
+    const float E0 = __builtin_amdgcn_exp2f(qv.x);
+    const float E1 = __builtin_amdgcn_exp2f(qv.y);
+    bool val0 = E0 >= 1.0f / 256, val1 = E1 >= 1.0f / 256;
+    if (CHECK) { val0 = val0 && (pos < st.lc0); val1 = val1 && (pos < st.lc1); }
+    if (!__any(val0 || val1)) return;                   // nobody takes this splat: every quantity below keeps its value
+    const v2f Ev = { val0 ? E0 : 0.0f, val1 ? E1 : 0.0f };
+    const float amax = 255.0f / 256, one = 1.0f;
+    const v2f am = { vmin(Ev.x, amax), vmin(Ev.y, amax) };
+    const v2f om = 1.0f - am;
+    const v2f rc = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
+    v2f Tv = st.T * rc;
+    Tv.x = vmin(Tv.x, one); Tv.y = vmin(Tv.y, one);
+    st.T = Tv;
+    const v2f w = am * Tv;
+    const v2f crg = w.x * st.G0 + w.y * st.G1;          // {sum w dR, sum w dG} over the lane's two pixels
+    const float v_b = __builtin_fmaf(w.x, st.gB.x, w.y * st.gB.y);
+    const v2f cdot = rec[R_CR] * st.gR + rec[R_CG] * st.gG + rec[R_CB] * st.gB;
+    const v2f diff = cdot - st.Bd;
+    v2f d_alpha = diff * Tv;
+    st.Bd = st.Bd + am * diff;
+    if (TRANS) d_alpha = d_alpha - st.gT * rc;
+    const v2f m = d_alpha * Ev;
+    const v2f my = m * dyv;
+    const float s0 = m.x + m.y;
+    const float s1 = my.x + my.y;
+    const float s2 = __builtin_fmaf(my.x, dyv.x, my.y * dyv.y);
+    const float mx = dx * s0;
+    // order: (Mx My Mxx Mxy Myy dr DB DG M0) -- dg / db swapped against the record, see wave_slot_fast
+    const float tot = reduce9_pk(mx, s1, dx * mx, dx * s1, s2, crg.x, v_b, crg.y, s0);
+    // ONE atomic instruction from the nine lanes that hold a total: scalar base = the splat's gradient record
+    const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pg) + pid_off);
+    asm volatile("s_mov_b64 exec, %2\n\t"
+                 "global_atomic_add_f32 %0, %1, %3\n\t"
+                 "s_mov_b64 exec, -1" : : "v"(slot_off), "v"(tot), "s"(writers), "s"(base) : "memory");
+}
+
+template <bool TRANS>
+__global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
+                                                                   const float* __restrict__ packed, const int* __restrict__ tiles, int K,
+                                                                   const float* __restrict__ final_T, const short* __restrict__ last,
+                                                                   const float* __restrict__ d_img, const float* __restrict__ d_trans,
+                                                                   float* __restrict__ packed_grad, const int* __restrict__ order,
+                                                                   int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode)
+{
+    constexpr int TH = 8, TW = 16;
+    const int lane = threadIdx.x & 63;
+    const int view = blockIdx.y;
+    const int nb = gridDim.x;
+    int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
+    const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
+    if (slot >= nslots) return;
+    int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
+    tile = rfl(tile);
+    if (tile <= 0 || tile > ntiles) return;
+    const int* __restrict__ si = start_index + (size_t)view * (ntiles + 2);
+    const int start = rfl(si[tile]);
+    const int end = rfl(si[tile + 1]);
+    if (start < 0 || start >= end) return;
+    const int* __restrict__ sp = sorted_points + (size_t)view * L + start;
+    const float* __restrict__ pk = packed + (size_t)view * N * REC;
+    float* __restrict__ pg = packed_grad + (size_t)view * N * GREC;
+
+    const int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
+    const int x = tx * TW + lane % TW;
+    const int q = lane / TW;
+    const int y0 = ty * TH + (q >> 1) * 4 + (q & 1);
+    const size_t plane = (size_t)Hp * Wp;
+    const size_t o0 = (size_t)y0 * Wp + x, o1 = (size_t)(y0 + 2) * Wp + x;
+    BwdFast st;
+    st.X = (float)x;
+    st.Y = v2f{ (float)y0, (float)(y0 + 2) };
+    st.T = v2f{ final_T[(size_t)view * plane + o0], final_T[(size_t)view * plane + o1] };
+    st.lc0 = last[(size_t)view * plane + o0];
+    st.lc1 = last[(size_t)view * plane + o1];
+    st.gR = v2f{ d_img[((size_t)view * 3) * plane + o0], d_img[((size_t)view * 3) * plane + o1] };
+    st.gG = v2f{ d_img[((size_t)view * 3 + 1) * plane + o0], d_img[((size_t)view * 3 + 1) * plane + o1] };
+    st.gB = v2f{ d_img[((size_t)view * 3 + 2) * plane + o0], d_img[((size_t)view * 3 + 2) * plane + o1] };
+    st.G0 = v2f{ st.gR.x, st.gG.x };
+    st.G1 = v2f{ st.gR.y, st.gG.y };
+    st.gT = v2f{ 0.0f, 0.0f };
+    if (TRANS) st.gT = st.T * v2f{ d_trans[(size_t)view * plane + o0], d_trans[(size_t)view * plane + o1] };      // T_final * dL/dT (raster.cu:665)
+    st.Bd = v2f{ 0.0f, 0.0f };
+    const int maxlast = rfl(wave_max_i(max(st.lc0, st.lc1)));
+    const int minlast = -rfl(wave_max_i(-min(st.lc0, st.lc1)));
+    const int n = min(maxlast, end - start);        // list positions n-1 .. 0 are walked
+    if (n <= 0) return;
+    int myslot = wave_slot(lane);
+    myslot = myslot == 6 ? 7 : (myslot == 7 ? 6 : myslot);       // reduce9_pk is fed (.., dr, db, dg, ..)
+    const unsigned long long writers = __ballot(myslot >= 0);
+    const unsigned slot_off = (unsigned)max(myslot, 0) * 4u;
+    // An even number of iterations (two per trip over a ping-pong pair of record registers): if n is odd the walk starts one
+    // position early, at `n`, with the record of position n-1 -- no pixel has last_contributor > n, so that splat adds nothing.
+    const int top = (n + 1) & ~1;
+    int pos = top - 1;                               // position of the splat in `ra`
+    int id_a, id_b;
+    f32x16 ra, rb;
+    id_request(id_a, sp, (unsigned)min(pos, n - 1) << 2);
+    id_request(id_b, sp, (unsigned)(pos - 1) << 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id_a), "+s"(id_b));
+    unsigned off_a = (unsigned)id_a << 6, off_b = (unsigned)id_b << 6;
+    rec_request(ra, pk, off_a);
+    rec_wait(ra);
+    // phase 1: positions that some pixel of the tile had already stopped before (pos >= minlast): per-pixel last_contributor test
+#define BWD_PAIR(CHK)                                                                                         \
+    {                                                                                                         \
+        rec_request(rb, pk, off_b);                                                                           \
+        id_request(id_a, sp, (unsigned)max(pos - 2, 0) << 2);                                                 \
+        bwd_splat_fast<TRANS, CHK>(st, ra, pos, off_a, slot_off, writers, pg);                                \
+        rec_id_wait(rb, id_a);                                                                                \
+        off_a = (unsigned)id_a << 6;                                                                          \
+        rec_request(ra, pk, off_a);                                                                           \
+        id_request(id_b, sp, (unsigned)max(pos - 3, 0) << 2);                                                 \
+        bwd_splat_fast<TRANS, CHK>(st, rb, pos - 1, off_b, slot_off, writers, pg);                            \
+        rec_id_wait(ra, id_b);                                                                                \
+        off_b = (unsigned)id_b << 6;                                                                          \
+        pos -= 2;                                                                                             \
+    }
+    for (; pos >= 1 && pos >= minlast; ) BWD_PAIR(true)
+    for (; pos >= 1; ) BWD_PAIR(false)
+#undef BWD_PAIR
+}
+
 LG_API int lg_set_tuning(int key, int value)
 {
     switch (key) {
     case 1: g_bwd_map = value; return 0;                                      // workgroup -> tile map of the blend backward (block_remap)
     case 2: g_fwd_map = value; return 0;                                      // ... of the blend forward
     case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
+    case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics
     default: return (int)hipErrorInvalidValue;
     }
 }
@@ -755,6 +941,12 @@ LG_API int lg_raster_backward(const int* sorted_points, const int* start_index, 
     if (tile_counters != nullptr) {          // measurement variant: the plain 8x16 kernel with the two counters
         if (TH != 8 || TW != 16 || enable_stat || d_trans) return (int)hipErrorInvalidValue;
         LAUNCH_RB(8, 16, false, false, true);
+    }
+    else if (TH == 8 && TW == 16 && !enable_stat && g_bwd_fast) {
+        if (d_trans) hipLaunchKernelGGL((raster_backward_fast_kernel<true>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
+                                        d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map);
+        else hipLaunchKernelGGL((raster_backward_fast_kernel<false>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
+                                d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map);
     }
     else if (TH == 8 && TW == 16) DISPATCH_RB(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RB(16, 16);
