@@ -31,7 +31,7 @@ _lib = None
 def build(force: bool = False) -> str:
     """Compile the C restatement (gcc, a second or two)."""
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "litegs_oracle.c")):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("litegs_oracle.c", "litegs_oracle_fp16.c")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liblitegs_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -316,6 +316,45 @@ def raster_backward(sorted_points, start_index, packed, final_T, last, d_img, H,
                               _i(V), _l(L), _i(N), _i(H), _i(W), _i(TH), _i(TW), _i(int(enable_stat)),
                               _p(d_ndc), _p(d_ic), _p(d_color), _p(d_opa), _p(esq))
     return d_ndc, d_ic, d_color, d_opa, esq
+
+
+# ---- the reference BINARY's blend arithmetic (half2, x128 transmittance scale), emulated: litegs_oracle_fp16.c -------------------
+def pack_params_fp16(packed):
+    """colour and opacity rounded to binary16 as GR/raster.cu:353-354 packs them (oracle record slots 5..8)"""
+    out = np.array(packed, dtype=np.float32, copy=True)
+    out[..., 5:9] = out[..., 5:9].astype(np.float16).astype(np.float32)
+    return out
+
+
+def raster_forward_fp16(sorted_points, start_index, packed, H, W, TH, TW):
+    """-> img, trans, last as the reference's half2 forward kernel computes them (packed: pack_params_fp16 output)"""
+    sorted_points = np.ascontiguousarray(sorted_points, np.int32)
+    start_index = np.ascontiguousarray(start_index, np.int32)
+    V, L = sorted_points.shape
+    N = packed.shape[1]
+    Hp, Wp = padded_hw(H, W, TH, TW)
+    img = np.zeros((V, 3, Hp, Wp), np.float32)
+    trans = np.ones((V, 1, Hp, Wp), np.float32)
+    last = np.zeros((V, 1, Hp, Wp), np.int16)
+    lib().orc_raster_forward_fp16(_p(sorted_points), _p(start_index), _p(_f32(packed)), _i(V), _l(L), _i(N), _i(H), _i(W), _i(TH), _i(TW),
+                                  _p(img), _p(trans), _p(last))
+    return img, trans, last
+
+
+def raster_backward_fp16(sorted_points, start_index, packed, final_T, last, d_img, H, W, TH, TW, inv_scaler=1.0):
+    """-> d_ndc, d_inv_cov, d_color, d_opacity as the reference's half2 backward kernel + unpack compute them"""
+    sorted_points = np.ascontiguousarray(sorted_points, np.int32)
+    start_index = np.ascontiguousarray(start_index, np.int32)
+    V, L = sorted_points.shape
+    N = packed.shape[1]
+    d_ndc = np.zeros((V, 4, N), np.float32)
+    d_ic = np.zeros((V, 2, 2, N), np.float32)
+    d_color = np.zeros((V, 3, N), np.float32)
+    d_opa = np.zeros((1, N), np.float32)
+    lib().orc_raster_backward_fp16(_p(sorted_points), _p(start_index), _p(_f32(packed)), _p(_f32(final_T)), _p(np.ascontiguousarray(last, np.int16)),
+                                   _p(_f32(d_img)), _f(inv_scaler), _i(V), _l(L), _i(N), _i(H), _i(W), _i(TH), _i(TW),
+                                   _p(d_ndc), _p(d_ic), _p(d_color), _p(d_opa))
+    return d_ndc, d_ic, d_color, d_opa
 
 
 def adam_chunk(param, grad, m, v, chunk_id, nvis, lr, b1=0.9, b2=0.999, eps=1e-15):
