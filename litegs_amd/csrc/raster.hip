@@ -149,7 +149,7 @@ __device__ __forceinline__ void rec_request(f32x16& rec, const float* __restrict
 }
 __device__ __forceinline__ void rec_wait(f32x16& rec) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rec)); }
 
-static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1;       // launch variants (lg_set_tuning)
+static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_bwd_noatomic = 0;       // launch variants (lg_set_tuning)
 
 // ---------------------------------------------------------------------------------------------
 // a13 rasterize_forward (reference: GR/raster.cu:162-332)
@@ -824,7 +824,8 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
                                                                    const float* __restrict__ final_T, const short* __restrict__ last,
                                                                    const float* __restrict__ d_img, const float* __restrict__ d_trans,
                                                                    float* __restrict__ packed_grad, const int* __restrict__ order,
-                                                                   int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode)
+                                                                   int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode,
+                                                                   int no_atomics)
 {
     constexpr int TH = 8, TW = 16;
     const int lane = threadIdx.x & 63;
@@ -870,7 +871,7 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     if (n <= 0) return;
     int myslot = wave_slot(lane);
     myslot = myslot == 6 ? 7 : (myslot == 7 ? 6 : myslot);       // reduce9_pk is fed (.., dr, db, dg, ..)
-    const unsigned long long writers = __ballot(myslot >= 0);
+    const unsigned long long writers = no_atomics ? 0ull : __ballot(myslot >= 0);
     const unsigned slot_off = (unsigned)max(myslot, 0) * 4u;
     // An even number of iterations (two per trip over a ping-pong pair of record registers): if n is odd the walk starts one
     // position early, at `n`, with the record of position n-1 -- no pixel has last_contributor > n, so that splat adds nothing.
@@ -910,6 +911,7 @@ LG_API int lg_set_tuning(int key, int value)
     case 1: g_bwd_map = value; return 0;                                      // workgroup -> tile map of the blend backward (block_remap)
     case 2: g_fwd_map = value; return 0;                                      // ... of the blend forward
     case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
+    case 6: g_bwd_noatomic = value; return 0;                                 // measurement only: 1 = the fast blend backward computes everything but issues no atomics (WRONG gradients)
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics
     default: return (int)hipErrorInvalidValue;
     }
@@ -944,9 +946,9 @@ LG_API int lg_raster_backward(const int* sorted_points, const int* start_index, 
     }
     else if (TH == 8 && TW == 16 && !enable_stat && g_bwd_fast) {
         if (d_trans) hipLaunchKernelGGL((raster_backward_fast_kernel<true>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
-                                        d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map);
+                                        d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_noatomic);
         else hipLaunchKernelGGL((raster_backward_fast_kernel<false>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
-                                d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map);
+                                d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_noatomic);
     }
     else if (TH == 8 && TW == 16) DISPATCH_RB(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RB(16, 16);

@@ -43,6 +43,12 @@ def ab(state):
     for v, name in ((0, "generic"), (1, "fast"), (0, "generic"), (1, "fast")):
         L.lg_set_tuning(5, v)
         measure(f"{state}: {name} kernel")
+    L.lg_set_tuning(6, 1)                               # measurement only: no gradient atomics (lr is zero here: nothing is trained on them)
+    measure(f"{state}: fast kernel, atomics off")
+    L.lg_set_tuning(6, 0)
+    L.lg_set_tuning(4, 0)
+    measure(f"{state}: fast kernel, no tile schedule")
+    L.lg_set_tuning(4, 1)
     tr.sched.step = step_fn
     for g, lr in zip(tr.opt.param_groups, lrs):
         g["lr"] = lr
