@@ -158,6 +158,13 @@ int lg_tile_range(const int32_t* sorted_keys, int V, long long L, int max_tile, 
  * scratch [V,L] uint32: only touched for lists longer than 1024. */
 int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
                        uint32_t* scratch, void* stream);
+/* Grouping by tile WITHOUT a sort (executor, per-tile-depth-sort mode; no reference counterpart: GR/binning.cu:205-220 uses a stable radix
+ * sort because its emission order must survive inside a tile, which the per-tile sort makes unnecessary): keys[L] (0 .. max_tile, unsorted)
+ * / vals[L] -> tile_start [max_tile + 2] as lg_tile_range would leave it for the sorted keys, out_vals[L] grouped by key (arbitrary order
+ * inside a key).  temp: 2 * (max_tile + 2) ints.  lg_tile_depth_sort_unordered then orders every list by (depth, id). */
+int lg_tile_group(const int32_t* keys, const int32_t* vals, long long L, int max_tile, int32_t* tile_start, int32_t* out_vals, void* temp, void* stream);
+int lg_tile_depth_sort_unordered(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
+                                 uint32_t* scratch, void* stream);
 int lg_memset_async(void* ptr, int value, long long bytes, void* stream);
 
 /* ---- raster.hip : GR/raster.h --------------------------------------------------------------- */
@@ -215,7 +222,9 @@ int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt
 /* process-wide executor options.  key 0 = depth order of the tile lists: 0 the reference's structure (depth sort of all
  * visible splats before the emission, wrapper.py:739-745), 1 per-tile depth sort after the tile sort (tilesort.hip; no sort over the
  * splats), 2 (default) choose per frame: 1 from 1 M compacted Gaussians on, 0 below.  Identical tables either way.  key 1 = margin of the depth-bound culling in percent (default 100): how far beyond
- * a tile's saturation point its bound for the frame's next visit lies.  Returns 0, or hipErrorInvalidValue for an unknown key / value. */
+ * a tile's saturation point its bound for the frame's next visit lies.  key 2 = (mode 1 only) 1 (default): group the instances by tile with
+ * per-tile counts and cursors (lg_tile_group's kernels) instead of the stable tile radix sort, 0: keep the radix sort; identical tables.
+ * Returns 0, or hipErrorInvalidValue for an unknown key / value. */
 int lg_fused_set_option(int key, int value);
 /* depth-order mode 1 only: emission order of the frames whose N = A*S equals n (a device permutation of 0..n-1 owned by the caller;
  * NULL = ascending ids).  Shapes the emission's workload, never the table (the per-tile sort orders by depth and id). */
@@ -225,6 +234,7 @@ long long lg_fused_workspace1_bytes(long long N);
 long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW);
 long long lg_fused_total_offset(long long N);
 long long lg_fused_tile_start_offset(long long L, long long N, int H, int W, int TH, int TW);   /* int32[ntiles+2] tile ranges in workspace 2 (valid after stage 2) */
+long long lg_fused_sorted_points_offset(long long L, long long N, int H, int W, int TH, int TW); /* int32[L] tile-grouped, depth-ordered splat ids in workspace 2 (valid after stage 2) */
 long long lg_fused_alloc_offset(long long N);   /* int32[N] tile counts per compacted Gaussian (valid after stage 1) */
 long long lg_fused_packed_offset(long long N);  /* float[N,16] packed splat records (valid after stage 1) */
 int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,

@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
                                                         long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
                                                         int* __restrict__ qcount /*[V][DUP_NQ], zero*/, uint32_t* __restrict__ qentries /*[V][DUP_NQ][cap]*/,
                                                         int* __restrict__ totals /*nullable [passes][256]*/, DigitSpec ds,
+                                                        int* __restrict__ tile_counts /*nullable [V][gx*gy+2], zero: instances per key (tile scatter)*/,
                                                         uint32_t* __restrict__ zero_ptr, long long zero_words,
                                                         uint32_t* __restrict__ ones_ptr, long long ones_words,
                                                         uint32_t* __restrict__ zero2_ptr, long long zero2_words,
@@ -298,6 +299,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             if (trunc_flag) atomicOr(trunc_flag, 1);          // the table was under-predicted: the culled run asks for the fallback
             if (totals)
                 for (int p = 0; p < ds.passes; p++) atomicAdd(&totals[p * 256], (int)(table_len - off));
+            if (tile_counts) atomicAdd(&tile_counts[(size_t)b * (gx * gy + 2)], (int)(table_len - off));
         }
     }
     // Threshold between the in-workgroup path and the queue: DUP_SMALL_HI when this group's entries still fit the LDS buffer
@@ -416,6 +418,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             const int g = t_goff[t] + (p - t_loff[t]);
             kout[g] = key;
             vout[g] = t_idx[t];
+            if (tile_counts) atomicAdd(&tile_counts[(size_t)b * (gx * gy + 2) + key], 1);
         }
         if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
     }
@@ -441,7 +444,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                                                       const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                       long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
                                                       const int* __restrict__ qcount, const uint32_t* __restrict__ qentries,
-                                                      int* __restrict__ totals, DigitSpec ds, const int* __restrict__ gate)
+                                                      int* __restrict__ totals, DigitSpec ds, int* __restrict__ tile_counts, const int* __restrict__ gate)
 {
     if (gate != nullptr && *gate == 0) return;
     __shared__ int w_minv[TPB / 64][DUP_MAX_SLICES];      // per-wave slice scratch
@@ -515,13 +518,14 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                 if (part != 0) continue;                                   // (the whole splat, by the wave that holds its first part)
                 int c = 0;
                 if (lane == srcl) c = (int)walk_tiles<TH, TW, true>(e, gx, my_idx, my_off, kout, vout);
-                if (totals) {                                              // count what was just written
+                if (totals || tile_counts) {                               // count what was just written
                     c = __shfl(c, srcl);
                     __threadfence();
                     for (int k0 = 0; k0 < c; k0 += 64) {
                         const bool act = k0 + lane < c;
                         const int32_t key = act ? __hip_atomic_load(kout + sgoff + k0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                        digit_hist_add(hist, (uint32_t)key, act, ds);
+                        if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
+                        if (tile_counts && act) atomicAdd(&tile_counts[(size_t)b * (gx * gy + 2) + key], 1);
                     }
                 }
                 continue;
@@ -566,12 +570,13 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                 for (int wq = lane; wq < DUP_MAX_RUN / 32; wq += 64) bitmap[wave][wq] = 0u;
                 if (part != 0) continue;
                 if (lane == srcl) walk_tiles<TH, TW, true>(e, gx, my_idx, my_off, kout, vout);
-                if (totals) {
+                if (totals || tile_counts) {
                     __threadfence();
                     for (int k0 = 0; k0 < run; k0 += 64) {
                         const bool act = k0 + lane < run;
                         const int32_t key = act ? __hip_atomic_load(kout + sgoff + k0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                        digit_hist_add(hist, (uint32_t)key, act, ds);
+                        if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
+                        if (tile_counts && act) atomicAdd(&tile_counts[(size_t)b * (gx * gy + 2) + key], 1);
                     }
                 }
                 continue;
@@ -601,6 +606,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                     key = (int32_t)(tk + 1);
                     kout[sgoff + k] = key;
                     vout[sgoff + k] = sidx;
+                    if (tile_counts) atomicAdd(&tile_counts[(size_t)b * (gx * gy + 2) + key], 1);
                 }
                 before += __popcll(word);
                 if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
@@ -625,13 +631,14 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
                 uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words, void* stream)
 {
     return lg_dup_emit_gated(ndc, inv_cov, opacity, packed, prefix, sorted_id, sorted_id_is_int64, V, N, H, W, TH, TW, table_len, keys, values,
-                             qcount, qentries, totals, begin_bit, end_bit, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words,
+                             qcount, qentries, totals, begin_bit, end_bit, nullptr, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words,
                              nullptr, nullptr, stream);
 }
 
 int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
                       int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
-                      int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
+                      int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, int* tile_counts,
+                      uint32_t* zero_ptr, long long zero_words,
                       uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words,
                       const int* gate, int* trunc_flag, void* stream)
 {
@@ -654,12 +661,12 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
     do {                                                                                                                                   \
         if (gx * gy + 1 <= 0xffff)                                                                                                         \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag); \
         else                                                                                                                               \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,   \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag); \
         hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
-                           N, H, W, gx, gy, table_len, keys, values, (const int*)qcount, (const uint32_t*)qentries, totals, ds, gate);      \
+                           N, H, W, gx, gy, table_len, keys, values, (const int*)qcount, (const uint32_t*)qentries, totals, ds, tile_counts, gate); \
     } while (0)
 #define DISPATCH_DUP(A_, B_)                                              \
     do {                                                                  \
@@ -1658,6 +1665,120 @@ LG_API int lg_tile_range_bounded(const int32_t* sorted_keys, int V, long long L,
     if (L <= 0) return 0;
     hipLaunchKernelGGL(tile_range_kernel, dim3(lg_cdiv(L, TPB * 4), V), dim3(TPB), 0, s, sorted_keys, L, n_dev, max_tile, out);
     LG_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile scatter (executor, per-tile-depth-sort mode; no reference counterpart).  The reference groups the instances by tile with a
+// STABLE radix sort because its emission order (depth) must survive inside every tile (GR/binning.cu:205-220).  When every tile's list is
+// re-ordered by (depth, id) afterwards (tilesort.hip) the order inside a tile is irrelevant, and grouping needs no sort at all: the
+// emission kernels count the instances per key (one fire-and-forget atomic each, lg_dup_emit_gated's tile_counts), one workgroup turns
+// the counts into the range table -- the very words tile_range_kernel would derive from the sorted keys -- and into write cursors, and
+// one pass drops every value at its tile's cursor.  Two radix passes (4 x 16 B per instance, rank + look-back chains) and the range
+// scan are replaced by 8 B read + 4 B written per instance.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) tile_offsets_kernel(const int* __restrict__ counts /*[max_tile + 2], bins 0..max_tile*/, int max_tile,
+                                                            const int* __restrict__ n_dev, long long L, int* __restrict__ cursor /*[max_tile + 2]*/,
+                                                            int32_t* __restrict__ out /*[max_tile + 2], pre-filled with -1*/, const int* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nb = max_tile + 1;
+    const int total = (int)bounded_n(L, n_dev);              // == the sum of the counts: every emitted entry (padding included) was counted
+    constexpr int PER = 16;
+    int carry = 0;
+    for (int base = 0; base < nb; base += 1024 * PER) {
+        const int b0 = base + t * PER;
+        int c[PER], s = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { c[k] = (b0 + k < nb) ? counts[b0 + k] : 0; s += c[k]; }
+        const int before = (b0 > 0 && b0 < nb) ? counts[b0 - 1] : 0;      // count of the bin in front of this thread's first
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int nbv = __shfl_up(incl, o); if (lane >= o) incl += nbv; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0, round_total = 0;
+        for (int w = 0; w < 16; w++) { if (w < wave) wbase += wsum[w]; round_total += wsum[w]; }
+        int p = carry + wbase + incl - s;
+        int prev = before;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int bin = b0 + k;
+            if (bin < nb) {
+                cursor[bin] = p;
+                // tileRange (GR/binning.cu:228-264): a run's start; the word after a run that is followed by a gap and a later run
+                if (c[k] > 0) out[bin] = p;
+                else if (prev > 0 && p < total) out[bin] = p;
+            }
+            p += c[k];
+            prev = c[k];
+        }
+        carry += round_total;
+        __syncthreads();
+    }
+    if (t == 0 && total > 0) out[max_tile + 1] = total;
+}
+
+__global__ void __launch_bounds__(TPB) tile_scatter_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals, long long L,
+                                                           const int* __restrict__ n_dev, int* __restrict__ cursor, int32_t* __restrict__ out_vals,
+                                                           const int* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * 4;
+    const long long n = bounded_n(L, n_dev);
+    if (i0 >= n) return;
+    int k[4], v[4];
+    if (i0 + 3 < n) {
+        const int4 kq = *reinterpret_cast<const int4*>(keys + i0), vq = *reinterpret_cast<const int4*>(vals + i0);
+        k[0] = kq.x; k[1] = kq.y; k[2] = kq.z; k[3] = kq.w; v[0] = vq.x; v[1] = vq.y; v[2] = vq.z; v[3] = vq.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { k[j] = (i0 + j < n) ? keys[i0 + j] : -1; v[j] = (i0 + j < n) ? vals[i0 + j] : 0; }
+    }
+    int pos[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pos[j] = k[j] >= 0 ? atomicAdd(&cursor[k[j]], 1) : -1;       // four independent returning atomics in flight
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (pos[j] >= 0) out_vals[pos[j]] = v[j];
+}
+
+// counts [max_tile + 2] (filled by the emission), cursor [max_tile + 2] scratch, tile_start [max_tile + 2] pre-filled with -1;
+// keys / vals: the emitted table (capacity L, valid entries min(L, *n_dev)); out_vals: values grouped by tile (any order inside a tile)
+int lg_tile_scatter_gated(const int32_t* keys, const int32_t* vals, long long L, const int* n_dev, int max_tile, const int* counts, int* cursor,
+                          int32_t* tile_start, int32_t* out_vals, const int* gate, void* stream)
+{
+    if (L <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, max_tile, n_dev, L, cursor, tile_start, gate);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(lg_cdiv(L, TPB * 4)), dim3(TPB), 0, s, keys, vals, L, n_dev, cursor, out_vals, gate);
+    LG_RETURN_LAST();
+}
+
+__global__ void __launch_bounds__(TPB) tile_count_kernel(const int32_t* __restrict__ keys, long long L, int* __restrict__ counts)
+{
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i < L) atomicAdd(&counts[keys[i]], 1);
+}
+
+// Stand-alone form of the tile scatter (tests, tools): an UNSORTED table keys[L] (0 = padding ... max_tile) / vals[L] -> tile_start
+// [max_tile + 2] exactly as lg_tile_range leaves it for the sorted table, and out_vals[L] = the values grouped by key, in arbitrary
+// order inside a key (follow with lg_tile_depth_sort_unordered).  temp: 2 * (max_tile + 2) ints.
+LG_API int lg_tile_group(const int32_t* keys, const int32_t* vals, long long L, int max_tile, int32_t* tile_start, int32_t* out_vals,
+                         void* temp, void* stream)
+{
+    LG_REQUIRE(tile_start, temp);
+    hipStream_t s = (hipStream_t)stream;
+    int* counts = (int*)temp;
+    int* cursor = counts + (max_tile + 2);
+    hipError_t err = hipMemsetAsync(tile_start, 0xFF, sizeof(int32_t) * (size_t)(max_tile + 2), s);
+    if (err != hipSuccess) return (int)err;
+    if (L <= 0) return 0;
+    LG_REQUIRE(keys, vals, out_vals);
+    err = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)(max_tile + 2), s);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(tile_count_kernel, dim3(lg_cdiv(L, TPB)), dim3(TPB), 0, s, keys, L, counts);
+    return lg_tile_scatter_gated(keys, vals, L, nullptr, max_tile, counts, cursor, tile_start, out_vals, nullptr, stream);
 }
 
 LG_API int lg_memset_async(void* ptr, int value, long long bytes, void* stream)

@@ -50,6 +50,11 @@ static bool use_tile_order(long long N)
 // A wider margin emits more instances but survives more drift of the scene between two visits of a frame before the gated fallback
 // has to re-run the frame unculled (key 1 of lg_fused_set_option; litegs_amd/fast.py adapts it per frame).
 static int g_bound_margin_pct = 100;
+// TILE mode: group the instances by tile with per-tile counts + cursors (binning.hip "Tile scatter") instead of the stable tile radix
+// sort -- the order inside a tile is re-made by the per-tile depth sort anyway.  Same table bit for bit.  Key 2 of lg_fused_set_option.
+static int g_tile_scatter = 1;
+#define LG_TILE_BINS_MAX (1 << 17)          // count words reserved (and cleared) per frame in workspace 1; frames with more tiles keep the radix sort
+static bool use_tile_scatter(long long N, int ntiles);
 
 // TILE mode only: the order in which the splats' instances are emitted (slot j -> splat order[j], a permutation of 0..n-1 on the
 // device, owned by the caller; nullptr or a length that does not match the frame's N = A*S: ascending ids).  The per-tile sort makes
@@ -68,10 +73,12 @@ LG_API int lg_fused_set_option(int key, int value)
 {
     if (key == 0 && (value == LG_DEPTH_ORDER_GLOBAL || value == LG_DEPTH_ORDER_TILE || value == LG_DEPTH_ORDER_AUTO)) { g_depth_order_mode = value; return 0; }
     if (key == 1 && value >= 1 && value <= 100000) { g_bound_margin_pct = value; return 0; }
+    if (key == 2 && (value == 0 || value == 1)) { g_tile_scatter = value; return 0; }
     return (int)hipErrorInvalidValue;
 }
 
-LG_API int lg_fused_get_option(int key) { return key == 0 ? g_depth_order_mode : (key == 1 ? g_bound_margin_pct : -1); }
+LG_API int lg_fused_get_option(int key) { return key == 0 ? g_depth_order_mode : (key == 1 ? g_bound_margin_pct : (key == 2 ? g_tile_scatter : -1)); }
+static bool use_tile_scatter(long long N, int ntiles) { return g_tile_scatter && use_tile_order(N) && ntiles + 2 <= LG_TILE_BINS_MAX; }
 #define LOG2E 1.4426950408889634f
 
 
@@ -294,9 +301,11 @@ struct Layout1 {      // sized by N = A*S (per-Gaussian buffers)
     size_t zeroed, zero_bytes, dsort_hdr, tsort_hdr, dsort_table, scan_status, dup_queue;
     // second set for the gated fallback of the depth-bound culling + its two device flags (fail flag | full total), same zeroed region
     size_t tsort_hdr2, scan_status2, dup_queue2, flags;
+    // per-key instance counts of the tile scatter, for the culled run and for its gated fallback (inside the zeroed region)
+    size_t tcount, tcount2;
 };
 struct Layout2 {      // sized by the tile-instance table length L
-    size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, tile_work, dup_entries, total;
+    size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, tile_work, dup_entries, tile_cursor, total;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -321,7 +330,9 @@ static Layout1 layout1(long long N)
     f.scan_status2 = take(4 * (size_t)lg_scan_status_words(N));
     f.dup_queue2 = take(4 * 64);
     f.flags = take(4 * 64);
-    f.zero_bytes = f.flags + 4 * 64 - f.zeroed;
+    f.tcount = take(4 * (size_t)LG_TILE_BINS_MAX);
+    f.tcount2 = take(4 * (size_t)LG_TILE_BINS_MAX);
+    f.zero_bytes = f.tcount2 + 4 * (size_t)LG_TILE_BINS_MAX - f.zeroed;
     f.total = o;
     return f;
 }
@@ -337,8 +348,19 @@ static Layout2 layout2(long long L, int ntiles, long long N)
     f.tile_start = take(sizeof(int) * ((size_t)ntiles + 2));
     f.tile_work = take(sizeof(int) * ((size_t)ntiles + 1));
     f.dup_entries = take(4 * (size_t)lg_dup_queue_entries(N, L));
+    f.tile_cursor = take(sizeof(int) * ((size_t)ntiles + 2));
     f.total = o;
     return f;
+}
+
+// where the blend kernels find the tile-grouped splat ids in workspace 2
+static size_t sorted_points_offset(const Layout2& f, long long N, int ntiles)
+{
+    if (use_tile_scatter(N, ntiles)) return f.tv_b;                 // tile scatter: emitted into tv_a, dropped at the cursors into tv_b
+    int bits = 0;
+    for (unsigned int mt = (unsigned int)ntiles; mt >>= 1;) bits++;
+    bits++;
+    return (lg_radix_sort_num_passes(0, bits) % 2 == 1) ? f.tv_b : f.tv_a;
 }
 
 LG_API long long lg_fused_workspace1_bytes(long long N) { return (long long)layout1(N > 0 ? N : 1).total; }
@@ -356,6 +378,12 @@ LG_API long long lg_fused_tile_start_offset(long long L, long long N, int H, int
 {
     int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     return (long long)layout2(L > 0 ? L : 1, ntiles, N).tile_start;
+}
+
+LG_API long long lg_fused_sorted_points_offset(long long L, long long N, int H, int W, int TH, int TW)
+{
+    int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    return (long long)sorted_points_offset(layout2(L > 0 ? L : 1, ntiles, N), N, ntiles);
 }
 
 // byte offset in workspace 1 of the exact instance total (prefix[N-1]) -- for the blocking first-visit path
@@ -488,7 +516,7 @@ static int tile_key_bits(int ntiles)
 // key/value emission -> stable tile sort -> tile ranges -> blend forward over the table described by `prefix`; Ls = table length this
 // run is sized for (<= the capacity L of the layout).  hdr / qcount: the zeroed scratch set to use.
 static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, long long Ls, int H, int W, int TH, int TW,
-                             int* tsort_hdr, int* qcount, const int* tiles, int K, int enable_stat,
+                             int* tsort_hdr, int* qcount, int* tcount, const int* tiles, int K, int enable_stat,
                              float* img, float* trans, short* last, int* frag_count, float* frag_weight, float* packed_grad_clear,
                              const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag, const int* gate,
                              const int* total_dev, hipStream_t s)
@@ -498,12 +526,30 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
     const bool tile_mode = use_tile_order(N);
     const void* depth_order = tile_mode ? (const void*)emission_order(N) : (odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));     // nullptr: emission in splat-id order
     const int bits = tile_key_bits(ntiles);
+    const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(f, N, ntiles));
+    int rc;
+    if (use_tile_scatter(N, ntiles)) {
+        // TILE mode without a sort: the emission counts the instances per key, one workgroup turns the counts into the range table and
+        // write cursors, one pass drops the values at their cursors, and the per-tile sort orders every list by (depth, id)
+        rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
+                               (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
+                               qcount, (uint32_t*)(w + f.dup_entries), nullptr, 0, bits, tcount, nullptr, 0,
+                               (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * N : 0, gate, fail_flag, s);
+        if (rc) return rc;
+        rc = lg_tile_scatter_gated((const int32_t*)(w + f.tk_a), (const int32_t*)(w + f.tv_a), Ls, total_dev, ntiles, tcount, (int*)(w + f.tile_cursor),
+                                   (int32_t*)(w + f.tile_start), (int32_t*)(w + f.tv_b), gate, s);
+        if (rc) return rc;
+        rc = lg_tile_depth_sort_gated((int32_t*)(w + f.tv_b), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L, (int)N, ntiles,
+                                      (uint32_t*)(w + f.tk_b), 1, gate, s);
+        if (rc) return rc;
+    } else {
     // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
     // clears the sort's look-back table.  No table memset: the bounded sort only reads the first prefix[N-1] entries, and a
     // truncated table (Ls < total) gets its tail zeroed by the first splat that does not fit.
-    int rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
+    rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
                                (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
-                               qcount, (uint32_t*)(w + f.dup_entries), tsort_hdr, 0, bits, (uint32_t*)(w + f.tsort_table),
+                               qcount, (uint32_t*)(w + f.dup_entries), tsort_hdr, 0, bits, nullptr, (uint32_t*)(w + f.tsort_table),
                                (long long)lg_radix_table_words(Ls, lg_radix_sort_num_passes(0, bits)),
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
                                (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * N : 0, gate, fail_flag, s);
@@ -514,12 +560,12 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
-    const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
     rc = lg_tile_range_prefilled(sorted_keys, 1, Ls, total_dev, ntiles, (int32_t*)(w + f.tile_start), s); if (rc) return rc;
     if (tile_mode) {      // depth order inside every tile; scratch for lists beyond 2048: the key buffer the tile sort did not end in
         rc = lg_tile_depth_sort_gated((int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L,
-                                      (int)N, ntiles, (uint32_t*)(w + (odd ? f.tk_a : f.tk_b)), gate, s);
+                                      (int)N, ntiles, (uint32_t*)(w + (odd ? f.tk_a : f.tk_b)), 0, gate, s);
         if (rc) return rc;
+    }
     }
     return lg_raster_forward_bounds(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
                                     enable_stat, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order, tiles ? nullptr : tile_work,
@@ -564,7 +610,7 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
     int* fail_flag = (int*)(w1 + f1.flags);
     const long long Ls = (cull_active && L_cull > 0 && L_cull < L) ? L_cull : L;
     const int* total_dev = (const int*)(w1 + f1.prefix) + (N - 1);
-    int rc = binning_and_blend(w1, f1, w, f, N, L, Ls, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr), (int*)(w1 + f1.dup_queue), tiles, K, enable_stat,
+    int rc = binning_and_blend(w1, f1, w, f, N, L, Ls, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr), (int*)(w1 + f1.dup_queue), (int*)(w1 + f1.tcount), tiles, K, enable_stat,
                                img, trans, last, frag_count, frag_weight, packed_grad_clear, order, tile_work, sched_in, sched_out,
                                cull_active, cull_active ? fail_flag : nullptr, nullptr, total_dev, s);
     if (rc) return rc;
@@ -595,7 +641,7 @@ static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2&
     rc = lg_gather_scan_gated((const int32_t*)(w1 + f1.alloc), depth_order, N, (int32_t*)(w1 + f1.prefix), (uint32_t*)(w1 + f1.scan_status2),
                               host_feedback_full, 0, fail_flag, full_total, s);
     if (rc) return rc;
-    return binning_and_blend(w1, f1, w, f, N, L, L, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr2), (int*)(w1 + f1.dup_queue2), nullptr, 0, 0,
+    return binning_and_blend(w1, f1, w, f, N, L, L, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr2), (int*)(w1 + f1.dup_queue2), (int*)(w1 + f1.tcount2), nullptr, 0, 0,
                              img, trans, last, nullptr, nullptr, packed_grad_clear, order, tile_work, sched_in, sched_out, 0, nullptr, fail_flag,
                              full_total, s);
 }
@@ -624,11 +670,7 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
     if ((long long)f1.total > ws1_bytes || (long long)f.total > ws2_bytes) return (int)hipErrorInvalidValue;
     const char* w1 = (const char*)ws1;
     const char* w = (const char*)ws2;
-    int bits = 0;
-    for (unsigned int mt = (unsigned int)ntiles; mt >>= 1;) bits++;
-    bits++;
-    const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
-    const int32_t* sorted_pts = (const int32_t*)(w + (odd ? f.tv_b : f.tv_a));
+    const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(f, N, ntiles));
     int rc = 0;
     if (!packed_grad_is_zero) { rc = lg_memset_async(packed_grad, 0, (long long)sizeof(float) * GREC * N, stream); if (rc) return rc; }
     rc = lg_raster_backward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, final_T, last, d_img, d_trans,

@@ -37,9 +37,16 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
 // table turns out too short for the prefix sums)
 int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
                       int sorted_id_is_int64, int V, int N, int H, int W, int TH, int TW, long long table_len, int32_t* keys, int32_t* values,
-                      int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, uint32_t* zero_ptr, long long zero_words,
+                      int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit,
+                      int* tile_counts /*nullable [V][tiles + 2], zero on entry: instances per key, for lg_tile_scatter_gated*/,
+                      uint32_t* zero_ptr, long long zero_words,
                       uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words,
                       const int* gate, int* trunc_flag, void* stream);
+
+// grouping by tile without a sort (binning.hip "Tile scatter"): per-key counts -> range table + cursors -> values dropped at their
+// tile's cursor.  Order inside a tile is arbitrary: follow with lg_tile_depth_sort_gated(any_order = 1).
+int lg_tile_scatter_gated(const int32_t* keys, const int32_t* vals, long long L, const int* n_dev, int max_tile, const int* counts, int* cursor,
+                          int32_t* tile_start /*pre-filled with -1*/, int32_t* out_vals, const int* gate, void* stream);
 
 // gathered inclusive scan in one launch; status = lg_scan_status_words(n) zero words; host_total (nullable) = pinned host int
 long long lg_scan_status_words(long long n);
@@ -50,8 +57,9 @@ int lg_gather_scan_gated(const int32_t* src, const int32_t* idx, long long n, in
                          int mode, const int* gate, int* total_out, void* stream);
 
 // per-tile depth sort of the tile-sorted value table (tilesort.hip); gate as above
+// any_order: the lists do not arrive in ascending id order (tile scatter): ties in depth are ordered by id explicitly
 int lg_tile_depth_sort_gated(int32_t* vals, const int32_t* tile_start, const float* depth /*[V,N] view depths*/, int V, long long L, int N, int ntiles,
-                             uint32_t* scratch, const int* gate, void* stream);
+                             uint32_t* scratch, int any_order, const int* gate, void* stream);
 
 // tileRange on a table whose output was pre-filled with -1
 int lg_tile_range_prefilled(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream);

@@ -187,7 +187,11 @@ TS_FN void ts_sort_tile(int* v, int n, uint64_t* sk, uint32_t* dk, DepthBits dep
 #endif
 
 // RCH: chunks of 64 the instantiation holds in registers (n <= 64 * RCH); the loops below are unrolled RCH times
-template <bool BALLOT, int RCH, class DepthBits>
+// ANY_ORDER: the list arrives in arbitrary order (the tile scatter of the executor's tile mode places instances through atomic cursors):
+// the stable passes then leave equal depth keys in arrival order, and a repair phase behind the last pass orders every run of equal
+// keys by ascending id -- an odd-even transposition on the ids of neighbours with equal keys, repeated until a sweep swaps nothing
+// (runs of equal depth are short: duplicated Gaussians right after a clone).  One neighbour comparison per element when there is no tie.
+template <bool BALLOT, int RCH, bool ANY_ORDER, class DepthBits>
 TS_FN void ts_radix_sort_tile_n(int* v, int n, uint32_t* exch /*[64 * RCH]*/, int* cnt /*[256]*/, DepthBits depth_bits TS_TID_ARG)
 {
     const int C = (n + 63) >> 6;
@@ -320,6 +324,80 @@ TS_FN void ts_radix_sort_tile_n(int* v, int n, uint32_t* exch /*[64 * RCH]*/, in
         }
         TS_SYNC(true);
     }
+    if (ANY_ORDER) {
+        // keys are final (only ids inside runs of equal keys may still move): element e is tied with e + 1 iff their keys are equal
+        TS_LOCAL(bool, eq, RCH);
+        TS_PHASE(tid, 64) {
+#pragma unroll
+            for (int c = 0; c < RCH; c++)
+                if (c < C && c * 64 + tid < n) exch[c * 64 + tid] = TS_L(key, c);
+        }
+        TS_SYNC(true);
+        bool any_tie = false;
+#ifdef LG_TILESORT_HOST
+        bool tie_t[64];
+#endif
+        TS_PHASE(tid, 64) {
+            bool t = false;
+#pragma unroll
+            for (int c = 0; c < RCH; c++) {
+                const int e = c * 64 + tid;
+                TS_L(eq, c) = (c < C && e + 1 < n) && exch[e + 1] == TS_L(key, c);
+                t |= TS_L(eq, c);
+            }
+#ifdef LG_TILESORT_HOST
+            tie_t[tid] = t;
+#else
+            any_tie = __any(t);
+#endif
+        }
+#ifdef LG_TILESORT_HOST
+        for (int t = 0; t < 64; t++) any_tie |= tie_t[t];
+#endif
+        if (any_tie) {
+            TS_SYNC(true);
+            TS_PHASE(tid, 64) {
+#pragma unroll
+                for (int c = 0; c < RCH; c++)
+                    if (c < C && c * 64 + tid < n) exch[c * 64 + tid] = (uint32_t)TS_L(id, c);
+            }
+            TS_SYNC(true);
+            for (int sweep = 0; sweep < 2 * n + 2; sweep++) {           // bounded; ends after the first pair of sweeps without a swap
+                bool swapped = false;
+                for (int parity = 0; parity < 2; parity++) {
+#ifdef LG_TILESORT_HOST
+                    bool sw_t[64];
+#endif
+                    TS_PHASE(tid, 64) {
+                        bool sw = false;
+#pragma unroll
+                        for (int c = 0; c < RCH; c++) {
+                            const int e = c * 64 + tid;
+                            if (c < C && (e & 1) == parity && TS_L(eq, c)) {
+                                const uint32_t a = exch[e], b = exch[e + 1];
+                                if (a > b) { exch[e] = b; exch[e + 1] = a; sw = true; }
+                            }
+                        }
+#ifdef LG_TILESORT_HOST
+                        sw_t[tid] = sw;
+#else
+                        swapped |= __any(sw);
+#endif
+                    }
+#ifdef LG_TILESORT_HOST
+                    for (int t = 0; t < 64; t++) swapped |= sw_t[t];
+#endif
+                    TS_SYNC(true);
+                }
+                if (!swapped) break;
+            }
+            TS_PHASE(tid, 64) {
+#pragma unroll
+                for (int c = 0; c < RCH; c++)
+                    if (c < C && c * 64 + tid < n) TS_L(id, c) = (int)exch[c * 64 + tid];
+            }
+        }
+    }
     TS_PHASE(tid, 64) {
 #pragma unroll
         for (int c = 0; c < RCH; c++)
@@ -328,10 +406,10 @@ TS_FN void ts_radix_sort_tile_n(int* v, int n, uint32_t* exch /*[64 * RCH]*/, in
 }
 
 // picks the smallest instantiation that holds the list
-template <bool BALLOT, class DepthBits>
+template <bool BALLOT, bool ANY_ORDER = false, class DepthBits>
 TS_FN void ts_radix_sort_tile(int* v, int n, uint32_t* exch /*[TS_RADIX_MAX]*/, int* cnt /*[256]*/, DepthBits depth_bits TS_TID_ARG)
 {
-    if (n <= 256) ts_radix_sort_tile_n<BALLOT, 4>(v, n, exch, cnt, depth_bits TS_TID_PASS);
-    else if (n <= 512) ts_radix_sort_tile_n<BALLOT, 8>(v, n, exch, cnt, depth_bits TS_TID_PASS);
-    else ts_radix_sort_tile_n<BALLOT, TS_RCHUNKS>(v, n, exch, cnt, depth_bits TS_TID_PASS);
+    if (n <= 256) ts_radix_sort_tile_n<BALLOT, 4, ANY_ORDER>(v, n, exch, cnt, depth_bits TS_TID_PASS);
+    else if (n <= 512) ts_radix_sort_tile_n<BALLOT, 8, ANY_ORDER>(v, n, exch, cnt, depth_bits TS_TID_PASS);
+    else ts_radix_sort_tile_n<BALLOT, TS_RCHUNKS, ANY_ORDER>(v, n, exch, cnt, depth_bits TS_TID_PASS);
 }

@@ -26,7 +26,7 @@
 // LDS of one workgroup: four wave-private regions of { exchange buffer 4 KB, digit counters 1 KB } for regime R; the 16 KB bitonic
 // buffer of regimes M / L aliases them (the regimes are separated by workgroup barriers).
 #define TS_WAVE_WORDS (TS_RADIX_MAX + 256)
-template <bool BALLOT>
+template <bool BALLOT, bool ANY_ORDER>
 __global__ void __launch_bounds__(256) tile_depth_sort_kernel(int* __restrict__ vals, const int* __restrict__ tile_start,
                                                               const float* __restrict__ depth, int ntiles, long long L, int N,
                                                               uint32_t* __restrict__ scratch, const int* __restrict__ gate)
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) tile_depth_sort_kernel(int* __restrict__ 
             const int n = (start >= 0 && end > start) ? end - start : 0;
             if (n >= 2 && n <= TS_RADIX_MAX) {
                 uint32_t* w32 = reinterpret_cast<uint32_t*>(lds) + wave * TS_WAVE_WORDS;
-                ts_radix_sort_tile<BALLOT>(v + start, n, w32, reinterpret_cast<int*>(w32 + TS_RADIX_MAX), depth_bits, lane);
+                ts_radix_sort_tile<BALLOT, ANY_ORDER>(v + start, n, w32, reinterpret_cast<int*>(w32 + TS_RADIX_MAX), depth_bits, lane);
             }
         }
     }
@@ -68,20 +68,23 @@ __global__ void __launch_bounds__(256) tile_depth_sort_kernel(int* __restrict__ 
     }
 }
 
-// vals [V, L] int32 splat ids grouped by tile (ascending id inside a tile), tile_start [V, ntiles + 2] (lg_tile_range), depth [V, N] view depths.
+// vals [V, L] int32 splat ids grouped by tile (ascending id inside a tile unless any_order), tile_start [V, ntiles + 2] (lg_tile_range), depth [V, N] view depths.
 // scratch [V, L] uint32 (any content; only touched for lists longer than 2048 -- nullable only if such lists cannot occur).
 // gate (nullable device int): nothing runs unless *gate != 0.
 int lg_tile_depth_sort_gated(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
-                             uint32_t* scratch, const int* gate, void* stream)
+                             uint32_t* scratch, int any_order, const int* gate, void* stream)
 {
     if (ntiles <= 0 || L <= 0 || V <= 0) return 0;
     // ranking inside a digit: the verified lane-ordered LDS add, or the ballot ranking when the device self-test says otherwise (binning.hip)
-    if (lg_radix_rank_mode() == 0)
-        hipLaunchKernelGGL(tile_depth_sort_kernel<false>, dim3(lg_cdiv(ntiles, 4), V), dim3(256), 0, (hipStream_t)stream, vals, tile_start, depth, ntiles,
-                           L, N, scratch, gate);
-    else
-        hipLaunchKernelGGL(tile_depth_sort_kernel<true>, dim3(lg_cdiv(ntiles, 4), V), dim3(256), 0, (hipStream_t)stream, vals, tile_start, depth, ntiles,
-                           L, N, scratch, gate);
+    const bool ballot = lg_radix_rank_mode() != 0;
+    const dim3 grid(lg_cdiv(ntiles, 4), V), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_TDS(B_, A_) hipLaunchKernelGGL((tile_depth_sort_kernel<B_, A_>), grid, block, 0, s, vals, tile_start, depth, ntiles, L, N, scratch, gate)
+    if (!ballot && !any_order) LAUNCH_TDS(false, false);
+    else if (!ballot) LAUNCH_TDS(false, true);
+    else if (!any_order) LAUNCH_TDS(true, false);
+    else LAUNCH_TDS(true, true);
+#undef LAUNCH_TDS
     LG_RETURN_LAST();
 }
 
@@ -89,5 +92,13 @@ LG_API int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const fl
                               uint32_t* scratch, void* stream)
 {
     if (vals == nullptr || tile_start == nullptr || depth == nullptr || scratch == nullptr) return (int)hipErrorInvalidValue;
-    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, nullptr, stream);
+    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 0, nullptr, stream);
+}
+
+// the same for lists that arrive in arbitrary order (lg_tile_group): equal depths are ordered by id explicitly
+LG_API int lg_tile_depth_sort_unordered(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
+                                        uint32_t* scratch, void* stream)
+{
+    if (vals == nullptr || tile_start == nullptr || depth == nullptr || scratch == nullptr) return (int)hipErrorInvalidValue;
+    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 1, nullptr, stream);
 }

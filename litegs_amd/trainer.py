@@ -183,7 +183,7 @@ class SyntheticTrainer(FrameTrainer):
 
     def __init__(self, n_gaussians: int, width: int, height: int, focal: float, n_frames: int = 8, seed: int = 0, sh_degree: int = 3,
                  device: Optional[torch.device] = None, radius: float = 4.0, cam_radius_frac: float = 0.5, loss_fn=None,
-                 scene=None, fused: bool = True, fuse_adam: bool = True):
+                 scene=None, fused: bool = True, fuse_adam: bool = True, noise_targets: bool = True):
         device = device or torch.device("cuda", torch.cuda.current_device())
         if scene is None:
             scene = S.make_scene(n_gaussians, seed=seed, sh_degree=sh_degree, radius=radius)
@@ -192,7 +192,8 @@ class SyntheticTrainer(FrameTrainer):
         rng = np.random.default_rng(seed + 1)
         frames: List[Frame] = []
         for k, (view, proj, planes) in enumerate(cams):
-            gt = torch.from_numpy(rng.random((1, 3, height, width), dtype=np.float32)).to(device)
+            # noise_targets=False: the caller assigns frames[k].gt itself (teacher renders, tests/convergence*.py)
+            gt = torch.from_numpy(rng.random((1, 3, height, width), dtype=np.float32)).to(device) if noise_targets else None
             frames.append(Frame(*[torch.from_numpy(x).to(device) for x in (view, proj, planes)], gt, k))
         opt, sched = opt_mod.get_optimizer(*params, 1.0, opt_mod.OptimizationParams())
         super().__init__(params, frames, height, width, opt, sched, None, sh_degree, device, loss_fn, fused, fuse_adam)

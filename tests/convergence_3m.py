@@ -1,0 +1,145 @@
+"""Long-horizon convergence at the headline size (north_star: "PSNR within 0.1 dB at 30k iters" on a 3 M-Gaussian scene).
+
+Teacher -> student at BASELINE configs[2]'s size: a seeded 3 M-Gaussian teacher cloud is rendered from `frames` orbit cameras at
+1920x1080 (targets); a perturbed student is trained for 30 000 iterations with the reference's schedule (litegs/training/trainer.py:
+108-195: epochs over the frames, SH degree = min(epoch // 5, 3), density control every 5 epochs with opacity decay, Morton re-sort after
+every densification, position-lr decay) by
+  executor x3  -- the native executor, three runs from the SAME student: float atomics reorder the blend backward's sums, so the three
+                  trajectories differ; their spread is the noise floor every other difference is to be read against;
+  operator     -- the same loop through the litegs_fused operator surface (what the reference's unmodified Python drives).
+PSNR (mean over 16 fixed frames against the teacher renders) every `eval_every` epochs.
+
+    python tests/convergence_3m.py --out gpurun_out/convergence_3m.md           (GPU box, ~5 minutes)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch_reference as TR                      # noqa: E402
+from convergence import perturb                   # noqa: E402
+from litegs_amd import synthetic as S             # noqa: E402
+from litegs_amd.trainer import SyntheticTrainer   # noqa: E402
+
+
+def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify, log):
+    from litegs_amd import densify as D
+    from litegs_amd.statistics import STATS
+    tr = SyntheticTrainer(cfg["n"], cfg["W"], cfg["H"], cfg["focal"], n_frames=cfg["frames"], seed=cfg["seed"], scene=student, fused=fused, noise_targets=False)
+    for k, t in enumerate(targets):
+        tr.frames[k].gt = t
+    ctl = tr.enable_densify(D.DensifyParams(**densify), total_epochs=epochs, seed=cfg["seed"]) if densify else None
+
+    def evaluate():
+        with torch.no_grad():
+            return float(np.mean([TR.psnr(tr.forward_only(k)[0].clamp(0, 1), targets[k][0]) for k in eval_frames]))
+
+    curve, sizes, at = [evaluate()], [tr.n_chunks * tr.S], [0]
+    torch.cuda.synchronize()
+    t0 = time.time()
+    rng = np.random.default_rng(cfg["seed"] + 7)
+    for epoch in range(epochs):
+        tr.degree = min(epoch // 5, 3)                       # trainer.py:111
+        order = rng.permutation(cfg["frames"])               # the reference's DataLoader shuffles
+        if ctl is not None:
+            with tr.begin_epoch(epoch):
+                for k in order:
+                    tr.step(int(k))
+            tr.end_epoch(epoch)
+        else:
+            for k in order:
+                tr.step(int(k))
+        if (epoch + 1) % eval_every == 0 or epoch == epochs - 1:
+            curve.append(evaluate()); sizes.append(tr.n_chunks * tr.S); at.append((epoch + 1) * cfg["frames"])
+    torch.cuda.synchronize()
+    secs = time.time() - t0
+    rd = tr.renderer
+    info = dict(psnr=curve, size=sizes, iterations=at, seconds=secs, ms_per_iteration=secs / (epochs * cfg["frames"]) * 1e3,
+                unculled_reruns=int(rd.fallbacks), truncated=int(rd.truncated_visits), finite=all(bool(torch.isfinite(p).all()) for p in tr.params))
+    if ctl is not None:
+        STATS.reset(1, 1, enabled_for_epoch=lambda e: False, device="cuda")
+        STATS.tile_schedule.clear(); STATS.tile_blend_count.clear()
+    del tr
+    torch.cuda.empty_cache()
+    log(f"{'executor' if fused else 'operator'}: {curve[0]:.3f} -> {curve[-1]:.3f} dB, {sizes[-1]} points, {secs:.1f} s ({info['ms_per_iteration']:.3f} ms / iteration)")
+    return info
+
+
+def run(iterations=30000, frames=150, n=3_000_000, W=1920, H=1080, focal=1200.0, seed=0, runs=3, eval_every=10, log=print):
+    cfg = dict(n=n, W=W, H=H, focal=focal, frames=frames, seed=seed)
+    epochs = iterations // frames
+    t0 = time.time()
+    teacher = S.make_scene(n, seed=seed)
+    student = perturb(teacher, seed + 1, amount=0.5)
+    teach = SyntheticTrainer(n, W, H, focal, n_frames=frames, seed=seed, scene=teacher, noise_targets=False)
+    targets = [teach.forward_only(k).clamp(0, 1).clone() for k in range(frames)]
+    del teach
+    torch.cuda.empty_cache()
+    eval_frames = list(range(0, frames, max(1, frames // 16)))[:16]
+    densify = dict(target_primitives=int(1.1 * n))                       # the reference's defaults otherwise (arguments.py:95-110)
+    out = dict(config=cfg, iterations=iterations, epochs=epochs, densify=densify, eval_frames=eval_frames)
+    log(f"targets rendered ({frames} frames {W}x{H}), {epochs} epochs; {time.time() - t0:.0f} s")
+    out["executor"] = [train(student, targets, cfg, True, epochs, eval_frames, eval_every, densify, log) for _ in range(runs)]
+    out["operator"] = train(student, targets, cfg, False, epochs, eval_frames, eval_every, densify, log)
+    out["seconds"] = time.time() - t0
+    return out
+
+
+def to_markdown(out):
+    cfg = out["config"]
+    ex, op = out["executor"], out["operator"]
+    L = [f"# Convergence at the headline size: {cfg['n']} Gaussians, {cfg['frames']} cameras {cfg['W']}x{cfg['H']}, {out['iterations']} iterations", "",
+         f"Teacher -> student (tests/convergence_3m.py): student = teacher + noise; {out['epochs']} epochs over {cfg['frames']} shuffled frames; SH degree "
+         f"min(epoch // 5, 3); density control with the reference's defaults (every 5 epochs from epoch 3 to 80 % of the run, opacity decay every "
+         f"10, prune by weight, budget {out['densify']['target_primitives']} primitives), Morton re-sort after each densification; reference learning "
+         f"rates and position-lr decay; L1 + 0.2 D-SSIM.  PSNR = mean over {len(out['eval_frames'])} fixed frames against the teacher renders.  "
+         f"Whole script: {out['seconds']:.0f} s on one MI355X.", "",
+         "| iterations | " + " | ".join(f"executor run {i + 1}" for i in range(len(ex))) + " | operator path | executor points | operator points |",
+         "|---:|" + "---:|" * (len(ex) + 3)]
+    for j, it in enumerate(ex[0]["iterations"]):
+        L.append(f"| {it} | " + " | ".join(f"{r['psnr'][j]:.3f}" for r in ex) + f" | {op['psnr'][j]:.3f} | {ex[0]['size'][j]} | {op['size'][j]} |")
+    fin = np.array([r["psnr"][-1] for r in ex])
+    tail = np.array([np.mean(r["psnr"][-3:]) for r in ex])
+    L += ["", "| quantity | value |", "|---|---:|",
+          f"| executor, final PSNR: mean of the runs | {fin.mean():.3f} dB |",
+          f"| executor, run-to-run spread of the final PSNR (max - min: the atomics-order noise floor) | {fin.max() - fin.min():.3f} dB |",
+          f"| operator path, final PSNR | {op['psnr'][-1]:.3f} dB |",
+          f"| final dPSNR, mean executor vs operator | {abs(fin.mean() - op['psnr'][-1]):.3f} dB |",
+          f"| the same on the mean of the last three evaluations | {abs(tail.mean() - np.mean(op['psnr'][-3:])):.3f} dB |",
+          f"| largest |dPSNR| between executor run 1 and the operator path over the whole curve | {np.abs(np.array(ex[0]['psnr']) - np.array(op['psnr'])).max():.3f} dB |",
+          f"| largest |dPSNR| between executor runs 1 and 2 over the whole curve | {np.abs(np.array(ex[0]['psnr']) - np.array(ex[1]['psnr'])).max():.3f} dB |" if len(ex) > 1 else "",
+          f"| ms per iteration (training + density control + evaluation), executor / operator | {np.mean([r['ms_per_iteration'] for r in ex]):.3f} / {op['ms_per_iteration']:.3f} |",
+          f"| frames repeated unculled (depth-bound fallback), executor runs | {', '.join(str(r['unculled_reruns']) for r in ex)} |",
+          f"| truncated tables observed | {', '.join(str(r['truncated']) for r in ex)} |",
+          f"| parameters finite at the end | {all(r['finite'] for r in ex) and op['finite']} |"]
+    return "\n".join(x for x in L if x != "") + "\n"
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/convergence_3m.md")
+    ap.add_argument("--iterations", type=int, default=30000)
+    ap.add_argument("--frames", type=int, default=150)
+    ap.add_argument("--n", type=int, default=3_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--eval-every", type=int, default=10)
+    a = ap.parse_args()
+    res = run(iterations=a.iterations, frames=a.frames, n=a.n, W=a.width, H=a.height, runs=a.runs, eval_every=a.eval_every)
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    with open(a.out, "w") as f:
+        f.write(to_markdown(res))
+    with open(os.path.splitext(a.out)[0] + ".json", "w") as f:
+        json.dump(res, f)
+    print(open(a.out).read())

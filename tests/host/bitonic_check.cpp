@@ -10,7 +10,7 @@
 #include <vector>
 #include "lg_tilesort_body.h"
 
-static int check(int n, int n_splats, int distinct_depths, std::mt19937& rng, bool radix = false)
+static int check(int n, int n_splats, int distinct_depths, std::mt19937& rng, bool radix = false, bool any_order = false)
 {
     std::vector<float> depth(n_splats);
     std::uniform_real_distribution<float> ud(0.01f, 40.0f);
@@ -27,13 +27,15 @@ static int check(int n, int n_splats, int distinct_depths, std::mt19937& rng, bo
     std::vector<int> want = v;
     auto bits = [&](int id) { uint32_t u; std::memcpy(&u, &depth[id], 4); return u; };
     std::stable_sort(want.begin(), want.end(), [&](int a, int b) { return ts_depth_key(bits(a)) < ts_depth_key(bits(b)); });
+    if (any_order) std::shuffle(v.begin(), v.end(), rng);          // the tile scatter's arrival order: the result must not depend on it
     std::vector<uint64_t> sk(TS_CHUNK);
     std::vector<uint32_t> dk(n);
     const bool small = n <= TS_SMALL;
     if (radix) {
         std::vector<uint32_t> exch(TS_RADIX_MAX);
         std::vector<int> cnt(256);
-        ts_radix_sort_tile<false>(v.data(), n, exch.data(), cnt.data(), bits);
+        if (any_order) ts_radix_sort_tile<false, true>(v.data(), n, exch.data(), cnt.data(), bits);
+        else ts_radix_sort_tile<false>(v.data(), n, exch.data(), cnt.data(), bits);
     } else {
         ts_sort_tile(v.data(), n, sk.data(), dk.data(), bits, small ? 64 : 256, small);
     }
@@ -62,6 +64,17 @@ int main()
         bad |= check(n, n + 5, 1, rng, true); cases++;
         bad |= check(n, n + 5, 200, rng, true); cases++;
     }
+    // regime R on lists that arrive in ARBITRARY order (tile scatter through atomic cursors): equal depths must still end in ascending id order
+    for (int n = 2; n <= TS_RADIX_MAX && !bad; n += (n < 130 ? 1 : 7)) { bad |= check(n, n + 9, 0, rng, true, true); cases++; }
+    for (int n : {2, 3, 5, 63, 64, 65, 128, 129, 500, 1000, 1023, 1024}) {
+        if (bad) break;
+        bad |= check(n, n + 5, 3, rng, true, true); cases++;           // long runs of equal depth
+        bad |= check(n, n + 5, 1, rng, true, true); cases++;           // one depth: every pass skipped, the repair does all the work
+        bad |= check(n, n + 5, 200, rng, true, true); cases++;         // short runs
+        bad |= check(n, n + 5, n / 2 + 1, rng, true, true); cases++;   // pairs (duplicated Gaussians)
+    }
+    // regimes M / L sort by the 64-bit key (depth, id): any arrival order
+    for (int n : {1025, 2048, 2049, 5000, 9000}) { if (bad) break; bad |= check(n, n + 5, 3, rng, false, true); bad |= check(n, n + 5, 0, rng, false, true); cases += 2; }
     // the flip/step pair generators enumerate disjoint pairs covering [0, P)
     for (int lp = 1; lp <= 12 && !bad; lp++) {
         const int P = 1 << lp;

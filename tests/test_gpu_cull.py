@@ -44,7 +44,7 @@ def _flags(rd):
     return ws1[off:off + 8].view(torch.int32).cpu().numpy()
 
 
-def test_culled_visit_is_bit_identical_and_emits_less():
+def test_culled_visit_is_bit_identical_and_emits_less(depth_order_mode):
     from litegs_amd import fast
     params, cam, origin, extend, H, W = _scene()
     w = torch.from_numpy(np.random.default_rng(2).standard_normal((1, 3, H, W)).astype(np.float32)).cuda()
@@ -70,7 +70,20 @@ def test_culled_visit_is_bit_identical_and_emits_less():
     assert rd.last_cull and _flags(rd)[0] == 0 and torch.equal(img0, img2)
 
 
-def test_violated_bounds_take_the_gated_fallback():
+@pytest.fixture(params=["global", "tile+scatter", "tile+radix"])
+def depth_order_mode(request):
+    """the three ways the executor builds the tile lists (csrc/fused.hip): depth sort of the splats + stable tile sort; per-tile depth sort
+    behind the tile scatter (no sort over the instances); per-tile depth sort behind the stable tile radix sort"""
+    from litegs_amd._lib import lib
+    L = lib()
+    prev = (L.lg_fused_get_option(0), L.lg_fused_get_option(2))
+    mode, scatter = {"global": (0, 1), "tile+scatter": (1, 1), "tile+radix": (1, 0)}[request.param]
+    assert L.lg_fused_set_option(0, mode) == 0 and L.lg_fused_set_option(2, scatter) == 0
+    yield request.param
+    L.lg_fused_set_option(0, prev[0]); L.lg_fused_set_option(2, prev[1])
+
+
+def test_violated_bounds_take_the_gated_fallback(depth_order_mode):
     from litegs_amd import fast
     params, cam, origin, extend, H, W = _scene()
     rd = fast.FusedRenderer(1, H, W)
@@ -87,7 +100,7 @@ def test_violated_bounds_take_the_gated_fallback():
     assert rd.last_cull and _flags(rd)[0] == 0 and torch.equal(img0, img2)
 
 
-def test_scene_change_between_visits_stays_exact():
+def test_scene_change_between_visits_stays_exact(depth_order_mode):
     """opacities drop between two visits (tiles saturate deeper than predicted): whatever the culled visit decides, the image equals
     the one a fresh, unculled renderer produces"""
     from litegs_amd import fast

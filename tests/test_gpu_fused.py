@@ -174,3 +174,61 @@ def test_fused_render_with_underpredicted_table(oracle):
         torch.cuda.synchronize()
     assert rd.truncated_visits == 1 and rd.last_sizes[1] == total
     assert_close(img3.cpu().numpy(), full_img, flip_frac=5e-5, name="healed img")
+
+
+def test_underpredicted_table_in_per_tile_depth_mode(oracle):
+    """The same accident in the executor's per-tile-depth-sort mode (no sort over the splats, tile scatter).  What is dropped is defined by
+    the EMISSION order, as in the reference (GR/binning.cu:63: the first splat whose range does not fit, and everything behind it) --
+    ascending splat id in this mode instead of depth (the reference's order would need the very splat sort the mode removes).  Pinned
+    here: the image is exactly that of the id-order truncated table with every list sorted by (depth, id); the visit is counted, and the
+    frame's next visit is sized exactly and is correct again."""
+    from litegs_amd import fast
+    from litegs_amd._lib import lib
+    name = "small"
+    c, params, view, proj, planes, origin, extend = _setup(name)
+    res = oracle_forward(name)
+    H, W = c["H"], c["W"]
+    L = lib()
+    prev = L.lg_fused_get_option(0)
+    try:
+        assert L.lg_fused_set_option(0, 1) == 0
+        rd = fast.FusedRenderer(1, H, W)
+        cam = fast.CameraFrame(view, proj, planes, 0)
+        with torch.no_grad():
+            rd.render(cam, origin, extend, *params, c["degree"])
+            torch.cuda.synchronize()
+            total = int(rd.fb_total[0])
+            assert total == res.n_instances
+            rd.fb_total[0] = int(0.3 * total)
+            img, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
+            torch.cuda.synchronize()
+        want = int(1.5 * int(0.3 * total))
+        assert rd.last_sizes[1] == want and int(rd.fb_total[0]) == total
+        op = res.act[4]
+        N = res.alloc.shape[1]
+        ident = np.arange(N, dtype=np.int64)[None]
+        prefix_id = np.cumsum(res.alloc, axis=-1, dtype=np.int64).astype(np.int32)
+        ks, vs, _, _ = oracle.create_table(res.ndc, res.inv_cov, op, prefix_id, ident, H, W, 8, 16, table_len=want)
+        depth = np.ascontiguousarray(res.view_pos[:, 2, :])
+        u = depth[0].view(np.uint32).astype(np.uint64)
+        dkey = np.where((u & 0x80000000) != 0, (~u) & 0xFFFFFFFF, u | 0x80000000)
+        bounds = np.flatnonzero(np.diff(ks[0])) + 1
+        vs = vs.copy()
+        for a, b in zip(np.r_[0, bounds], np.r_[bounds, ks.shape[1]]):
+            if ks[0, a] != 0:
+                ids = vs[0, a:b]
+                vs[0, a:b] = ids[np.lexsort((ids, dkey[ids]))]
+        ntiles = ((H + 7) // 8) * ((W + 15) // 16)
+        ts = oracle.tile_range(ks, ntiles)
+        ref_img, *_ = oracle.raster_forward(vs, ts, res.packed, H, W, 8, 16)
+        ref_img = np.clip(ref_img[..., :H, :W], 0, 1)
+        full_img = np.clip(res.img[..., :H, :W], 0, 1)
+        assert np.abs(ref_img - full_img).max() > 0.05
+        assert_close(img.cpu().numpy(), ref_img, flip_frac=5e-5, name="truncated img (tile mode)")
+        with torch.no_grad():
+            img3, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
+            torch.cuda.synchronize()
+        assert rd.truncated_visits == 1 and rd.last_sizes[1] == total
+        assert_close(img3.cpu().numpy(), full_img, flip_frac=5e-5, name="healed img (tile mode)")
+    finally:
+        L.lg_fused_set_option(0, prev)

@@ -120,3 +120,86 @@ def test_training_steps_agree_between_the_two_modes():
     # the blend backward's float atomics reorder the sums (tests/test_gpu_convergence.py measures that spread)
     np.testing.assert_allclose(res[0][0][:4], res[1][0][:4], rtol=2e-4)
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-2)
+
+
+@pytest.mark.parametrize("case", ["mixed", "ties"])
+def test_tile_group_and_unordered_sort_equal_sorted_pipeline(case):
+    """Grouping by tile WITHOUT a sort (lg_tile_group: per-key counts -> range table + cursors -> scatter) followed by the per-tile sort for
+    lists in arbitrary order: same range table as tileRange of the sorted keys, same lists as lexsort by (depth key, id) -- with padding
+    keys (0), empty tiles, every list-length regime of the per-tile sort and heavy ties in depth."""
+    from litegs_amd import fused
+    from litegs_amd._lib import check, lib
+    rng = np.random.default_rng({"mixed": 11, "ties": 12}[case])
+    lengths = [3, 0, 1, 2, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2048, 2049, 0, 0, 4500, 7] + list(rng.integers(0, 700, size=150)) + [0, 0, 9]
+    ntiles = len(lengths) + 2                                        # trailing tiles stay empty
+    N = 50000
+    depth = rng.uniform(0.01, 50.0, size=N).astype(np.float32)
+    if case == "ties":
+        depth = rng.choice(np.array([0.5, 1.0, 1.0000001, 7.25, -2.0], dtype=np.float32), size=N)
+    keys = np.concatenate([np.full((int(n),), t, np.int32) for t, n in enumerate(lengths)])          # key 0 (3 entries) = padding
+    vals = np.concatenate([rng.choice(N, size=int(n), replace=False).astype(np.int32) for n in lengths])
+    perm = rng.permutation(len(keys))
+    keys_u, vals_u = keys[perm], vals[perm]
+    L = len(keys)
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    tk, tv = torch.from_numpy(keys_u.copy()).to(dev), torch.from_numpy(vals_u.copy()).to(dev)
+    start = torch.empty((1, ntiles + 2), dtype=torch.int32, device=dev)
+    out = torch.full((1, L), -7, dtype=torch.int32, device=dev)
+    temp = torch.empty((2 * (ntiles + 2),), dtype=torch.int32, device=dev)
+    check(lib().lg_tile_group(tk.data_ptr(), tv.data_ptr(), L, ntiles, start.data_ptr(), out.data_ptr(), temp.data_ptr(), s), "tile_group")
+    want_start = fused.tileRange(torch.from_numpy(np.sort(keys_u, kind="stable")[None]).to(dev), ntiles)
+    assert torch.equal(start, want_start)
+    got = out.cpu().numpy()[0]
+    off = 0
+    for t, n in enumerate(lengths):                                  # grouped: every segment holds exactly its key's values
+        np.testing.assert_array_equal(np.sort(got[off:off + n]), np.sort(vals[keys == t]))
+        off += int(n)
+    pk = torch.from_numpy(depth[None].copy()).to(dev)
+    scratch = torch.zeros((1, L), dtype=torch.int32, device=dev)
+    check(lib().lg_tile_depth_sort_unordered(out.data_ptr(), start.data_ptr(), pk.data_ptr(), 1, L, N, ntiles, scratch.data_ptr(), s), "tile_depth_sort_unordered")
+    got = out.cpu().numpy()[0]
+    st = start.cpu().numpy()[0]
+    off = 0
+    for t, n in enumerate(lengths):
+        n = int(n)
+        ids = vals[keys == t]
+        if t >= 1 and n >= 1 and st[t] >= 0 and st[t + 1] > st[t]:
+            assert (st[t], st[t + 1]) == (off, off + n)
+            order = np.lexsort((ids, _depth_key(depth[ids])))
+            np.testing.assert_array_equal(got[off:off + n], ids[order], err_msg=f"tile {t} n={n}")
+        off += n
+
+
+def test_executor_tables_match_the_oracle_with_the_tile_scatter(oracle):
+    """the executor's tile-instance table in per-tile-depth-sort mode with the tile scatter (no radix sort over the instances): tile ranges and
+    the depth-ordered lists bit for bit against the oracle's reference pipeline (stable depth sort, emission, stable tile sort)"""
+    from litegs_amd import fast, render as R
+    from litegs_amd._lib import lib
+    from tests.util import case, oracle_forward
+    L = lib()
+    c = case("small")
+    res = oracle_forward("small")
+    H, W = c["H"], c["W"]
+    params = [torch.from_numpy(p).cuda() for p in c["params"]]
+    view, proj, planes = [torch.from_numpy(x).cuda() for x in (c["view"], c["proj"], c["planes"])]
+    origin, extend = R.get_cluster_AABB(params[0], params[1].exp(), torch.nn.functional.normalize(params[2], dim=0))
+    prev = (L.lg_fused_get_option(0), L.lg_fused_get_option(2))
+    try:
+        for scatter in (1, 0):
+            assert L.lg_fused_set_option(0, 1) == 0 and L.lg_fused_set_option(2, scatter) == 0
+            rd = fast.FusedRenderer(1, H, W)
+            cam = fast.CameraFrame(view, proj, planes, 0)
+            with torch.no_grad():
+                rd.render(cam, origin, extend, *params, c["degree"])
+            torch.cuda.synchronize()
+            ws2, table_len, N = rd.last_ws2
+            o_pts = L.lg_fused_sorted_points_offset(table_len, N, H, W, 8, 16)
+            o_ts = L.lg_fused_tile_start_offset(table_len, N, H, W, 8, 16)
+            ntiles = res.tile_start.shape[1] - 2
+            ts = ws2[o_ts:o_ts + 4 * (ntiles + 2)].view(torch.int32).cpu().numpy()
+            pts = ws2[o_pts:o_pts + 4 * res.n_instances].view(torch.int32).cpu().numpy()
+            np.testing.assert_array_equal(ts, res.tile_start[0], err_msg=f"scatter={scatter}")
+            np.testing.assert_array_equal(pts, res.sorted_point[0], err_msg=f"scatter={scatter}")
+    finally:
+        L.lg_fused_set_option(0, prev[0]); L.lg_fused_set_option(2, prev[1])
