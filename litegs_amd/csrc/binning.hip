@@ -1720,6 +1720,106 @@ __global__ void __launch_bounds__(1024) tile_offsets_kernel(const int* __restric
     if (t == 0 && total > 0) out[max_tile + 1] = total;
 }
 
+// Global atomics are the expensive primitive here (measured on MI355X, profiles/r03_scatter_ab.log: one atomic per instance for the
+// counts plus one returning atomic per instance for the cursors -- 8 M at 3 M Gaussians -- cost 110 us MORE than the two radix passes
+// they replaced).  So both passes aggregate in LDS first: a workgroup takes TG_ITEMS consecutive instances -- neighbours in emission
+// order are spatial neighbours and share their tiles -- counts them per key in a 16-bit LDS histogram (two keys per 32-bit word; a
+// workgroup's count of one key is at most TG_ITEMS < 65536, so the halves never carry into each other) and goes to global memory once
+// per (workgroup, key): a few hundred atomics per 4096 instances.
+#define TG_BINS 16384                      // keys 0 .. TG_BINS - 1 (1080p at 8x16: 16 201)
+#define TG_PER_THREAD 16
+#define TG_ITEMS (TPB * TG_PER_THREAD)     // 4096 instances per workgroup
+
+__device__ __forceinline__ void tg_load(const int32_t* __restrict__ src, long long i0, long long n, int out[TG_PER_THREAD], int fill)
+{
+    // thread t takes items i0 + t * 4 + r * (TPB * 4) + {0..3}: 16-byte loads, a wave covers 1 KB per round
+#pragma unroll
+    for (int r = 0; r < TG_PER_THREAD / 4; r++) {
+        const long long i = i0 + (long long)r * (TPB * 4) + (long long)threadIdx.x * 4;
+        if (i + 3 < n) {
+            const int4 q = *reinterpret_cast<const int4*>(src + i);
+            out[4 * r] = q.x; out[4 * r + 1] = q.y; out[4 * r + 2] = q.z; out[4 * r + 3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) out[4 * r + j] = (i + j < n) ? src[i + j] : fill;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TPB) tile_count_lds_kernel(const int32_t* __restrict__ keys, long long L, const int* __restrict__ n_dev,
+                                                             int* __restrict__ counts, const int* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    __shared__ unsigned int hist[TG_BINS / 2];
+    const long long n = bounded_n(L, n_dev);
+    const long long i0 = (long long)blockIdx.x * TG_ITEMS;
+    if (i0 >= n) return;
+    for (int w = threadIdx.x; w < TG_BINS / 2; w += TPB) hist[w] = 0u;
+    __syncthreads();
+    int k[TG_PER_THREAD];
+    tg_load(keys, i0, n, k, -1);
+#pragma unroll
+    for (int j = 0; j < TG_PER_THREAD; j++)
+        if (k[j] >= 0) atomicAdd(&hist[k[j] >> 1], 1u << ((k[j] & 1) * 16));
+    __syncthreads();
+    for (int w = threadIdx.x; w < TG_BINS / 2; w += TPB) {
+        const unsigned int c = hist[w];
+        if (c & 0xffffu) atomicAdd(&counts[2 * w], (int)(c & 0xffffu));
+        if (c >> 16) atomicAdd(&counts[2 * w + 1], (int)(c >> 16));
+    }
+}
+
+__global__ void __launch_bounds__(TPB) tile_scatter_lds_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals, long long L,
+                                                               const int* __restrict__ n_dev, int* __restrict__ cursor, int32_t* __restrict__ out_vals,
+                                                               const int* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    __shared__ unsigned int hist[TG_BINS / 2];     // per key: first the workgroup's count, then the index of the key's entry in base[]
+    __shared__ int base[TG_ITEMS];                 // start of this workgroup's run inside the key's segment (at most one entry per instance)
+    __shared__ int nlist;
+    const long long n = bounded_n(L, n_dev);
+    const long long i0 = (long long)blockIdx.x * TG_ITEMS;
+    if (i0 >= n) return;
+    for (int w = threadIdx.x; w < TG_BINS / 2; w += TPB) hist[w] = 0u;
+    if (threadIdx.x == 0) nlist = 0;
+    __syncthreads();
+    int k[TG_PER_THREAD], v[TG_PER_THREAD], rank[TG_PER_THREAD];
+    tg_load(keys, i0, n, k, -1);
+    tg_load(vals, i0, n, v, 0);
+#pragma unroll
+    for (int j = 0; j < TG_PER_THREAD; j++) {
+        rank[j] = 0;
+        if (k[j] >= 0) {
+            const int sh = (k[j] & 1) * 16;
+            rank[j] = (int)((atomicAdd(&hist[k[j] >> 1], 1u << sh) >> sh) & 0xffffu);       // position inside the workgroup's run of this key
+        }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < TG_BINS / 2; w += TPB) {
+        const unsigned int c = hist[w];
+        if (c == 0u) continue;
+        unsigned int packed = 0u;
+        if (c & 0xffffu) {
+            const int e = atomicAdd(&nlist, 1);
+            base[e] = atomicAdd(&cursor[2 * w], (int)(c & 0xffffu));
+            packed |= (unsigned int)e;
+        }
+        if (c >> 16) {
+            const int e = atomicAdd(&nlist, 1);
+            base[e] = atomicAdd(&cursor[2 * w + 1], (int)(c >> 16));
+            packed |= (unsigned int)e << 16;
+        }
+        hist[w] = packed;                           // entry indices are < TG_ITEMS <= 65535
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TG_PER_THREAD; j++)
+        if (k[j] >= 0) {
+            const int e = (int)((hist[k[j] >> 1] >> ((k[j] & 1) * 16)) & 0xffffu);
+            out_vals[base[e] + rank[j]] = v[j];
+        }
+}
+
 __global__ void __launch_bounds__(TPB) tile_scatter_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals, long long L,
                                                            const int* __restrict__ n_dev, int* __restrict__ cursor, int32_t* __restrict__ out_vals,
                                                            const int* __restrict__ gate)
@@ -1745,20 +1845,31 @@ __global__ void __launch_bounds__(TPB) tile_scatter_kernel(const int32_t* __rest
 
 // counts [max_tile + 2] (filled by the emission), cursor [max_tile + 2] scratch, tile_start [max_tile + 2] pre-filled with -1;
 // keys / vals: the emitted table (capacity L, valid entries min(L, *n_dev)); out_vals: values grouped by tile (any order inside a tile)
-int lg_tile_scatter_gated(const int32_t* keys, const int32_t* vals, long long L, const int* n_dev, int max_tile, const int* counts, int* cursor,
-                          int32_t* tile_start, int32_t* out_vals, const int* gate, void* stream)
+__global__ void __launch_bounds__(TPB) tile_count_kernel(const int32_t* __restrict__ keys, long long L, const int* __restrict__ n_dev,
+                                                         int* __restrict__ counts, const int* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i < bounded_n(L, n_dev)) atomicAdd(&counts[keys[i]], 1);
+}
+
+// counts [max_tile + 2] zero on entry when count_keys != 0 (then counted here from the emitted keys, in LDS-aggregated form), else filled by
+// the caller; cursor [max_tile + 2] scratch, tile_start [max_tile + 2] pre-filled with -1; keys / vals: the emitted table (capacity L, valid
+// entries min(L, *n_dev)); out_vals: values grouped by tile (any order inside a tile)
+int lg_tile_scatter_gated(const int32_t* keys, const int32_t* vals, long long L, const int* n_dev, int max_tile, int* counts, int count_keys,
+                          int* cursor, int32_t* tile_start, int32_t* out_vals, const int* gate, void* stream)
 {
     if (L <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    const bool lds = max_tile + 1 <= TG_BINS;
+    if (count_keys) {
+        if (lds) hipLaunchKernelGGL(tile_count_lds_kernel, dim3(lg_cdiv(L, TG_ITEMS)), dim3(TPB), 0, s, keys, L, n_dev, counts, gate);
+        else hipLaunchKernelGGL(tile_count_kernel, dim3(lg_cdiv(L, TPB)), dim3(TPB), 0, s, keys, L, n_dev, counts, gate);
+    }
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, max_tile, n_dev, L, cursor, tile_start, gate);
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(lg_cdiv(L, TPB * 4)), dim3(TPB), 0, s, keys, vals, L, n_dev, cursor, out_vals, gate);
+    if (lds) hipLaunchKernelGGL(tile_scatter_lds_kernel, dim3(lg_cdiv(L, TG_ITEMS)), dim3(TPB), 0, s, keys, vals, L, n_dev, cursor, out_vals, gate);
+    else hipLaunchKernelGGL(tile_scatter_kernel, dim3(lg_cdiv(L, TPB * 4)), dim3(TPB), 0, s, keys, vals, L, n_dev, cursor, out_vals, gate);
     LG_RETURN_LAST();
-}
-
-__global__ void __launch_bounds__(TPB) tile_count_kernel(const int32_t* __restrict__ keys, long long L, int* __restrict__ counts)
-{
-    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (i < L) atomicAdd(&counts[keys[i]], 1);
 }
 
 // Stand-alone form of the tile scatter (tests, tools): an UNSORTED table keys[L] (0 = padding ... max_tile) / vals[L] -> tile_start
@@ -1777,8 +1888,7 @@ LG_API int lg_tile_group(const int32_t* keys, const int32_t* vals, long long L, 
     LG_REQUIRE(keys, vals, out_vals);
     err = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)(max_tile + 2), s);
     if (err != hipSuccess) return (int)err;
-    hipLaunchKernelGGL(tile_count_kernel, dim3(lg_cdiv(L, TPB)), dim3(TPB), 0, s, keys, L, counts);
-    return lg_tile_scatter_gated(keys, vals, L, nullptr, max_tile, counts, cursor, tile_start, out_vals, nullptr, stream);
+    return lg_tile_scatter_gated(keys, vals, L, nullptr, max_tile, counts, 1, cursor, tile_start, out_vals, nullptr, stream);
 }
 
 LG_API int lg_memset_async(void* ptr, int value, long long bytes, void* stream)

@@ -529,15 +529,15 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
     const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(f, N, ntiles));
     int rc;
     if (use_tile_scatter(N, ntiles)) {
-        // TILE mode without a sort: the emission counts the instances per key, one workgroup turns the counts into the range table and
-        // write cursors, one pass drops the values at their cursors, and the per-tile sort orders every list by (depth, id)
+        // TILE mode without a sort: the emitted keys are counted per key (LDS-aggregated), one workgroup turns the counts into the range
+        // table and write cursors, one pass drops the values at their cursors, and the per-tile sort orders every list by (depth, id)
         rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
                                (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
-                               qcount, (uint32_t*)(w + f.dup_entries), nullptr, 0, bits, tcount, nullptr, 0,
+                               qcount, (uint32_t*)(w + f.dup_entries), nullptr, 0, bits, nullptr, nullptr, 0,
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
                                (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * N : 0, gate, fail_flag, s);
         if (rc) return rc;
-        rc = lg_tile_scatter_gated((const int32_t*)(w + f.tk_a), (const int32_t*)(w + f.tv_a), Ls, total_dev, ntiles, tcount, (int*)(w + f.tile_cursor),
+        rc = lg_tile_scatter_gated((const int32_t*)(w + f.tk_a), (const int32_t*)(w + f.tv_a), Ls, total_dev, ntiles, tcount, 1, (int*)(w + f.tile_cursor),
                                    (int32_t*)(w + f.tile_start), (int32_t*)(w + f.tv_b), gate, s);
         if (rc) return rc;
         rc = lg_tile_depth_sort_gated((int32_t*)(w + f.tv_b), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L, (int)N, ntiles,

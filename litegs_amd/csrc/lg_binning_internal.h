@@ -45,7 +45,8 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
 
 // grouping by tile without a sort (binning.hip "Tile scatter"): per-key counts -> range table + cursors -> values dropped at their
 // tile's cursor.  Order inside a tile is arbitrary: follow with lg_tile_depth_sort_gated(any_order = 1).
-int lg_tile_scatter_gated(const int32_t* keys, const int32_t* vals, long long L, const int* n_dev, int max_tile, const int* counts, int* cursor,
+int lg_tile_scatter_gated(const int32_t* keys, const int32_t* vals, long long L, const int* n_dev, int max_tile,
+                          int* counts /*zero on entry if count_keys, else filled by the emission*/, int count_keys, int* cursor,
                           int32_t* tile_start /*pre-filled with -1*/, int32_t* out_vals, const int* gate, void* stream);
 
 // gathered inclusive scan in one launch; status = lg_scan_status_words(n) zero words; host_total (nullable) = pinned host int

@@ -149,7 +149,17 @@ __device__ __forceinline__ void rec_request(f32x16& rec, const float* __restrict
 }
 __device__ __forceinline__ void rec_wait(f32x16& rec) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rec)); }
 
-static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_bwd_noatomic = 0;       // launch variants (lg_set_tuning)
+// the id of a list position through the scalar path as well (one s_load_dword, two splats ahead of its use): no vector load of the
+// list, no v_readlane per splat
+__device__ __forceinline__ void id_request(int& id, const int* __restrict__ sp, unsigned byte_off)
+{
+    asm volatile("s_load_dword %0, %1, %2" : "=s"(id) : "s"(sp), "s"(byte_off));
+}
+__device__ __forceinline__ void rec_id_wait(f32x16& rec, int& id) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rec), "+s"(id)); }
+// v_min_f32 without the canonicalising v_max the compiler puts in front of fminf when it cannot prove its operand quiet
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_bwd_noatomic = 0, g_fwd_fast = 1;       // launch variants (lg_set_tuning)
 
 // ---------------------------------------------------------------------------------------------
 // a13 rasterize_forward (reference: GR/raster.cu:162-332)
@@ -206,6 +216,87 @@ __device__ __forceinline__ bool fwd_splat(FwdState<PPL>& st, const f32x16& rec, 
     return true;
 }
 
+// the blend loop of the generic kernel (any tile shape, statistics): ids 64 at a time in a VGPR, handed out by v_readlane
+template <int PPL, bool STAT>
+__device__ __forceinline__ void fwd_generic_loop(FwdState<PPL>& st, const int* __restrict__ sp, const float* __restrict__ pk, int n, int lane,
+                                                 int* __restrict__ frag_count, float* __restrict__ frag_weight, int& visited, bool& live)
+{
+    // ids of the list, 64 at a time: lane l of `nxt` holds the id at position c0 + l + 1, i.e. the splat to REQUEST while
+    // position c0 + l is blended (clamped at the list end: the surplus request is never used)
+    unsigned off_a = (unsigned)rfl(sp[0]) << 6, off_b = 0;
+    f32x16 ra, rb;
+    rec_request(ra, pk, off_a);
+    int nxt = sp[min(lane + 1, n - 1)];
+    rec_wait(ra);
+    for (int c0 = 0; c0 < n && live; c0 += 64) {
+        const int cnt = min(64, n - c0);                            // positions c0 .. c0 + cnt - 1 in this chunk
+        const int nxt_next = sp[min(c0 + 64 + lane + 1, n - 1)];    // next chunk's ids, in flight while this chunk is blended
+        for (int j = 0; j < cnt; j += 2) {                          // cnt is even except possibly in the last chunk
+            off_b = (unsigned)__builtin_amdgcn_readlane(nxt, j) << 6;
+            rec_request(rb, pk, off_b);
+            live = fwd_splat<PPL, STAT>(st, ra, c0 + j + 1, lane, off_a, frag_count, frag_weight);
+            rec_wait(rb);
+            if (!live) break;
+            visited = c0 + j + 1;
+            if (j + 1 >= cnt) break;                                // odd tail: the list ends here
+            off_a = (unsigned)__builtin_amdgcn_readlane(nxt, j + 1) << 6;
+            rec_request(ra, pk, off_a);
+            live = fwd_splat<PPL, STAT>(st, rb, c0 + j + 2, lane, off_b, frag_count, frag_weight);
+            rec_wait(ra);
+            if (!live) break;
+            visited = c0 + j + 2;
+        }
+        nxt = nxt_next;
+    }
+}
+
+// The default 8x16 tile without statistics, forward: the lane's two pixels as packed 2-vectors (exponent, weight, colour accumulation,
+// transmittance: v_pk_* do two pixels per issue slot), splat ids through the scalar path, last_contributor as an add-with-carry of the
+// activity mask, and a splat that no pixel takes (alpha < 1/256 everywhere) leaves after the alpha evaluation -- with alpha = 0 the
+// colour sums and the transmittance keep their values.  36 -> 24 VALU instructions per (tile, splat).
+struct FwdFast {
+    float X;
+    v2f Y, T, Cr, Cg, Cb;
+    int lc0, lc1;
+};
+// lc += (lane's bit of mask): one add-with-carry, the carry-in being the activity mask itself
+__device__ __forceinline__ void add_mask_bit(int& lc, unsigned long long mask)
+{
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %2" : "+v"(lc), "=s"(carry_out) : "s"(mask));
+}
+// lanes of mask: min(a, b); other lanes: 0 -- the mask is the SGPR pair a ballot left, used as it is
+__device__ __forceinline__ float min_where(float a, float b, unsigned long long mask)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2\n\tv_cndmask_b32_e64 %0, 0, %0, %3" : "=&v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ bool fwd_splat_fast(FwdFast& st, const f32x16& rec)
+{
+    const unsigned long long act0 = __builtin_amdgcn_ballot_w64(st.T.x > 1.0f / 8192), act1 = __builtin_amdgcn_ballot_w64(st.T.y > 1.0f / 8192);
+    if ((act0 | act1) == 0ull) return false;         // checked BEFORE blending, as the reference does
+    const float dx = rec[R_PX] - st.X;
+    const float t1 = rec[R_B2] * dx;
+    const float t0 = __builtin_fmaf(rec[R_A2] * dx, dx, rec[R_LO]);
+    const v2f dyv = rec[R_PY] - st.Y;
+    const v2f qv = dyv * (rec[R_C2] * dyv + t1) + t0;
+    const float E0 = __builtin_amdgcn_exp2f(qv.x);
+    const float E1 = __builtin_amdgcn_exp2f(qv.y);
+    add_mask_bit(st.lc0, act0);                      // == number of splats visited while active (activity is monotone)
+    add_mask_bit(st.lc1, act1);
+    const unsigned long long val0 = act0 & __builtin_amdgcn_ballot_w64(E0 >= 1.0f / 256), val1 = act1 & __builtin_amdgcn_ballot_w64(E1 >= 1.0f / 256);
+    if ((val0 | val1) == 0ull) return true;          // nobody takes this splat: alpha = 0 everywhere
+    const float amax = 255.0f / 256;
+    const v2f alpha = { min_where(E0, amax, val0), min_where(E1, amax, val1) };
+    const v2f w = st.T * alpha;
+    st.Cr = rec[R_CR] * w + st.Cr;
+    st.Cg = rec[R_CG] * w + st.Cg;
+    st.Cb = rec[R_CB] * w + st.Cb;
+    st.T = st.T - w;                                 // T * (1 - alpha)
+    return true;
+}
+
 template <int TH, int TW, bool STAT>
 __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
                                                              const float* __restrict__ packed, const int* __restrict__ tiles, int K,
@@ -214,7 +305,7 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
                                                              const int* __restrict__ order, int* __restrict__ tile_work,
                                                              const int* __restrict__ sched_in, int* __restrict__ sched_out, int zb_check,
                                                              int* __restrict__ fail_flag, const int* __restrict__ gate,
-                                                             int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode)
+                                                             int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int fast)
 {
     if (gate != nullptr && *gate == 0) return;              // fallback launch of the depth-bound culling that is not needed
     constexpr int PPL = TileMap<TH, TW>::PPL;
@@ -246,34 +337,44 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     bool live = true;
     const int n = (start >= 0 && end > start) ? end - start : 0;
     const int* __restrict__ sp = sorted_points + (size_t)view * L + (start >= 0 ? start : 0);
-    if (n > 0) {
-        // ids of the list, 64 at a time: lane l of `nxt` holds the id at position c0 + l + 1, i.e. the splat to REQUEST while
-        // position c0 + l is blended (clamped at the list end: the surplus request is never used)
-        unsigned off_a = (unsigned)rfl(sp[0]) << 6, off_b = 0;
-        f32x16 ra, rb;
-        rec_request(ra, pk, off_a);
-        int nxt = sp[min(lane + 1, n - 1)];
-        rec_wait(ra);
-        for (int c0 = 0; c0 < n && live; c0 += 64) {
-            const int cnt = min(64, n - c0);                            // positions c0 .. c0 + cnt - 1 in this chunk
-            const int nxt_next = sp[min(c0 + 64 + lane + 1, n - 1)];    // next chunk's ids, in flight while this chunk is blended
-            for (int j = 0; j < cnt; j += 2) {                          // cnt is even except possibly in the last chunk
-                off_b = (unsigned)__builtin_amdgcn_readlane(nxt, j) << 6;
-                rec_request(rb, pk, off_b);
-                live = fwd_splat<PPL, STAT>(st, ra, c0 + j + 1, lane, off_a, frag_count, frag_weight);
-                rec_wait(rb);
+    if constexpr (PPL == 2 && !STAT) {
+        if (n > 0 && fast) {
+            FwdFast f;
+            f.X = st.X; f.Y = v2f{ st.Y[0], st.Y[1] }; f.T = v2f{ 1.0f, 1.0f };
+            f.Cr = f.Cg = f.Cb = v2f{ 0.0f, 0.0f };
+            f.lc0 = f.lc1 = 0;
+            // position p's record is requested while position p - 1 is blended, its id one step earlier (clamped at the list end: the
+            // surplus requests are never used)
+            int id_a, id_b;
+            f32x16 ra, rb;
+            id_request(id_a, sp, 0u);
+            id_request(id_b, sp, (unsigned)min(1, n - 1) << 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id_a), "+s"(id_b));
+            rec_request(ra, pk, (unsigned)id_a << 6);
+            rec_wait(ra);
+            for (int pos = 0; pos < n; pos += 2) {                            // `ra` holds position pos
+                rec_request(rb, pk, (unsigned)id_b << 6);
+                id_request(id_a, sp, (unsigned)min(pos + 2, n - 1) << 2);
+                live = fwd_splat_fast(f, ra);
+                rec_id_wait(rb, id_a);
                 if (!live) break;
-                visited = c0 + j + 1;
-                if (j + 1 >= cnt) break;                                // odd tail: the list ends here
-                off_a = (unsigned)__builtin_amdgcn_readlane(nxt, j + 1) << 6;
-                rec_request(ra, pk, off_a);
-                live = fwd_splat<PPL, STAT>(st, rb, c0 + j + 2, lane, off_b, frag_count, frag_weight);
-                rec_wait(ra);
+                visited = pos + 1;
+                if (pos + 1 >= n) break;                                       // odd tail: the list ends here
+                rec_request(ra, pk, (unsigned)id_a << 6);
+                id_request(id_b, sp, (unsigned)min(pos + 3, n - 1) << 2);
+                live = fwd_splat_fast(f, rb);
+                rec_id_wait(ra, id_b);
                 if (!live) break;
-                visited = c0 + j + 2;
+                visited = pos + 2;
             }
-            nxt = nxt_next;
+            st.T[0] = f.T.x; st.T[1] = f.T.y;
+            st.Cr[0] = f.Cr.x; st.Cr[1] = f.Cr.y; st.Cg[0] = f.Cg.x; st.Cg[1] = f.Cg.y; st.Cb[0] = f.Cb.x; st.Cb[1] = f.Cb.y;
+            st.lc[0] = f.lc0; st.lc[1] = f.lc1;
+        } else if (n > 0) {
+            fwd_generic_loop<PPL, STAT>(st, sp, pk, n, lane, frag_count, frag_weight, visited, live);
         }
+    } else if (n > 0) {
+        fwd_generic_loop<PPL, STAT>(st, sp, pk, n, lane, frag_count, frag_weight, visited, live);
     }
     // work done for this tile (splats walked before every pixel saturated): the schedule key of the backward and of the next visit
     if (tile_work != nullptr && lane == 0) tile_work[(size_t)view * (ntiles + 1) + tile] = visited;
@@ -356,7 +457,7 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_RF(A_, B_, S_) hipLaunchKernelGGL((raster_forward_kernel<A_, B_, S_>), grid, block, 0, s, sorted_points, start_index, packed, \
-                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map)
+                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map, g_fwd_fast)
 #define DISPATCH_RF(A_, B_) do { if (enable_stat) LAUNCH_RF(A_, B_, true); else LAUNCH_RF(A_, B_, false); } while (0)
     if (TH == 8 && TW == 16) DISPATCH_RF(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RF(16, 16);
@@ -734,11 +835,6 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
 //  * the atomic's address is a scalar base (record of the splat) + a constant per-lane offset.
 // Results: the same nine sums (the additions inside a lane associate differently: fp32 rounding only).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void id_request(int& id, const int* __restrict__ sp, unsigned byte_off)
-{
-    asm volatile("s_load_dword %0, %1, %2" : "=s"(id) : "s"(sp), "s"(byte_off));
-}
-__device__ __forceinline__ void rec_id_wait(f32x16& rec, int& id) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rec), "+s"(id)); }
 
 // Nine totals; the adds behind the permlane32 swaps are packed (two totals per issue slot).  Input order chosen so that every packed
 // operand is a pair the producer leaves in adjacent registers: (v0, v2), (v1, v3), (v4, v6) and (v5, v7) -- v5 / v7 being the
@@ -763,8 +859,6 @@ __device__ __forceinline__ float reduce9_pk(float v0, float v1, float v2, float 
     r += xor_dpp1(r);
     return r;
 }
-// v_min_f32 without the canonicalising v_max the compiler puts in front of fminf when it cannot prove its operand quiet
-__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 struct BwdFast {
     float X;
@@ -775,7 +869,7 @@ struct BwdFast {
 
 template <bool TRANS, bool CHECK>
 __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, int pos, unsigned pid_off, unsigned slot_off,
-                                               unsigned long long writers, float* __restrict__ pg)
+                                               unsigned long long writers, float* __restrict__ pg, unsigned private_base)
 {
     const float dx = rec[R_PX] - st.X;
     const float t1 = rec[R_B2] * dx;
@@ -812,7 +906,9 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     // order: (Mx My Mxx Mxy Myy dr DB DG M0) -- dg / db swapped against the record, see wave_slot_fast
     const float tot = reduce9_pk(mx, s1, dx * mx, dx * s1, s2, crg.x, v_b, crg.y, s0);
     // ONE atomic instruction from the nine lanes that hold a total: scalar base = the splat's gradient record
-    const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pg) + pid_off);
+    // private_base != 0 (measurement only, lg_set_tuning key 6 = 2): every (tile, position mod 64) adds into a line of its own
+    const unsigned target = private_base ? private_base + (((unsigned)pos & 63u) << 6) : pid_off;
+    const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pg) + target);
     asm volatile("s_mov_b64 exec, %2\n\t"
                  "global_atomic_add_f32 %0, %1, %3\n\t"
                  "s_mov_b64 exec, -1" : : "v"(slot_off), "v"(tot), "s"(writers), "s"(base) : "memory");
@@ -871,7 +967,9 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     if (n <= 0) return;
     int myslot = wave_slot(lane);
     myslot = myslot == 6 ? 7 : (myslot == 7 ? 6 : myslot);       // reduce9_pk is fed (.., dr, db, dg, ..)
-    const unsigned long long writers = no_atomics ? 0ull : __ballot(myslot >= 0);
+    // no_atomics (measurement only, WRONG gradients): 1 = no atomic at all, 2 = uncontended private lines, 3 = one lane (one dword) per record
+    const unsigned long long writers = no_atomics == 1 ? 0ull : (no_atomics == 3 ? 1ull : __ballot(myslot >= 0));
+    const unsigned private_base = no_atomics == 2 ? (unsigned)((((unsigned long long)tile << 12) % (((unsigned long long)N << 6) - 16384ull)) & ~4095ull) + 64u : 0u;
     const unsigned slot_off = (unsigned)max(myslot, 0) * 4u;
     // An even number of iterations (two per trip over a ping-pong pair of record registers): if n is odd the walk starts one
     // position early, at `n`, with the record of position n-1 -- no pixel has last_contributor > n, so that splat adds nothing.
@@ -890,12 +988,12 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     {                                                                                                         \
         rec_request(rb, pk, off_b);                                                                           \
         id_request(id_a, sp, (unsigned)max(pos - 2, 0) << 2);                                                 \
-        bwd_splat_fast<TRANS, CHK>(st, ra, pos, off_a, slot_off, writers, pg);                                \
+        bwd_splat_fast<TRANS, CHK>(st, ra, pos, off_a, slot_off, writers, pg, private_base);                                \
         rec_id_wait(rb, id_a);                                                                                \
         off_a = (unsigned)id_a << 6;                                                                          \
         rec_request(ra, pk, off_a);                                                                           \
         id_request(id_b, sp, (unsigned)max(pos - 3, 0) << 2);                                                 \
-        bwd_splat_fast<TRANS, CHK>(st, rb, pos - 1, off_b, slot_off, writers, pg);                            \
+        bwd_splat_fast<TRANS, CHK>(st, rb, pos - 1, off_b, slot_off, writers, pg, private_base);                            \
         rec_id_wait(ra, id_b);                                                                                \
         off_b = (unsigned)id_b << 6;                                                                          \
         pos -= 2;                                                                                             \
@@ -912,6 +1010,7 @@ LG_API int lg_set_tuning(int key, int value)
     case 2: g_fwd_map = value; return 0;                                      // ... of the blend forward
     case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
     case 6: g_bwd_noatomic = value; return 0;                                 // measurement only: 1 = the fast blend backward computes everything but issues no atomics (WRONG gradients)
+    case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics
     default: return (int)hipErrorInvalidValue;
     }

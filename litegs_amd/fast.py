@@ -45,6 +45,9 @@ def _apply_env_options() -> None:
         if mode not in ("tile", "global", "auto"):
             raise ValueError("LITEGS_DEPTH_ORDER must be 'global', 'tile' or 'auto'")
         check(lib().lg_fused_set_option(0, {"global": 0, "tile": 1, "auto": 2}[mode]), "set_option")
+    scatter = os.environ.get("LITEGS_TILE_SCATTER")       # 1: group by tile with counts + cursors in the per-tile mode; 0: stable tile radix sort
+    if scatter is not None:
+        check(lib().lg_fused_set_option(2, 1 if scatter != "0" else 0), "set_option")
 
 
 class FusedRenderer:

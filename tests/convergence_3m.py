@@ -59,6 +59,9 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
         else:
             for k in order:
                 tr.step(int(k))
+        if os.environ.get("LITEGS_CONV_VERBOSE"):
+            torch.cuda.synchronize()
+            log(f"   epoch {epoch} done: {tr.n_chunks * tr.S} points, degree {tr.degree}")
         if (epoch + 1) % eval_every == 0 or epoch == epochs - 1:
             curve.append(evaluate()); sizes.append(tr.n_chunks * tr.S); at.append((epoch + 1) * cfg["frames"])
     torch.cuda.synchronize()
@@ -75,7 +78,7 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
     return info
 
 
-def run(iterations=30000, frames=150, n=3_000_000, W=1920, H=1080, focal=1200.0, seed=0, runs=3, eval_every=10, log=print):
+def run(iterations=30000, frames=150, n=3_000_000, W=1920, H=1080, focal=1200.0, seed=0, runs=3, eval_every=10, log=lambda *a: print(*a, flush=True)):
     cfg = dict(n=n, W=W, H=H, focal=focal, frames=frames, seed=seed)
     epochs = iterations // frames
     t0 = time.time()

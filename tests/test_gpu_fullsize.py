@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, case, oracle_forward
+from tests.util import assert_close, case, oracle_forward, GRAD_FLIP, IMG_FLIP
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +45,7 @@ def test_fullsize_render_forward_backward_matches_oracle(oracle, name):
     assert abs(int(rd.fb_total[0]) - res.n_instances) <= max(2, int(2e-6 * res.n_instances)), (int(rd.fb_total[0]), res.n_instances)
     # image, 1e-4 (north_star), with the bounded allowance for threshold flips documented in tests/util.py
     ref_img = np.clip(res.img[..., :H, :W], 0, 1)
-    assert_close(img.detach().cpu().numpy(), ref_img, flip_frac=5e-5, name="img")
+    assert_close(img.detach().cpu().numpy(), ref_img, **IMG_FLIP, name="img")
     d_img = np.zeros_like(res.img)
     inside = (res.img[..., :H, :W] >= 0) & (res.img[..., :H, :W] <= 1)
     d_img[..., :H, :W] = w_host * inside
@@ -53,7 +53,7 @@ def test_fullsize_render_forward_backward_matches_oracle(oracle, name):
     for p, g_ref, nm in zip(params, grads, ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]):
         got = p.grad.compacted_values.cpu().numpy()
         got = got.reshape(g_ref.shape[:-2] + (-1, g_ref.shape[-1]))[..., :res.nvis, :]
-        assert_close(got.reshape(g_ref.shape), g_ref, atol=1e-4, flip_frac=1e-3, flip_atol=5e-2, normalize=True, name=f"grad.{nm}")
+        assert_close(got.reshape(g_ref.shape), g_ref, atol=1e-4, normalize=True, **GRAD_FLIP, name=f"grad.{nm}")
 
 
 @pytest.mark.parametrize("name", ["10k_400", "500k_1080p"])
@@ -69,7 +69,7 @@ def test_fullsize_operator_path(oracle, name):
                                                    c["degree"], (H, W), pp)
     assert int(vis_num.item()) == res.nvis
     assert int((prim_vis > 0).sum().item()) == int((res.alloc > 0).sum())
-    assert_close(img.detach().cpu().numpy(), np.clip(res.img[..., :H, :W], 0, 1), flip_frac=5e-5, name="img")
+    assert_close(img.detach().cpu().numpy(), np.clip(res.img[..., :H, :W], 0, 1), **IMG_FLIP, name="img")
     img.sum().backward()
     assert all(torch.isfinite(p.grad.compacted_values).all() for p in params)
 

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, case, oracle_forward
+from tests.util import assert_close, case, oracle_forward, GRAD_FLIP, IMG_FLIP
 
 pytestmark = pytest.mark.gpu
 
@@ -48,10 +48,10 @@ def test_fused_render_matches_oracle_and_operator_path(oracle, name):
     d_img[..., :H, :W] = w.cpu().numpy() * inside
     (grads, _) = oracle.render_backward(res, c["params"], c["view"], c["proj"], d_img, H, W, c["degree"])
     for it in range(2):
-        assert_close(outs[it][0], ref_img, flip_frac=5e-5, name=f"img[{it}]")
+        assert_close(outs[it][0], ref_img, **IMG_FLIP, name=f"img[{it}]")
         for g, g_ref, nm in zip(outs[it][1], grads, ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]):
             got = g.reshape(g_ref.shape[:-2] + (-1, g_ref.shape[-1]))[..., :res.nvis, :]
-            assert_close(got.reshape(g_ref.shape), g_ref, atol=1e-4, flip_frac=1e-3, flip_atol=5e-2, normalize=True, name=f"grad.{nm}[{it}]")
+            assert_close(got.reshape(g_ref.shape), g_ref, atol=1e-4, normalize=True, **GRAD_FLIP, name=f"grad.{nm}[{it}]")
 
     # 2. vs the operator path: same arithmetic -> identical image, gradients equal up to atomic summation order
     for p in params:
@@ -166,14 +166,14 @@ def test_fused_render_with_underpredicted_table(oracle):
     ref_img = np.clip(ref_img[..., :H, :W], 0, 1)
     full_img = np.clip(res.img[..., :H, :W], 0, 1)
     assert np.abs(ref_img - full_img).max() > 0.05, "the truncation must be visible in this case"
-    assert_close(img.cpu().numpy(), ref_img, flip_frac=5e-5, name="truncated img")
+    assert_close(img.cpu().numpy(), ref_img, **IMG_FLIP, name="truncated img")
     # the truncation is silent in the reference; here the next visit notices (the true total came back through the feedback slot),
     # counts it and sizes its table exactly again
     with torch.no_grad():
         img3, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
         torch.cuda.synchronize()
     assert rd.truncated_visits == 1 and rd.last_sizes[1] == total
-    assert_close(img3.cpu().numpy(), full_img, flip_frac=5e-5, name="healed img")
+    assert_close(img3.cpu().numpy(), full_img, **IMG_FLIP, name="healed img")
 
 
 def test_underpredicted_table_in_per_tile_depth_mode(oracle):
@@ -224,11 +224,11 @@ def test_underpredicted_table_in_per_tile_depth_mode(oracle):
         ref_img = np.clip(ref_img[..., :H, :W], 0, 1)
         full_img = np.clip(res.img[..., :H, :W], 0, 1)
         assert np.abs(ref_img - full_img).max() > 0.05
-        assert_close(img.cpu().numpy(), ref_img, flip_frac=5e-5, name="truncated img (tile mode)")
+        assert_close(img.cpu().numpy(), ref_img, **IMG_FLIP, name="truncated img (tile mode)")
         with torch.no_grad():
             img3, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
             torch.cuda.synchronize()
         assert rd.truncated_visits == 1 and rd.last_sizes[1] == total
-        assert_close(img3.cpu().numpy(), full_img, flip_frac=5e-5, name="healed img (tile mode)")
+        assert_close(img3.cpu().numpy(), full_img, **IMG_FLIP, name="healed img (tile mode)")
     finally:
         L.lg_fused_set_option(0, prev)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, case, oracle_forward, d_img_for
+from tests.util import assert_close, case, oracle_forward, d_img_for, GRAD_FLIP
 
 pytestmark = pytest.mark.gpu
 
@@ -305,7 +305,7 @@ def test_raster_backward(F, oracle, name, trans):
                                dev(d_trans) if trans else None, None, torch.tensor(0.5).cuda(), H, W, 8, 16, True)
     names = ["d_ndc", "d_cov2d_inv", "d_color", "d_opacity", "err_sum", "err_square_sum"]
     for g, r, n in zip([got[0], got[1], got[2], got[3], got[5]], ref, [names[0], names[1], names[2], names[3], names[5]]):
-        assert_close(host(g), r, atol=1e-4, flip_frac=5e-4, flip_atol=5e-2, normalize=True, name=n)
+        assert_close(host(g), r, atol=1e-4, normalize=True, **GRAD_FLIP, name=n)
     assert (host(got[4]) == 0).all()
     assert np.abs(ref[0]).max() > 0
 

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, case, oracle_forward, pinned_count
+from tests.util import assert_close, case, oracle_forward, pinned_count, GRAD_FLIP, IMG_FLIP
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +27,7 @@ def test_render_forward_backward_matches_oracle(oracle, name):
     valid_length = vis_num * pp.cluster_size
     img, trans, depth, normal, prim_vis = R.render(view, proj, xyz, scale, rot, color, opacity, valid_length, None, None, c["degree"], (H, W), pp)
     ref_img = np.clip(res.img[..., :H, :W], 0, 1)
-    assert_close(img.detach().cpu().numpy(), ref_img, flip_frac=5e-5, name="img")
+    assert_close(img.detach().cpu().numpy(), ref_img, **IMG_FLIP, name="img")
     assert int((prim_vis > 0).sum().item()) == int((res.alloc > 0).sum())
 
     rng = np.random.default_rng(4)
@@ -42,7 +42,7 @@ def test_render_forward_backward_matches_oracle(oracle, name):
         g = p.grad
         assert g.shape == p.shape, "CompactedTensor must claim the full parameter shape"
         vals = g.compacted_values.cpu().numpy().reshape(g_ref.shape[:-2] + (-1, g_ref.shape[-1]))[..., :res.nvis, :]
-        assert_close(vals.reshape(g_ref.shape), g_ref, atol=1e-4, flip_frac=1e-3, flip_atol=5e-2, normalize=True, name=f"grad.{nm}")
+        assert_close(vals.reshape(g_ref.shape), g_ref, atol=1e-4, normalize=True, **GRAD_FLIP, name=f"grad.{nm}")
 
 
 def test_training_step_updates_only_visible_chunks(oracle):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, case
+from tests.util import assert_close, case, GRAD_FLIP, IMG_FLIP
 
 pytestmark = pytest.mark.gpu
 
@@ -51,10 +51,10 @@ def test_tile_shapes_match_oracle(oracle, tile):
             rd = fast.FusedRenderer(1, H, W, tile=tile)
             img, vis_id, vis_num = rd.render(fast.CameraFrame(view, proj, planes, 0), origin, extend, *params, c["degree"])
         assert int(vis_num.item()) == res.nvis
-        assert_close(img.detach().cpu().numpy(), ref_img, flip_frac=5e-5, name=f"img[{mode}]")
+        assert_close(img.detach().cpu().numpy(), ref_img, **IMG_FLIP, name=f"img[{mode}]")
         (img * dev(w)).sum().backward()
         for p, g_ref, nm in zip(params, grads, NAMES):
             vals = p.grad.compacted_values.cpu().numpy().reshape(g_ref.shape[:-2] + (-1, g_ref.shape[-1]))[..., :res.nvis, :]
-            assert_close(vals.reshape(g_ref.shape), g_ref, atol=1e-4, flip_frac=1e-3, flip_atol=5e-2, normalize=True, name=f"grad.{nm}[{mode}]")
+            assert_close(vals.reshape(g_ref.shape), g_ref, atol=1e-4, normalize=True, **GRAD_FLIP, name=f"grad.{nm}[{mode}]")
         imgs.append(img.detach().cpu().numpy())
     assert np.array_equal(imgs[0], imgs[1]), "executor and operator path must render the same image bit for bit"

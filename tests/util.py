@@ -16,7 +16,12 @@ from litegs_amd import synthetic as S
 # elements) and are bounded, not ignored: flipped elements must still be within FLIP_ATOL.
 ATOL = 1e-4
 FLIP_FRAC = 2e-5
-FLIP_ATOL = 2e-2
+# A flipped decision moves a pixel by at most one minimal contribution, colour * alpha_min = 1/256 = 3.9e-3 (observed: <= 1.1e-3).
+FLIP_ATOL = 5e-3
+# Allowances of the comparisons that ever showed a flip, sized from what the GPU runs observe (profiles/r03_flip_counts.jsonl: <= 24 of
+# 6.2 M pixels, <= 4 gradient elements beyond 1e-4 normalised with max 2.1e-4) -- 10x the observation, not a fraction of the tensor:
+IMG_FLIP = dict(flip_frac=5e-5, flip_max=250)
+GRAD_FLIP = dict(flip_frac=1e-4, flip_max=40, flip_atol=2e-3)
 
 
 _PINS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flip_pins.json")
@@ -57,9 +62,9 @@ def pinned_count(name, count, size, ceiling, max_err=0.0, atol=ATOL):
         assert count <= pin, f"{key}: {count} flipped elements, pinned at {pin}"
 
 
-def assert_close(got, ref, atol=ATOL, flip_frac=0.0, flip_atol=FLIP_ATOL, normalize=False, name=""):
-    """|got - ref| <= atol everywhere, except for at most ceil(flip_frac * size) "flipped" elements, which must still be within
-    flip_atol.  Whenever an allowance is given, the OBSERVED count is logged (gpurun_out/flip_counts.jsonl, and printed) and must not
+def assert_close(got, ref, atol=ATOL, flip_frac=0.0, flip_atol=FLIP_ATOL, normalize=False, name="", flip_max=None):
+    """|got - ref| <= atol everywhere, except for at most min(ceil(flip_frac * size), flip_max) "flipped" elements, which must still be
+    within flip_atol.  Whenever an allowance is given, the OBSERVED count is logged (gpurun_out/flip_counts.jsonl, and printed) and must not
     exceed the count pinned for this (test, tensor) in tests/golden/flip_pins.json; an unpinned comparison fails unless
     LITEGS_COLLECT_FLIPS=1 (the collection run that produces the pins)."""
     got = np.asarray(got, dtype=np.float64)
@@ -73,6 +78,8 @@ def assert_close(got, ref, atol=ATOL, flip_frac=0.0, flip_atol=FLIP_ATOL, normal
     bad = err > atol
     nbad = int(bad.sum())
     allowed = int(np.ceil(flip_frac * err.size))
+    if flip_max is not None:
+        allowed = min(allowed, int(flip_max))
     if flip_frac > 0:
         pinned_count(name, nbad, int(err.size), allowed, float(err.max()) if err.size else 0.0, atol)
     assert nbad <= allowed, f"{name}: {nbad} elements exceed {atol} (allowed {allowed}); max err {err.max():.3e}"

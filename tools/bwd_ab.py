@@ -43,9 +43,22 @@ def ab(state):
     for v, name in ((0, "generic"), (1, "fast"), (0, "generic"), (1, "fast")):
         L.lg_set_tuning(5, v)
         measure(f"{state}: {name} kernel")
-    L.lg_set_tuning(6, 1)                               # measurement only: no gradient atomics (lr is zero here: nothing is trained on them)
-    measure(f"{state}: fast kernel, atomics off")
+    # measurement only (lr is zero here: nothing is trained on the wrong gradients): no atomics / uncontended private lines / one dword per record
+    for v, name in ((1, "atomics off"), (2, "atomics to private lines"), (3, "one-dword atomics"), (0, "normal")):
+        L.lg_set_tuning(6, v)
+        measure(f"{state}: fast kernel, {name}")
     L.lg_set_tuning(6, 0)
+    for v, name in ((0, "generic"), (1, "packed"), (0, "generic"), (1, "packed")):      # blend forward: generic loop vs the packed 8x16 loop
+        L.lg_set_tuning(7, v)
+        for i in range(8):
+            tr.forward_only(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(64):
+            tr.forward_only(i % 8)
+        torch.cuda.synchronize()
+        print(f"{state}: forward only, {name} blend forward   {(time.perf_counter() - t0) / 64 * 1e3:7.4f} ms", flush=True)
+    L.lg_set_tuning(7, 1)
     L.lg_set_tuning(4, 0)
     measure(f"{state}: fast kernel, no tile schedule")
     L.lg_set_tuning(4, 1)
