@@ -1681,18 +1681,24 @@ __global__ void __launch_bounds__(1024) tile_offsets_kernel(const int* __restric
                                                             int32_t* __restrict__ out /*[max_tile + 2], pre-filled with -1*/, const int* __restrict__ gate)
 {
     if (gate != nullptr && *gate == 0) return;
+    // One workgroup; the counts pass through LDS so that every global access is coalesced (a thread scanning 16 consecutive bins
+    // straight from memory touches a cache line of its own per load: 23 us for 16 201 bins; this form: a third of that).
+    constexpr int PER = 8, CHUNK = 1024 * PER;
+    __shared__ int sc[CHUNK + 1];          // sc[1 + i] = count of bin base + i; sc[0] = count of the bin in front of the chunk
+    __shared__ int so[CHUNK];              // range-table word of bin base + i (or -1)
     __shared__ int wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nb = max_tile + 1;
     const int total = (int)bounded_n(L, n_dev);              // == the sum of the counts: every emitted entry (padding included) was counted
-    constexpr int PER = 16;
     int carry = 0;
-    for (int base = 0; base < nb; base += 1024 * PER) {
-        const int b0 = base + t * PER;
+    for (int base = 0; base < nb; base += CHUNK) {
+        for (int i = t; i < CHUNK; i += 1024) sc[1 + i] = (base + i < nb) ? counts[base + i] : 0;
+        if (t == 0) sc[0] = base > 0 ? counts[base - 1] : 0;
+        __syncthreads();
         int c[PER], s = 0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { c[k] = (b0 + k < nb) ? counts[b0 + k] : 0; s += c[k]; }
-        const int before = (b0 > 0 && b0 < nb) ? counts[b0 - 1] : 0;      // count of the bin in front of this thread's first
+        for (int k = 0; k < PER; k++) { c[k] = sc[1 + t * PER + k]; s += c[k]; }
+        int prev = sc[t * PER];
         int incl = s;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int nbv = __shfl_up(incl, o); if (lane >= o) incl += nbv; }
@@ -1701,20 +1707,21 @@ __global__ void __launch_bounds__(1024) tile_offsets_kernel(const int* __restric
         int wbase = 0, round_total = 0;
         for (int w = 0; w < 16; w++) { if (w < wave) wbase += wsum[w]; round_total += wsum[w]; }
         int p = carry + wbase + incl - s;
-        int prev = before;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            const int bin = b0 + k;
-            if (bin < nb) {
-                cursor[bin] = p;
-                // tileRange (GR/binning.cu:228-264): a run's start; the word after a run that is followed by a gap and a later run
-                if (c[k] > 0) out[bin] = p;
-                else if (prev > 0 && p < total) out[bin] = p;
-            }
+            const int i = t * PER + k;
+            // tileRange (GR/binning.cu:228-264): a run's start; the word after a run that is followed by a gap and a later run
+            so[i] = (c[k] > 0 || (prev > 0 && p < total)) ? p : -1;
+            sc[1 + i] = p;                                    // becomes the cursor (each thread rewrites only its own slots)
             p += c[k];
             prev = c[k];
         }
         carry += round_total;
+        __syncthreads();
+        for (int i = t; i < CHUNK && base + i < nb; i += 1024) {
+            cursor[base + i] = sc[1 + i];
+            if (so[i] >= 0) out[base + i] = so[i];
+        }
         __syncthreads();
     }
     if (t == 0 && total > 0) out[max_tile + 1] = total;
