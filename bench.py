@@ -99,13 +99,15 @@ def percentiles(ms):
     return {"ms_p10": round(pick(0.10), 4), "ms_p50": round(pick(0.50), 4), "ms_p90": round(pick(0.90), 4), "samples": len(ms)}
 
 
-def timed_steps(step_fn, n):
+def timed_steps(step_fn, n, flush=None):
     """n steps, one event on the launch stream behind each: -> per-step milliseconds (start of the list = first step's duration)"""
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
     evs[0].record()
     for i in range(n):
         step_fn(i)
         evs[i + 1].record()
+    if flush is not None:
+        flush()
     torch.cuda.synchronize()
     return [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
 
@@ -192,11 +194,12 @@ def steady_state(tr, args, n_frames):
     t0 = time.perf_counter()
     for i in range(args.soak_steps):
         tr.step(i % n_frames)
+    tr.flush()
     torch.cuda.synchronize()
     soak_s = time.perf_counter() - t0
     reruns_soak = rd.fallbacks - fb0
     fb1 = rd.fallbacks
-    ms = timed_steps(lambda i: tr.step(i % n_frames), 100)
+    ms = timed_steps(lambda i: tr.step(i % n_frames), 100, tr.flush)
     reruns = rd.fallbacks - fb1
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -210,6 +213,7 @@ def steady_state(tr, args, n_frames):
            "gaussians_with_adam_history": int(fa.touched.sum().item()) if fa.touched is not None else None,
            "instances_emitted": int(rd.fb_total[0]), "instances_full": int(rd.full_total[0]),
            "unculled_reruns_in_soak": int(reruns_soak), "unculled_reruns_in_100_timed_steps": int(reruns),
+           "speculative_replayed_steps_total": int(tr.spec_replays),
            "margin_pct": sorted(set(int(m) for m in rd.margin))}
     out["roofline"] = roofline_probe(tr, list(range(n_frames)))
     out["finite"] = all(bool(torch.isfinite(p).all()) for p in tr.params)
@@ -337,6 +341,9 @@ def main():
     if args.operator_path and world > 1:
         raise SystemExit("--operator-path is a single-GPU measurement")
     tr = SyntheticTrainer(n, W, H, focal, n_frames=args.frames * world, scene=scene, fused=not args.operator_path)
+    # single-GPU executor: culled steps run speculatively (no gated repeat launches; a failed step is replayed by the trainer, exactly) --
+    # tr.flush() inside every timed region makes the replays part of what is timed
+    tr.speculative = (world == 1 and not args.operator_path and os.environ.get("LITEGS_SPECULATIVE", "1") != "0")
     hook = None
     if world > 1:
         from litegs_amd import dp
@@ -378,6 +385,7 @@ def main():
         tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
         step_no += 1
         step_events[i + 1].record()
+    tr.flush()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -437,7 +445,8 @@ def main():
         }
         if not args.operator_path:
             rd = tr.renderer
-            result["depth_bound_culling"] = {"enabled": bool(rd.cull_enabled), "margin_pct": sorted(set(int(m) for m in rd.margin)),
+            result["depth_bound_culling"] = {"enabled": bool(rd.cull_enabled), "speculative": bool(tr.speculative), "replayed_steps": int(tr.spec_replays),
+                                             "margin_pct": sorted(set(int(m) for m in rd.margin)),
                                              "unculled_reruns_observed": int(rd.fallbacks), "truncated_tables_observed": int(rd.truncated_visits),
                                              "visits": int(sum(rd.visits)),
                                              "full_instances": int(rd.full_total[frame_of(0)])}

@@ -214,6 +214,10 @@ int lg_l1_ssim_forward_raster(const float* img, int Hp, int Wp, const float* gt,
                               float* dmaps, float* partial, float* loss, void* stream);
 int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt, const float* dmaps, const float* grad_out,
                                int planes, int H, int W, float lam, float* d_img, void* stream);
+/* the training step's pair: lg_l1_ssim_forward_raster(loss = NULL) + this backward, which also writes the loss value from the forward's
+ * partial sums (same summation order as the stand-alone reduction: same bits) -- one launch less per step */
+int lg_l1_ssim_backward_raster_value(const float* img, int Hp, int Wp, const float* gt, const float* dmaps, const float* grad_out,
+                                     int planes, int H, int W, float lam, float* d_img, const float* partial, float* loss, void* stream);
 
 /* ---- fused.hip : native executor of the whole path (one C call enqueues a stage; same arithmetic as the operators above).
  * There is no counterpart in the reference (its executor is the Python in litegs/render/__init__.py:11-94 + wrapper.py); these
@@ -230,6 +234,11 @@ int lg_fused_set_option(int key, int value);
  * NULL = ascending ids).  Shapes the emission's workload, never the table (the per-tile sort orders by depth and id). */
 int lg_fused_set_emission_order(const int32_t* order, long long n);
 int lg_fused_get_option(int key);
+/* Speculative depth-bound culling (fused.hip "Speculative culling"): while a context is set, a culled lg_fused_stage2 enqueues no gated
+ * repeat; a violated bound raises *poison (sticky, device) and its pinned mirror, and every lg_fused_backward_adam returns at once while
+ * it is raised, otherwise stores step_id into *applied_host.  The caller replays the steps after *applied_host (the first one unculled)
+ * after clearing both words.  NULL poison switches back to the gated repeat.  Process-wide, like lg_fused_set_option. */
+int lg_fused_set_speculation(int* poison, int* poison_host, int* applied_host, int step_id);
 long long lg_fused_workspace1_bytes(long long N);
 long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW);
 long long lg_fused_total_offset(long long N);

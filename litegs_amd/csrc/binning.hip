@@ -1802,21 +1802,30 @@ __global__ void __launch_bounds__(TPB) tile_scatter_lds_kernel(const int32_t* __
         }
     }
     __syncthreads();
+    // the keys this workgroup holds, compacted: base[e] = key << 16 | count for now (key < 2^14, count <= 4096)
     for (int w = threadIdx.x; w < TG_BINS / 2; w += TPB) {
         const unsigned int c = hist[w];
         if (c == 0u) continue;
         unsigned int packed = 0u;
         if (c & 0xffffu) {
             const int e = atomicAdd(&nlist, 1);
-            base[e] = atomicAdd(&cursor[2 * w], (int)(c & 0xffffu));
+            base[e] = (int)(((unsigned int)(2 * w) << 16) | (c & 0xffffu));
             packed |= (unsigned int)e;
         }
         if (c >> 16) {
             const int e = atomicAdd(&nlist, 1);
-            base[e] = atomicAdd(&cursor[2 * w + 1], (int)(c >> 16));
+            base[e] = (int)(((unsigned int)(2 * w + 1) << 16) | (c >> 16));
             packed |= (unsigned int)e << 16;
         }
         hist[w] = packed;                           // entry indices are < TG_ITEMS <= 65535
+    }
+    __syncthreads();
+    // one returning atomic per (workgroup, key), spread evenly over the threads so that their round trips overlap (issued from the
+    // scan loop above, a thread that happens to own several non-empty words would pay them one after the other)
+    const int nl = nlist;
+    for (int e = threadIdx.x; e < nl; e += TPB) {
+        const unsigned int kc = (unsigned int)base[e];
+        base[e] = atomicAdd(&cursor[kc >> 16], (int)(kc & 0xffffu));
     }
     __syncthreads();
 #pragma unroll

@@ -69,6 +69,24 @@ LG_API int lg_fused_set_emission_order(const int32_t* order, long long n)
 }
 static const int32_t* emission_order(long long N) { return (g_emit_order != nullptr && g_emit_order_n == N) ? g_emit_order : nullptr; }
 
+// Speculative culling (no reference counterpart).  The exactness of the depth-bound culling rests on a repeat of the frame without
+// culling whenever a bound was violated.  Enqueued unconditionally as gated launches that repeat costs eight empty dependent launches
+// (~39 us) in EVERY step.  With a speculation context set, a culled training step enqueues no repeat at all: a violated bound (or a
+// truncated culled table) raises the sticky device word `poison` (mirrored into pinned host memory), every fused backward + Adam
+// launch that finds it raised returns without touching anything -- so from the failed step on NO parameter, moment or flag changes --
+// and every launch that does run records its step number in the pinned word `applied`.  The host (litegs_amd/trainer.py) notices the
+// mirror one or two steps later, synchronises, and replays the steps after `applied` in order, the first of them unculled: the
+// parameter sequence is exactly the one the gated repeat would have produced.  Renders that are not followed by a fused Adam step
+// (evaluation, gradient-hook data parallelism) keep the gated repeat.
+struct Speculation { int* poison; int* poison_host; int* applied_host; int step_id; };
+static Speculation g_spec = { nullptr, nullptr, nullptr, 0 };
+LG_API int lg_fused_set_speculation(int* poison /*device int, zero = healthy; NULL switches speculation off*/, int* poison_host /*pinned mirror*/,
+                                    int* applied_host /*pinned: step number of the last fused Adam launch that ran*/, int step_id)
+{
+    g_spec.poison = poison; g_spec.poison_host = poison_host; g_spec.applied_host = applied_host; g_spec.step_id = step_id;
+    return 0;
+}
+
 LG_API int lg_fused_set_option(int key, int value)
 {
     if (key == 0 && (value == LG_DEPTH_ORDER_GLOBAL || value == LG_DEPTH_ORDER_TILE || value == LG_DEPTH_ORDER_AUTO)) { g_depth_order_mode = value; return 0; }
@@ -225,9 +243,14 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
                                              float* __restrict__ m_sh0, float* __restrict__ m_shr, float* __restrict__ m_opa,
                                              float* __restrict__ v_pos, float* __restrict__ v_scale, float* __restrict__ v_rot,
                                              float* __restrict__ v_sh0, float* __restrict__ v_shr, float* __restrict__ v_opa,
-                                             unsigned char* __restrict__ touched, const int* __restrict__ emitted)
+                                             unsigned char* __restrict__ touched, const int* __restrict__ emitted,
+                                             const int* __restrict__ poison, int* __restrict__ applied_host, int step_id)
 {
     const int a = blockIdx.x, t = threadIdx.x;
+    if (poison != nullptr) {                 // speculative culling: a failed step (this one or an earlier one) -> nothing is updated
+        if (*poison != 0) return;
+        if (a == 0 && t == 0) __hip_atomic_store(applied_host, step_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (a >= visible_chunks_num[0]) return;
     const size_t od = (size_t)a * S + t;
     constexpr int NB = (DEG + 1) * (DEG + 1);
@@ -518,7 +541,7 @@ static int tile_key_bits(int ntiles)
 static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, long long Ls, int H, int W, int TH, int TW,
                              int* tsort_hdr, int* qcount, int* tcount, const int* tiles, int K, int enable_stat,
                              float* img, float* trans, short* last, int* frag_count, float* frag_weight, float* packed_grad_clear,
-                             const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag, const int* gate,
+                             const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag, int* fail_host, const int* gate,
                              const int* total_dev, hipStream_t s)
 {
     const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
@@ -569,7 +592,7 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
     }
     return lg_raster_forward_bounds(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
                                     enable_stat, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order, tiles ? nullptr : tile_work,
-                                    tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, (zb_check & 1) | (g_bound_margin_pct << 8), fail_flag, gate, s);
+                                    tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, (zb_check & 1) | (g_bound_margin_pct << 8), fail_flag, fail_host, gate, s);
 }
 
 static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, int H, int W, int TH, int TW,
@@ -607,14 +630,15 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
     if (tiles != nullptr || enable_stat) { sched_in = nullptr; sched_out = nullptr; order_out = nullptr; if (cull_active) return (int)hipErrorInvalidValue; }
     int* tile_work = order_out ? (int*)(w + f.tile_work) : nullptr;
     if (cull_active && (sched_in == nullptr || sched_out == nullptr)) return (int)hipErrorInvalidValue;
-    int* fail_flag = (int*)(w1 + f1.flags);
+    const bool spec = cull_active && g_spec.poison != nullptr;          // no gated repeat: a failure poisons the following Adam launches instead
+    int* fail_flag = spec ? g_spec.poison : (int*)(w1 + f1.flags);
     const long long Ls = (cull_active && L_cull > 0 && L_cull < L) ? L_cull : L;
     const int* total_dev = (const int*)(w1 + f1.prefix) + (N - 1);
     int rc = binning_and_blend(w1, f1, w, f, N, L, Ls, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr), (int*)(w1 + f1.dup_queue), (int*)(w1 + f1.tcount), tiles, K, enable_stat,
                                img, trans, last, frag_count, frag_weight, packed_grad_clear, order, tile_work, sched_in, sched_out,
-                               cull_active, cull_active ? fail_flag : nullptr, nullptr, total_dev, s);
+                               cull_active, cull_active ? fail_flag : nullptr, spec ? g_spec.poison_host : nullptr, nullptr, total_dev, s);
     if (rc) return rc;
-    if (cull_active) { rc = culling_fallback(w1, f1, w, f, N, L, H, W, TH, TW, img, trans, last, packed_grad_clear, order, tile_work, sched_in, sched_out,
+    if (cull_active && !spec) { rc = culling_fallback(w1, f1, w, f, N, L, H, W, TH, TW, img, trans, last, packed_grad_clear, order, tile_work, sched_in, sched_out,
                                               host_feedback_full, view_host, proj_host, degree, chunks, pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, A, S, s);
                        if (rc) return rc; }
     if (order_out != nullptr) return lg_tile_order(tile_work, 1, ntiles, order_out, s);
@@ -642,7 +666,7 @@ static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2&
                               host_feedback_full, 0, fail_flag, full_total, s);
     if (rc) return rc;
     return binning_and_blend(w1, f1, w, f, N, L, L, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr2), (int*)(w1 + f1.dup_queue2), (int*)(w1 + f1.tcount2), nullptr, 0, 0,
-                             img, trans, last, nullptr, nullptr, packed_grad_clear, order, tile_work, sched_in, sched_out, 0, nullptr, fail_flag,
+                             img, trans, last, nullptr, nullptr, packed_grad_clear, order, tile_work, sched_in, sched_out, 0, nullptr, nullptr, fail_flag,
                              full_total, s);
 }
 
@@ -710,7 +734,8 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
     AdamRates ar = { lr6[0], lr6[1], lr6[2], lr6[3], lr6[4], lr6[5], b1, b2, eps };
 #define LAUNCH_PA(D) hipLaunchKernelGGL(project_backward_adam_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, ar, chunks, S, A, R, \
                                         (const float4*)packed_grad, grad_inv_scaler, pos, scale, rot, sh0, shr, opa,                          \
-                                        m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa, v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched, emitted)
+                                        m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa, v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched, emitted, \
+                                        (const int*)g_spec.poison, g_spec.applied_host, g_spec.step_id)
     switch (degree) {
     case 0: LAUNCH_PA(0); break;
     case 1: LAUNCH_PA(1); break;

@@ -78,5 +78,5 @@ int lg_frustum_culling_chain(const float* origin, const float* ext, const float*
 int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
                              int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
                              float* img, float* trans, short* last, int* frag_count, float* frag_weight,
-                             const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag, const int* gate,
-                             void* stream);
+                             const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag,
+                             int* fail_host /*nullable pinned mirror: receives 1 when fail_flag is raised*/, const int* gate, void* stream);

@@ -202,13 +202,14 @@ __global__ void __launch_bounds__(1024) l1_ssim_reduce_kernel(const float* __res
 }
 
 static int l1_ssim_forward_launch(const float* img, long long img_ps, int img_rs, int clamp01, const float* gt, int planes, int H, int W,
-                                  float lam, float* dmaps, float* partial, float* loss, void* stream)
+                                  float lam, float* dmaps, float* partial, float* loss /*NULL: the backward reduces the partial sums*/, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(lg_cdiv(W, TS), lg_cdiv(H, TS), planes);
     hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(256), 0, s, img, img_ps, img_rs, clamp01, gt, H, W, dmaps, partial);
     int nblocks = grid.x * grid.y * grid.z;
-    hipLaunchKernelGGL(l1_ssim_reduce_kernel, dim3(1), dim3(1024), 0, s, partial, nblocks, 1.0f / ((float)planes * H * W), lam, loss);
+    if (loss != nullptr)
+        hipLaunchKernelGGL(l1_ssim_reduce_kernel, dim3(1), dim3(1024), 0, s, partial, nblocks, 1.0f / ((float)planes * H * W), lam, loss);
     LG_RETURN_LAST();
 }
 
@@ -221,9 +222,9 @@ LG_API int lg_l1_ssim_forward(const float* img, const float* gt, int planes, int
 
 // img: raw raster output [planes][Hp][Wp] (tile-padded); the loss is taken on clamp(img[:, :H, :W], 0, 1)
 LG_API int lg_l1_ssim_forward_raster(const float* img, int Hp, int Wp, const float* gt, int planes, int H, int W, float lam,
-                                     float* dmaps, float* partial, float* loss, void* stream)
+                                     float* dmaps, float* partial, float* loss /*NULL: left to lg_l1_ssim_backward_raster_value*/, void* stream)
 {
-    LG_REQUIRE(img, gt, dmaps, partial, loss);
+    LG_REQUIRE(img, gt, dmaps, partial);
     if (Hp < H || Wp < W) return (int)hipErrorInvalidValue;
     return l1_ssim_forward_launch(img, (long long)Hp * Wp, Wp, 1, gt, planes, H, W, lam, dmaps, partial, loss, stream);
 }
@@ -239,8 +240,28 @@ LG_API long long lg_l1_ssim_partial_floats(int planes, int H, int W)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) l1_ssim_backward_kernel(const float* __restrict__ img, long long img_ps, int img_rs, int clamp01,
                                                                const float* __restrict__ gt,
                                                                const float* __restrict__ dmaps, const float* __restrict__ grad_out,
-                                                               int H, int W, int Hp, int Wp, float lam, float inv_n, float* __restrict__ d_img)
+                                                               int H, int W, int Hp, int Wp, float lam, float inv_n, float* __restrict__ d_img,
+                                                               const float* __restrict__ partial /*nullable*/, int nblocks, float* __restrict__ loss)
 {
+    // The loss VALUE on the side (training step: nothing reads it between the forward and the backward, and a launch of its own costs
+    // ~5 us of dependent-launch latency): the first workgroup sums the forward's per-workgroup partial sums exactly as
+    // l1_ssim_reduce_kernel does -- same strided partial sums per (virtual) thread, same shuffle tree, same final order: same bits.
+    if (partial != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        __shared__ double rs[16], rl[16];
+        for (int q = 0; q < 4; q++) {
+            double sacc = 0.0, lacc = 0.0;
+            for (int k = q * 256 + (int)threadIdx.x; k < nblocks; k += 1024) { sacc += partial[2 * k]; lacc += partial[2 * k + 1]; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { sacc += __shfl_down(sacc, off); lacc += __shfl_down(lacc, off); }
+            if ((threadIdx.x & 63) == 0) { rs[4 * q + (threadIdx.x >> 6)] = sacc; rl[4 * q + (threadIdx.x >> 6)] = lacc; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double ts = 0, tl = 0;
+            for (int w = 0; w < 16; w++) { ts += rs[w]; tl += rl[w]; }
+            loss[0] = (float)((1.0 - lam) * tl * inv_n + lam * (1.0 - ts * inv_n));
+        }
+    }
     // one LDS buffer for the three input halo tiles and their horizontally blurred versions (see the forward kernel)
     constexpr int SM_FLOATS = 3 * TIN * (TIN + 1), SHB_FLOATS = 3 * TIN * (TS + 1);
     __shared__ float lds[SM_FLOATS > SHB_FLOATS ? SM_FLOATS : SHB_FLOATS];
@@ -354,18 +375,30 @@ LG_API int lg_l1_ssim_backward(const float* img, const float* gt, const float* d
     LG_REQUIRE(img, gt, dmaps, grad_out, d_img);
     dim3 grid(lg_cdiv(W, TS), lg_cdiv(H, TS), planes);
     hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, (long long)H * W, W, 0, gt, dmaps, grad_out,
-                       H, W, H, W, lam, 1.0f / ((float)planes * H * W), d_img);
+                       H, W, H, W, lam, 1.0f / ((float)planes * H * W), d_img, (const float*)nullptr, 0, (float*)nullptr);
     LG_RETURN_LAST();
 }
 
 // gradient w.r.t. the RAW raster image (see lg_l1_ssim_forward_raster); d_img [planes][Hp][Wp]
+LG_API int lg_l1_ssim_backward_raster_value(const float* img, int Hp, int Wp, const float* gt, const float* dmaps, const float* grad_out,
+                                            int planes, int H, int W, float lam, float* d_img, const float* partial, float* loss, void* stream);
+
 LG_API int lg_l1_ssim_backward_raster(const float* img, int Hp, int Wp, const float* gt, const float* dmaps, const float* grad_out,
                                       int planes, int H, int W, float lam, float* d_img, void* stream)
 {
+    return lg_l1_ssim_backward_raster_value(img, Hp, Wp, gt, dmaps, grad_out, planes, H, W, lam, d_img, nullptr, nullptr, stream);
+}
+
+// The training step's pair: lg_l1_ssim_forward_raster with loss == NULL leaves only the per-workgroup partial sums, and this backward
+// also writes the loss value (partial / loss both given) -- one launch less per step; identical value (same summation order).
+LG_API int lg_l1_ssim_backward_raster_value(const float* img, int Hp, int Wp, const float* gt, const float* dmaps, const float* grad_out,
+                                            int planes, int H, int W, float lam, float* d_img, const float* partial, float* loss, void* stream)
+{
     LG_REQUIRE(img, gt, dmaps, grad_out, d_img);
-    if (Hp < H || Wp < W) return (int)hipErrorInvalidValue;
+    if (Hp < H || Wp < W || ((partial == nullptr) != (loss == nullptr))) return (int)hipErrorInvalidValue;
     dim3 grid(lg_cdiv(Wp, TS), lg_cdiv(Hp, TS), planes);
+    const int nblocks = lg_cdiv(W, TS) * lg_cdiv(H, TS) * planes;                  // the FORWARD's grid
     hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, (long long)Hp * Wp, Wp, 1, gt, dmaps, grad_out,
-                       H, W, Hp, Wp, lam, 1.0f / ((float)planes * H * W), d_img);
+                       H, W, Hp, Wp, lam, 1.0f / ((float)planes * H * W), d_img, partial, nblocks, loss);
     LG_RETURN_LAST();
 }

@@ -159,7 +159,7 @@ __device__ __forceinline__ void rec_id_wait(f32x16& rec, int& id) { asm volatile
 // v_min_f32 without the canonicalising v_max the compiler puts in front of fminf when it cannot prove its operand quiet
 __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_bwd_noatomic = 0, g_fwd_fast = 2;       // launch variants (lg_set_tuning)
+static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_bwd_noatomic = 0, g_fwd_fast = 1;       // launch variants (lg_set_tuning)
 
 // ---------------------------------------------------------------------------------------------
 // a13 rasterize_forward (reference: GR/raster.cu:162-332)
@@ -297,51 +297,6 @@ __device__ __forceinline__ bool fwd_splat_fast(FwdFast& st, const f32x16& rec)
     return true;
 }
 
-// With 24 VALU instructions per (tile, splat) the forward no longer hides the latency of ONE scalar record load per splat (the
-// scalar-memory counter lgkmcnt only supports "wait for everything", so a scalar prefetch cannot run more than one splat ahead):
-// profiles/r03_sq_counters_fresh.md, 31 % fewer instructions bought 8 % of time.  The records of this loop therefore come through the
-// VECTOR memory path -- every lane loads the same address (one cache line request per instruction; the 10 dwords the blend needs:
-// 4 + 4 + 1 + 1) -- whose counter vmcnt retires in order: the record of position p + 2 is requested before position p is blended
-// and `s_waitcnt vmcnt(8)` (two younger records of four loads each may still be in flight) is all the synchronisation there is.
-// Extra loads the compiler issues in between only make these waits stronger (in-order retirement), never weaker.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x3 __attribute__((ext_vector_type(3)));
-struct RecV { f32x4 q0; float c2; f32x3 col; float lo; };       // dwords 0-3 | 4 | 6-8 | 15 of the record: px py A2 B2 | C2 | r g b | log2 opacity
-__device__ __forceinline__ void recv_request(RecV& r, const float* __restrict__ pk, unsigned byte_off, int vzero)
-{
-    const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pk) + byte_off);      // uniform: scalar ALU
-    asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
-                 "global_load_dword %1, %4, %5 offset:16\n\t"
-                 "global_load_dwordx3 %2, %4, %5 offset:24\n\t"
-                 "global_load_dword %3, %4, %5 offset:60"
-                 : "=&v"(r.q0), "=&v"(r.c2), "=&v"(r.col), "=&v"(r.lo) : "v"(vzero), "s"(base) : "memory");
-}
-__device__ __forceinline__ void recv_wait2(RecV& r) { asm volatile("s_waitcnt vmcnt(8)" : "+v"(r.q0), "+v"(r.c2), "+v"(r.col), "+v"(r.lo)); }
-// Branch-free: with every pixel inactive the masks are empty and nothing changes, so the caller may test the return value (activity
-// BEFORE this splat, as the reference tests it) after the call.
-__device__ __forceinline__ bool fwd_splat_fast_v(FwdFast& st, const RecV& rec)
-{
-    const unsigned long long act0 = __builtin_amdgcn_ballot_w64(st.T.x > 1.0f / 8192), act1 = __builtin_amdgcn_ballot_w64(st.T.y > 1.0f / 8192);
-    const float dx = rec.q0.x - st.X;
-    const float t1 = rec.q0.w * dx;
-    const float t0 = __builtin_fmaf(rec.q0.z * dx, dx, rec.lo);
-    const v2f dyv = rec.q0.y - st.Y;
-    const v2f qv = dyv * (rec.c2 * dyv + t1) + t0;
-    const float E0 = __builtin_amdgcn_exp2f(qv.x);
-    const float E1 = __builtin_amdgcn_exp2f(qv.y);
-    add_mask_bit(st.lc0, act0);
-    add_mask_bit(st.lc1, act1);
-    const unsigned long long val0 = act0 & __builtin_amdgcn_ballot_w64(E0 >= 1.0f / 256), val1 = act1 & __builtin_amdgcn_ballot_w64(E1 >= 1.0f / 256);
-    const float amax = 255.0f / 256;
-    const v2f alpha = { min_where(E0, amax, val0), min_where(E1, amax, val1) };
-    const v2f w = st.T * alpha;
-    st.Cr = rec.col.x * w + st.Cr;
-    st.Cg = rec.col.y * w + st.Cg;
-    st.Cb = rec.col.z * w + st.Cb;
-    st.T = st.T - w;
-    return (act0 | act1) != 0ull;
-}
-
 template <int TH, int TW, bool STAT>
 __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
                                                              const float* __restrict__ packed, const int* __restrict__ tiles, int K,
@@ -349,10 +304,13 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
                                                              int* __restrict__ frag_count, float* __restrict__ frag_weight,
                                                              const int* __restrict__ order, int* __restrict__ tile_work,
                                                              const int* __restrict__ sched_in, int* __restrict__ sched_out, int zb_check,
-                                                             int* __restrict__ fail_flag, const int* __restrict__ gate,
+                                                             int* __restrict__ fail_flag, int* __restrict__ fail_host, const int* __restrict__ gate,
                                                              int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int fast)
 {
     if (gate != nullptr && *gate == 0) return;              // fallback launch of the depth-bound culling that is not needed
+    // speculative executor (fused.hip): a failure raised earlier in this step (a truncated table) reaches the host mirror here
+    if (fail_host != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && *fail_flag != 0)
+        __hip_atomic_store(fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     constexpr int PPL = TileMap<TH, TW>::PPL;
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
@@ -388,40 +346,6 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
             f.X = st.X; f.Y = v2f{ st.Y[0], st.Y[1] }; f.T = v2f{ 1.0f, 1.0f };
             f.Cr = f.Cg = f.Cb = v2f{ 0.0f, 0.0f };
             f.lc0 = f.lc1 = 0;
-            if (fast == 2) {
-                // records through the vector memory path, two splats ahead (see RecV); ids 64 at a time in a VGPR, v_readlane per splat
-                int vzero;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-                int ids_next = sp[min(lane, n - 1)];
-                for (int c0 = 0; c0 < n && live; c0 += 64) {
-                    const int cnt = min(64, n - c0);
-                    const int ids = ids_next;
-                    ids_next = sp[min(c0 + 64 + lane, n - 1)];                  // next chunk's ids: in flight while this chunk is blended
-                    RecV A, B, C;
-                    recv_request(A, pk, (unsigned)__builtin_amdgcn_readlane(ids, 0) << 6, vzero);
-                    recv_request(B, pk, (unsigned)__builtin_amdgcn_readlane(ids, min(1, cnt - 1)) << 6, vzero);
-                    for (int j = 0; j < cnt; j += 3) {                          // A holds position j, B j + 1 (clamped at the chunk end: never used)
-                        recv_request(C, pk, (unsigned)__builtin_amdgcn_readlane(ids, min(j + 2, cnt - 1)) << 6, vzero);
-                        recv_wait2(A);
-                        live = fwd_splat_fast_v(f, A);
-                        if (!live) break;
-                        visited = c0 + j + 1;
-                        if (j + 1 >= cnt) break;
-                        recv_request(A, pk, (unsigned)__builtin_amdgcn_readlane(ids, min(j + 3, cnt - 1)) << 6, vzero);
-                        recv_wait2(B);
-                        live = fwd_splat_fast_v(f, B);
-                        if (!live) break;
-                        visited = c0 + j + 2;
-                        if (j + 2 >= cnt) break;
-                        recv_request(B, pk, (unsigned)__builtin_amdgcn_readlane(ids, min(j + 4, cnt - 1)) << 6, vzero);
-                        recv_wait2(C);
-                        live = fwd_splat_fast_v(f, C);
-                        if (!live) break;
-                        visited = c0 + j + 3;
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing of this chunk's requests stays in flight
-                }
-            } else {
             // position p's record is requested while position p - 1 is blended, its id one step earlier (clamped at the list end: the
             // surplus requests are never used)
             int id_a, id_b;
@@ -445,7 +369,6 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
                 rec_id_wait(ra, id_b);
                 if (!live) break;
                 visited = pos + 2;
-            }
             }
             st.T[0] = f.T.x; st.T[1] = f.T.y;
             st.Cr[0] = f.Cr.x; st.Cr[1] = f.Cr.y; st.Cg[0] = f.Cg.x; st.Cg[1] = f.Cg.y; st.Cb[0] = f.Cb.x; st.Cb[1] = f.Cb.y;
@@ -493,7 +416,10 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
             for (int k = 1; k < LG_PYR_LEVELS; k++)             // positive floats order like their bit patterns
                 atomicMax(reinterpret_cast<unsigned int*>(sched_out) + lg_sched_level_offset(gx, gy, k) + (ty0 >> k) * lg_pyr_w(gx, k) + (tx0 >> k),
                           __float_as_uint(znew));
-            if (!ok && fail_flag != nullptr) atomicOr(fail_flag, 1);
+            if (!ok && fail_flag != nullptr) {
+                atomicOr(fail_flag, 1);
+                if (fail_host != nullptr) __hip_atomic_store(fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     const size_t plane = (size_t)Hp * Wp;
@@ -514,7 +440,7 @@ LG_API int lg_raster_forward(const int* sorted_points, const int* start_index, c
                              const int* order /*nullable [V,T]: tile schedule (a permutation of 1..T)*/, int* tile_work /*nullable [V,T+1]*/, void* stream)
 {
     return lg_raster_forward_bounds(sorted_points, start_index, packed, tiles, K, V, L, N, H, W, TH, TW, enable_stat, img, trans, last,
-                                    frag_count, frag_weight, order, tile_work, nullptr, nullptr, 0, nullptr, nullptr, stream);
+                                    frag_count, frag_weight, order, tile_work, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
 
 // The executor's entry: the same blend, reading / filling the per-frame depth-bound blocks (single view; record dword 12 must hold the
@@ -525,7 +451,7 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
                              const int* order, int* tile_work, const int* sched_in /*nullable: previous visit's block (the bounds used)*/,
                              int* sched_out /*nullable: this visit's block; its first lg_sched_clear_words() words are zero*/,
                              int zb_check /*bit 0 clear: nothing was culled, only produce new bounds; bits 8..: bound margin in percent (0 = 50)*/,
-                             int* fail_flag, const int* gate, void* stream)
+                             int* fail_flag, int* fail_host /*nullable pinned mirror of fail_flag*/, const int* gate, void* stream)
 {
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
@@ -537,7 +463,7 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_RF(A_, B_, S_) hipLaunchKernelGGL((raster_forward_kernel<A_, B_, S_>), grid, block, 0, s, sorted_points, start_index, packed, \
-                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map, g_fwd_fast)
+                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, fail_host, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map, g_fwd_fast)
 #define DISPATCH_RF(A_, B_) do { if (enable_stat) LAUNCH_RF(A_, B_, true); else LAUNCH_RF(A_, B_, false); } while (0)
     if (TH == 8 && TW == 16) DISPATCH_RF(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RF(16, 16);
@@ -1090,7 +1016,7 @@ LG_API int lg_set_tuning(int key, int value)
     case 2: g_fwd_map = value; return 0;                                      // ... of the blend forward
     case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
     case 6: g_bwd_noatomic = value; return 0;                                 // measurement only: 1 = the fast blend backward computes everything but issues no atomics (WRONG gradients)
-    case 7: g_fwd_fast = value; return 0;                                     // 8x16 tiles without statistics: 0 generic blend loop, 1 packed loop with scalar record loads, 2 (default) packed loop with vector record loads two splats ahead
+    case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics
     default: return (int)hipErrorInvalidValue;
     }

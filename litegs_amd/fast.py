@@ -106,6 +106,24 @@ class FusedRenderer:
         # enqueued, so that the union-of-visibility collective runs on RCCL's stream underneath the whole forward + blend backward
         self.after_cull = None
         self._cull_scratch, self._cull_chunks, self._cull_epoch = None, -1, 0
+        # speculative culling (csrc/fused.hip): set by FrameTrainer when it takes over the replay of failed steps
+        self.spec = None              # dict(poison=device int32[1], poison_host / applied_host = pinned int32[1])
+        self.spec_step = 0            # number of the training step being enqueued
+        self.force_full = False       # the next render runs unculled (the first replayed step)
+
+    def enable_speculation(self, device):
+        if self.spec is None:
+            self.spec = dict(poison=torch.zeros((1,), dtype=torch.int32, device=device),
+                             poison_host=torch.zeros((1,), dtype=torch.int32).pin_memory(),
+                             applied_host=torch.zeros((1,), dtype=torch.int32).pin_memory())
+        return self.spec
+
+    def speculation_args(self, active: bool):
+        """arguments of lg_fused_set_speculation for the coming call (all NULL: the gated repeat / an unconditional Adam)"""
+        if active and self.spec is not None:
+            sp = self.spec
+            return (sp["poison"].data_ptr(), sp["poison_host"].data_ptr(), sp["applied_host"].data_ptr(), int(self.spec_step))
+        return (None, None, None, 0)
 
     def reset_feedback(self):
         """parameters were replaced / re-sorted: forget everything predicted from earlier visits (sizes, schedules, depth bounds)"""
@@ -238,7 +256,8 @@ class _RenderFn(torch.autograd.Function):
                 in_ptr = R.sched[k, cur].data_ptr()
             out_ptr = R.sched[k, 1 - cur].data_ptr()
         refresh = R.visits[k] % R.cull_refresh == 0
-        cull = bool(R.cull_enabled and in_ptr is not None and R.full_total[k] > 0 and pred_total > 0 and not refresh)
+        cull = bool(R.cull_enabled and in_ptr is not None and R.full_total[k] > 0 and pred_total > 0 and not refresh and not R.force_full)
+        R.force_full = False
         order_ptr = (R.tile_order.data_ptr() + 4 * R.ntiles * k) if use_sched else None
         order_in = order_ptr if (use_sched and R.tile_order_valid[k]) else None
         order_out = order_ptr if (use_sched and (refresh or not R.tile_order_valid[k])) else None
@@ -277,6 +296,8 @@ class _RenderFn(torch.autograd.Function):
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
         pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
         L.lg_fused_set_option(1, int(R.margin[k]))
+        # a culled render that a fused Adam step follows may run speculatively (no gated repeat); anything else keeps the repeat
+        L.lg_fused_set_speculation(*R.speculation_args(cull and R.fuse_optimizer and any(ctx.needs_input_grad)))
         check(L.lg_fused_stage2(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes, tp, K,
                                 1 if stat else 0, img.data_ptr(), trans.data_ptr(), last.data_ptr(),
                                 fc.data_ptr() if stat else None, fw.data_ptr() if stat else None,
@@ -433,6 +454,7 @@ class FusedAdam:
         vs = [self.opt.state[p]["exp_avg_sq"] for p in ps]
         lr6 = (ctypes.c_float * 6)(*[float(self._by_name[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]])
         R, fr = self.renderer, pend["frame"]
+        lib().lg_fused_set_speculation(*R.speculation_args(True))
         check(lib().lg_fused_backward_adam(pend["A"], pend["S"], R.H, R.W, fr.view_ptr, fr.proj_ptr, pend["degree"], pend["chunks"], pend["Rr"],
                                            pend["vis_ids"].data_ptr(), pend["vis_num"].data_ptr(), pend["pg"].data_ptr(), None,
                                            *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms], *[v.data_ptr() for v in vs],

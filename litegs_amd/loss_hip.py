@@ -46,7 +46,9 @@ class RasterL1SSIM(torch.autograd.Function):
     their backward (four elementwise launches + a zero-filled padded gradient in plain torch) live inside the two loss kernels."""
 
     @staticmethod
-    def forward(ctx, raw: torch.Tensor, gt: torch.Tensor):
+    def forward(ctx, raw: torch.Tensor, gt: torch.Tensor, value_in_backward: bool = False):
+        """value_in_backward: the loss VALUE is written by the backward kernel (one launch less per training step); until backward()
+        has run the returned tensor is uninitialised -- for loops that call backward() right away and read the value afterwards."""
         if not (raw.is_cuda and gt.is_cuda) or raw.dtype != torch.float32 or gt.dtype != torch.float32:
             raise RuntimeError("raster_l1_ssim_loss: float32 GPU tensors required (no CPU path)")
         if not raw.is_contiguous():
@@ -61,8 +63,9 @@ class RasterL1SSIM(torch.autograd.Function):
         partial = torch.empty((L.lg_l1_ssim_partial_floats(B * C, H, W),), dtype=torch.float32, device=raw.device)
         loss = torch.empty((), dtype=torch.float32, device=raw.device)
         check(L.lg_l1_ssim_forward_raster(raw.data_ptr(), Hp, Wp, gt.data_ptr(), B * C, H, W, LAMBDA_DSSIM, dmaps.data_ptr(),
-                                          partial.data_ptr(), loss.data_ptr(), _s()), "l1_ssim_forward_raster")
+                                          partial.data_ptr(), None if value_in_backward else loss.data_ptr(), _s()), "l1_ssim_forward_raster")
         ctx.save_for_backward(raw, gt, dmaps)
+        ctx.pending = (partial, loss) if value_in_backward else None
         return loss
 
     @staticmethod
@@ -72,10 +75,12 @@ class RasterL1SSIM(torch.autograd.Function):
         Hp, Wp = raw.shape[-2], raw.shape[-1]
         d_raw = torch.empty_like(raw)
         g = grad_out.contiguous()
-        check(lib().lg_l1_ssim_backward_raster(raw.data_ptr(), Hp, Wp, gt.data_ptr(), dmaps.data_ptr(), g.data_ptr(), B * C, H, W,
-                                               LAMBDA_DSSIM, d_raw.data_ptr(), _s()), "l1_ssim_backward_raster")
-        return d_raw, None
+        partial, loss = ctx.pending if ctx.pending is not None else (None, None)
+        check(lib().lg_l1_ssim_backward_raster_value(raw.data_ptr(), Hp, Wp, gt.data_ptr(), dmaps.data_ptr(), g.data_ptr(), B * C, H, W,
+                                                     LAMBDA_DSSIM, d_raw.data_ptr(), partial.data_ptr() if partial is not None else None,
+                                                     loss.data_ptr() if loss is not None else None, _s()), "l1_ssim_backward_raster")
+        return d_raw, None, None
 
 
-def raster_l1_ssim_loss(raw: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
-    return RasterL1SSIM.apply(raw, gt)
+def raster_l1_ssim_loss(raw: torch.Tensor, gt: torch.Tensor, value_in_backward: bool = False) -> torch.Tensor:
+    return RasterL1SSIM.apply(raw, gt, value_in_backward)

@@ -66,6 +66,12 @@ class FrameTrainer:
         # position learning rate reaches its final value after the same number of FRAMES as on one GPU
         self.sched_ticks = 1
         self.last = {}
+        # speculative culling (csrc/fused.hip): culled steps enqueue no gated repeat; a failed step poisons the Adam launches from there on
+        # and is replayed here, unculled, together with the steps enqueued behind it.  Parameters are final only after flush().
+        self.speculative = False
+        self._spec_ring = []          # (step number, frame index, learning rates) of the steps that may still have to be replayed
+        self._spec_next = 1
+        self.spec_replays = 0
 
     # -------------------------------------------------------------------------------------------
     def forward(self, frame: Frame, raw: bool = False):
@@ -88,6 +94,73 @@ class FrameTrainer:
         """grad_hook: None, a gradient hook (dp.GradientExchange.hook: parameter gradients are materialised and exchanged) or a
         dp.MomentExchange (native executor only: the blend backward's moment records are exchanged, backward + Adam stay fused;
         peer_frames = the frame indices of ranks 0..W-1 of this step)."""
+        spec = self.speculative and grad_hook is None and self.fused and self.fuse_adam and self.raw_loss and not STATS.active
+        if self._spec_ring and not spec:
+            self.flush()                                  # leaving the speculative regime: everything enqueued so far must have landed
+        if spec:
+            self._spec_poll()
+            self.renderer.enable_speculation(self.device)
+            self.renderer.spec_step = self._spec_next
+            self._spec_ring.append((self._spec_next, frame_index, [float(g["lr"]) for g in self.opt.param_groups]))
+            self._spec_next += 1
+            if len(self._spec_ring) > 256:                # steps whose Adam launch has reported in need no replay any more
+                done = int(self.renderer.spec["applied_host"][0])
+                self._spec_ring = [r for r in self._spec_ring if r[0] > done]
+        elif self.renderer.spec is not None:
+            self.renderer.spec_step = 0
+            self.renderer.spec = None
+        loss = self._step_body(frame_index, grad_hook, hook_slot, peer_frames)
+        for _ in range(self.sched_ticks):
+            self.sched.step()
+        return loss
+
+    # -- speculative culling: notice, replay ------------------------------------------------------------------------------------
+    def _spec_poll(self):
+        sp = self.renderer.spec
+        if sp is not None and int(sp["poison_host"][0]) != 0:
+            self._spec_recover()
+
+    def _spec_recover(self):
+        """a culled step failed: from that step on no Adam launch changed anything.  Replay them in order -- the first one unculled --
+        with the learning rates they were enqueued with."""
+        R = self.renderer
+        while True:
+            torch.cuda.current_stream().synchronize()
+            sp = R.spec
+            if sp is None or int(sp["poison_host"][0]) == 0:
+                break
+            done = int(sp["applied_host"][0])
+            todo = [r for r in self._spec_ring if r[0] > done]
+            self._spec_ring = []
+            sp["poison"].zero_()
+            sp["poison_host"][0] = 0
+            torch.cuda.current_stream().synchronize()
+            current = [float(g["lr"]) for g in self.opt.param_groups]
+            for i, (no, frame_index, lrs) in enumerate(todo):
+                for g, lr in zip(self.opt.param_groups, lrs):
+                    g["lr"] = lr
+                R.spec_step = no
+                R.force_full = (i == 0)
+                if i == 0:                                # the frame whose bounds were violated: what the gated repeat's bookkeeping does
+                    k = self.frames[frame_index % len(self.frames)].cam.index
+                    R.fallbacks += 1
+                    R.clean_visits[k] = 0
+                    if not R.margin_fixed:
+                        R.margin[k] = min(R.margin[k] * 2, R.margin_hi)
+                self._spec_ring.append((no, frame_index, lrs))
+                self._step_body(frame_index, None, 0, None)
+                self.spec_replays += 1
+            for g, lr in zip(self.opt.param_groups, current):
+                g["lr"] = lr
+
+    def flush(self):
+        """the parameters reflect every step enqueued so far (speculative mode: failed steps are replayed first); synchronises"""
+        torch.cuda.current_stream().synchronize()
+        if self.renderer.spec is not None:
+            self._spec_recover()
+        self._spec_ring = []
+
+    def _step_body(self, frame_index: int, grad_hook=None, hook_slot: int = 0, peer_frames=None):
         frame = self.frames[frame_index % len(self.frames)]
         moments = grad_hook is not None and hasattr(grad_hook, "step") and not callable(grad_hook)
         if moments and not (self.fused and self.fuse_adam):
@@ -98,7 +171,7 @@ class FrameTrainer:
         img, vis_id, vis_num, prim_vis = self.forward(frame, raw=self.raw_loss)
         if self.raw_loss:
             from . import loss_hip
-            loss = loss_hip.raster_l1_ssim_loss(img, frame.gt)
+            loss = loss_hip.raster_l1_ssim_loss(img, frame.gt, value_in_backward=True)      # backward() follows at once
         else:
             loss = self.loss_fn(img, frame.gt)
         loss.backward(self._unit)
@@ -115,13 +188,13 @@ class FrameTrainer:
         else:
             self.opt.step(vis_id, vis_num, prim_vis)
         self.opt.zero_grad(set_to_none=True)
-        for _ in range(self.sched_ticks):
-            self.sched.step()
         self.last = dict(loss=loss.detach(), vis_num=vis_num)
         return loss
 
     @torch.no_grad()
     def forward_only(self, frame_index: int):
+        if self._spec_ring:
+            self.flush()
         frame = self.frames[frame_index % len(self.frames)]
         return self.forward(frame)[0]
 
@@ -129,6 +202,8 @@ class FrameTrainer:
     def _rebind(self):
         """parameters were replaced / re-sorted: refresh everything derived from them (chunk AABBs, cached pointers, the per-frame
         size predictions of the GPU-driven protocol -- a first-visit blocking read is cheaper than a truncated table)."""
+        if self._spec_ring:
+            self.flush()
         by_name = {g["name"]: g["params"][0] for g in self.opt.param_groups}
         self.params = [by_name[n] for n in ("xyz", "scale", "rot", "sh_0", "sh_rest", "opacity")]
         self.n_chunks, self.S = self.params[0].shape[-2], self.params[0].shape[-1]
@@ -156,6 +231,8 @@ class FrameTrainer:
 
     def begin_epoch(self, epoch: int):
         """Morton re-sort one epoch after every densification (trainer.py:113-116); returns the statistics guard for the epoch."""
+        if self._spec_ring:
+            self.flush()
         ctl = getattr(self, "controller", None)
         if ctl is not None and (epoch - 1) % ctl.p.densification_interval == 0:
             from . import scene
@@ -164,6 +241,8 @@ class FrameTrainer:
         return STATS.epoch(epoch)
 
     def end_epoch(self, epoch: int):
+        if self._spec_ring:
+            self.flush()
         ctl = getattr(self, "controller", None)
         if ctl is not None:
             ctl.step(self.opt, epoch)
@@ -171,6 +250,8 @@ class FrameTrainer:
     def workload_stats(self, frame_index: int = 0):
         """N_vis (Gaussians after chunk culling), I (tile instances) for one frame -- host sync, call outside timed regions."""
         frame = self.frames[frame_index % len(self.frames)]
+        if self._spec_ring:
+            self.flush()
         torch.cuda.synchronize()
         k = int(frame.idx_tensor[0])
         if self.fused:

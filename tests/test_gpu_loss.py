@@ -46,3 +46,21 @@ def test_raster_loss_equals_clamp_crop_then_loss(H, W, Hp, Wp):
     assert g_hip[..., H:, :].abs().max().item() == 0 if Hp > H else True
     outside = (raw.detach() < 0) | (raw.detach() > 1)
     assert g_hip[outside].abs().max().item() == 0
+
+
+def test_loss_value_written_by_the_backward_is_the_same_value():
+    """the training step's pairing (forward without the reduction launch, the backward also sums the partial sums): bit-identical loss value
+    and gradient"""
+    from litegs_amd import loss_hip
+    torch.manual_seed(3)
+    H, W, Hp, Wp = 270, 480, 272, 480
+    raw = (torch.rand((1, 3, Hp, Wp), device="cuda") * 1.4 - 0.2).requires_grad_(True)
+    gt = torch.rand((1, 3, H, W), device="cuda")
+    one = torch.ones((), device="cuda")
+    a = loss_hip.raster_l1_ssim_loss(raw, gt)
+    a.backward(one)
+    ga = raw.grad.clone(); raw.grad = None
+    b = loss_hip.raster_l1_ssim_loss(raw, gt, value_in_backward=True)
+    b.backward(one)
+    torch.cuda.synchronize()
+    assert torch.equal(a.detach(), b.detach()) and torch.equal(ga, raw.grad)

@@ -48,7 +48,7 @@ def ab(state):
         L.lg_set_tuning(6, v)
         measure(f"{state}: fast kernel, {name}")
     L.lg_set_tuning(6, 0)
-    for v, name in ((0, "generic"), (1, "packed, scalar records"), (2, "packed, vector records 2 ahead"), (0, "generic"), (1, "packed, scalar records"), (2, "packed, vector records 2 ahead")):
+    for v, name in ((0, "generic"), (1, "packed"), (0, "generic"), (1, "packed")):      # blend forward: generic loop vs the packed 8x16 loop
         L.lg_set_tuning(7, v)
         for i in range(8):
             tr.forward_only(i)
@@ -58,7 +58,7 @@ def ab(state):
             tr.forward_only(i % 8)
         torch.cuda.synchronize()
         print(f"{state}: forward only, {name} blend forward   {(time.perf_counter() - t0) / 64 * 1e3:7.4f} ms", flush=True)
-    L.lg_set_tuning(7, 2)
+    L.lg_set_tuning(7, 1)
     L.lg_set_tuning(4, 0)
     measure(f"{state}: fast kernel, no tile schedule")
     L.lg_set_tuning(4, 1)
