@@ -71,6 +71,8 @@ class FrameTrainer:
         self.speculative = False
         self._spec_ring = []          # (step number, frame index, learning rates) of the steps that may still have to be replayed
         self._spec_next = 1
+        self._spec_events = []        # one event behind every speculative step still in flight
+        self.spec_depth = 2           # steps the host may run ahead of the device in speculative mode
         self.spec_replays = 0
 
     # -------------------------------------------------------------------------------------------
@@ -98,18 +100,26 @@ class FrameTrainer:
         if self._spec_ring and not spec:
             self.flush()                                  # leaving the speculative regime: everything enqueued so far must have landed
         if spec:
+            # The host must not run far ahead of the device: everything enqueued behind a failed step is wasted and replayed.  Two steps
+            # in flight keep the device busy (enqueueing a step takes a third of its run time); the wait is on the step before those.
+            if len(self._spec_events) >= self.spec_depth:
+                self._spec_events.pop(0).synchronize()
             self._spec_poll()
             self.renderer.enable_speculation(self.device)
             self.renderer.spec_step = self._spec_next
             self._spec_ring.append((self._spec_next, frame_index, [float(g["lr"]) for g in self.opt.param_groups]))
             self._spec_next += 1
-            if len(self._spec_ring) > 256:                # steps whose Adam launch has reported in need no replay any more
+            if len(self._spec_ring) > 64:                 # steps whose Adam launch has reported in need no replay any more
                 done = int(self.renderer.spec["applied_host"][0])
                 self._spec_ring = [r for r in self._spec_ring if r[0] > done]
         elif self.renderer.spec is not None:
             self.renderer.spec_step = 0
             self.renderer.spec = None
         loss = self._step_body(frame_index, grad_hook, hook_slot, peer_frames)
+        if spec:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._spec_events.append(ev)
         for _ in range(self.sched_ticks):
             self.sched.step()
         return loss
@@ -132,6 +142,7 @@ class FrameTrainer:
             done = int(sp["applied_host"][0])
             todo = [r for r in self._spec_ring if r[0] > done]
             self._spec_ring = []
+            self._spec_events = []
             sp["poison"].zero_()
             sp["poison_host"][0] = 0
             torch.cuda.current_stream().synchronize()
@@ -159,6 +170,7 @@ class FrameTrainer:
         if self.renderer.spec is not None:
             self._spec_recover()
         self._spec_ring = []
+        self._spec_events = []
 
     def _step_body(self, frame_index: int, grad_hook=None, hook_slot: int = 0, peer_frames=None):
         frame = self.frames[frame_index % len(self.frames)]

@@ -80,6 +80,7 @@ def psnr(img: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
 @torch.no_grad()
 def evaluate(trainer: FrameTrainer, frames: Sequence[Frame]) -> float:
     """mean PSNR over ``frames``, forward only (trainer.py:165-193)"""
+    trainer.flush()                          # speculative mode: the parameters must reflect every step enqueued so far
     vals = []
     for fr in frames:
         img = trainer.forward(fr)[0]
@@ -155,6 +156,7 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
         exchange = dp_mod.MomentExchange(trainer.params, world, n_slots=(len(frames) + world - 1) // world)
     trainer.exchange = exchange
     trainer.sched_ticks = world                           # the lr schedule counts frames, not optimizer steps (FrameTrainer.sched_ticks)
+    trainer.speculative = (world == 1 and fused)          # single GPU: speculative depth-bound culling (csrc/fused.hip); flushed at every epoch boundary
     say(f"[litegs_amd] {len(frames)} training frames {W}x{H}, {len(test_frames_dev)} test frames, {init_points_num} initial points, "
         f"{total_epoch} epochs, world {world}, scene radius {norm_radius:.3f}")
 
@@ -167,6 +169,7 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
                 trainer.step(peers[rank], exchange, slot, peers)
         if exchange is not None:
             exchange.check()
+        trainer.flush()
         record = {"epoch": epoch, "points": trainer.n_chunks * trainer.S}
         if epoch in test_epochs:
             record["psnr_train"] = evaluate(trainer, frames)

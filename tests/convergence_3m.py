@@ -38,6 +38,7 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
     tr = SyntheticTrainer(cfg["n"], cfg["W"], cfg["H"], cfg["focal"], n_frames=cfg["frames"], seed=cfg["seed"], scene=student, fused=fused, noise_targets=False)
     for k, t in enumerate(targets):
         tr.frames[k].gt = t
+    tr.speculative = fused                                   # the executor's speculative culling, as bench.py and training.start run it
     ctl = tr.enable_densify(D.DensifyParams(**densify), total_epochs=epochs, seed=cfg["seed"]) if densify else None
 
     def evaluate():
@@ -68,7 +69,7 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
     secs = time.time() - t0
     rd = tr.renderer
     info = dict(psnr=curve, size=sizes, iterations=at, seconds=secs, ms_per_iteration=secs / (epochs * cfg["frames"]) * 1e3,
-                unculled_reruns=int(rd.fallbacks), truncated=int(rd.truncated_visits), finite=all(bool(torch.isfinite(p).all()) for p in tr.params))
+                unculled_reruns=int(rd.fallbacks), replayed_steps=int(tr.spec_replays), truncated=int(rd.truncated_visits), finite=all(bool(torch.isfinite(p).all()) for p in tr.params))
     if ctl is not None:
         STATS.reset(1, 1, enabled_for_epoch=lambda e: False, device="cuda")
         STATS.tile_schedule.clear(); STATS.tile_blend_count.clear()
@@ -122,7 +123,8 @@ def to_markdown(out):
           f"| largest |dPSNR| between executor run 1 and the operator path over the whole curve | {np.abs(np.array(ex[0]['psnr']) - np.array(op['psnr'])).max():.3f} dB |",
           f"| largest |dPSNR| between executor runs 1 and 2 over the whole curve | {np.abs(np.array(ex[0]['psnr']) - np.array(ex[1]['psnr'])).max():.3f} dB |" if len(ex) > 1 else "",
           f"| ms per iteration (training + density control + evaluation), executor / operator | {np.mean([r['ms_per_iteration'] for r in ex]):.3f} / {op['ms_per_iteration']:.3f} |",
-          f"| frames repeated unculled (depth-bound fallback), executor runs | {', '.join(str(r['unculled_reruns']) for r in ex)} |",
+          f"| frames repeated unculled (a depth bound was violated), executor runs | {', '.join(str(r['unculled_reruns']) for r in ex)} |",
+          f"| steps replayed by the speculative executor (the failed step and those enqueued behind it) | {', '.join(str(r.get('replayed_steps', 0)) for r in ex)} |",
           f"| truncated tables observed | {', '.join(str(r['truncated']) for r in ex)} |",
           f"| parameters finite at the end | {all(r['finite'] for r in ex) and op['finite']} |"]
     return "\n".join(x for x in L if x != "") + "\n"
