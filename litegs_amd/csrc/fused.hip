@@ -53,6 +53,16 @@ static int g_bound_margin_pct = 100;
 // TILE mode: group the instances by tile with per-tile counts + cursors (binning.hip "Tile scatter") instead of the stable tile radix
 // sort -- the order inside a tile is re-made by the per-tile depth sort anyway.  Same table bit for bit.  Key 2 of lg_fused_set_option.
 static int g_tile_scatter = 1;
+// Gradient replicas for splats that cover many tiles (raster.hip): key 3 of lg_fused_set_option, read by lg_fused_stage1 (the projection
+// assigns the replica lines) -- on only when every consumer of the gradient records folds them (the fused backward kernels of this file).
+static int g_grad_replicas = 0;
+// the replica line counter: a device int owned by the caller (persistent: the projection that assigns lines cannot also clear its own
+// counter).  It is reset by the kernel that consumes the records at the end of a training step (project_backward_adam / project_fused_backward).
+static int* g_hot_counter = nullptr;
+LG_API int lg_fused_set_hot_counter(int* counter_dev) { g_hot_counter = counter_dev; return 0; }
+static bool replicas_on() { return g_grad_replicas != 0 && g_hot_counter != nullptr; }
+#define LG_HOT_MIN_TILES 128               // a splat with at least this many tile instances gets R = 2^k <= 64 lines, ~64 instances per line
+__host__ __device__ static inline long long hot_capacity(long long N) { return N / 4 + 1024; }
 #define LG_TILE_BINS_MAX (1 << 17)          // count words reserved (and cleared) per frame in workspace 1; frames with more tiles keep the radix sort
 static bool use_tile_scatter(long long N, int ntiles);
 
@@ -92,10 +102,11 @@ LG_API int lg_fused_set_option(int key, int value)
     if (key == 0 && (value == LG_DEPTH_ORDER_GLOBAL || value == LG_DEPTH_ORDER_TILE || value == LG_DEPTH_ORDER_AUTO)) { g_depth_order_mode = value; return 0; }
     if (key == 1 && value >= 1 && value <= 100000) { g_bound_margin_pct = value; return 0; }
     if (key == 2 && (value == 0 || value == 1)) { g_tile_scatter = value; return 0; }
+    if (key == 3 && (value == 0 || value == 1)) { g_grad_replicas = value; return 0; }
     return (int)hipErrorInvalidValue;
 }
 
-LG_API int lg_fused_get_option(int key) { return key == 0 ? g_depth_order_mode : (key == 1 ? g_bound_margin_pct : (key == 2 ? g_tile_scatter : -1)); }
+LG_API int lg_fused_get_option(int key) { return key == 0 ? g_depth_order_mode : (key == 1 ? g_bound_margin_pct : (key == 2 ? g_tile_scatter : (key == 3 ? g_grad_replicas : -1))); }
 static bool use_tile_scatter(long long N, int ntiles) { return g_tile_scatter && use_tile_order(N) && ntiles + 2 <= LG_TILE_BINS_MAX; }
 #define LOG2E 1.4426950408889634f
 
@@ -114,7 +125,8 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
                                      float* __restrict__ view_z, int* __restrict__ alloc, float4* __restrict__ packed, int gx, int gy,
                                      uint32_t* __restrict__ zero_ptr, long long zero_words,
                                      uint32_t* __restrict__ zero3_ptr, long long zero3_words,
-                                     const float* __restrict__ bound_pyr, const int* __restrict__ gate)
+                                     const float* __restrict__ bound_pyr, const int* __restrict__ gate,
+                                     int* __restrict__ hot_of /*nullable*/, int* __restrict__ hot_lines, int hot_cap)
 {
     if (gate != nullptr && *gate == 0) return;          // fallback launch of the depth-bound culling that is not needed
     const int a = blockIdx.x, t = threadIdx.x;
@@ -127,6 +139,7 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     if (a >= visible_chunks_num[0]) {
         alloc[i] = 0;
         view_z[i] = 3.0e38f;            // sorts last and emits nothing
+        if (hot_of != nullptr) hot_of[i] = -1;
         return;
     }
     const size_t CS = (size_t)C * S;
@@ -152,6 +165,17 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     // keeps its count (sign bit set: the culled view of the prefix sum counts it as 0) but emits nothing
     if (bound_pyr != nullptr && tiles > 0 && v[2] > lg_bound_query(bound_pyr, gx, gy, rect[0], rect[1], rect[2], rect[3]))
         tiles |= (int)0x80000000u;
+    // ---- gradient replicas (raster.hip): R = 2^k lines behind the N regular ones for a splat that many tiles will add to
+    if (hot_of != nullptr) {
+        int hot = -1;
+        if (tiles >= LG_HOT_MIN_TILES) {
+            int k = 31 - __clz(tiles >> 6);                  // ~64 instances per line
+            k = k > 6 ? 6 : k;
+            const int base = atomicAdd(hot_lines, 1 << k);
+            if (base + (1 << k) <= hot_cap) hot = (base << 6) | k;
+        }
+        hot_of[i] = hot;
+    }
     // ---- SH -> RGB (+0.5, no clamp).  Only for splats that are emitted: a third of the Gaussians of the visible CHUNKS fail
     // the fine test (frustum / opacity / degenerate), most of the rest are culled by depth, and the 48 SH coefficients are 76 % of
     // a Gaussian's bytes
@@ -197,9 +221,11 @@ __global__ void project_fused_backward_kernel(const int64_t* __restrict__ visibl
                                               const float* __restrict__ opa, int C, int S, int A, int R,
                                               const float4* __restrict__ packed_grad, const float* __restrict__ grad_inv_scaler,
                                               float* __restrict__ d_pos, float* __restrict__ d_scale, float* __restrict__ d_rot,
-                                              float* __restrict__ d_sh0, float* __restrict__ d_shr, float* __restrict__ d_opa)
+                                              float* __restrict__ d_sh0, float* __restrict__ d_shr, float* __restrict__ d_opa,
+                                              const int* __restrict__ hot_of, int* __restrict__ hot_counter)
 {
     const int a = blockIdx.x, t = threadIdx.x;
+    if (hot_counter != nullptr && a == 0 && t == 0) *hot_counter = 0;        // the next frame's projection assigns replica lines from 0
     const size_t AS = (size_t)A * S;
     const size_t od = (size_t)a * S + t;
     constexpr int NB = (DEG + 1) * (DEG + 1);
@@ -212,7 +238,7 @@ __global__ void project_fused_backward_kernel(const int64_t* __restrict__ visibl
     const float sc = grad_inv_scaler ? grad_inv_scaler[0] : 1.0f;
     GaussGrads G;
     float mom[9];
-    load_moments(packed_grad, od, mom);
+    load_moments_folded(packed_grad, od, (long long)AS, hot_of, mom);
     gaussian_backward<DEG>(cam, mom, sc, pos[sd], pos[CS + sd], pos[2 * CS + sd],
                            scale[sd], scale[CS + sd], scale[2 * CS + sd], rot[sd], rot[CS + sd], rot[2 * CS + sd], rot[3 * CS + sd], opa[sd], G);
 #pragma unroll
@@ -244,9 +270,11 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
                                              float* __restrict__ v_pos, float* __restrict__ v_scale, float* __restrict__ v_rot,
                                              float* __restrict__ v_sh0, float* __restrict__ v_shr, float* __restrict__ v_opa,
                                              unsigned char* __restrict__ touched, const int* __restrict__ emitted,
-                                             const int* __restrict__ poison, int* __restrict__ applied_host, int step_id)
+                                             const int* __restrict__ poison, int* __restrict__ applied_host, int step_id,
+                                             const int* __restrict__ hot_of, int* __restrict__ hot_counter)
 {
     const int a = blockIdx.x, t = threadIdx.x;
+    if (hot_counter != nullptr && a == 0 && t == 0) *hot_counter = 0;        // the next frame's projection assigns replica lines from 0
     if (poison != nullptr) {                 // speculative culling: a failed step (this one or an earlier one) -> nothing is updated
         if (*poison != 0) return;
         if (a == 0 && t == 0) __hip_atomic_store(applied_host, step_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -263,7 +291,7 @@ __global__ void project_backward_adam_kernel(const int64_t* __restrict__ visible
     // by depth).  A splat that was not emitted was never blended: its gradient record is the zeros it was cleared to, and for the
     // no-op test below 4 bytes tell as much as the 64-byte record (two thirds of the Gaussians of the visible chunks)
     if (emitted != nullptr && touched != nullptr && emitted[od] <= 0 && touched[sd] == 0) return;
-    load_moments(packed_grad, od, mom);
+    load_moments_folded(packed_grad, od, (long long)A * S, hot_of, mom);
     // Exact skip of no-op updates.  touched[g] == 0 asserts that both Adam moments of every row of Gaussian g are (+-)0 -- it has never
     // received a gradient.  If this frame's nine blend moments are all zero as well, every parameter gradient is 0 and the update is
     // m' = b1*0 + (1-b1)*0 = 0, v' = 0, p' = p - lr*0/(sqrt(0)+eps) = p: bit for bit what is already in memory, so the 708 B of
@@ -326,6 +354,7 @@ struct Layout1 {      // sized by N = A*S (per-Gaussian buffers)
     size_t tsort_hdr2, scan_status2, dup_queue2, flags;
     // per-key instance counts of the tile scatter, for the culled run and for its gated fallback (inside the zeroed region)
     size_t tcount, tcount2;
+    size_t hot_of;                        // int32[N]: replica assignment per compacted splat (-1: none)
 };
 struct Layout2 {      // sized by the tile-instance table length L
     size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, tile_work, dup_entries, tile_cursor, total;
@@ -356,6 +385,7 @@ static Layout1 layout1(long long N)
     f.tcount = take(4 * (size_t)LG_TILE_BINS_MAX);
     f.tcount2 = take(4 * (size_t)LG_TILE_BINS_MAX);
     f.zero_bytes = f.tcount2 + 4 * (size_t)LG_TILE_BINS_MAX - f.zeroed;
+    f.hot_of = take(4 * (size_t)N);
     f.total = o;
     return f;
 }
@@ -387,6 +417,9 @@ static size_t sorted_points_offset(const Layout2& f, long long N, int ntiles)
 }
 
 LG_API long long lg_fused_workspace1_bytes(long long N) { return (long long)layout1(N > 0 ? N : 1).total; }
+
+// lines (16 floats each) of the gradient accumulator of a frame with N compacted Gaussians: the N regular records + the replica region
+LG_API long long lg_fused_grad_lines(long long N) { return N + hot_capacity(N); }
 
 LG_API long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW)
 {
@@ -449,7 +482,7 @@ struct Scene {            // what the projection kernel reads (raw parameters + 
 
 static int launch_projection(const Scene& sc, const Camera& cam, int TH, int TW, char* w, const Layout1& f, bool zero_duty,
                              const int* sched_in /*nullable: cull against its depth bounds*/, int* sched_out /*nullable: head cleared*/,
-                             const int* gate, hipStream_t s)
+                             const int* gate, hipStream_t s, bool hot = false)
 {
     const float* bound_pyr = reinterpret_cast<const float*>(sched_in);
     float* view_z = (float*)(w + f.view_z); float4* packed = (float4*)(w + f.packed);
@@ -458,7 +491,8 @@ static int launch_projection(const Scene& sc, const Camera& cam, int TH, int TW,
 #define LAUNCH_PF(D, A_, B_) hipLaunchKernelGGL((project_fused_kernel<D, A_, B_>), dim3(sc.A), dim3(sc.S), 0, s, sc.vis_ids, sc.vis_num, cam,   \
                                                 sc.pos, sc.scale, sc.rot, sc.sh0, sc.shr, sc.opa, sc.chunks, sc.S, sc.A, view_z, alloc, packed, \
                                                 gx, gy, (uint32_t*)(w + f.zeroed), zero_duty ? (long long)(f.zero_bytes / 4) : 0LL,             \
-                                                (uint32_t*)sched_out, sched_out ? lg_sched_clear_words(gx, gy) : 0LL, bound_pyr, gate)
+                                                (uint32_t*)sched_out, sched_out ? lg_sched_clear_words(gx, gy) : 0LL, bound_pyr, gate,     \
+                                                hot ? (int*)(w + f.hot_of) : (int*)nullptr, g_hot_counter, (int)hot_capacity((long long)sc.A * sc.S))
 #define DISPATCH_PF(A_, B_)                                                  \
     switch (sc.degree) {                                                     \
     case 0: LAUNCH_PF(0, A_, B_); break;                                     \
@@ -509,7 +543,7 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
     char* w = (char*)ws1;
     Camera cam = make_camera(view_host, proj_host, H, W);
     Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
-    rc = launch_projection(sc, cam, TH, TW, w, f, true, sched_cull, sched_out, nullptr, s); if (rc) return rc;
+    rc = launch_projection(sc, cam, TH, TW, w, f, true, sched_cull, sched_out, nullptr, s, replicas_on()); if (rc) return rc;
     if (use_tile_order(N)) {
         // no splat sort: instances are emitted in splat-id order and every tile's list is depth-sorted after the tile sort
         // (tilesort.hip).  Inclusive scan of the tile counts in id order; prefix[N-1] (the table length) also goes to the host feedback slot
@@ -558,7 +592,7 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
                                (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
                                qcount, (uint32_t*)(w + f.dup_entries), nullptr, 0, bits, nullptr, nullptr, 0,
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
-                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * N : 0, gate, fail_flag, s);
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (replicas_on() ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
         if (rc) return rc;
         rc = lg_tile_scatter_gated((const int32_t*)(w + f.tk_a), (const int32_t*)(w + f.tv_a), Ls, total_dev, ntiles, tcount, 1, (int*)(w + f.tile_cursor),
                                    (int32_t*)(w + f.tile_start), (int32_t*)(w + f.tv_b), gate, s);
@@ -575,7 +609,7 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
                                qcount, (uint32_t*)(w + f.dup_entries), tsort_hdr, 0, bits, nullptr, (uint32_t*)(w + f.tsort_table),
                                (long long)lg_radix_table_words(Ls, lg_radix_sort_num_passes(0, bits)),
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
-                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * N : 0, gate, fail_flag, s);
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (replicas_on() ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
     if (rc) return rc;
     // instance count on the device: only that many entries are sorted and range-scanned
     rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
@@ -696,14 +730,18 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
     const char* w = (const char*)ws2;
     const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(f, N, ntiles));
     int rc = 0;
-    if (!packed_grad_is_zero) { rc = lg_memset_async(packed_grad, 0, (long long)sizeof(float) * GREC * N, stream); if (rc) return rc; }
-    rc = lg_raster_backward(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, final_T, last, d_img, d_trans,
-                            1, L, (int)N, H, W, TH, TW, enable_stat, packed_grad, err_square_sum, nullptr, tiles ? nullptr : order, stream);
+    const bool hot = replicas_on();             // the caller sets option 3 as it was for this frame's lg_fused_stage1
+    const int* hot_of = hot ? (const int*)(w1 + f1.hot_of) : nullptr;
+    if (!packed_grad_is_zero) { rc = lg_memset_async(packed_grad, 0, (long long)sizeof(float) * GREC * (hot ? lg_fused_grad_lines(N) : N), stream); if (rc) return rc; }
+    rc = lg_raster_backward_hot(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, final_T, last, d_img, d_trans,
+                                1, L, (int)N, H, W, TH, TW, enable_stat, packed_grad, err_square_sum, nullptr, tiles ? nullptr : order,
+                                hot_of, hot ? hot_capacity(N) : 0, stream);
     if (rc) return rc;
     if (d_pos == nullptr) return 0;
     Camera cam = make_camera(view_host, proj_host, H, W);
 #define LAUNCH_PB(D) hipLaunchKernelGGL(project_fused_backward_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, pos, scale, rot, opa, \
-                                        chunks, S, A, R, (const float4*)packed_grad, grad_inv_scaler, d_pos, d_scale, d_rot, d_sh0, d_shr, d_opa)
+                                        chunks, S, A, R, (const float4*)packed_grad, grad_inv_scaler, d_pos, d_scale, d_rot, d_sh0, d_shr, d_opa, \
+                                        hot_of, hot ? g_hot_counter : (int*)nullptr)
     switch (degree) {
     case 0: LAUNCH_PB(0); break;
     case 1: LAUNCH_PB(1); break;
@@ -728,6 +766,9 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
                                   const int* emitted /*nullable [A*S]: the tile counts stage 1 left in workspace 1 (lg_fused_alloc_offset)*/, void* stream)
 {
     if (A <= 0) return 0;
+    // gradient replicas: with option 3 on (as it was for this frame's lg_fused_stage1) the assignment sits in the same workspace 1 as `emitted`
+    const int* hot_of = (replicas_on() && emitted != nullptr)
+                            ? (const int*)((const char*)emitted - layout1((long long)A * S).alloc + layout1((long long)A * S).hot_of) : nullptr;
     if (S > 1024 || S <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     Camera cam = make_camera(view_host, proj_host, H, W);
@@ -735,7 +776,7 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
 #define LAUNCH_PA(D) hipLaunchKernelGGL(project_backward_adam_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, ar, chunks, S, A, R, \
                                         (const float4*)packed_grad, grad_inv_scaler, pos, scale, rot, sh0, shr, opa,                          \
                                         m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa, v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched, emitted, \
-                                        (const int*)g_spec.poison, g_spec.applied_host, g_spec.step_id)
+                                        (const int*)g_spec.poison, g_spec.applied_host, g_spec.step_id, hot_of, hot_of ? g_hot_counter : (int*)nullptr)
     switch (degree) {
     case 0: LAUNCH_PA(0); break;
     case 1: LAUNCH_PA(1); break;

@@ -80,3 +80,10 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
                              float* img, float* trans, short* last, int* frag_count, float* frag_weight,
                              const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag,
                              int* fail_host /*nullable pinned mirror: receives 1 when fail_flag is raised*/, const int* gate, void* stream);
+
+// blend backward with gradient replicas for the splats that cover many tiles (raster.hip)
+int lg_raster_backward_hot(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
+                           const float* final_T, const short* last, const float* d_img, const float* d_trans,
+                           int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
+                           float* packed_grad, float* err_square_sum, int* tile_counters, const int* order,
+                           const int* hot_of, long long hot_lines, void* stream);

@@ -74,6 +74,25 @@ __device__ __forceinline__ void load_moments(const float4* __restrict__ packed_g
     mom[0] = a.x; mom[1] = a.y; mom[2] = a.z; mom[3] = a.w; mom[4] = b.x; mom[5] = b.y; mom[6] = b.z; mom[7] = b.w; mom[8] = rec[2].x;
 }
 
+// Gradient replicas (raster.hip "replicas"): the blend backward adds the moments of a splat that covers many tiles into one of R lines
+// behind the N regular records instead of hammering a single line; hot = (first replica line << 6) | log2 R, or -1.  The consumer sums
+// the regular record and the R replicas.
+__device__ __forceinline__ void load_moments_folded(const float4* __restrict__ packed_grad, size_t od, long long N, const int* __restrict__ hot_of,
+                                                    float (&mom)[9])
+{
+    load_moments(packed_grad, od, mom);
+    if (hot_of == nullptr) return;
+    const int hot = hot_of[od];
+    if (hot < 0) return;
+    const int R = 1 << (hot & 63);
+    const float4* __restrict__ rec = packed_grad + ((size_t)N + (size_t)(hot >> 6)) * (LG_GREC / 4);
+    for (int r = 0; r < R; r++) {
+        const float4 a = rec[r * (LG_GREC / 4)], b = rec[r * (LG_GREC / 4) + 1];
+        const float c = rec[r * (LG_GREC / 4) + 2].x;
+        mom[0] += a.x; mom[1] += a.y; mom[2] += a.z; mom[3] += a.w; mom[4] += b.x; mom[5] += b.y; mom[6] += b.z; mom[7] += b.w; mom[8] += c;
+    }
+}
+
 struct AdamRates { float lr_pos, lr_sh0, lr_shr, lr_opa, lr_scale, lr_rot, b1, b2, eps; };
 
 __device__ __forceinline__ void adam_row(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, size_t o, float g,

@@ -927,7 +927,7 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
                                                                    const float* __restrict__ d_img, const float* __restrict__ d_trans,
                                                                    float* __restrict__ packed_grad, const int* __restrict__ order,
                                                                    int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode,
-                                                                   int no_atomics)
+                                                                   int no_atomics, const int* __restrict__ hot_of)
 {
     constexpr int TH = 8, TW = 16;
     const int lane = threadIdx.x & 63;
@@ -987,26 +987,37 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     id_request(id_b, sp, (unsigned)(pos - 1) << 2);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id_a), "+s"(id_b));
     unsigned off_a = (unsigned)id_a << 6, off_b = (unsigned)id_b << 6;
+    // replicas: a splat that covers many tiles has R = 2^k gradient lines behind the N regular ones (hot_of: first line << 6 | k, -1: none;
+    // assigned by the projection, fused.hip); this tile adds into replica (tile mod R) -- same-line contention at the memory-side atomic
+    // units was 70-80 % of what the atomics cost (profiles/r03_bwd_ab.log).  The word travels with the splat's record (scalar path).
+    const int* __restrict__ hot = hot_of != nullptr ? hot_of : sp;        // without replicas the loads below still go somewhere valid
+    const unsigned hot_on = hot_of != nullptr ? 1u : 0u;
+    int hot_a = -1, hot_b = -1;
     rec_request(ra, pk, off_a);
-    rec_wait(ra);
+    id_request(hot_a, hot, hot_on ? (unsigned)id_a << 2 : 0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(hot_a));
     // phase 1: positions that some pixel of the tile had already stopped before (pos >= minlast): per-pixel last_contributor test
+#define HOT_TARGET(h, off) ((hot_on && (h) >= 0) ? (((unsigned)N + ((unsigned)(h) >> 6) + ((unsigned)tile & ((1u << ((h) & 63)) - 1u))) << 6) : (off))
 #define BWD_PAIR(CHK)                                                                                         \
     {                                                                                                         \
         rec_request(rb, pk, off_b);                                                                           \
+        id_request(hot_b, hot, hot_on ? off_b >> 4 : 0u);                                                     \
         id_request(id_a, sp, (unsigned)max(pos - 2, 0) << 2);                                                 \
-        bwd_splat_fast<TRANS, CHK>(st, ra, pos, off_a, slot_off, writers, pg, private_base);                                \
-        rec_id_wait(rb, id_a);                                                                                \
+        bwd_splat_fast<TRANS, CHK>(st, ra, pos, HOT_TARGET(hot_a, off_a), slot_off, writers, pg, private_base);              \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rb), "+s"(id_a), "+s"(hot_b));                             \
         off_a = (unsigned)id_a << 6;                                                                          \
         rec_request(ra, pk, off_a);                                                                           \
+        id_request(hot_a, hot, hot_on ? off_a >> 4 : 0u);                                                     \
         id_request(id_b, sp, (unsigned)max(pos - 3, 0) << 2);                                                 \
-        bwd_splat_fast<TRANS, CHK>(st, rb, pos - 1, off_b, slot_off, writers, pg, private_base);                            \
-        rec_id_wait(ra, id_b);                                                                                \
+        bwd_splat_fast<TRANS, CHK>(st, rb, pos - 1, HOT_TARGET(hot_b, off_b), slot_off, writers, pg, private_base);          \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(id_b), "+s"(hot_a));                             \
         off_b = (unsigned)id_b << 6;                                                                          \
         pos -= 2;                                                                                             \
     }
     for (; pos >= 1 && pos >= minlast; ) BWD_PAIR(true)
     for (; pos >= 1; ) BWD_PAIR(false)
 #undef BWD_PAIR
+#undef HOT_TARGET
 }
 
 LG_API int lg_set_tuning(int key, int value)
@@ -1028,12 +1039,25 @@ LG_API int lg_raster_backward(const int* sorted_points, const int* start_index, 
                               float* packed_grad /*[V,N,16] zeroed*/, float* err_square_sum /*[V,1,N] zeroed*/,
                               int* tile_counters /*nullable [V,T+1,2]*/, const int* order /*nullable [V,T]*/, void* stream)
 {
+    return lg_raster_backward_hot(sorted_points, start_index, packed, tiles, K, final_T, last, d_img, d_trans, V, L, N, H, W, TH, TW, enable_stat,
+                                  packed_grad, err_square_sum, tile_counters, order, nullptr, 0, stream);
+}
+
+// The executor's entry: hot_of (nullable int32[N], V == 1) assigns replica lines to the splats that cover many tiles; packed_grad then has
+// N + hot_lines lines (the consumer folds them: lg_gaussian_bwd.h load_moments_folded).  Only the 8x16 fast kernel uses them.
+int lg_raster_backward_hot(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
+                           const float* final_T, const short* last, const float* d_img, const float* d_trans,
+                           int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
+                           float* packed_grad, float* err_square_sum, int* tile_counters, const int* order,
+                           const int* hot_of, long long hot_lines, void* stream)
+{
     LG_REQUIRE(sorted_points, start_index, packed, final_T, last, d_img, packed_grad);
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
     const int nslots = tiles ? K : ntiles;
     if (nslots <= 0) return 0;
-    if (N >= (1 << 26)) return (int)hipErrorInvalidValue;          // 32-bit record offsets
+    if ((long long)N + hot_lines >= (1 << 26)) return (int)hipErrorInvalidValue;          // 32-bit record offsets
+    if (hot_of != nullptr && V != 1) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     if (!g_use_order) order = nullptr;
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
@@ -1051,9 +1075,9 @@ LG_API int lg_raster_backward(const int* sorted_points, const int* start_index, 
     }
     else if (TH == 8 && TW == 16 && !enable_stat && g_bwd_fast) {
         if (d_trans) hipLaunchKernelGGL((raster_backward_fast_kernel<true>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
-                                        d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_noatomic);
+                                        d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_noatomic, hot_of);
         else hipLaunchKernelGGL((raster_backward_fast_kernel<false>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
-                                d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_noatomic);
+                                d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_noatomic, hot_of);
     }
     else if (TH == 8 && TW == 16) DISPATCH_RB(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RB(16, 16);

@@ -107,6 +107,10 @@ class FusedRenderer:
         self.after_cull = None
         self._cull_scratch, self._cull_chunks, self._cull_epoch = None, -1, 0
         # speculative culling (csrc/fused.hip): set by FrameTrainer when it takes over the replay of failed steps
+        # gradient replicas (csrc/raster.hip): splats that cover many tiles get several gradient lines; on for renders whose records only
+        # the fused backward kernels consume (no statistics, no data-parallel exchange).  LITEGS_GRAD_REPLICAS=0 disables.
+        self.replicas_enabled = os.environ.get("LITEGS_GRAD_REPLICAS", "1") != "0"
+        self.hot_counter = None
         self.spec = None              # dict(poison=device int32[1], poison_host / applied_host = pinned int32[1])
         self.spec_step = 0            # number of the training step being enqueued
         self.force_full = False       # the next render runs unculled (the first replayed step)
@@ -213,11 +217,17 @@ class _RenderFn(torch.autograd.Function):
             A = min(int(1.2 * pred_vis), chunks)
         A = max(A, 1)
         N = A * S
+        stat = STATS.active
+        replicas = bool(R.replicas_enabled and R.fuse_optimizer and R.after_cull is None and not stat and any(ctx.needs_input_grad))
+        if replicas and R.hot_counter is None:
+            R.hot_counter = torch.zeros((1,), dtype=torch.int32, device=dev)
+        if R.hot_counter is not None:
+            L.lg_fused_set_hot_counter(R.hot_counter.data_ptr())
+        L.lg_fused_set_option(3, 1 if replicas else 0)
         if R.interleave_emission and L.lg_fused_get_option(0) != 0:
             L.lg_fused_set_emission_order(R.emission_order(A, S, dev).data_ptr(), N)
         ws1_bytes = L.lg_fused_workspace1_bytes(N)
         ws1 = torch.empty((ws1_bytes,), dtype=torch.uint8, device=dev)
-        stat = STATS.active
         tiles = STATS.schedule_for_current_frame()
         # depth-bound culling: bookkeeping of the sizing feedback (the emitted total of a culled visit is not the full table length)
         pred_total = int(R.fb_total[k])
@@ -294,7 +304,8 @@ class _RenderFn(torch.autograd.Function):
         if tiles is not None:
             img.zero_(); trans.fill_(1.0); last.zero_()
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
-        pg = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
+        pg_lines = L.lg_fused_grad_lines(N) if replicas else N
+        pg = torch.empty((pg_lines, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
         L.lg_fused_set_option(1, int(R.margin[k]))
         # a culled render that a fused Adam step follows may run speculatively (no gated repeat); anything else keeps the repeat
         L.lg_fused_set_speculation(*R.speculation_args(cull and R.fuse_optimizer and any(ctx.needs_input_grad)))
@@ -321,6 +332,7 @@ class _RenderFn(torch.autograd.Function):
             R.tile_order_valid[k] = True
         ctx.order_ptr = order_ptr if (use_sched and R.tile_order_valid[k]) else None
         ctx.pg = pg
+        ctx.replicas = replicas
         if stat:
             STATS.update_tile_schedule(last, R.TH, R.TW)
         ctx.R, ctx.frame, ctx.meta = R, frame, (A, S, table_len, int(degree), chunks, sh_rest.shape[0], ws1_bytes, ws2_bytes, stat)
@@ -345,8 +357,9 @@ class _RenderFn(torch.autograd.Function):
         g_img = g_img.contiguous()
         pg, pg_zero = ctx.pg, 1
         if pg is None:
-            pg, pg_zero = torch.empty((N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev), 0
+            pg, pg_zero = torch.empty((L.lg_fused_grad_lines(N) if ctx.replicas else N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev), 0
         ctx.pg = None
+        L.lg_fused_set_option(3, 1 if ctx.replicas else 0)          # as it was for this frame's stage 1
         esq = torch.zeros((1, 1, N), dtype=torch.float32, device=dev) if stat else None
         tiles = ctx.tiles
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
@@ -369,7 +382,8 @@ class _RenderFn(torch.autograd.Function):
                 STATS.add_moments("fragment_weight", fw, fw * fw, fc)
                 STATS.add_moments("fragment_err", _d_opacity(pg, ws1, N), esq, fc)
             # ws1 rides along: its tile counts tell the fused backward + Adam which gradient records can only be zero
-            R.pending = dict(pg=pg, A=A, S=S, frame=frame, degree=degree, chunks=chunks, Rr=Rr, vis_ids=vis_ids, vis_num=vis_num, ws1=ws1)
+            R.pending = dict(pg=pg, A=A, S=S, frame=frame, degree=degree, chunks=chunks, Rr=Rr, vis_ids=vis_ids, vis_num=vis_num, ws1=ws1,
+                             replicas=ctx.replicas)
             return (None,) * 11
         d_pos = torch.empty((3, A, S), dtype=torch.float32, device=dev)
         d_scale = torch.empty((3, A, S), dtype=torch.float32, device=dev)
@@ -455,6 +469,7 @@ class FusedAdam:
         lr6 = (ctypes.c_float * 6)(*[float(self._by_name[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]])
         R, fr = self.renderer, pend["frame"]
         lib().lg_fused_set_speculation(*R.speculation_args(True))
+        lib().lg_fused_set_option(3, 1 if pend.get("replicas") else 0)
         check(lib().lg_fused_backward_adam(pend["A"], pend["S"], R.H, R.W, fr.view_ptr, fr.proj_ptr, pend["degree"], pend["chunks"], pend["Rr"],
                                            pend["vis_ids"].data_ptr(), pend["vis_num"].data_ptr(), pend["pg"].data_ptr(), None,
                                            *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms], *[v.data_ptr() for v in vs],

@@ -232,3 +232,25 @@ def test_underpredicted_table_in_per_tile_depth_mode(oracle):
         assert_close(img3.cpu().numpy(), full_img, **IMG_FLIP, name="healed img (tile mode)")
     finally:
         L.lg_fused_set_option(0, prev)
+
+
+def test_gradient_replicas_do_not_change_the_update():
+    """Gradient replicas (csrc/raster.hip: splats that cover >= 128 tiles spread their blend-backward atomics over 2^k lines, folded by the
+    fused backward + Adam): one training step from the same state with and without them gives the same parameters and moments up to the
+    summation order -- on a camera inside the cloud, where near splats cover hundreds of tiles."""
+    from litegs_amd.trainer import SyntheticTrainer
+    out = {}
+    for on in (True, False):
+        tr = SyntheticTrainer(120_000, 640, 360, 380.0, n_frames=2, seed=7, cam_radius_frac=0.4)
+        tr.renderer.replicas_enabled = on
+        tr.step(0); tr.step(1); tr.step(0)
+        torch.cuda.synchronize()
+        out[on] = ([p.detach().clone() for p in tr.params], [tr.opt.state[p]["exp_avg"].clone() for p in tr.params],
+                   tr.renderer.pending is None, tr.renderer.hot_counter)
+    assert out[True][3] is not None and out[False][3] is None            # the replica path really ran in one of the two
+    for a, b in zip(out[True][1], out[False][1]):                         # first moments: linear in the gradients
+        scale = max(b.abs().max().item(), 1e-12)
+        assert (a - b).abs().max().item() <= 2e-4 * scale
+    for a, b in zip(out[True][0], out[False][0]):
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max().item() <= 5e-3                         # Adam turns last-bit gradient differences into +-lr steps
