@@ -237,9 +237,11 @@ int lg_fused_get_option(int key);
 /* key 3 of lg_fused_set_option = gradient replicas (default 0): splats that cover >= 128 tiles get 2^k <= 64 lines behind the N regular
  * gradient records, the blend backward adds into replica (tile mod 2^k), the fused backward kernels fold them -- removes the same-line
  * contention at the memory-side atomic units.  The gradient accumulator then has lg_fused_grad_lines(N) lines; the option must have the
- * same value for lg_fused_stage1, lg_fused_stage2, lg_fused_backward and lg_fused_backward_adam of one frame, and a persistent device
- * counter must be registered (reset by the backward kernels at the end of a step). */
+ * same value for lg_fused_stage1, lg_fused_stage2 and lg_fused_backward of one frame, lg_fused_backward_adam is told through
+ * lg_fused_set_hot_table, and a persistent device counter must be registered (reset by the backward kernels at the end of a step). */
 int lg_fused_set_hot_counter(int* counter_dev);
+int lg_fused_set_hot_table(const int* hot_of);   /* one-shot: the replica assignment (workspace 1 + lg_fused_hot_offset(N)) the next lg_fused_backward_adam folds; NULL = none */
+long long lg_fused_hot_offset(long long N);
 long long lg_fused_grad_lines(long long N);
 /* Speculative depth-bound culling (fused.hip "Speculative culling"): while a context is set, a culled lg_fused_stage2 enqueues no gated
  * repeat; a violated bound raises *poison (sticky, device) and its pinned mirror, and every lg_fused_backward_adam returns at once while

@@ -61,6 +61,10 @@ static int g_grad_replicas = 0;
 static int* g_hot_counter = nullptr;
 LG_API int lg_fused_set_hot_counter(int* counter_dev) { g_hot_counter = counter_dev; return 0; }
 static bool replicas_on() { return g_grad_replicas != 0 && g_hot_counter != nullptr; }
+// the replica assignment of the frame whose records the NEXT lg_fused_backward_adam consumes (workspace 1 + lg_fused_hot_offset(N), or
+// NULL); one-shot: the call clears it, so a stale pointer can never be folded into another frame's update
+static const int* g_hot_table = nullptr;
+LG_API int lg_fused_set_hot_table(const int* hot_of) { g_hot_table = hot_of; return 0; }
 #define LG_HOT_MIN_TILES 128               // a splat with at least this many tile instances gets R = 2^k <= 64 lines, ~64 instances per line
 __host__ __device__ static inline long long hot_capacity(long long N) { return N / 4 + 1024; }
 #define LG_TILE_BINS_MAX (1 << 17)          // count words reserved (and cleared) per frame in workspace 1; frames with more tiles keep the radix sort
@@ -448,6 +452,9 @@ LG_API long long lg_fused_total_offset(long long N) { return (long long)(layout1
 // byte offset in workspace 1 of the packed splat records float[N,16] (raster.hip layout): read by the statistics hook
 LG_API long long lg_fused_packed_offset(long long N) { return (long long)layout1(N).packed; }
 
+// byte offset in workspace 1 of the replica assignment int32[N] (valid after a stage 1 that ran with option 3 on)
+LG_API long long lg_fused_hot_offset(long long N) { return (long long)layout1(N).hot_of; }
+
 // byte offset in workspace 1 of the per-Gaussian tile counts int32[N] (allocate_size, wrapper.py:726-733): read by the statistics hook
 LG_API long long lg_fused_alloc_offset(long long N) { return (long long)layout1(N).alloc; }
 
@@ -766,9 +773,8 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
                                   const int* emitted /*nullable [A*S]: the tile counts stage 1 left in workspace 1 (lg_fused_alloc_offset)*/, void* stream)
 {
     if (A <= 0) return 0;
-    // gradient replicas: with option 3 on (as it was for this frame's lg_fused_stage1) the assignment sits in the same workspace 1 as `emitted`
-    const int* hot_of = (replicas_on() && emitted != nullptr)
-                            ? (const int*)((const char*)emitted - layout1((long long)A * S).alloc + layout1((long long)A * S).hot_of) : nullptr;
+    const int* hot_of = g_hot_table;          // gradient replicas of this frame (lg_fused_set_hot_table), one-shot
+    g_hot_table = nullptr;
     if (S > 1024 || S <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     Camera cam = make_camera(view_host, proj_host, H, W);

@@ -469,7 +469,10 @@ class FusedAdam:
         lr6 = (ctypes.c_float * 6)(*[float(self._by_name[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]])
         R, fr = self.renderer, pend["frame"]
         lib().lg_fused_set_speculation(*R.speculation_args(True))
-        lib().lg_fused_set_option(3, 1 if pend.get("replicas") else 0)
+        hot = None
+        if pend.get("replicas") and "ws1" in pend:
+            hot = pend["ws1"].data_ptr() + lib().lg_fused_hot_offset(pend["A"] * pend["S"])
+        lib().lg_fused_set_hot_table(hot)
         check(lib().lg_fused_backward_adam(pend["A"], pend["S"], R.H, R.W, fr.view_ptr, fr.proj_ptr, pend["degree"], pend["chunks"], pend["Rr"],
                                            pend["vis_ids"].data_ptr(), pend["vis_num"].data_ptr(), pend["pg"].data_ptr(), None,
                                            *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms], *[v.data_ptr() for v in vs],

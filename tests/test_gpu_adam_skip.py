@@ -37,7 +37,8 @@ def test_skipping_untouched_gaussians_is_bit_exact(degree):
     flags0 = tr.fadam._touched_flags().clone()
     by = {g["name"]: g["params"][0] for g in tr.opt.param_groups}
     params = [by[n] for n in ORDER]
-    # one more forward + blend backward; its moment records stay pending
+    # one more forward + blend backward; its moment records stay pending (no gradient replicas: _apply below calls the C entry directly)
+    tr.renderer.replicas_enabled = False
     tr.renderer.fuse_optimizer = True
     img, vis_id, vis_num, _ = tr.forward(tr.frames[1], raw=True)
     loss_hip.raster_l1_ssim_loss(img, tr.frames[1].gt).backward()
