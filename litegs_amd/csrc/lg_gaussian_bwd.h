@@ -86,10 +86,22 @@ __device__ __forceinline__ void load_moments_folded(const float4* __restrict__ p
     if (hot < 0) return;
     const int R = 1 << (hot & 63);
     const float4* __restrict__ rec = packed_grad + ((size_t)N + (size_t)(hot >> 6)) * (LG_GREC / 4);
-    for (int r = 0; r < R; r++) {
-        const float4 a = rec[r * (LG_GREC / 4)], b = rec[r * (LG_GREC / 4) + 1];
-        const float c = rec[r * (LG_GREC / 4) + 2].x;
-        mom[0] += a.x; mom[1] += a.y; mom[2] += a.z; mom[3] += a.w; mom[4] += b.x; mom[5] += b.y; mom[6] += b.z; mom[7] += b.w; mom[8] += c;
+    // eight lines (24 loads) in flight at a time: one line after the other, a splat with 64 replicas would stall its workgroup for 64
+    // dependent round trips
+    for (int r0 = 0; r0 < R; r0 += 8) {
+        float4 a[8], b[8];
+        float c[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int r = (r0 + j < R) ? r0 + j : r0;            // R is a power of two: r0 itself is always a valid line (counted once below)
+            a[j] = rec[r * (LG_GREC / 4)]; b[j] = rec[r * (LG_GREC / 4) + 1]; c[j] = rec[r * (LG_GREC / 4) + 2].x;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (r0 + j < R) {
+                mom[0] += a[j].x; mom[1] += a[j].y; mom[2] += a[j].z; mom[3] += a[j].w;
+                mom[4] += b[j].x; mom[5] += b[j].y; mom[6] += b[j].z; mom[7] += b[j].w; mom[8] += c[j];
+            }
     }
 }
 
