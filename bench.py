@@ -172,7 +172,7 @@ def roofline_probe(tr, frames, steps_per_frame=2):
     hbm_frac, valu_frac = hbm / HBM_PEAK_GBS, valu / VALU_PEAK_TFLOPS
     binding_valu = valu_frac >= hbm_frac
     return {
-        "bound": "valu" if binding_valu else "hbm", "kernel": "raster_backward_kernel",
+        "bound": "valu" if binding_valu else "hbm", "kernel": "raster_backward_fast_kernel<false>",
         "achieved": round(valu if binding_valu else hbm, 3), "peak": VALU_PEAK_TFLOPS if binding_valu else HBM_PEAK_GBS,
         "unit": "TFLOP/s" if binding_valu else "GB/s", "frac": round(valu_frac if binding_valu else hbm_frac, 4),
         "traffic": None,
