@@ -21,6 +21,26 @@ from .statistics import STATS
 from .wrapper import CompactedTensor
 
 
+_GUARD_ALLOC = os.environ.get("LITEGS_GUARD_ALLOC", "0") == "1"
+
+
+def _empty(shape, dtype, device, zero: bool = False, align: int = 16):
+    """torch.empty / torch.zeros for the executor's per-frame buffers.  LITEGS_GUARD_ALLOC=1 (debugging aid; pair it with
+    PYTORCH_NO_CUDA_MEMORY_CACHING=1 so that every tensor is a device mapping of its own): the tensor is placed so that it ENDS where its
+    page-granular allocation ends (`align`-byte granularity), which turns a read or write past the end of a buffer into an immediate
+    memory access fault instead of a silent access to a neighbour."""
+    if not _GUARD_ALLOC:
+        return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    padded = (nbytes + align - 1) // align * align
+    total = max((padded + 4095) // 4096 * 4096, 4096)
+    raw = (torch.zeros if zero else torch.empty)((total,), dtype=torch.uint8, device=device)
+    return raw[total - padded: total - padded + nbytes].view(dtype).view(*shape)
+
+
 def _s() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -48,6 +68,9 @@ def _apply_env_options() -> None:
     scatter = os.environ.get("LITEGS_TILE_SCATTER")       # 1: group by tile with counts + cursors in the per-tile mode; 0: stable tile radix sort
     if scatter is not None:
         check(lib().lg_fused_set_option(2, 1 if scatter != "0" else 0), "set_option")
+    desc = os.environ.get("LITEGS_SLICE_DESC")            # 0: the key emission repeats the tile walk instead of reading the projection's slices
+    if desc is not None:
+        check(lib().lg_fused_set_option(4, 1 if desc != "0" else 0), "set_option")
 
 
 class FusedRenderer:
@@ -198,9 +221,9 @@ class _RenderFn(torch.autograd.Function):
         chunks, S = xyz.shape[-2], xyz.shape[-1]
         k = frame.index
         s = _s()
-        visibility = torch.empty((chunks,), dtype=torch.bool, device=dev)
-        vis_num = torch.empty((1,), dtype=torch.int32, device=dev)
-        vis_ids = torch.empty((chunks,), dtype=torch.int64, device=dev)
+        visibility = _empty((chunks,), torch.bool, dev)
+        vis_num = _empty((1,), torch.int32, dev)
+        vis_ids = _empty((chunks,), torch.int64, dev)
         fb_vis_ptr = R.fb_vis.data_ptr() + 4 * k
         fb_tot_ptr = R.fb_total.data_ptr() + 4 * k
         common = (origin.data_ptr(), extend.data_ptr(), frame.planes.data_ptr(), chunks, frame.view_ptr, frame.proj_ptr, R.H, R.W, R.TH, R.TW,
@@ -220,14 +243,14 @@ class _RenderFn(torch.autograd.Function):
         stat = STATS.active
         replicas = bool(R.replicas_enabled and R.fuse_optimizer and R.after_cull is None and not stat and any(ctx.needs_input_grad))
         if replicas and R.hot_counter is None:
-            R.hot_counter = torch.zeros((1,), dtype=torch.int32, device=dev)
+            R.hot_counter = _empty((1,), torch.int32, dev, zero=True)
         if R.hot_counter is not None:
             L.lg_fused_set_hot_counter(R.hot_counter.data_ptr())
         L.lg_fused_set_option(3, 1 if replicas else 0)
         if R.interleave_emission and L.lg_fused_get_option(0) != 0:
             L.lg_fused_set_emission_order(R.emission_order(A, S, dev).data_ptr(), N)
         ws1_bytes = L.lg_fused_workspace1_bytes(N)
-        ws1 = torch.empty((ws1_bytes,), dtype=torch.uint8, device=dev)
+        ws1 = _empty((ws1_bytes,), torch.uint8, dev, align=64)            # 64-byte records read by 64-byte scalar loads
         tiles = STATS.schedule_for_current_frame()
         # depth-bound culling: bookkeeping of the sizing feedback (the emitted total of a culled visit is not the full table length)
         pred_total = int(R.fb_total[k])
@@ -257,8 +280,8 @@ class _RenderFn(torch.autograd.Function):
                 R.clean_visits[k] = 0
         use_sched = not stat and tiles is None
         if use_sched and R.sched is None:
-            R.sched = torch.empty((R.n_frames, 2, L.lg_sched_words(R.H, R.W, R.TH, R.TW)), dtype=torch.int32, device=dev)
-            R.tile_order = torch.empty((R.n_frames, R.ntiles), dtype=torch.int32, device=dev)
+            R.sched = _empty((R.n_frames, 2, L.lg_sched_words(R.H, R.W, R.TH, R.TW)), torch.int32, dev)
+            R.tile_order = _empty((R.n_frames, R.ntiles), torch.int32, dev)
         in_ptr = out_ptr = None
         if use_sched:
             cur = R.sched_cur[k]
@@ -289,15 +312,15 @@ class _RenderFn(torch.autograd.Function):
         grow = max(1.0, R.margin_written[k] / max(R.margin_emitted[k], 1))
         len_cull = min(table_len, int(1.5 * grow * pred_total) + 65536) if cull else table_len
         ws2_bytes = L.lg_fused_workspace2_bytes(table_len, N, R.H, R.W, R.TH, R.TW)
-        ws2 = torch.empty((ws2_bytes,), dtype=torch.uint8, device=dev)
-        img = torch.empty((1, 3, R.Hp, R.Wp), dtype=torch.float32, device=dev)
-        trans = torch.empty((1, 1, R.Hp, R.Wp), dtype=torch.float32, device=dev)
-        last = torch.empty((1, 1, R.Hp, R.Wp), dtype=torch.int16, device=dev)
+        ws2 = _empty((ws2_bytes,), torch.uint8, dev)
+        img = _empty((1, 3, R.Hp, R.Wp), torch.float32, dev)
+        trans = _empty((1, 1, R.Hp, R.Wp), torch.float32, dev)
+        last = _empty((1, 1, R.Hp, R.Wp), torch.int16, dev)
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
         fc = fw = None
         if stat:
-            fc = torch.zeros((1, 1, N), dtype=torch.int32, device=dev)
-            fw = torch.zeros((1, 1, N), dtype=torch.float32, device=dev)
+            fc = _empty((1, 1, N), torch.int32, dev, zero=True)
+            fw = _empty((1, 1, N), torch.float32, dev, zero=True)
             STATS.set_compaction(vis_ids[:A], vis_num)
             a_off = L.lg_fused_alloc_offset(N)                # b_visible = allocate_size != 0 (wrapper.py:733-736)
             STATS.add_visible((ws1[a_off:a_off + 4 * N].view(torch.int32) != 0).view(1, N))
@@ -305,7 +328,7 @@ class _RenderFn(torch.autograd.Function):
             img.zero_(); trans.fill_(1.0); last.zero_()
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
         pg_lines = L.lg_fused_grad_lines(N) if replicas else N
-        pg = torch.empty((pg_lines, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
+        pg = _empty((pg_lines, L.lg_packed_grad_floats()), torch.float32, dev) if any(ctx.needs_input_grad) else None
         L.lg_fused_set_option(1, int(R.margin[k]))
         # a culled render that a fused Adam step follows may run speculatively (no gated repeat); anything else keeps the repeat
         L.lg_fused_set_speculation(*R.speculation_args(cull and R.fuse_optimizer and any(ctx.needs_input_grad)))
@@ -357,10 +380,10 @@ class _RenderFn(torch.autograd.Function):
         g_img = g_img.contiguous()
         pg, pg_zero = ctx.pg, 1
         if pg is None:
-            pg, pg_zero = torch.empty((L.lg_fused_grad_lines(N) if ctx.replicas else N, L.lg_packed_grad_floats()), dtype=torch.float32, device=dev), 0
+            pg, pg_zero = _empty((L.lg_fused_grad_lines(N) if ctx.replicas else N, L.lg_packed_grad_floats()), torch.float32, dev), 0
         ctx.pg = None
         L.lg_fused_set_option(3, 1 if ctx.replicas else 0)          # as it was for this frame's stage 1
-        esq = torch.zeros((1, 1, N), dtype=torch.float32, device=dev) if stat else None
+        esq = _empty((1, 1, N), torch.float32, dev, zero=True) if stat else None
         tiles = ctx.tiles
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
         if R.fuse_optimizer:
@@ -385,12 +408,12 @@ class _RenderFn(torch.autograd.Function):
             R.pending = dict(pg=pg, A=A, S=S, frame=frame, degree=degree, chunks=chunks, Rr=Rr, vis_ids=vis_ids, vis_num=vis_num, ws1=ws1,
                              replicas=ctx.replicas)
             return (None,) * 11
-        d_pos = torch.empty((3, A, S), dtype=torch.float32, device=dev)
-        d_scale = torch.empty((3, A, S), dtype=torch.float32, device=dev)
-        d_rot = torch.empty((4, A, S), dtype=torch.float32, device=dev)
-        d_sh0 = torch.empty((3, A, S), dtype=torch.float32, device=dev)
-        d_shr = torch.empty((Rr * 3, A, S), dtype=torch.float32, device=dev)
-        d_opa = torch.empty((1, A, S), dtype=torch.float32, device=dev)
+        d_pos = _empty((3, A, S), torch.float32, dev)
+        d_scale = _empty((3, A, S), torch.float32, dev)
+        d_rot = _empty((4, A, S), torch.float32, dev)
+        d_sh0 = _empty((3, A, S), torch.float32, dev)
+        d_shr = _empty((Rr * 3, A, S), torch.float32, dev)
+        d_opa = _empty((1, A, S), torch.float32, dev)
         check(L.lg_fused_backward(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes,
                                   frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
                                   xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
