@@ -243,11 +243,6 @@ int lg_fused_set_hot_counter(int* counter_dev);
 int lg_fused_set_hot_table(const int* hot_of);   /* one-shot: the replica assignment (workspace 1 + lg_fused_hot_offset(N)) the next lg_fused_backward_adam folds; NULL = none */
 long long lg_fused_hot_offset(long long N);
 long long lg_fused_grad_lines(long long N);
-/* key 4 of lg_fused_set_option = slice descriptors (default 1; grids of at most 255 x 255 tiles): the projection's exact tile count
- * (reference: GR/binning.cu:310-373) already walks every slice of a splat's tile rectangle; it leaves (first tile, tiles) per slice in
- * 32 bytes per splat of at most 256 tiles, and the key emission (reference: GR/binning.cu:376-437, which repeats the walk) reads them
- * instead of redoing the ellipse arithmetic.  Identical tables.  Same value for lg_fused_stage1 and lg_fused_stage2 of one frame. */
-long long lg_fused_slices_offset(long long N);
 /* Speculative depth-bound culling (fused.hip "Speculative culling"): while a context is set, a culled lg_fused_stage2 enqueues no gated
  * repeat; a violated bound raises *poison (sticky, device) and its pinned mirror, and every lg_fused_backward_adam returns at once while
  * it is raised, otherwise stores step_id into *applied_host.  The caller replays the steps after *applied_host (the first one unculled)

@@ -83,7 +83,6 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 //    waits for it (measured: 2.3 ms of a 4.9 ms training step at 3 M Gaussians).
 #define DUP_SMALL 32
 #define DUP_SMALL_HI 256
-static_assert(DUP_SMALL_HI == LG_DESC_MAX_TILES, "the projection describes exactly the splats the in-workgroup path can take");
 #define DUP_LDS_ENTRIES (TPB * DUP_SMALL)
 #define DUP_MAX_SLICES 256
 #define DUP_MAX_RUN 32768      // tiles one splat may touch on the cooperative path (bitmap of 4 KiB per wave)
@@ -210,9 +209,7 @@ __device__ __forceinline__ void zero_duty(uint32_t* __restrict__ p, long long wo
 // The six floats the tile walk needs.  SoA (operator path: separate ndc / inv_cov / opacity tensors, six 4-byte gathers = six
 // cache lines per splat) or the fused executor's 64-byte packed record (one line): at 3 M Gaussians the SoA gathers alone move
 // ~450 MB of cache lines for 14 MB of useful data.
-// slices (nullable, with packed): the 32-byte slice descriptors the fused projection left for every splat of at most DUP_SMALL_HI tiles
-// (lg_tilewalk.h): the in-workgroup path then reads the slices instead of redoing the ellipse arithmetic of the walk.
-struct SplatSrc { const float* ndc; const float* inv_cov; const float* opacity; const float4* packed; const uint4* slices; };
+struct SplatSrc { const float* ndc; const float* inv_cov; const float* opacity; const float4* packed; };
 
 template <bool PACKED>
 __device__ __forceinline__ void load_splat(const SplatSrc& src, size_t b, int N, int idx, float& nx, float& ny, float& a, float& bb,
@@ -234,7 +231,7 @@ __device__ __forceinline__ void load_splat(const SplatSrc& src, size_t b, int N,
 // LdsKeyT: uint16_t when every tile id + 1 fits 16 bits (anything up to ~8 MPixel at 8x16 tiles) -- halves the staging buffer, one
 // more workgroup per CU for this latency-bound kernel.
 template <int TH, int TW, typename IdxT, bool PACKED, typename LdsKeyT>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) dup_small_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
+__global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
                                                         const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                         long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
                                                         int* __restrict__ qcount /*[V][DUP_NQ], zero*/, uint32_t* __restrict__ qentries /*[V][DUP_NQ][cap]*/,
@@ -346,21 +343,13 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))
         if (nent) qb = atomicAdd(qcount + (size_t)b * DUP_NQ + (grp % DUP_NQ), nent);
     }
 
-    // 3. geometry of the small splats: their slice descriptor when the projection left one, else the extent for the walk
+    // 3. geometry of the small splats
     SplatExtent e;
-    uint32_t dw[7], dhead = LG_DESC_NO_SLICES << 9;
     if (small) {
         idx = sorted_id ? (int)sorted_id[(size_t)b * N + j] : j;          // no order given: slots are the splats themselves
-        if (PACKED && src.slices != nullptr) {
-            const uint4* d = src.slices + ((size_t)b * N + idx) * 2;
-            const uint4 d0 = d[0], d1 = d[1];
-            dw[0] = d0.x; dw[1] = d0.y; dw[2] = d0.z; dw[3] = d0.w; dw[4] = d1.x; dw[5] = d1.y; dw[6] = d1.z; dhead = d1.w;
-        }
-        if (((dhead >> 9) & 31u) == LG_DESC_NO_SLICES) {
-            float nx, ny, a, bb, cc, o;
-            load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
-            splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
-        }
+        float nx, ny, a, bb, cc, o;
+        load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
+        splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
     }
     if (tid == 0) qbase_s = qb;
     __syncthreads();
@@ -396,31 +385,8 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(5, 8))
     t_idx[tid] = idx;
     if (tid == 0) t_loff[TPB] = total_small;
     if (small) {
-        const uint32_t nsl = (dhead >> 9) & 31u;
-        if (nsl == LG_DESC_NO_SLICES) {
-            t_stride[tid] = ((e.rmaxy - e.rminy) < (e.rmaxx - e.rminx)) ? 1 : gx;       // walk_tiles' isY rule
-            walk_tiles<TH, TW, true, LdsKeyT>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf, reinterpret_cast<unsigned int*>(sstarts));
-        } else {
-            // the same entries walk_tiles would leave, from the descriptor: slice i covers `len` tiles from `first` along v at u = u0 + i
-            const bool isY = (dhead & 1u) != 0u;
-            const uint32_t u0 = (dhead >> 1) & 255u;
-            t_stride[tid] = isY ? 1 : gx;
-            int o2 = loff;
-            for (uint32_t i = 0; i < nsl; i++) {
-                const uint32_t ent = dw[0] & 0xffffu;
-                dw[0] = __builtin_amdgcn_alignbit(dw[1], dw[0], 16); dw[1] = __builtin_amdgcn_alignbit(dw[2], dw[1], 16);
-                dw[2] = __builtin_amdgcn_alignbit(dw[3], dw[2], 16); dw[3] = __builtin_amdgcn_alignbit(dw[4], dw[3], 16);
-                dw[4] = __builtin_amdgcn_alignbit(dw[5], dw[4], 16); dw[5] = __builtin_amdgcn_alignbit(dw[6], dw[5], 16);
-                dw[6] >>= 16;
-                const uint32_t first = ent & 255u, len = ent >> 8;
-                if (len > 0u) {
-                    const uint32_t key = isY ? (u0 + i) * (uint32_t)gx + first : first * (uint32_t)gx + (u0 + i);
-                    buf[o2] = (LdsKeyT)(key + 1u);
-                    atomicOr(reinterpret_cast<unsigned int*>(sstarts) + (o2 >> 5), 1u << (o2 & 31));
-                    o2 += (int)len;
-                }
-            }
-        }
+        t_stride[tid] = ((e.rmaxy - e.rminy) < (e.rmaxx - e.rminx)) ? 1 : gx;       // walk_tiles' isY rule
+        walk_tiles<TH, TW, true, LdsKeyT>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf, reinterpret_cast<unsigned int*>(sstarts));
     }
     __syncthreads();
     int sbase = 0;                                        // set bits below position p0
@@ -674,7 +640,7 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
                       int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, int* tile_counts,
                       uint32_t* zero_ptr, long long zero_words,
                       uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words,
-                      const int* gate, int* trunc_flag, void* stream, const void* slices)
+                      const int* gate, int* trunc_flag, void* stream)
 {
     if (N <= 0) return 0;
     if (packed && sorted_id_is_int64) return (int)hipErrorInvalidValue;     // packed records: fused executor only (int32 order)
@@ -690,8 +656,7 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
         if (ds.passes < 1 || ds.passes > SORT_MAX_PASSES_DUP) return (int)hipErrorInvalidValue;
         ds.last_mask = (1u << ((end_bit - begin_bit) - (ds.passes - 1) * 8)) - 1u;
     }
-    if (slices != nullptr && (packed == nullptr || !lg_desc_grid_ok(gx, gy))) return (int)hipErrorInvalidValue;
-    SplatSrc src = { ndc, inv_cov, opacity, (const float4*)packed, (const uint4*)slices };
+    SplatSrc src = { ndc, inv_cov, opacity, (const float4*)packed };
 #define LAUNCH_DUP(A_, B_, T_, P_)                                                                                                          \
     do {                                                                                                                                   \
         if (gx * gy + 1 <= 0xffff)                                                                                                         \

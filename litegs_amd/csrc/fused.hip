@@ -56,7 +56,6 @@ static int g_tile_scatter = 1;
 // Gradient replicas for splats that cover many tiles (raster.hip): key 3 of lg_fused_set_option, read by lg_fused_stage1 (the projection
 // assigns the replica lines) -- on only when every consumer of the gradient records folds them (the fused backward kernels of this file).
 static int g_grad_replicas = 0;
-static int g_slice_desc = 1;                    // option 4
 // the replica line counter: a device int owned by the caller (persistent: the projection that assigns lines cannot also clear its own
 // counter).  It is reset by the kernel that consumes the records at the end of a training step (project_backward_adam / project_fused_backward).
 static int* g_hot_counter = nullptr;
@@ -108,23 +107,10 @@ LG_API int lg_fused_set_option(int key, int value)
     if (key == 1 && value >= 1 && value <= 100000) { g_bound_margin_pct = value; return 0; }
     if (key == 2 && (value == 0 || value == 1)) { g_tile_scatter = value; return 0; }
     if (key == 3 && (value == 0 || value == 1)) { g_grad_replicas = value; return 0; }
-    if (key == 4 && (value == 0 || value == 1)) { g_slice_desc = value; return 0; }
     return (int)hipErrorInvalidValue;
 }
 
-LG_API int lg_fused_get_option(int key)
-{
-    switch (key) {
-    case 0: return g_depth_order_mode;
-    case 1: return g_bound_margin_pct;
-    case 2: return g_tile_scatter;
-    case 3: return g_grad_replicas;
-    case 4: return g_slice_desc;
-    default: return -1;
-    }
-}
-// slice descriptors: the projection's tile walk hands its slices to the key emission (lg_tilewalk.h, binning.hip dup_small_kernel)
-static bool use_slice_desc(int gx, int gy) { return g_slice_desc && lg_desc_grid_ok(gx, gy); }
+LG_API int lg_fused_get_option(int key) { return key == 0 ? g_depth_order_mode : (key == 1 ? g_bound_margin_pct : (key == 2 ? g_tile_scatter : (key == 3 ? g_grad_replicas : -1))); }
 static bool use_tile_scatter(long long N, int ntiles) { return g_tile_scatter && use_tile_order(N) && ntiles + 2 <= LG_TILE_BINS_MAX; }
 #define LOG2E 1.4426950408889634f
 
@@ -144,12 +130,9 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
                                      uint32_t* __restrict__ zero_ptr, long long zero_words,
                                      uint32_t* __restrict__ zero3_ptr, long long zero3_words,
                                      const float* __restrict__ bound_pyr, const int* __restrict__ gate,
-                                     int* __restrict__ hot_of /*nullable*/, int* __restrict__ hot_lines, int hot_cap,
-                                     uint4* __restrict__ slices /*nullable [N][2]*/)
+                                     int* __restrict__ hot_of /*nullable*/, int* __restrict__ hot_lines, int hot_cap)
 {
     if (gate != nullptr && *gate == 0) return;          // fallback launch of the depth-bound culling that is not needed
-    // per-thread staging of the slice descriptor the tile walk leaves (9 words apart: conflict-free 16-bit writes and word reads)
-    extern __shared__ uint32_t desc_lds[];
     const int a = blockIdx.x, t = threadIdx.x;
     const size_t N = (size_t)A * S;
     const size_t i = (size_t)a * S + t;
@@ -181,19 +164,11 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     lg_cov2d(T9, cam.V, J6, c4);
     lg_inv2x2(c4[0], c4[1], c4[2], c4[3], i4);
     int rect[4];
-    uint32_t* my_desc = desc_lds + t * 9;
-    uint32_t desc_head = 0u;
-    int tiles = lg_tile_count<TH, TW>(n[0], n[1], v[2], i4[0], i4[1], i4[3], o, cam.H, cam.W, gx, gy, rect,
-                                      reinterpret_cast<uint16_t*>(my_desc), &desc_head);     // a8, fused
+    int tiles = lg_tile_count<TH, TW>(n[0], n[1], v[2], i4[0], i4[1], i4[3], o, cam.H, cam.W, gx, gy, rect);     // a8, fused
     // ---- depth-bound culling (see "depth-bound culling" below): deeper than the saturation bound of every tile of its rectangle ->
     // keeps its count (sign bit set: the culled view of the prefix sum counts it as 0) but emits nothing
     if (bound_pyr != nullptr && tiles > 0 && v[2] > lg_bound_query(bound_pyr, gx, gy, rect[0], rect[1], rect[2], rect[3]))
         tiles |= (int)0x80000000u;
-    // ---- slice descriptor for the key emission (binning.hip dup_small_kernel): only splats its in-workgroup path can take
-    if (slices != nullptr && tiles > 0 && tiles <= LG_DESC_MAX_TILES) {
-        slices[2 * i] = make_uint4(my_desc[0], my_desc[1], my_desc[2], my_desc[3]);
-        slices[2 * i + 1] = make_uint4(my_desc[4], my_desc[5], my_desc[6], desc_head);
-    }
     // ---- gradient replicas (raster.hip): R = 2^k lines behind the N regular ones for a splat that many tiles will add to
     if (hot_of != nullptr) {
         int hot = -1;
@@ -384,7 +359,6 @@ struct Layout1 {      // sized by N = A*S (per-Gaussian buffers)
     // per-key instance counts of the tile scatter, for the culled run and for its gated fallback (inside the zeroed region)
     size_t tcount, tcount2;
     size_t hot_of;                        // int32[N]: replica assignment per compacted splat (-1: none)
-    size_t slices;                        // uint4[N][2]: slice descriptors of the splats with 1..LG_DESC_MAX_TILES tiles (lg_tilewalk.h)
 };
 struct Layout2 {      // sized by the tile-instance table length L
     size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, tile_work, dup_entries, tile_cursor, total;
@@ -416,7 +390,6 @@ static Layout1 layout1(long long N)
     f.tcount2 = take(4 * (size_t)LG_TILE_BINS_MAX);
     f.zero_bytes = f.tcount2 + 4 * (size_t)LG_TILE_BINS_MAX - f.zeroed;
     f.hot_of = take(4 * (size_t)N);
-    f.slices = take(32 * (size_t)N);
     f.total = o;
     return f;
 }
@@ -482,9 +455,6 @@ LG_API long long lg_fused_packed_offset(long long N) { return (long long)layout1
 // byte offset in workspace 1 of the replica assignment int32[N] (valid after a stage 1 that ran with option 3 on)
 LG_API long long lg_fused_hot_offset(long long N) { return (long long)layout1(N).hot_of; }
 
-// byte offset in workspace 1 of the slice descriptors uint32[N][8] (valid after a stage 1 that ran with option 4 on; lg_tilewalk.h) -- tests
-LG_API long long lg_fused_slices_offset(long long N) { return (long long)layout1(N).slices; }
-
 // byte offset in workspace 1 of the per-Gaussian tile counts int32[N] (allocate_size, wrapper.py:726-733): read by the statistics hook
 LG_API long long lg_fused_alloc_offset(long long N) { return (long long)layout1(N).alloc; }
 
@@ -525,12 +495,11 @@ static int launch_projection(const Scene& sc, const Camera& cam, int TH, int TW,
     float* view_z = (float*)(w + f.view_z); float4* packed = (float4*)(w + f.packed);
     int* alloc = (int*)(w + f.alloc);
     const int gx = (cam.W + TW - 1) / TW, gy = (cam.H + TH - 1) / TH;
-#define LAUNCH_PF(D, A_, B_) hipLaunchKernelGGL((project_fused_kernel<D, A_, B_>), dim3(sc.A), dim3(sc.S), (size_t)sc.S * 36, s, sc.vis_ids, sc.vis_num, cam,   \
+#define LAUNCH_PF(D, A_, B_) hipLaunchKernelGGL((project_fused_kernel<D, A_, B_>), dim3(sc.A), dim3(sc.S), 0, s, sc.vis_ids, sc.vis_num, cam,   \
                                                 sc.pos, sc.scale, sc.rot, sc.sh0, sc.shr, sc.opa, sc.chunks, sc.S, sc.A, view_z, alloc, packed, \
                                                 gx, gy, (uint32_t*)(w + f.zeroed), zero_duty ? (long long)(f.zero_bytes / 4) : 0LL,             \
                                                 (uint32_t*)sched_out, sched_out ? lg_sched_clear_words(gx, gy) : 0LL, bound_pyr, gate,     \
-                                                hot ? (int*)(w + f.hot_of) : (int*)nullptr, g_hot_counter, (int)hot_capacity((long long)sc.A * sc.S), \
-                                                use_slice_desc(gx, gy) ? (uint4*)(w + f.slices) : (uint4*)nullptr)
+                                                hot ? (int*)(w + f.hot_of) : (int*)nullptr, g_hot_counter, (int)hot_capacity((long long)sc.A * sc.S))
 #define DISPATCH_PF(A_, B_)                                                  \
     switch (sc.degree) {                                                     \
     case 0: LAUNCH_PF(0, A_, B_); break;                                     \
@@ -630,8 +599,7 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
                                (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
                                qcount, (uint32_t*)(w + f.dup_entries), nullptr, 0, bits, nullptr, nullptr, 0,
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
-                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (replicas_on() ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s,
-                               use_slice_desc((W + TW - 1) / TW, (H + TH - 1) / TH) ? (const void*)(w1 + f1.slices) : nullptr);
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (replicas_on() ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
         if (rc) return rc;
         rc = lg_tile_scatter_gated((const int32_t*)(w + f.tk_a), (const int32_t*)(w + f.tv_a), Ls, total_dev, ntiles, tcount, 1, (int*)(w + f.tile_cursor),
                                    (int32_t*)(w + f.tile_start), (int32_t*)(w + f.tv_b), gate, s);
@@ -648,8 +616,7 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
                                qcount, (uint32_t*)(w + f.dup_entries), tsort_hdr, 0, bits, nullptr, (uint32_t*)(w + f.tsort_table),
                                (long long)lg_radix_table_words(Ls, lg_radix_sort_num_passes(0, bits)),
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
-                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (replicas_on() ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s,
-                               use_slice_desc((W + TW - 1) / TW, (H + TH - 1) / TH) ? (const void*)(w1 + f1.slices) : nullptr);
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (replicas_on() ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
     if (rc) return rc;
     // instance count on the device: only that many entries are sorted and range-scanned
     rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,

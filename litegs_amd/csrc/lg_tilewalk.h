@@ -58,27 +58,10 @@ __device__ __forceinline__ void splat_extent(float ndcx, float ndcy, float ic00,
 // lds_slice_starts (with lds_keys): instead of one key per tile, ONE entry per non-empty slice -- the slice's first key at the slice's
 // first position plus a bit in a bitmap over positions; the consumer rebuilds key = first + (position - start) * stride, stride = 1
 // when slices run along y (isY: consecutive tiles in x) and gx otherwise.  Removes the per-tile loop from the serial walk.
-// DESCRIBE (with slice_desc): the walk also leaves one 16-bit word per slice, (first tile along v) | (tiles in the slice) << 8, for the
-// first LG_DESC_SLICES slices -- the "slice descriptor" the fused projection hands to the key emission so that the emission does not
-// repeat this arithmetic (lg_desc_header below).  Only meaningful while both grid dimensions stay below 256.
-#define LG_DESC_SLICES 14
-#define LG_DESC_MAX_TILES 256          // splats with more tiles are never emitted by the in-workgroup path (binning.hip DUP_SMALL_HI)
-#define LG_DESC_NO_SLICES 31u          // header code: more than LG_DESC_SLICES slices, the consumer walks the splat itself
-__host__ __device__ static inline bool lg_desc_grid_ok(int gx, int gy) { return gx <= 255 && gy <= 255; }
-// header word of a descriptor: bit 0 = slices run along y (consecutive tiles of a slice are neighbours in x: key stride 1, else gx),
-// bits 1..8 = first slice coordinate, bits 9..13 = number of slices (or LG_DESC_NO_SLICES)
-__device__ __forceinline__ uint32_t lg_desc_header(const SplatExtent& e)
-{
-    const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
-    const bool isY = ys < xs;                                           // walk_tiles' rule
-    const int u0 = isY ? e.rminy : e.rminx, n = isY ? ys : xs;
-    return (isY ? 1u : 0u) | ((uint32_t)u0 << 1) | ((n <= LG_DESC_SLICES ? (uint32_t)n : LG_DESC_NO_SLICES) << 9);
-}
-
-template <int TH, int TW, bool EMIT, typename LdsKeyT = int32_t, bool DESCRIBE = false>
+template <int TH, int TW, bool EMIT, typename LdsKeyT = int32_t>
 __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int32_t idx, long long off,
                                                int32_t* __restrict__ keys, int32_t* __restrict__ values, LdsKeyT* lds_keys = nullptr,
-                                               unsigned int* lds_slice_starts = nullptr, uint16_t* slice_desc = nullptr)
+                                               unsigned int* lds_slice_starts = nullptr)
 {
     const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
     const bool isY = ys < xs;
@@ -110,8 +93,6 @@ __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int
         int min_tile_v = max(rect_min_v, min(rect_max_v, lg_f2i(ellipse_min / BLOCK_V)));
         int max_tile_v = min(rect_max_v, max(rect_min_v, lg_f2i(ellipse_max / BLOCK_V + 1)));
         count += (uint32_t)(max_tile_v - min_tile_v);
-        if (DESCRIBE && u - rect_min_u < LG_DESC_SLICES)
-            slice_desc[u - rect_min_u] = (uint16_t)((uint32_t)min_tile_v | ((uint32_t)(max_tile_v - min_tile_v) << 8));
         if (EMIT && lds_slice_starts) {
             if (max_tile_v > min_tile_v) {
                 const uint32_t key = isY ? (uint32_t)(u * gx + min_tile_v) : (uint32_t)(min_tile_v * gx + u);
@@ -139,10 +120,9 @@ __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int
 
 // visibility test + exact tile count of one splat (reference: GR/binning.cu:310-373); rect (nullable) receives the tile rectangle
 // [x0, x1) x [y0, y1) the walk stays inside
-// slice_desc (nullable, LG_DESC_SLICES 16-bit words private to the caller) + desc_header: the slice descriptor of the splat (above)
 template <int TH, int TW>
 __device__ __forceinline__ int lg_tile_count(float nx, float ny, float view_z, float a, float bb, float c, float o, int H, int W, int gx, int gy,
-                                             int* rect = nullptr, uint16_t* slice_desc = nullptr, uint32_t* desc_header = nullptr)
+                                             int* rect = nullptr)
 {
     float disc = bb * bb - a * c;
     bool vis = !((nx < -1.3f) || (nx > 1.3f) || (ny < -1.3f) || (ny > 1.3f) || (view_z <= 0.2f) || (o < 1.0f / 255));
@@ -152,10 +132,6 @@ __device__ __forceinline__ int lg_tile_count(float nx, float ny, float view_z, f
     splat_extent<TH, TW>(nx, ny, a, bb, c, o, H, W, gx, gy, e);
     if ((e.rmaxy - e.rminy) * (e.rmaxx - e.rminx) <= 0) return 0;
     if (rect) { rect[0] = e.rminx; rect[1] = e.rmaxx; rect[2] = e.rminy; rect[3] = e.rmaxy; }
-    if (slice_desc != nullptr) {
-        *desc_header = lg_desc_header(e);
-        return (int)walk_tiles<TH, TW, false, int32_t, true>(e, gx, 0, 0, nullptr, nullptr, nullptr, nullptr, slice_desc);
-    }
     return (int)walk_tiles<TH, TW, false>(e, gx, 0, 0, nullptr, nullptr);
 }
 

@@ -68,9 +68,6 @@ def _apply_env_options() -> None:
     scatter = os.environ.get("LITEGS_TILE_SCATTER")       # 1: group by tile with counts + cursors in the per-tile mode; 0: stable tile radix sort
     if scatter is not None:
         check(lib().lg_fused_set_option(2, 1 if scatter != "0" else 0), "set_option")
-    desc = os.environ.get("LITEGS_SLICE_DESC")            # 0: the key emission repeats the tile walk instead of reading the projection's slices
-    if desc is not None:
-        check(lib().lg_fused_set_option(4, 1 if desc != "0" else 0), "set_option")
 
 
 class FusedRenderer:

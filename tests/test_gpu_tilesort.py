@@ -203,53 +203,3 @@ def test_executor_tables_match_the_oracle_with_the_tile_scatter(oracle):
             np.testing.assert_array_equal(pts, res.sorted_point[0], err_msg=f"scatter={scatter}")
     finally:
         L.lg_fused_set_option(0, prev[0]); L.lg_fused_set_option(2, prev[1])
-
-
-def test_slice_descriptors_leave_the_tables_unchanged(oracle):
-    """the key emission reads the slices the projection's tile count already walked (option 4) instead of repeating the walk: tile ranges
-    and lists bit for bit against the oracle, in both list-building modes, on a cloud with needle-shaped splats -- diagonal needles have
-    more slices than a descriptor holds (14) and few tiles, so the in-kernel walk of exactly those splats is exercised as well"""
-    from litegs_amd import fast, render as R
-    from litegs_amd._lib import lib
-    from oracle import oracle as O
-    from tests.util import case
-    L = lib()
-    c = case("small", seed=3)
-    H, W = c["H"], c["W"]
-    params = [p.copy() for p in c["params"]]
-    rng = np.random.default_rng(11)
-    needle = rng.random(params[1].shape[1:]) < 0.12                 # [C,S]
-    params[1][0][needle] = np.log(1.2); params[1][1][needle] = np.log(0.004); params[1][2][needle] = np.log(0.004)
-    res = O.render_forward(params, c["view"], c["proj"], c["planes"], H, W, c["degree"])
-    dev = [torch.from_numpy(p).cuda() for p in params]
-    view, proj, planes = [torch.from_numpy(x).cuda() for x in (c["view"], c["proj"], c["planes"])]
-    origin, extend = R.get_cluster_AABB(dev[0], dev[1].exp(), torch.nn.functional.normalize(dev[2], dim=0))
-    prev = (L.lg_fused_get_option(0), L.lg_fused_get_option(4))
-    ntiles = res.tile_start.shape[1] - 2
-    try:
-        for mode in (1, 0):
-            for desc in (1, 0):
-                assert L.lg_fused_set_option(0, mode) == 0 and L.lg_fused_set_option(4, desc) == 0
-                rd = fast.FusedRenderer(1, H, W)
-                with torch.no_grad():
-                    img = rd.render(fast.CameraFrame(view, proj, planes, 0), origin, extend, *dev, c["degree"])[0]
-                torch.cuda.synchronize()
-                ws2, table_len, N = rd.last_ws2
-                assert table_len >= res.n_instances
-                o_pts = L.lg_fused_sorted_points_offset(table_len, N, H, W, 8, 16)
-                o_ts = L.lg_fused_tile_start_offset(table_len, N, H, W, 8, 16)
-                ts = ws2[o_ts:o_ts + 4 * (ntiles + 2)].view(torch.int32).cpu().numpy()
-                pts = ws2[o_pts:o_pts + 4 * res.n_instances].view(torch.int32).cpu().numpy()
-                np.testing.assert_array_equal(ts, res.tile_start[0], err_msg=f"mode={mode} desc={desc}")
-                np.testing.assert_array_equal(pts, res.sorted_point[0], err_msg=f"mode={mode} desc={desc}")
-                if desc:
-                    ws1, N1 = rd.last_ws1
-                    off = L.lg_fused_slices_offset(N1)
-                    head = ws1[off:off + 32 * N1].view(torch.int32).view(N1, 8)[:, 7].cpu().numpy()
-                    a_off = L.lg_fused_alloc_offset(N1)
-                    cnt = ws1[a_off:a_off + 4 * N1].view(torch.int32).cpu().numpy()
-                    described = (cnt > 0) & (cnt <= 256)
-                    nsl = (head[described] >> 9) & 31
-                    assert described.sum() > 500 and (nsl == 31).sum() >= 3 and ((nsl >= 1) & (nsl <= 14)).sum() > 500, (described.sum(), (nsl == 31).sum())
-    finally:
-        L.lg_fused_set_option(0, prev[0]); L.lg_fused_set_option(4, prev[1])
