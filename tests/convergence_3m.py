@@ -32,6 +32,25 @@ from litegs_amd import synthetic as S             # noqa: E402
 from litegs_amd.trainer import SyntheticTrainer   # noqa: E402
 
 
+def _snapshot(path, tag, tr):
+    """debugging aid (LITEGS_CONV_SNAPSHOT=<file>): one JSON line per epoch with every device segment / block of the caching allocator and
+    the addresses of the trainer's long-lived tensors -- enough to attribute the address of a GPU memory access fault afterwards"""
+    segs = [[s["address"], s["total_size"], [[b.get("address", 0), b["size"], b["state"][0]] for b in s["blocks"]]] for s in torch.cuda.memory_snapshot()]
+    named = {}
+    if tr is not None:
+        for i, prm in enumerate(tr.params):
+            named[f"param{i}"] = [prm.data_ptr(), prm.numel() * prm.element_size()]
+        rd = getattr(tr, "renderer", None)
+        for name in ("sched", "tile_order", "hot_counter", "_cull_scratch"):
+            t = getattr(rd, name, None) if rd is not None else None
+            if t is not None:
+                named[name] = [t.data_ptr(), t.numel() * t.element_size()]
+    with open(path, "a") as f:
+        f.write(json.dumps(dict(tag=tag, segments=segs, named=named)) + "\n")
+        f.flush()
+        os.fsync(f.fileno())
+
+
 def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify, log):
     from litegs_amd import densify as D
     from litegs_amd.statistics import STATS
@@ -60,6 +79,8 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
         else:
             for k in order:
                 tr.step(int(k))
+        if os.environ.get("LITEGS_CONV_SNAPSHOT"):
+            _snapshot(os.environ["LITEGS_CONV_SNAPSHOT"], f"{'executor' if fused else 'operator'} epoch {epoch}", tr)
         if os.environ.get("LITEGS_CONV_VERBOSE"):
             torch.cuda.synchronize()
             log(f"   epoch {epoch} done: {tr.n_chunks * tr.S} points, degree {tr.degree}")
@@ -93,8 +114,16 @@ def run(iterations=30000, frames=150, n=3_000_000, W=1920, H=1080, focal=1200.0,
     densify = dict(target_primitives=int(1.1 * n))                       # the reference's defaults otherwise (arguments.py:95-110)
     out = dict(config=cfg, iterations=iterations, epochs=epochs, densify=densify, eval_frames=eval_frames)
     log(f"targets rendered ({frames} frames {W}x{H}), {epochs} epochs; {time.time() - t0:.0f} s")
-    out["executor"] = [train(student, targets, cfg, True, epochs, eval_frames, eval_every, densify, log) for _ in range(runs)]
-    out["operator"] = train(student, targets, cfg, False, epochs, eval_frames, eval_every, densify, log)
+    out["executor"] = []
+    for _ in range(runs):
+        out["executor"].append(train(student, targets, cfg, True, epochs, eval_frames, eval_every, densify, log))
+        if os.environ.get("LITEGS_CONV_PARTIAL"):                       # completed curves survive a later failure
+            with open(os.environ["LITEGS_CONV_PARTIAL"], "w") as f:
+                json.dump(out, f)
+    if os.environ.get("LITEGS_CONV_SKIP_OPERATOR"):                     # executor runs only: the operator curve is taken from an earlier run's JSON
+        out["operator"] = json.load(open(os.environ["LITEGS_CONV_SKIP_OPERATOR"]))["operator"]
+    else:
+        out["operator"] = train(student, targets, cfg, False, epochs, eval_frames, eval_every, densify, log)
     out["seconds"] = time.time() - t0
     return out
 
