@@ -68,3 +68,37 @@ def test_statistic_mode_fused_equals_operator_path_and_oracle(oracle):
     got_w = sf["fragment_weight"][0].reshape(w_full.shape)
     assert np.array_equal(got_cnt, 2 * cnt_full)
     assert np.abs(got_w - 2 * w_full).max() < 1e-3 * max(w_full.max(), 1e-9)
+
+
+def test_executor_keeps_its_own_schedule_and_culling_after_a_statistics_epoch():
+    """the reference rasterises along the statistics helper's cached tile list in every render after the first statistics epoch
+    (litegs/render/__init__.py:75-79); the list is a permutation of all tiles, so the executor keeps its own schedule and depth-bound
+    culling outside statistics renders: same image bit for bit, and the revisits really run culled"""
+    from litegs_amd.statistics import STATS
+    from litegs_amd.trainer import SyntheticTrainer
+    tr = SyntheticTrainer(60000, 640, 360, 500.0, n_frames=2, seed=5)
+    STATS.tile_schedule.clear(); STATS.tile_blend_count.clear()
+    STATS.reset(tr.n_chunks, tr.S, enabled_for_epoch=lambda e: True, device="cuda")
+    try:
+        with STATS.epoch(0):
+            for k in range(2):
+                tr.forward_only(k)
+        assert len(STATS.tile_schedule) == 2
+        out = {}
+        for always in (False, True):
+            tr.renderer.stat_schedule_always = always
+            torch.cuda.synchronize()                     # pinned feedback words of the previous renders have landed
+            tr.renderer.reset_feedback()
+            imgs, culled = [], False
+            for visit in range(4):
+                for k in range(2):
+                    imgs.append(tr.forward_only(k).clone())
+                    culled |= bool(tr.renderer.last_cull)
+            torch.cuda.synchronize()
+            out[always] = (imgs, culled)
+        assert out[False][1] and not out[True][1]
+        for a, b in zip(out[False][0], out[True][0]):
+            assert torch.equal(a, b)
+    finally:
+        STATS.reset(1, 1, enabled_for_epoch=lambda e: False, device="cuda")
+        STATS.tile_schedule.clear(); STATS.tile_blend_count.clear()
