@@ -130,7 +130,7 @@ class FusedRenderer:
         # gradient replicas (csrc/raster.hip): splats that cover many tiles get several gradient lines; on for renders whose records only
         # the fused backward kernels consume (no statistics, no data-parallel exchange).  LITEGS_GRAD_REPLICAS=0 disables.
         self.replicas_enabled = os.environ.get("LITEGS_GRAD_REPLICAS", "1") != "0"
-        self.stat_schedule_always = os.environ.get("LITEGS_STAT_TILE_SCHEDULE", "stat") == "always"
+        self.stat_schedule_always = os.environ.get("LITEGS_STAT_TILE_SCHEDULE", "always") != "stat"
         self.hot_counter = None
         self.spec = None              # dict(poison=device int32[1], poison_host / applied_host = pinned int32[1])
         self.spec_step = 0            # number of the training step being enqueued
@@ -250,10 +250,12 @@ class _RenderFn(torch.autograd.Function):
         ws1_bytes = L.lg_fused_workspace1_bytes(N)
         ws1 = _empty((ws1_bytes,), torch.uint8, dev, align=64)            # 64-byte records read by 64-byte scalar loads
         # The reference rasterises along the statistics helper's cached heavy-first tile list whenever a frame has one, i.e. in every render
-        # after the first statistics epoch (litegs/render/__init__.py:75-79).  That list is a permutation of ALL tiles -- a schedule, not a
-        # selection -- so outside statistics renders the executor keeps its own schedule, depth bounds and speculative culling instead
-        # (same image); before this, a training run with density control lost them for good after epoch 5.
-        # LITEGS_STAT_TILE_SCHEDULE=always: the reference's behaviour.
+        # after the first statistics epoch (litegs/render/__init__.py:75-79), and so does the executor by default: from then on its own
+        # schedule, depth bounds and speculative culling are idle.  The list is a permutation of ALL tiles -- a schedule, not a selection --
+        # so LITEGS_STAT_TILE_SCHEDULE=stat keeps the executor's own machinery outside statistics renders (same image,
+        # test_gpu_stats.py).  Measured over the first 4500 iterations of tests/convergence_3m.py (150 cameras: a frame is revisited
+        # after 150 steps of a fast-changing cloud, bounds are violated often): 1.66 ms / iteration against 1.49 with the reference's
+        # behaviour -- hence not the default.
         tiles = STATS.schedule_for_current_frame() if (stat or R.stat_schedule_always) else None
         # depth-bound culling: bookkeeping of the sizing feedback (the emitted total of a culled visit is not the full table length)
         pred_total = int(R.fb_total[k])

@@ -149,7 +149,7 @@ def to_markdown(out):
           f"| operator path, final PSNR | {op['psnr'][-1]:.3f} dB |",
           f"| final dPSNR, mean executor vs operator | {abs(fin.mean() - op['psnr'][-1]):.3f} dB |",
           f"| the same on the mean of the last three evaluations | {abs(tail.mean() - np.mean(op['psnr'][-3:])):.3f} dB |",
-          f"| largest |dPSNR| between executor run 1 and the operator path over the whole curve | {np.abs(np.array(ex[0]['psnr']) - np.array(op['psnr'])).max():.3f} dB |",
+          f"| largest |dPSNR| between executor run 1 and the operator path over the whole curve | {np.abs(np.array(ex[0]['psnr']) - np.array(op['psnr'])).max():.3f} dB |" if len(ex[0]['psnr']) == len(op['psnr']) else "",
           f"| largest |dPSNR| between executor runs 1 and 2 over the whole curve | {np.abs(np.array(ex[0]['psnr']) - np.array(ex[1]['psnr'])).max():.3f} dB |" if len(ex) > 1 else "",
           f"| ms per iteration (training + density control + evaluation), executor / operator | {np.mean([r['ms_per_iteration'] for r in ex]):.3f} / {op['ms_per_iteration']:.3f} |",
           f"| frames repeated unculled (a depth bound was violated), executor runs | {', '.join(str(r['unculled_reruns']) for r in ex)} |",
