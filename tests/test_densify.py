@@ -4,7 +4,6 @@ out.  Copies must be bit-identical; the split children's positions / scales go t
 import os
 
 import numpy as np
-import pytest
 import torch
 
 from litegs_amd import densify as D

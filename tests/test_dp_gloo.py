@@ -3,7 +3,6 @@ The device primitives are injected as plain-torch ops (the product's HipOps need
 import os
 import socket
 
-import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

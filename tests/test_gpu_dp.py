@@ -4,7 +4,6 @@ tests/test_dp_gloo.py; multi-GPU runs are the driver's.)"""
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 

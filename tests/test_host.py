@@ -49,7 +49,7 @@ def test_compacted_tensor_claims_full_shape():
 def test_oracle_binning_invariants(oracle):
     """Every emitted instance lies inside its splat's tile rectangle, tiles are sorted, depth order holds inside tiles, and the
     table is a permutation of the unsorted emission (size-independent properties also used at full size on the GPU)."""
-    from tests.util import case, oracle_forward
+    from tests.util import oracle_forward
     res = oracle_forward("small")
     keys, vals = res.sorted_tile[0], res.sorted_point[0]
     assert (np.diff(keys) >= 0).all()

@@ -2,11 +2,9 @@
 usage: python tools/densify_profile.py executor|operator [frames] [epochs]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 from litegs_amd import synthetic as S, densify as D
 from litegs_amd.trainer import SyntheticTrainer
-from litegs_amd.statistics import STATS
 
 fused = sys.argv[1] == "executor"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 30
