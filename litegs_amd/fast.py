@@ -329,7 +329,9 @@ class _RenderFn(torch.autograd.Function):
             STATS.set_compaction(vis_ids[:A], vis_num)
             a_off = L.lg_fused_alloc_offset(N)                # b_visible = allocate_size != 0 (wrapper.py:733-736)
             STATS.add_visible((ws1[a_off:a_off + 4 * N].view(torch.int32) != 0).view(1, N))
-        if tiles is not None:
+        if tiles is not None and tiles.shape[1] != R.ntiles:
+            # a partial tile list leaves the other tiles' pixels at "nothing blended".  The statistics helper's cached list is a permutation
+            # of all tiles (statistics.py update_tile_schedule: the argsort of the per-tile blend counts): every pixel is written, no fills
             img.zero_(); trans.fill_(1.0); last.zero_()
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
         pg_lines = L.lg_fused_grad_lines(N) if replicas else N
