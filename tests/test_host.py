@@ -111,3 +111,21 @@ def test_train_loop_schedule_with_a_fake_trainer():
     log.clear()
     T.train(FakeTrainer(), 1)                                                      # single process: no hook, every frame once
     assert [s[1:4] for s in log if s[0] == "step"] == [(k, False, k) for k in range(6)]
+
+
+def test_guard_allocator_places_buffers_at_the_end_of_their_allocation(monkeypatch):
+    """LITEGS_GUARD_ALLOC=1 (tools/fault_hunt.py): every per-frame buffer of the executor ends within `align` bytes of the end of a
+    page-granular allocation of its own, so that an access past its end leaves the mapping; shapes, dtypes and contents are unchanged"""
+    import torch
+    from litegs_amd import fast
+    monkeypatch.setattr(fast, "_GUARD_ALLOC", True)
+    for shape, dtype, align in (((3, 5), torch.float32, 16), ((7,), torch.bool, 16), ((1, 1, 9, 3), torch.int16, 16), ((4097,), torch.uint8, 64)):
+        t = fast._empty(shape, dtype, "cpu", zero=True, align=align)
+        assert tuple(t.shape) == shape and t.dtype == dtype and t.is_contiguous() and not t.any()
+        st = t.untyped_storage()
+        end_of_tensor = t.data_ptr() + t.numel() * t.element_size()
+        assert st.nbytes() % 4096 == 0 and 0 <= st.data_ptr() + st.nbytes() - end_of_tensor < align
+        assert (t.data_ptr() - st.data_ptr()) % align == 0
+    monkeypatch.setattr(fast, "_GUARD_ALLOC", False)
+    t = fast._empty((2, 3), torch.float32, "cpu")
+    assert t.untyped_storage().nbytes() == 24
