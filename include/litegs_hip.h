@@ -165,6 +165,9 @@ int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const float* de
 int lg_tile_group(const int32_t* keys, const int32_t* vals, long long L, int max_tile, int32_t* tile_start, int32_t* out_vals, void* temp, void* stream);
 int lg_tile_depth_sort_unordered(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
                                  uint32_t* scratch, void* stream);
+/* process-wide: 1 = lists of 1025 .. 4096 entries are sorted by the four waves of a workgroup with the wave regime's radix sort instead
+ * of the bitonic network (identical tables; default 0 until measured -- profiles/r03_tilesort_scaling.log is the motive). */
+int lg_tile_depth_sort_set_regime_w(int on);
 int lg_memset_async(void* ptr, int value, long long bytes, void* stream);
 
 /* ---- raster.hip : GR/raster.h --------------------------------------------------------------- */

@@ -9,6 +9,9 @@ import torch
 from litegs_amd._lib import lib, check
 
 L_ = lib()
+if os.environ.get("LITEGS_TS_REGIME_W") == "1":          # A/B: lists of 1025..4096 through the workgroup radix sort
+    check(L_.lg_tile_depth_sort_set_regime_w(1), "regime W")
+    print("regime W on")
 ntiles, N = 16200, 1_200_000
 lengths = [int(x) for x in sys.argv[1:]] or [250, 700, 1000, 1500, 2500, 4000]
 dev = torch.device("cuda", 0)
