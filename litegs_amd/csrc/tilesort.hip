@@ -13,8 +13,8 @@
 //   regime R  2 <= n <= 1024  : one wave per tile (four tiles per workgroup): stable LSD radix sort on the 32-bit depth key with the elements
 //                               in registers, 5 KB of LDS per wave (digit counters + a 4-byte exchange buffer), no workgroup barriers;
 //                               ties keep the ascending id order the list arrives in (lg_tilesort_body.h)
-//   regime W  n <= 4096       : (optional, lg_tile_depth_sort_set_regime_w; off by default until it has been measured) the workgroup's four
-//                               waves together on ONE list with the radix sort of regime R: wave-private ranking, destinations chained
+//   regime W  n <= 4096       : (optional, lg_tile_depth_sort_set_regime_w; a second launch, off by default until it has been measured on the
+//                               device) the workgroup's four waves together on ONE list with the radix sort of regime R: wave-private ranking, destinations chained
 //                               across the waves (lg_tilesort_body.h).  Motive: the bitonic regimes below cost 4x more per instance than
 //                               regime R (profiles/r03_tilesort_scaling.log)
 //   regime M  n <= 2048       : the workgroup's four waves together, bitonic network on (depth key, id) in 16 KB of LDS
