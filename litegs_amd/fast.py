@@ -131,6 +131,10 @@ class FusedRenderer:
         # the fused backward kernels consume (no statistics, no data-parallel exchange).  LITEGS_GRAD_REPLICAS=0 disables.
         self.replicas_enabled = os.environ.get("LITEGS_GRAD_REPLICAS", "1") != "0"
         self.stat_schedule_always = os.environ.get("LITEGS_STAT_TILE_SCHEDULE", "always") != "stat"
+        # Experimental, off by default (unmeasured): in the automatic depth-order mode, a frame whose previous visit emitted more than this
+        # many instances per tile on average takes the splat sort + stable tile radix sort (17 us per million instances + 75 us) instead of
+        # tile scatter + per-tile sort, whose long-list regimes cost 30-34 us per million (profiles/r03_tilesort_scaling.log).
+        self.long_list_global = int(os.environ.get("LITEGS_LONG_LIST_GLOBAL", "0"))
         self.hot_counter = None
         self.spec = None              # dict(poison=device int32[1], poison_host / applied_host = pinned int32[1])
         self.spec_step = 0            # number of the training step being enqueued
@@ -300,6 +304,11 @@ class _RenderFn(torch.autograd.Function):
         order_in = order_ptr if (use_sched and R.tile_order_valid[k]) else None
         order_out = order_ptr if (use_sched and (refresh or not R.tile_order_valid[k])) else None
         R.visits[k] += 1
+        # per-frame override of the depth-order mode (see long_list_global): the same value must hold for stage 1, stage 2 and the backward
+        mode_override = None
+        if R.long_list_global > 0 and pred_total > R.long_list_global * R.ntiles and L.lg_fused_get_option(0) == 2:
+            mode_override = 0
+            L.lg_fused_set_option(0, 0)
         check(L.lg_fused_stage1(*common, do_cull, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), A, ws1.data_ptr(), ws1_bytes,
                                 fb_vis_ptr if do_cull else None, fb_tot_ptr, *(R.cull_scratch(chunks, dev) if do_cull else (None, 0)),
                                 in_ptr if cull else None, out_ptr, s), "fused stage1")
@@ -347,6 +356,9 @@ class _RenderFn(torch.autograd.Function):
                                 frame.view_ptr, frame.proj_ptr, int(degree), chunks,
                                 xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), sh_0.data_ptr(), sh_rest.data_ptr(), opacity.data_ptr(),
                                 vis_ids.data_ptr(), vis_num.data_ptr(), s), "fused stage2")
+        if mode_override is not None:
+            L.lg_fused_set_option(0, 2)
+        ctx.mode_override = mode_override
         if use_sched:
             R.sched_cur[k] = 1 - R.sched_cur[k]
             R.sched_valid[k] = True
@@ -390,6 +402,8 @@ class _RenderFn(torch.autograd.Function):
             pg, pg_zero = _empty((L.lg_fused_grad_lines(N) if ctx.replicas else N, L.lg_packed_grad_floats()), torch.float32, dev), 0
         ctx.pg = None
         L.lg_fused_set_option(3, 1 if ctx.replicas else 0)          # as it was for this frame's stage 1
+        if ctx.mode_override is not None:
+            L.lg_fused_set_option(0, ctx.mode_override)              # ... and so the depth-order mode (where the blend finds its lists)
         esq = _empty((1, 1, N), torch.float32, dev, zero=True) if stat else None
         tiles = ctx.tiles
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
@@ -403,6 +417,8 @@ class _RenderFn(torch.autograd.Function):
                                       trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
                                       pg.data_ptr(), pg_zero, esq.data_ptr() if stat else None, None, None, None, None, None, None, ctx.order_ptr, _s()),
                   "fused blend backward")
+            if ctx.mode_override is not None:
+                L.lg_fused_set_option(0, 2)
             if R.probe_events is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
@@ -429,6 +445,8 @@ class _RenderFn(torch.autograd.Function):
                                   d_pos.data_ptr(), d_scale.data_ptr(), d_rot.data_ptr(), d_sh0.data_ptr(), d_shr.data_ptr(), d_opa.data_ptr(),
                                   ctx.order_ptr, _s()),
               "fused backward")
+        if ctx.mode_override is not None:
+            L.lg_fused_set_option(0, 2)
         if stat:
             fc, fw = ctx.stat_bufs
             # d_opacity of the activated opacity = packed_grad slot 8 (rasterize_backward's 4th output)
