@@ -106,6 +106,10 @@ class FusedRenderer:
         self.margin_lo, self.margin_hi = 100, 400
         self.margin = [self.margin_fixed or self.margin_lo] * n_frames
         self.clean_visits = [0] * n_frames
+        # visits a frame renders unculled after one of its depth bounds was violated (0 = cull again at once, the measured default);
+        # LITEGS_CULL_COOLDOWN=<visits>: an unmeasured knob for many-camera runs, where a frame's bounds age 100+ steps between visits
+        self.cull_cooldown = int(os.environ.get("LITEGS_CULL_COOLDOWN", "0"))
+        self.cooldown = [0] * n_frames
         self.margin_written = [self.margin[0]] * n_frames    # margin of the bounds a frame's next visit will cull with
         self.margin_emitted = [self.margin[0]] * n_frames    # margin of the bounds behind the frame's last emitted total (fb_total)
         self.fallbacks = 0                                   # visits that were re-run unculled (observed one visit later)
@@ -165,6 +169,7 @@ class FusedRenderer:
         self.last_capacity = [0] * n
         self.margin = [self.margin_fixed or self.margin_lo] * n
         self.clean_visits = [0] * n
+        self.cooldown = [0] * n
         self.margin_written = [self.margin[0]] * n
         self.margin_emitted = [self.margin[0]] * n
 
@@ -280,6 +285,7 @@ class _RenderFn(torch.autograd.Function):
             R.fb_full[k] = 0
             R.fallbacks += 1
             R.clean_visits[k] = 0
+            R.cooldown[k] = R.cull_cooldown
             if not R.margin_fixed:
                 R.margin[k] = min(R.margin[k] * 2, R.margin_hi)
         elif not R.margin_fixed:
@@ -298,7 +304,10 @@ class _RenderFn(torch.autograd.Function):
                 in_ptr = R.sched[k, cur].data_ptr()
             out_ptr = R.sched[k, 1 - cur].data_ptr()
         refresh = R.visits[k] % R.cull_refresh == 0
-        cull = bool(R.cull_enabled and in_ptr is not None and R.full_total[k] > 0 and pred_total > 0 and not refresh and not R.force_full)
+        cull = bool(R.cull_enabled and in_ptr is not None and R.full_total[k] > 0 and pred_total > 0 and not refresh and not R.force_full
+                    and R.cooldown[k] == 0)
+        if R.cooldown[k] > 0:
+            R.cooldown[k] -= 1
         R.force_full = False
         order_ptr = (R.tile_order.data_ptr() + 4 * R.ntiles * k) if use_sched else None
         order_in = order_ptr if (use_sched and R.tile_order_valid[k]) else None

@@ -156,6 +156,7 @@ class FrameTrainer:
                     k = self.frames[frame_index % len(self.frames)].cam.index
                     R.fallbacks += 1
                     R.clean_visits[k] = 0
+                    R.cooldown[k] = R.cull_cooldown
                     if not R.margin_fixed:
                         R.margin[k] = min(R.margin[k] * 2, R.margin_hi)
                 self._spec_ring.append((no, frame_index, lrs))
