@@ -165,9 +165,10 @@ int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const float* de
 int lg_tile_group(const int32_t* keys, const int32_t* vals, long long L, int max_tile, int32_t* tile_start, int32_t* out_vals, void* temp, void* stream);
 int lg_tile_depth_sort_unordered(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
                                  uint32_t* scratch, void* stream);
-/* process-wide: 1 = lists of 1025 .. 4096 entries are sorted by the four waves of a workgroup with the wave regime's radix sort instead
- * of the bitonic network (identical tables; default 0 until measured -- profiles/r03_tilesort_scaling.log is the motive). */
-int lg_tile_depth_sort_set_regime_w(int on);
+/* the same with wg_radix = 1: lists of 1025 .. 4096 entries are sorted by the four waves of a workgroup with the wave regime's radix sort
+ * instead of the bitonic network (identical tables); any_order = 1: the lists arrive in arbitrary order (lg_tile_group) */
+int lg_tile_depth_sort_ex(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
+                          uint32_t* scratch, int any_order, int wg_radix, void* stream);
 int lg_memset_async(void* ptr, int value, long long bytes, void* stream);
 
 /* ---- raster.hip : GR/raster.h --------------------------------------------------------------- */
@@ -226,39 +227,56 @@ int lg_l1_ssim_backward_raster_value(const float* img, int Hp, int Wp, const flo
  * There is no counterpart in the reference (its executor is the Python in litegs/render/__init__.py:11-94 + wrapper.py); these
  * entry points are what litegs_amd/fast.py binds.  view_host/proj_host are HOST float[16] (row-vector 4x4, passed to kernels by value).
  * Workspace 1 holds per-Gaussian buffers for N = A*S, workspace 2 the tile-instance table of length L. */
-/* process-wide executor options.  key 0 = depth order of the tile lists: 0 the reference's structure (depth sort of all
- * visible splats before the emission, wrapper.py:739-745), 1 per-tile depth sort after the tile sort (tilesort.hip; no sort over the
- * splats), 2 (default) choose per frame: 1 from 1 M compacted Gaussians on, 0 below.  Identical tables either way.  key 1 = margin of the depth-bound culling in percent (default 100): how far beyond
- * a tile's saturation point its bound for the frame's next visit lies.  key 2 = (mode 1 only) 1 (default): group the instances by tile with
- * per-tile counts and cursors (lg_tile_group's kernels) instead of the stable tile radix sort, 0: keep the radix sort; identical tables.
- * Returns 0, or hipErrorInvalidValue for an unknown key / value. */
-int lg_fused_set_option(int key, int value);
-/* depth-order mode 1 only: emission order of the frames whose N = A*S equals n (a device permutation of 0..n-1 owned by the caller;
- * NULL = ascending ids).  Shapes the emission's workload, never the table (the per-tile sort orders by depth and id). */
-int lg_fused_set_emission_order(const int32_t* order, long long n);
-int lg_fused_get_option(int key);
-/* key 3 of lg_fused_set_option = gradient replicas (default 0): splats that cover >= 128 tiles get 2^k <= 64 lines behind the N regular
- * gradient records, the blend backward adds into replica (tile mod 2^k), the fused backward kernels fold them -- removes the same-line
- * contention at the memory-side atomic units.  The gradient accumulator then has lg_fused_grad_lines(N) lines; the option must have the
- * same value for lg_fused_stage1, lg_fused_stage2 and lg_fused_backward of one frame, lg_fused_backward_adam is told through
- * lg_fused_set_hot_table, and a persistent device counter must be registered (reset by the backward kernels at the end of a step). */
-int lg_fused_set_hot_counter(int* counter_dev);
-int lg_fused_set_hot_table(const int* hot_of);   /* one-shot: the replica assignment (workspace 1 + lg_fused_hot_offset(N)) the next lg_fused_backward_adam folds; NULL = none */
+/* Execution context of the native executor: everything the lg_fused_* entry points need beyond their tensors.  A plain HOST struct owned
+ * by the caller (one per renderer), read during the call only: the library keeps NO pointer into it and has no process-wide executor
+ * state, so any number of renderers / trainers / devices can live in one process.  NULL = the defaults in brackets.
+ *   depth_order   [2] how each tile's list gets its depth order: 0 the reference's structure (depth sort of all visible splats before
+ *                 the emission, wrapper.py:739-745), 1 per-tile depth sort after the grouping (tilesort.hip; no sort over the splats),
+ *                 2 choose per frame: 1 from 1 M compacted Gaussians on, 0 below.  Identical tables either way.
+ *   bound_margin_pct [100] depth-bound culling: how far beyond a tile's saturation point its bound for the frame's next visit lies.
+ *   tile_scatter  [1] (depth order 1 only) group the instances by tile with per-tile counts and cursors (lg_tile_group's kernels)
+ *                 instead of the stable tile radix sort; identical tables.
+ *   grad_replicas [0] splats that cover >= 128 tiles get 2^k <= 64 gradient lines behind the N regular records, the blend backward adds
+ *                 into replica (tile mod 2^k), the fused backward kernels fold them (removes same-line contention at the memory-side
+ *                 atomic units).  The gradient accumulator then has lg_fused_grad_lines(N) lines; the value must be the same for
+ *                 lg_fused_stage1 / stage2 / backward of one frame, and hot_counter must point to a persistent device int (zero at first;
+ *                 the backward kernels reset it at the end of a step).  lg_fused_backward_adam is handed the assignment table
+ *                 (workspace 1 + lg_fused_hot_offset(N)) as an argument.
+ *   poison, poison_host, applied_host, step_id [NULL, NULL, NULL, 0] speculative depth-bound culling: with poison set, a culled
+ *                 lg_fused_stage2 enqueues no gated repeat; a violated bound raises *poison (sticky device int) and its pinned mirror
+ *                 *poison_host, and every lg_fused_backward_adam returns at once while it is raised, otherwise stores step_id into
+ *                 *applied_host (pinned).  The caller replays the steps after *applied_host (the first one unculled) after clearing both
+ *                 words.  The pinned words must outlive every launch that can store into them: take them from lg_host_words_alloc. */
+typedef struct LgFusedCtx {
+    int32_t struct_bytes;       /* sizeof(LgFusedCtx): checked by every entry point */
+    int32_t depth_order;
+    int32_t bound_margin_pct;
+    int32_t tile_scatter;
+    int32_t grad_replicas;
+    int32_t step_id;
+    int32_t debug_validate;     /* 1: lg_fused_stage2 checks the grouped table on the device before anything indexes with it (debug_words) */
+    int32_t tilesort_wg_radix;  /* [0] per-tile sort: lists of 1025 .. 4096 entries through the workgroup radix sort instead of the bitonic regimes */
+    int* hot_counter;           /* device int32[1] */
+    int* poison;                /* device int32[1] */
+    int* poison_host;           /* pinned int32[1] */
+    int* applied_host;          /* pinned int32[1] */
+    int* debug_words;           /* pinned int32[8], zero: first violation found by the table check {code, tile, position, value, bound, ...} */
+} LgFusedCtx;
+/* Pinned host words for everything the device stores into asynchronously (sizing feedback, speculation mirrors, exchange headers).
+ * They come from an arena inside the library that is never unmapped: a kernel that is still in flight when its owner dies stores into
+ * memory that is still there, and a freed word is handed out again only after a device synchronisation.  n int32 words, zeroed. */
+int* lg_host_words_alloc(int n);
+void lg_host_words_free(int* words, int n);
 long long lg_fused_hot_offset(long long N);
 long long lg_fused_grad_lines(long long N);
-/* Speculative depth-bound culling (fused.hip "Speculative culling"): while a context is set, a culled lg_fused_stage2 enqueues no gated
- * repeat; a violated bound raises *poison (sticky, device) and its pinned mirror, and every lg_fused_backward_adam returns at once while
- * it is raised, otherwise stores step_id into *applied_host.  The caller replays the steps after *applied_host (the first one unculled)
- * after clearing both words.  NULL poison switches back to the gated repeat.  Process-wide, like lg_fused_set_option. */
-int lg_fused_set_speculation(int* poison, int* poison_host, int* applied_host, int step_id);
 long long lg_fused_workspace1_bytes(long long N);
 long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int TH, int TW);
 long long lg_fused_total_offset(long long N);
 long long lg_fused_tile_start_offset(long long L, long long N, int H, int W, int TH, int TW);   /* int32[ntiles+2] tile ranges in workspace 2 (valid after stage 2) */
-long long lg_fused_sorted_points_offset(long long L, long long N, int H, int W, int TH, int TW); /* int32[L] tile-grouped, depth-ordered splat ids in workspace 2 (valid after stage 2) */
+long long lg_fused_sorted_points_offset(const LgFusedCtx* ctx, long long L, long long N, int H, int W, int TH, int TW); /* int32[L] tile-grouped, depth-ordered splat ids in workspace 2 (valid after stage 2) */
 long long lg_fused_alloc_offset(long long N);   /* int32[N] tile counts per compacted Gaussian (valid after stage 1) */
 long long lg_fused_packed_offset(long long N);  /* float[N,16] packed splat records (valid after stage 1) */
-int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
+int lg_fused_stage1(const LgFusedCtx* ctx, const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
                     const float* view_host, const float* proj_host, int H, int W, int TH, int TW, int degree,
                     const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,
                     int do_cull, uint8_t* visibility, int* vis_num, int64_t* vis_ids, int A,
@@ -268,7 +286,7 @@ int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float
                     int* sched_out /*nullable: the depth-bound block the coming lg_fused_stage2 fills; its head is cleared here*/,
                     void* stream);
 long long lg_fused_cull_scratch_bytes(int chunks);
-int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
+int lg_fused_stage2(const LgFusedCtx* ctx, int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                     void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
                     float* img, float* trans, short* last, int* frag_count, float* frag_weight,
                     float* packed_grad_clear /*nullable [N,16]: zeroed on the side for the coming lg_fused_backward*/,
@@ -284,7 +302,7 @@ int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, voi
                     const int64_t* vis_ids, const int* vis_num, void* stream);
 long long lg_sched_words(int H, int W, int TH, int TW);   /* 32-bit words of a per-frame depth-bound block (csrc/lg_tilewalk.h) */
 long long lg_fused_flags_offset(long long N);   /* int32[2] in workspace 1: {fallback flag of the last stage 2, full table length if it ran} */
-int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
+int lg_fused_backward(const LgFusedCtx* ctx, int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
                       const void* ws2, long long ws2_bytes, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                       const int64_t* vis_ids, const int* vis_num,
                       const float* pos, const float* scale, const float* rot, const float* opa,
@@ -292,7 +310,7 @@ int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, c
                       const float* grad_inv_scaler, int enable_stat, float* packed_grad, int packed_grad_is_zero, float* err_square_sum,
                       float* d_pos, float* d_scale, float* d_rot, float* d_sh0, float* d_shr, float* d_opa,
                       const int* order /*nullable int32[T]: the frame's tile schedule*/, void* stream);
-int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_host, const float* proj_host, int degree, int chunks, int R,
+int lg_fused_backward_adam(const LgFusedCtx* ctx, const int* hot_of /*nullable: this frame's replica assignment*/, int A, int S, int H, int W, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                            const int64_t* vis_ids, const int* vis_num, const float* packed_grad, const float* grad_inv_scaler,
                            float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
                            float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,

@@ -27,8 +27,8 @@ def parse_header(path: str = HEADER_PATH):
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
     protos = {}
-    for m in re.finditer(r"\b(int|long long|void)\s+(lg_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
-        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+    for m in re.finditer(r"\b(int|long long|void)\s*(\*?)\s*\b(lg_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, ptr, name, args = m.group(1), m.group(2), m.group(3), m.group(4).strip()
         argtypes = []
         if args and args != "void":
             for a in args.split(","):
@@ -41,7 +41,7 @@ def parse_header(path: str = HEADER_PATH):
                 if tname not in _SCALARS:
                     raise ValueError(f"cannot parse argument '{a}' of {name}")
                 argtypes.append(_SCALARS[tname])
-        protos[name] = (_SCALARS[ret], argtypes)
+        protos[name] = (ctypes.c_void_p if ptr else _SCALARS[ret], argtypes)
     return protos
 
 

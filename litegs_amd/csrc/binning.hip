@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         off = (j == 0) ? 0 : pf[j - 1];
         const long long c = pf[j] - off;
         if (c > 0 && off + c <= table_len) cnt = (int)c;
-        else if (c > 0 && off < table_len) {
+        else if (c > 0 && off <= table_len) {           // (off == table_len: nothing left to pad, but the table IS too short -- raise the flag)
             // first splat that does not fit (GR/binning.cu:63 drops it and, prefix being monotone, every later one): the rest of
             // the table becomes key 0 = "no tile".  Values too (the table is not pre-cleared on the fused path), and the padding keys
             // are counted into the sort's digit totals (digit 0 of every pass) -- the sort then handles exactly table_len keys.

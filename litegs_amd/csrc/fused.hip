@@ -41,77 +41,112 @@
 #define LG_DEPTH_ORDER_TILE 1
 #define LG_DEPTH_ORDER_AUTO 2
 #define LG_AUTO_TILE_N 1000000
-static int g_depth_order_mode = LG_DEPTH_ORDER_AUTO;
-static bool use_tile_order(long long N)
-{
-    return g_depth_order_mode == LG_DEPTH_ORDER_TILE || (g_depth_order_mode == LG_DEPTH_ORDER_AUTO && N >= LG_AUTO_TILE_N);
-}
-// depth-bound culling: how far (percent of the splats walked, at least 16 splats) beyond a tile's saturation point its next bound lies.
-// A wider margin emits more instances but survives more drift of the scene between two visits of a frame before the gated fallback
-// has to re-run the frame unculled (key 1 of lg_fused_set_option; litegs_amd/fast.py adapts it per frame).
-static int g_bound_margin_pct = 100;
-// TILE mode: group the instances by tile with per-tile counts + cursors (binning.hip "Tile scatter") instead of the stable tile radix
-// sort -- the order inside a tile is re-made by the per-tile depth sort anyway.  Same table bit for bit.  Key 2 of lg_fused_set_option.
-static int g_tile_scatter = 1;
-// Gradient replicas for splats that cover many tiles (raster.hip): key 3 of lg_fused_set_option, read by lg_fused_stage1 (the projection
-// assigns the replica lines) -- on only when every consumer of the gradient records folds them (the fused backward kernels of this file).
-static int g_grad_replicas = 0;
-// the replica line counter: a device int owned by the caller (persistent: the projection that assigns lines cannot also clear its own
-// counter).  It is reset by the kernel that consumes the records at the end of a training step (project_backward_adam / project_fused_backward).
-static int* g_hot_counter = nullptr;
-LG_API int lg_fused_set_hot_counter(int* counter_dev) { g_hot_counter = counter_dev; return 0; }
-static bool replicas_on() { return g_grad_replicas != 0 && g_hot_counter != nullptr; }
-// the replica assignment of the frame whose records the NEXT lg_fused_backward_adam consumes (workspace 1 + lg_fused_hot_offset(N), or
-// NULL); one-shot: the call clears it, so a stale pointer can never be folded into another frame's update
-static const int* g_hot_table = nullptr;
-LG_API int lg_fused_set_hot_table(const int* hot_of) { g_hot_table = hot_of; return 0; }
 #define LG_HOT_MIN_TILES 128               // a splat with at least this many tile instances gets R = 2^k <= 64 lines, ~64 instances per line
 __host__ __device__ static inline long long hot_capacity(long long N) { return N / 4 + 1024; }
 #define LG_TILE_BINS_MAX (1 << 17)          // count words reserved (and cleared) per frame in workspace 1; frames with more tiles keep the radix sort
-static bool use_tile_scatter(long long N, int ntiles);
 
-// TILE mode only: the order in which the splats' instances are emitted (slot j -> splat order[j], a permutation of 0..n-1 on the
-// device, owned by the caller; nullptr or a length that does not match the frame's N = A*S: ascending ids).  The per-tile sort makes
-// the table independent of this order; it only shapes the emission's workload: consecutive ids are spatial neighbours -- all large
-// or all small -- while an interleaved order gives every 256-slot group the mix of sizes the emission kernels were tuned for.
-static const int32_t* g_emit_order = nullptr;
-static long long g_emit_order_n = 0;
-LG_API int lg_fused_set_emission_order(const int32_t* order, long long n)
+// The executor has NO process-wide state: every entry point resolves its options and its per-renderer device / pinned words from the
+// caller's LgFusedCtx (include/litegs_hip.h) for the duration of the call.
+//  * depth_order / tile_scatter: see above.  bound_margin_pct: how far (percent of the splats walked, at least 16 splats) beyond a tile's
+//    saturation point its next depth bound lies -- a wider margin emits more instances but survives more drift of the scene between two
+//    visits of a frame (litegs_amd/fast.py adapts it per frame).
+//  * grad_replicas + hot_counter: gradient replicas for splats that cover many tiles (raster.hip).  The replica line counter is a
+//    persistent device int owned by the renderer (the projection that assigns lines cannot also clear its own counter); it is reset by the
+//    kernel that consumes the records at the end of a training step (project_backward_adam / project_fused_backward).
+//  * Speculative culling (no reference counterpart).  The exactness of the depth-bound culling rests on a repeat of the frame without
+//    culling whenever a bound was violated.  Enqueued unconditionally as gated launches that repeat costs eight empty dependent launches
+//    (~39 us) in EVERY step.  With `poison` set, a culled training step enqueues no repeat at all: a violated bound (or a truncated culled
+//    table) raises the sticky device word `poison` (mirrored into pinned host memory), every fused backward + Adam launch that finds it
+//    raised returns without touching anything -- so from the failed step on NO parameter, moment or flag changes -- and every launch that
+//    does run records its step number in the pinned word `applied`.  The host (litegs_amd/trainer.py) notices the mirror one or two steps
+//    later, synchronises, and replays the steps after `applied` in order, the first of them unculled: the parameter sequence is exactly
+//    the one the gated repeat would have produced.  Renders that are not followed by a fused Adam step (evaluation, gradient-hook data
+//    parallelism) keep the gated repeat.
+struct Exec {
+    int depth_order, margin_pct, tile_scatter, replicas, step_id, validate, wg_radix;
+    int *hot_counter, *poison, *poison_host, *applied_host, *debug_words;
+};
+static int resolve_ctx(const LgFusedCtx* c, Exec& x)
 {
-    g_emit_order = order; g_emit_order_n = order ? n : 0;
+    x = Exec{ LG_DEPTH_ORDER_AUTO, 100, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr };
+    if (c == nullptr) return 0;
+    if (c->struct_bytes != (int32_t)sizeof(LgFusedCtx)) return (int)hipErrorInvalidValue;          // caller built against another header
+    if (c->depth_order < 0 || c->depth_order > 2 || c->bound_margin_pct < 1 || c->bound_margin_pct > 100000) return (int)hipErrorInvalidValue;
+    if (c->grad_replicas && c->hot_counter == nullptr) return (int)hipErrorInvalidValue;
+    if (c->poison != nullptr && (c->poison_host == nullptr || c->applied_host == nullptr)) return (int)hipErrorInvalidValue;
+    if (c->debug_validate && c->debug_words == nullptr) return (int)hipErrorInvalidValue;
+    x.depth_order = c->depth_order; x.margin_pct = c->bound_margin_pct; x.tile_scatter = c->tile_scatter ? 1 : 0;
+    x.replicas = c->grad_replicas ? 1 : 0; x.step_id = c->step_id; x.validate = c->debug_validate ? 1 : 0; x.wg_radix = c->tilesort_wg_radix ? 1 : 0;
+    x.hot_counter = c->hot_counter; x.poison = c->poison; x.poison_host = c->poison_host; x.applied_host = c->applied_host;
+    x.debug_words = c->debug_words;
     return 0;
 }
-static const int32_t* emission_order(long long N) { return (g_emit_order != nullptr && g_emit_order_n == N) ? g_emit_order : nullptr; }
-
-// Speculative culling (no reference counterpart).  The exactness of the depth-bound culling rests on a repeat of the frame without
-// culling whenever a bound was violated.  Enqueued unconditionally as gated launches that repeat costs eight empty dependent launches
-// (~39 us) in EVERY step.  With a speculation context set, a culled training step enqueues no repeat at all: a violated bound (or a
-// truncated culled table) raises the sticky device word `poison` (mirrored into pinned host memory), every fused backward + Adam
-// launch that finds it raised returns without touching anything -- so from the failed step on NO parameter, moment or flag changes --
-// and every launch that does run records its step number in the pinned word `applied`.  The host (litegs_amd/trainer.py) notices the
-// mirror one or two steps later, synchronises, and replays the steps after `applied` in order, the first of them unculled: the
-// parameter sequence is exactly the one the gated repeat would have produced.  Renders that are not followed by a fused Adam step
-// (evaluation, gradient-hook data parallelism) keep the gated repeat.
-struct Speculation { int* poison; int* poison_host; int* applied_host; int step_id; };
-static Speculation g_spec = { nullptr, nullptr, nullptr, 0 };
-LG_API int lg_fused_set_speculation(int* poison /*device int, zero = healthy; NULL switches speculation off*/, int* poison_host /*pinned mirror*/,
-                                    int* applied_host /*pinned: step number of the last fused Adam launch that ran*/, int step_id)
+static bool use_tile_order(const Exec& x, long long N)
 {
-    g_spec.poison = poison; g_spec.poison_host = poison_host; g_spec.applied_host = applied_host; g_spec.step_id = step_id;
-    return 0;
+    return x.depth_order == LG_DEPTH_ORDER_TILE || (x.depth_order == LG_DEPTH_ORDER_AUTO && N >= LG_AUTO_TILE_N);
+}
+static bool use_tile_scatter(const Exec& x, long long N, int ntiles) { return x.tile_scatter && use_tile_order(x, N) && ntiles + 2 <= LG_TILE_BINS_MAX; }
+
+// ---------------------------------------------------------------------------------------------
+// Pinned host words (lg_host_words_alloc): one arena per process, never unmapped.  The device stores sizing feedback, speculation
+// mirrors and exchange headers into pinned words asynchronously; handing those words out from the torch host allocator ties their
+// lifetime to a Python tensor the allocator may recycle or unmap while a launch is still in flight.  Here a freed range is quarantined
+// and re-issued only after a device synchronisation, and the pages themselves stay mapped for the life of the process.
+// ---------------------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct HostRange { int* p; int n; };
+std::mutex g_hw_mutex;
+std::vector<HostRange> g_hw_free, g_hw_quarantine;
+int* g_hw_chunk = nullptr;
+int g_hw_chunk_left = 0;
+constexpr int HW_CHUNK_WORDS = 1 << 16;          // 256 KB of pinned memory per arena chunk
+}
+LG_API int* lg_host_words_alloc(int n)
+{
+    if (n <= 0) return nullptr;
+    n = (n + 15) & ~15;                          // 64-byte granules: no two owners share a cache line
+    std::lock_guard<std::mutex> lock(g_hw_mutex);
+    auto take_free = [&]() -> int* {
+        for (size_t i = 0; i < g_hw_free.size(); i++)
+            if (g_hw_free[i].n >= n) {
+                int* p = g_hw_free[i].p;
+                if (g_hw_free[i].n > n) { g_hw_free[i].p += n; g_hw_free[i].n -= n; }
+                else { g_hw_free[i] = g_hw_free.back(); g_hw_free.pop_back(); }
+                return p;
+            }
+        return nullptr;
+    };
+    int* p = take_free();
+    if (p == nullptr && !g_hw_quarantine.empty()) {
+        // nothing on the device can still be storing into a quarantined range once everything enqueued so far has completed
+        if (hipDeviceSynchronize() == hipSuccess) {
+            for (const HostRange& r : g_hw_quarantine) g_hw_free.push_back(r);
+            g_hw_quarantine.clear();
+            p = take_free();
+        }
+    }
+    if (p == nullptr) {
+        if (n > g_hw_chunk_left) {
+            const int words = n > HW_CHUNK_WORDS ? n : HW_CHUNK_WORDS;
+            void* mem = nullptr;
+            if (hipHostMalloc(&mem, sizeof(int) * (size_t)words, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return nullptr;
+            g_hw_chunk = (int*)mem; g_hw_chunk_left = words;          // the rest of the previous chunk is abandoned (never unmapped)
+        }
+        p = g_hw_chunk; g_hw_chunk += n; g_hw_chunk_left -= n;
+    }
+    for (int i = 0; i < n; i++) p[i] = 0;
+    return p;
+}
+LG_API void lg_host_words_free(int* words, int n)
+{
+    if (words == nullptr || n <= 0) return;
+    n = (n + 15) & ~15;
+    std::lock_guard<std::mutex> lock(g_hw_mutex);
+    g_hw_quarantine.push_back(HostRange{ words, n });
 }
 
-LG_API int lg_fused_set_option(int key, int value)
-{
-    if (key == 0 && (value == LG_DEPTH_ORDER_GLOBAL || value == LG_DEPTH_ORDER_TILE || value == LG_DEPTH_ORDER_AUTO)) { g_depth_order_mode = value; return 0; }
-    if (key == 1 && value >= 1 && value <= 100000) { g_bound_margin_pct = value; return 0; }
-    if (key == 2 && (value == 0 || value == 1)) { g_tile_scatter = value; return 0; }
-    if (key == 3 && (value == 0 || value == 1)) { g_grad_replicas = value; return 0; }
-    return (int)hipErrorInvalidValue;
-}
-
-LG_API int lg_fused_get_option(int key) { return key == 0 ? g_depth_order_mode : (key == 1 ? g_bound_margin_pct : (key == 2 ? g_tile_scatter : (key == 3 ? g_grad_replicas : -1))); }
-static bool use_tile_scatter(long long N, int ntiles) { return g_tile_scatter && use_tile_order(N) && ntiles + 2 <= LG_TILE_BINS_MAX; }
 #define LOG2E 1.4426950408889634f
 
 
@@ -411,9 +446,9 @@ static Layout2 layout2(long long L, int ntiles, long long N)
 }
 
 // where the blend kernels find the tile-grouped splat ids in workspace 2
-static size_t sorted_points_offset(const Layout2& f, long long N, int ntiles)
+static size_t sorted_points_offset(const Exec& x, const Layout2& f, long long N, int ntiles)
 {
-    if (use_tile_scatter(N, ntiles)) return f.tv_b;                 // tile scatter: emitted into tv_a, dropped at the cursors into tv_b
+    if (use_tile_scatter(x, N, ntiles)) return f.tv_b;                 // tile scatter: emitted into tv_a, dropped at the cursors into tv_b
     int bits = 0;
     for (unsigned int mt = (unsigned int)ntiles; mt >>= 1;) bits++;
     bits++;
@@ -440,10 +475,12 @@ LG_API long long lg_fused_tile_start_offset(long long L, long long N, int H, int
     return (long long)layout2(L > 0 ? L : 1, ntiles, N).tile_start;
 }
 
-LG_API long long lg_fused_sorted_points_offset(long long L, long long N, int H, int W, int TH, int TW)
+LG_API long long lg_fused_sorted_points_offset(const LgFusedCtx* ctx, long long L, long long N, int H, int W, int TH, int TW)
 {
+    Exec x;
+    if (resolve_ctx(ctx, x)) return -1;
     int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    return (long long)sorted_points_offset(layout2(L > 0 ? L : 1, ntiles, N), N, ntiles);
+    return (long long)sorted_points_offset(x, layout2(L > 0 ? L : 1, ntiles, N), N, ntiles);
 }
 
 // byte offset in workspace 1 of the exact instance total (prefix[N-1]) -- for the blocking first-visit path
@@ -489,17 +526,18 @@ struct Scene {            // what the projection kernel reads (raw parameters + 
 
 static int launch_projection(const Scene& sc, const Camera& cam, int TH, int TW, char* w, const Layout1& f, bool zero_duty,
                              const int* sched_in /*nullable: cull against its depth bounds*/, int* sched_out /*nullable: head cleared*/,
-                             const int* gate, hipStream_t s, bool hot = false)
+                             const int* gate, hipStream_t s, int* hot_counter /*nullable: assign gradient replica lines*/)
 {
     const float* bound_pyr = reinterpret_cast<const float*>(sched_in);
     float* view_z = (float*)(w + f.view_z); float4* packed = (float4*)(w + f.packed);
     int* alloc = (int*)(w + f.alloc);
     const int gx = (cam.W + TW - 1) / TW, gy = (cam.H + TH - 1) / TH;
+    const bool hot = hot_counter != nullptr;
 #define LAUNCH_PF(D, A_, B_) hipLaunchKernelGGL((project_fused_kernel<D, A_, B_>), dim3(sc.A), dim3(sc.S), 0, s, sc.vis_ids, sc.vis_num, cam,   \
                                                 sc.pos, sc.scale, sc.rot, sc.sh0, sc.shr, sc.opa, sc.chunks, sc.S, sc.A, view_z, alloc, packed, \
                                                 gx, gy, (uint32_t*)(w + f.zeroed), zero_duty ? (long long)(f.zero_bytes / 4) : 0LL,             \
                                                 (uint32_t*)sched_out, sched_out ? lg_sched_clear_words(gx, gy) : 0LL, bound_pyr, gate,     \
-                                                hot ? (int*)(w + f.hot_of) : (int*)nullptr, g_hot_counter, (int)hot_capacity((long long)sc.A * sc.S))
+                                                hot ? (int*)(w + f.hot_of) : (int*)nullptr, hot_counter, (int)hot_capacity((long long)sc.A * sc.S))
 #define DISPATCH_PF(A_, B_)                                                  \
     switch (sc.degree) {                                                     \
     case 0: LAUNCH_PF(0, A_, B_); break;                                     \
@@ -523,7 +561,7 @@ static int launch_projection(const Scene& sc, const Camera& cam, int TH, int TW,
 // Afterwards prefix[N-1] (device) is the table length; it is copied to host_feedback_total if given.
 // sched_cull (nullable): this frame's sched block of its previous visit -> depth-bound culling against its bounds.
 // sched_out (nullable): the block this visit's blend forward will fill; its head is cleared here.
-LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
+LG_API int lg_fused_stage1(const LgFusedCtx* ctx, const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,
                            const float* view_host, const float* proj_host, int H, int W, int TH, int TW, int degree,
                            const float* pos, const float* scale, const float* rot, const float* sh0, const float* shr, const float* opa, int S,
                            int do_cull, uint8_t* visibility, int* vis_num, int64_t* vis_ids, int A,
@@ -533,7 +571,9 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
                            const int* sched_cull, int* sched_out, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    int rc;
+    Exec x;
+    int rc = resolve_ctx(ctx, x);
+    if (rc) return rc;
     if (do_cull) {
         if (cull_scratch)
             rc = lg_frustum_culling_chain(aabb_origin, aabb_ext, planes_dev, 1, chunks, visibility, vis_num, vis_ids, cull_scratch, cull_epoch,
@@ -550,11 +590,11 @@ LG_API int lg_fused_stage1(const float* aabb_origin, const float* aabb_ext, cons
     char* w = (char*)ws1;
     Camera cam = make_camera(view_host, proj_host, H, W);
     Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
-    rc = launch_projection(sc, cam, TH, TW, w, f, true, sched_cull, sched_out, nullptr, s, replicas_on()); if (rc) return rc;
-    if (use_tile_order(N)) {
+    rc = launch_projection(sc, cam, TH, TW, w, f, true, sched_cull, sched_out, nullptr, s, x.replicas ? x.hot_counter : nullptr); if (rc) return rc;
+    if (use_tile_order(x, N)) {
         // no splat sort: instances are emitted in splat-id order and every tile's list is depth-sorted after the tile sort
         // (tilesort.hip).  Inclusive scan of the tile counts in id order; prefix[N-1] (the table length) also goes to the host feedback slot
-        return lg_gather_scan_gated((const int32_t*)(w + f.alloc), emission_order(N), N, (int32_t*)(w + f.prefix),
+        return lg_gather_scan_gated((const int32_t*)(w + f.alloc), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
                                     (uint32_t*)(w + f.scan_status), host_feedback_total, sched_cull ? 1 : 0, nullptr, nullptr, stream);
     }
     float* view_z = (float*)(w + f.view_z);
@@ -577,9 +617,72 @@ static int tile_key_bits(int ntiles)
     return bits + 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Table validators (LgFusedCtx.debug_validate; debugging aid, off in production: two extra launches per frame).  Everything behind the
+// key emission indexes memory with what the table holds -- a key selects a counter and a cursor, a splat id a depth word and a 64-byte
+// record through the scalar path -- so one word of garbage in the table is a wild access two kernels later.  With the flag on, the
+// emitted keys and the grouped table are checked on the device BEFORE anything indexes with them; an offending word is reported to the
+// caller's pinned debug_words {code, where, value, bound, valid entries, -, -, reports so far} (code 1: key outside 0..tiles at table
+// position `where`; 2: range of tile `where` ends at `value` beyond the valid entries; 3: splat id `value` at position `where` outside
+// 0..N-1) and neutralised (key 0 / empty range / id 0), so that a long run survives to tell where it happened.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void validate_report(int* __restrict__ lock, int* __restrict__ dbg, int code, int where, int value, int bound, int n)
+{
+    if (atomicCAS(lock, 0, 1) != 0) return;               // first report of this frame wins (the lock word is cleared with the frame's scratch)
+    const int seen = __hip_atomic_load(dbg + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 1, where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 2, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 3, bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 4, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 7, seen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 0, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(256) validate_keys_kernel(int32_t* __restrict__ keys, long long L, const int* __restrict__ n_dev, int ntiles,
+                                                            int* __restrict__ lock, int* __restrict__ dbg, const int* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    long long n = L;
+    if (n_dev != nullptr && (long long)*n_dev < n) n = *n_dev;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int k = keys[i];
+        if (k < 0 || k > ntiles) { validate_report(lock, dbg, 1, (int)i, k, ntiles, (int)n); keys[i] = 0; }
+    }
+}
+
+__global__ void __launch_bounds__(256) validate_table_kernel(int32_t* __restrict__ vals, int32_t* __restrict__ tile_start, long long L,
+                                                             const int* __restrict__ n_dev, int ntiles, int N,
+                                                             int* __restrict__ lock, int* __restrict__ dbg, const int* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    long long n = L;
+    if (n_dev != nullptr && (long long)*n_dev < n) n = *n_dev;
+    const long long stride = (long long)gridDim.x * 256, gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long t = gid + 1; t <= ntiles; t += stride) {
+        const int start = tile_start[t], end = tile_start[t + 1];
+        if (start >= 0 && end > start && (long long)end > n) { validate_report(lock, dbg, 2, (int)t, end, start, (int)n); tile_start[t] = -1; }
+    }
+    for (long long i = gid; i < n; i += stride) {
+        const int id = vals[i];
+        if ((unsigned)id >= (unsigned)N) { validate_report(lock, dbg, 3, (int)i, id, N, (int)n); vals[i] = 0; }
+    }
+}
+
+#define LG_VALIDATE_LOCK_WORD 8            // int index inside Layout1::flags (cleared with the frame's scratch by the projection)
+static int validate_keys(const Exec& x, int32_t* keys, long long L, const int* n_dev, int ntiles, int* lock, const int* gate, hipStream_t s)
+{
+    hipLaunchKernelGGL(validate_keys_kernel, dim3(2048), dim3(256), 0, s, keys, L, n_dev, ntiles, lock, x.debug_words, gate);
+    return (int)hipGetLastError();
+}
+static int validate_table(const Exec& x, int32_t* vals, int32_t* tile_start, long long L, const int* n_dev, int ntiles, int N, int* lock, const int* gate, hipStream_t s)
+{
+    hipLaunchKernelGGL(validate_table_kernel, dim3(2048), dim3(256), 0, s, vals, tile_start, L, n_dev, ntiles, N, lock, x.debug_words, gate);
+    return (int)hipGetLastError();
+}
+
 // key/value emission -> stable tile sort -> tile ranges -> blend forward over the table described by `prefix`; Ls = table length this
 // run is sized for (<= the capacity L of the layout).  hdr / qcount: the zeroed scratch set to use.
-static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, long long Ls, int H, int W, int TH, int TW,
+static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, long long Ls, int H, int W, int TH, int TW,
                              int* tsort_hdr, int* qcount, int* tcount, const int* tiles, int K, int enable_stat,
                              float* img, float* trans, short* last, int* frag_count, float* frag_weight, float* packed_grad_clear,
                              const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag, int* fail_host, const int* gate,
@@ -587,25 +690,27 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
 {
     const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
-    const bool tile_mode = use_tile_order(N);
-    const void* depth_order = tile_mode ? (const void*)emission_order(N) : (odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));     // nullptr: emission in splat-id order
+    const bool tile_mode = use_tile_order(x, N);
+    const void* depth_order = tile_mode ? (const void*)nullptr : (odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));     // nullptr: emission in splat-id order
     const int bits = tile_key_bits(ntiles);
-    const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(f, N, ntiles));
+    const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(x, f, N, ntiles));
     int rc;
-    if (use_tile_scatter(N, ntiles)) {
+    if (use_tile_scatter(x, N, ntiles)) {
         // TILE mode without a sort: the emitted keys are counted per key (LDS-aggregated), one workgroup turns the counts into the range
         // table and write cursors, one pass drops the values at their cursors, and the per-tile sort orders every list by (depth, id)
         rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
                                (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
                                qcount, (uint32_t*)(w + f.dup_entries), nullptr, 0, bits, nullptr, nullptr, 0,
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
-                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (replicas_on() ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
         if (rc) return rc;
+        if (x.validate) { rc = validate_keys(x, (int32_t*)(w + f.tk_a), Ls, total_dev, ntiles, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
         rc = lg_tile_scatter_gated((const int32_t*)(w + f.tk_a), (const int32_t*)(w + f.tv_a), Ls, total_dev, ntiles, tcount, 1, (int*)(w + f.tile_cursor),
                                    (int32_t*)(w + f.tile_start), (int32_t*)(w + f.tv_b), gate, s);
         if (rc) return rc;
+        if (x.validate) { rc = validate_table(x, (int32_t*)(w + f.tv_b), (int32_t*)(w + f.tile_start), Ls, total_dev, ntiles, (int)N, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
         rc = lg_tile_depth_sort_gated((int32_t*)(w + f.tv_b), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L, (int)N, ntiles,
-                                      (uint32_t*)(w + f.tk_b), 1, gate, s);
+                                      (uint32_t*)(w + f.tk_b), 1, x.wg_radix, gate, s);
         if (rc) return rc;
     } else {
     // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
@@ -616,7 +721,7 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
                                qcount, (uint32_t*)(w + f.dup_entries), tsort_hdr, 0, bits, nullptr, (uint32_t*)(w + f.tsort_table),
                                (long long)lg_radix_table_words(Ls, lg_radix_sort_num_passes(0, bits)),
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
-                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (replicas_on() ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
     if (rc) return rc;
     // instance count on the device: only that many entries are sorted and range-scanned
     rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
@@ -625,18 +730,19 @@ static int binning_and_blend(char* w1, const Layout1& f1, char* w, const Layout2
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
     rc = lg_tile_range_prefilled(sorted_keys, 1, Ls, total_dev, ntiles, (int32_t*)(w + f.tile_start), s); if (rc) return rc;
+    if (x.validate) { rc = validate_table(x, (int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (int32_t*)(w + f.tile_start), Ls, total_dev, ntiles, (int)N, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
     if (tile_mode) {      // depth order inside every tile; scratch for lists beyond 2048: the key buffer the tile sort did not end in
         rc = lg_tile_depth_sort_gated((int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L,
-                                      (int)N, ntiles, (uint32_t*)(w + (odd ? f.tk_a : f.tk_b)), 0, gate, s);
+                                      (int)N, ntiles, (uint32_t*)(w + (odd ? f.tk_a : f.tk_b)), 0, x.wg_radix, gate, s);
         if (rc) return rc;
     }
     }
     return lg_raster_forward_bounds(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
                                     enable_stat, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order, tiles ? nullptr : tile_work,
-                                    tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, (zb_check & 1) | (g_bound_margin_pct << 8), fail_flag, fail_host, gate, s);
+                                    tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, (zb_check & 1) | (x.margin_pct << 8), fail_flag, fail_host, gate, s);
 }
 
-static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, int H, int W, int TH, int TW,
+static int culling_fallback(const Exec& x, char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, int H, int W, int TH, int TW,
                             float* img, float* trans, short* last, float* packed_grad_clear, const int* order, int* tile_work,
                             const int* sched_in, int* sched_out, int* host_feedback_full,
                             const float* view_host, const float* proj_host, int degree, int chunks,
@@ -650,7 +756,7 @@ static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2&
 // cull_active: stage 1 culled against sched_in -> the bounds are verified and the gated fallback (which needs the projection's inputs
 // again) is enqueued; L_cull <= L then sizes the culled run.  host_feedback_full (nullable, pinned): receives the full table length
 // when the fallback ran.
-LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
+LG_API int lg_fused_stage2(const LgFusedCtx* ctx, int A, int S, long long L, int H, int W, int TH, int TW, void* ws1, long long ws1_bytes,
                            void* ws2, long long ws2_bytes, const int* tiles, int K, int enable_stat,
                            float* img, float* trans, short* last, int* frag_count, float* frag_weight,
                            float* packed_grad_clear /*nullable: [N,16] gradient accumulator of the coming backward, zeroed on the side*/,
@@ -661,6 +767,8 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
 {
     if (A <= 0 || L <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
+    Exec x;
+    { const int rcx = resolve_ctx(ctx, x); if (rcx) return rcx; }
     const long long N = (long long)A * S;
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH, ntiles = gx * gy;
     Layout1 f1 = layout1(N);
@@ -671,22 +779,22 @@ LG_API int lg_fused_stage2(int A, int S, long long L, int H, int W, int TH, int 
     if (tiles != nullptr || enable_stat) { sched_in = nullptr; sched_out = nullptr; order_out = nullptr; if (cull_active) return (int)hipErrorInvalidValue; }
     int* tile_work = order_out ? (int*)(w + f.tile_work) : nullptr;
     if (cull_active && (sched_in == nullptr || sched_out == nullptr)) return (int)hipErrorInvalidValue;
-    const bool spec = cull_active && g_spec.poison != nullptr;          // no gated repeat: a failure poisons the following Adam launches instead
-    int* fail_flag = spec ? g_spec.poison : (int*)(w1 + f1.flags);
+    const bool spec = cull_active && x.poison != nullptr;          // no gated repeat: a failure poisons the following Adam launches instead
+    int* fail_flag = spec ? x.poison : (int*)(w1 + f1.flags);
     const long long Ls = (cull_active && L_cull > 0 && L_cull < L) ? L_cull : L;
     const int* total_dev = (const int*)(w1 + f1.prefix) + (N - 1);
-    int rc = binning_and_blend(w1, f1, w, f, N, L, Ls, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr), (int*)(w1 + f1.dup_queue), (int*)(w1 + f1.tcount), tiles, K, enable_stat,
+    int rc = binning_and_blend(x, w1, f1, w, f, N, L, Ls, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr), (int*)(w1 + f1.dup_queue), (int*)(w1 + f1.tcount), tiles, K, enable_stat,
                                img, trans, last, frag_count, frag_weight, packed_grad_clear, order, tile_work, sched_in, sched_out,
-                               cull_active, cull_active ? fail_flag : nullptr, spec ? g_spec.poison_host : nullptr, nullptr, total_dev, s);
+                               cull_active, cull_active ? fail_flag : nullptr, spec ? x.poison_host : nullptr, nullptr, total_dev, s);
     if (rc) return rc;
-    if (cull_active && !spec) { rc = culling_fallback(w1, f1, w, f, N, L, H, W, TH, TW, img, trans, last, packed_grad_clear, order, tile_work, sched_in, sched_out,
+    if (cull_active && !spec) { rc = culling_fallback(x, w1, f1, w, f, N, L, H, W, TH, TW, img, trans, last, packed_grad_clear, order, tile_work, sched_in, sched_out,
                                               host_feedback_full, view_host, proj_host, degree, chunks, pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, A, S, s);
                        if (rc) return rc; }
     if (order_out != nullptr) return lg_tile_order(tile_work, 1, ntiles, order_out, s);
     return 0;
 }
 
-static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, int H, int W, int TH, int TW,
+static int culling_fallback(const Exec& x, char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, int H, int W, int TH, int TW,
                             float* img, float* trans, short* last, float* packed_grad_clear, const int* order, int* tile_work,
                             const int* sched_in, int* sched_out, int* host_feedback_full,
                             const float* view_host, const float* proj_host, int degree, int chunks,
@@ -700,13 +808,13 @@ static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2&
     // culling (records of the culled splats carry no colour yet) and clears the head of sched_out again.
     Camera cam = make_camera(view_host, proj_host, H, W);
     Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
-    rc = launch_projection(sc, cam, TH, TW, w1, f1, false, nullptr, sched_out, fail_flag, s); if (rc) return rc;
+    rc = launch_projection(sc, cam, TH, TW, w1, f1, false, nullptr, sched_out, fail_flag, s, nullptr); if (rc) return rc;
     const bool odd32 = lg_radix_sort_num_passes(0, 32) % 2 == 1;
-    const int32_t* depth_order = use_tile_order(N) ? emission_order(N) : (const int32_t*)(odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));
+    const int32_t* depth_order = use_tile_order(x, N) ? (const int32_t*)nullptr : (const int32_t*)(odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));
     rc = lg_gather_scan_gated((const int32_t*)(w1 + f1.alloc), depth_order, N, (int32_t*)(w1 + f1.prefix), (uint32_t*)(w1 + f1.scan_status2),
                               host_feedback_full, 0, fail_flag, full_total, s);
     if (rc) return rc;
-    return binning_and_blend(w1, f1, w, f, N, L, L, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr2), (int*)(w1 + f1.dup_queue2), (int*)(w1 + f1.tcount2), nullptr, 0, 0,
+    return binning_and_blend(x, w1, f1, w, f, N, L, L, H, W, TH, TW, (int*)(w1 + f1.tsort_hdr2), (int*)(w1 + f1.dup_queue2), (int*)(w1 + f1.tcount2), nullptr, 0, 0,
                              img, trans, last, nullptr, nullptr, packed_grad_clear, order, tile_work, sched_in, sched_out, 0, nullptr, nullptr, fail_flag,
                              full_total, s);
 }
@@ -715,7 +823,7 @@ static int culling_fallback(char* w1, const Layout1& f1, char* w, const Layout2&
 LG_API long long lg_fused_flags_offset(long long N) { return (long long)layout1(N).flags; }
 
 // Backward: blend backward (atomics into packed_grad) -> fused per-Gaussian backward -> six compact gradients.
-LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
+LG_API int lg_fused_backward(const LgFusedCtx* ctx, int A, int S, long long L, int H, int W, int TH, int TW, const void* ws1, long long ws1_bytes,
                              const void* ws2, long long ws2_bytes, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                              const int64_t* vis_ids, const int* vis_num,
                              const float* pos, const float* scale, const float* rot, const float* opa,
@@ -728,6 +836,8 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
 {
     if (A <= 0 || L <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
+    Exec x;
+    { const int rcx = resolve_ctx(ctx, x); if (rcx) return rcx; }
     const long long N = (long long)A * S;
     const int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     Layout1 f1 = layout1(N);
@@ -735,9 +845,9 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
     if ((long long)f1.total > ws1_bytes || (long long)f.total > ws2_bytes) return (int)hipErrorInvalidValue;
     const char* w1 = (const char*)ws1;
     const char* w = (const char*)ws2;
-    const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(f, N, ntiles));
+    const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(x, f, N, ntiles));
     int rc = 0;
-    const bool hot = replicas_on();             // the caller sets option 3 as it was for this frame's lg_fused_stage1
+    const bool hot = x.replicas != 0;           // the context holds what this frame's lg_fused_stage1 ran with
     const int* hot_of = hot ? (const int*)(w1 + f1.hot_of) : nullptr;
     if (!packed_grad_is_zero) { rc = lg_memset_async(packed_grad, 0, (long long)sizeof(float) * GREC * (hot ? lg_fused_grad_lines(N) : N), stream); if (rc) return rc; }
     rc = lg_raster_backward_hot(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, final_T, last, d_img, d_trans,
@@ -748,7 +858,7 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
     Camera cam = make_camera(view_host, proj_host, H, W);
 #define LAUNCH_PB(D) hipLaunchKernelGGL(project_fused_backward_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, pos, scale, rot, opa, \
                                         chunks, S, A, R, (const float4*)packed_grad, grad_inv_scaler, d_pos, d_scale, d_rot, d_sh0, d_shr, d_opa, \
-                                        hot_of, hot ? g_hot_counter : (int*)nullptr)
+                                        hot_of, hot ? x.hot_counter : (int*)nullptr)
     switch (degree) {
     case 0: LAUNCH_PB(0); break;
     case 1: LAUNCH_PB(1); break;
@@ -763,7 +873,7 @@ LG_API int lg_fused_backward(int A, int S, long long L, int H, int W, int TH, in
 // Second half of the backward fused with the optimizer: packed_grad (left by lg_fused_backward with d_pos == NULL) ->
 // per-Gaussian gradients in registers -> Adam on param / exp_avg / exp_avg_sq of the visible chunks.  lr6 (host) =
 // {xyz, sh_0, sh_rest, opacity, scale, rot}, the reference's group order (litegs/training/optimizer.py:80-87).
-LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_host, const float* proj_host, int degree, int chunks, int R,
+LG_API int lg_fused_backward_adam(const LgFusedCtx* ctx, const int* hot_of, int A, int S, int H, int W, const float* view_host, const float* proj_host, int degree, int chunks, int R,
                                   const int64_t* vis_ids, const int* vis_num, const float* packed_grad, const float* grad_inv_scaler,
                                   float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
                                   float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
@@ -773,8 +883,9 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
                                   const int* emitted /*nullable [A*S]: the tile counts stage 1 left in workspace 1 (lg_fused_alloc_offset)*/, void* stream)
 {
     if (A <= 0) return 0;
-    const int* hot_of = g_hot_table;          // gradient replicas of this frame (lg_fused_set_hot_table), one-shot
-    g_hot_table = nullptr;
+    Exec x;
+    { const int rcx = resolve_ctx(ctx, x); if (rcx) return rcx; }
+    if (hot_of != nullptr && x.hot_counter == nullptr) return (int)hipErrorInvalidValue;
     if (S > 1024 || S <= 0) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     Camera cam = make_camera(view_host, proj_host, H, W);
@@ -782,7 +893,7 @@ LG_API int lg_fused_backward_adam(int A, int S, int H, int W, const float* view_
 #define LAUNCH_PA(D) hipLaunchKernelGGL(project_backward_adam_kernel<D>, dim3(A), dim3(S), 0, s, vis_ids, vis_num, cam, ar, chunks, S, A, R, \
                                         (const float4*)packed_grad, grad_inv_scaler, pos, scale, rot, sh0, shr, opa,                          \
                                         m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa, v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched, emitted, \
-                                        (const int*)g_spec.poison, g_spec.applied_host, g_spec.step_id, hot_of, hot_of ? g_hot_counter : (int*)nullptr)
+                                        (const int*)x.poison, x.applied_host, x.step_id, hot_of, hot_of ? x.hot_counter : (int*)nullptr)
     switch (degree) {
     case 0: LAUNCH_PA(0); break;
     case 1: LAUNCH_PA(1); break;

@@ -159,7 +159,7 @@ __device__ __forceinline__ void rec_id_wait(f32x16& rec, int& id) { asm volatile
 // v_min_f32 without the canonicalising v_max the compiler puts in front of fminf when it cannot prove its operand quiet
 __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_bwd_noatomic = 0, g_fwd_fast = 1;       // launch variants (lg_set_tuning)
+static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_fwd_fast = 1;       // launch variants (lg_set_tuning: A/B hooks of tools/ and tests/, plain ints)
 
 // ---------------------------------------------------------------------------------------------
 // a13 rasterize_forward (reference: GR/raster.cu:162-332)
@@ -875,7 +875,7 @@ struct BwdFast {
 
 template <bool TRANS, bool CHECK>
 __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, int pos, unsigned pid_off, unsigned slot_off,
-                                               unsigned long long writers, float* __restrict__ pg, unsigned private_base)
+                                               unsigned long long writers, float* __restrict__ pg)
 {
     const float dx = rec[R_PX] - st.X;
     const float t1 = rec[R_B2] * dx;
@@ -912,9 +912,7 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     // order: (Mx My Mxx Mxy Myy dr DB DG M0) -- dg / db swapped against the record, see wave_slot_fast
     const float tot = reduce9_pk(mx, s1, dx * mx, dx * s1, s2, crg.x, v_b, crg.y, s0);
     // ONE atomic instruction from the nine lanes that hold a total: scalar base = the splat's gradient record
-    // private_base != 0 (measurement only, lg_set_tuning key 6 = 2): every (tile, position mod 64) adds into a line of its own
-    const unsigned target = private_base ? private_base + (((unsigned)pos & 63u) << 6) : pid_off;
-    const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pg) + target);
+    const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pg) + pid_off);
     asm volatile("s_mov_b64 exec, %2\n\t"
                  "global_atomic_add_f32 %0, %1, %3\n\t"
                  "s_mov_b64 exec, -1" : : "v"(slot_off), "v"(tot), "s"(writers), "s"(base) : "memory");
@@ -927,7 +925,7 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
                                                                    const float* __restrict__ d_img, const float* __restrict__ d_trans,
                                                                    float* __restrict__ packed_grad, const int* __restrict__ order,
                                                                    int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode,
-                                                                   int no_atomics, const int* __restrict__ hot_of)
+                                                                   const int* __restrict__ hot_of)
 {
     constexpr int TH = 8, TW = 16;
     const int lane = threadIdx.x & 63;
@@ -973,9 +971,7 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     if (n <= 0) return;
     int myslot = wave_slot(lane);
     myslot = myslot == 6 ? 7 : (myslot == 7 ? 6 : myslot);       // reduce9_pk is fed (.., dr, db, dg, ..)
-    // no_atomics (measurement only, WRONG gradients): 1 = no atomic at all, 2 = uncontended private lines, 3 = one lane (one dword) per record
-    const unsigned long long writers = no_atomics == 1 ? 0ull : (no_atomics == 3 ? 1ull : __ballot(myslot >= 0));
-    const unsigned private_base = no_atomics == 2 ? (unsigned)((((unsigned long long)tile << 12) % (((unsigned long long)N << 6) - 16384ull)) & ~4095ull) + 64u : 0u;
+    const unsigned long long writers = __ballot(myslot >= 0);
     const unsigned slot_off = (unsigned)max(myslot, 0) * 4u;
     // An even number of iterations (two per trip over a ping-pong pair of record registers): if n is odd the walk starts one
     // position early, at `n`, with the record of position n-1 -- no pixel has last_contributor > n, so that splat adds nothing.
@@ -1003,13 +999,13 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
         rec_request(rb, pk, off_b);                                                                           \
         id_request(hot_b, hot, hot_on ? off_b >> 4 : 0u);                                                     \
         id_request(id_a, sp, (unsigned)max(pos - 2, 0) << 2);                                                 \
-        bwd_splat_fast<TRANS, CHK>(st, ra, pos, HOT_TARGET(hot_a, off_a), slot_off, writers, pg, private_base);              \
+        bwd_splat_fast<TRANS, CHK>(st, ra, pos, HOT_TARGET(hot_a, off_a), slot_off, writers, pg);              \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rb), "+s"(id_a), "+s"(hot_b));                             \
         off_a = (unsigned)id_a << 6;                                                                          \
         rec_request(ra, pk, off_a);                                                                           \
         id_request(hot_a, hot, hot_on ? off_a >> 4 : 0u);                                                     \
         id_request(id_b, sp, (unsigned)max(pos - 3, 0) << 2);                                                 \
-        bwd_splat_fast<TRANS, CHK>(st, rb, pos - 1, HOT_TARGET(hot_b, off_b), slot_off, writers, pg, private_base);          \
+        bwd_splat_fast<TRANS, CHK>(st, rb, pos - 1, HOT_TARGET(hot_b, off_b), slot_off, writers, pg);          \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(id_b), "+s"(hot_a));                             \
         off_b = (unsigned)id_b << 6;                                                                          \
         pos -= 2;                                                                                             \
@@ -1026,7 +1022,6 @@ LG_API int lg_set_tuning(int key, int value)
     case 1: g_bwd_map = value; return 0;                                      // workgroup -> tile map of the blend backward (block_remap)
     case 2: g_fwd_map = value; return 0;                                      // ... of the blend forward
     case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
-    case 6: g_bwd_noatomic = value; return 0;                                 // measurement only: 1 = the fast blend backward computes everything but issues no atomics (WRONG gradients)
     case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics
     default: return (int)hipErrorInvalidValue;
@@ -1075,9 +1070,9 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
     }
     else if (TH == 8 && TW == 16 && !enable_stat && g_bwd_fast) {
         if (d_trans) hipLaunchKernelGGL((raster_backward_fast_kernel<true>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
-                                        d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_noatomic, hot_of);
+                                        d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, hot_of);
         else hipLaunchKernelGGL((raster_backward_fast_kernel<false>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
-                                d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, g_bwd_noatomic, hot_of);
+                                d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, hot_of);
     }
     else if (TH == 8 && TW == 16) DISPATCH_RB(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RB(16, 16);

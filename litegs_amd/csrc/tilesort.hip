@@ -13,8 +13,7 @@
 //   regime R  2 <= n <= 1024  : one wave per tile (four tiles per workgroup): stable LSD radix sort on the 32-bit depth key with the elements
 //                               in registers, 5 KB of LDS per wave (digit counters + a 4-byte exchange buffer), no workgroup barriers;
 //                               ties keep the ascending id order the list arrives in (lg_tilesort_body.h)
-//   regime W  n <= 4096       : (optional, lg_tile_depth_sort_set_regime_w; a second launch, off by default until it has been measured on the
-//                               device) the workgroup's four waves together on ONE list with the radix sort of regime R: wave-private ranking, destinations chained
+//   regime W  n <= 4096       : (optional, wg_radix; a second launch) the workgroup's four waves together on ONE list with the radix sort of regime R: wave-private ranking, destinations chained
 //                               across the waves (lg_tilesort_body.h).  Motive: the bitonic regimes below cost 4x more per instance than
 //                               regime R (profiles/r03_tilesort_scaling.log)
 //   regime M  n <= 2048       : the workgroup's four waves together, bitonic network on (depth key, id) in 16 KB of LDS
@@ -96,14 +95,11 @@ __global__ void __launch_bounds__(256) tile_depth_sort_wg_kernel(int* __restrict
 // vals [V, L] int32 splat ids grouped by tile (ascending id inside a tile unless any_order), tile_start [V, ntiles + 2] (lg_tile_range), depth [V, N] view depths.
 // scratch [V, L] uint32 (any content; only touched for lists longer than 2048 -- nullable only if such lists cannot occur).
 // gate (nullable device int): nothing runs unless *gate != 0.
-static int g_regime_w = 0;
-// 1: lists of 1025 .. 4096 entries take the workgroup radix sort (regime W) instead of the bitonic regimes.  Identical tables.
-LG_API int lg_tile_depth_sort_set_regime_w(int on) { g_regime_w = on ? 1 : 0; return 0; }
-
 int lg_tile_depth_sort_gated(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
-                             uint32_t* scratch, int any_order, const int* gate, void* stream)
+                             uint32_t* scratch, int any_order, int wg_radix, const int* gate, void* stream)
 {
     if (ntiles <= 0 || L <= 0 || V <= 0) return 0;
+    const int g_regime_w = wg_radix ? 1 : 0;
     // ranking inside a digit: the verified lane-ordered LDS add, or the ballot ranking when the device self-test says otherwise (binning.hip)
     const bool ballot = lg_radix_rank_mode() != 0;
     const dim3 grid(lg_cdiv(ntiles, 4), V), block(256);
@@ -130,7 +126,7 @@ LG_API int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const fl
                               uint32_t* scratch, void* stream)
 {
     if (vals == nullptr || tile_start == nullptr || depth == nullptr || scratch == nullptr) return (int)hipErrorInvalidValue;
-    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 0, nullptr, stream);
+    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 0, 0, nullptr, stream);
 }
 
 // the same for lists that arrive in arbitrary order (lg_tile_group): equal depths are ordered by id explicitly
@@ -138,5 +134,12 @@ LG_API int lg_tile_depth_sort_unordered(int32_t* vals, const int32_t* tile_start
                                         uint32_t* scratch, void* stream)
 {
     if (vals == nullptr || tile_start == nullptr || depth == nullptr || scratch == nullptr) return (int)hipErrorInvalidValue;
-    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 1, nullptr, stream);
+    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 1, 0, nullptr, stream);
+}
+
+LG_API int lg_tile_depth_sort_ex(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
+                                 uint32_t* scratch, int any_order, int wg_radix, void* stream)
+{
+    if (vals == nullptr || tile_start == nullptr || depth == nullptr || scratch == nullptr) return (int)hipErrorInvalidValue;
+    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, any_order, wg_radix, nullptr, stream);
 }

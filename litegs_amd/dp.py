@@ -99,8 +99,9 @@ class GradientExchange:
         self.last_k = (0, 0)
         self._touched = None                       # columns of the dense gradient buffer the previous sparse exchange added to
         self.fb_union = torch.zeros((n_slots,), dtype=torch.int32)
-        if p0.is_cuda:
-            self.fb_union = self.fb_union.pin_memory()
+        if p0.is_cuda:                             # the device stores into these words: library arena, never unmapped (hostwords.py)
+            from .hostwords import pinned_int32
+            self.fb_union, self._fb_union_owner = pinned_int32((n_slots,))
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.use_avg = backend == "nccl"           # RCCL implements AVG; gloo does not
         self.last_alloc = 0
@@ -298,13 +299,18 @@ class MomentExchange:
         self.cuda = bool(p0.is_cuda)
         if self.cuda:
             torch.cuda.current_stream().synchronize()
+        if getattr(self, "in_flight", None):             # records dropped by the last steps before the re-bind are reported, never reset away
+            self._raise_if_dropped(self.steps)
+            if int(self.overflow.item()) != 0:
+                raise RuntimeError("litegs_amd.dp: a record block overflowed its predicted capacity; gradients of that step were truncated")
         self.mask = torch.zeros((self.chunks,), dtype=torch.int32, device=dev)
         self.slot = torch.zeros((self.world, self.chunks * self.S), dtype=torch.int32, device=dev)
         self.overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
         # per slot: {largest count of the job, overflow marker}, written by the device (csrc/dp.hip: dp_slotmap_kernel)
         self.fb_k = torch.zeros((self.n_slots, 2), dtype=torch.int32)
-        if self.cuda:
-            self.fb_k = self.fb_k.pin_memory()
+        if self.cuda:                                    # library arena: never unmapped under a launch in flight (hostwords.py)
+            from .hostwords import pinned_int32
+            self.fb_k, self._fb_k_owner = pinned_int32((self.n_slots, 2))
         self.fb_event = [None] * self.n_slots            # recorded behind the kernel that writes fb_k[slot]
         self.in_flight = []                              # (step number, slot) of steps whose overflow word has not been read yet
         self.steps = 0
@@ -318,9 +324,13 @@ class MomentExchange:
         if n_slots > self.n_slots:
             if self.cuda:
                 torch.cuda.current_stream().synchronize()
-            grown = torch.zeros((n_slots, 2), dtype=torch.int32)
+            if self.cuda:
+                from .hostwords import pinned_int32
+                grown, owner = pinned_int32((n_slots, 2))
+            else:
+                grown, owner = torch.zeros((n_slots, 2), dtype=torch.int32), None
             grown[: self.n_slots] = self.fb_k
-            self.fb_k = grown.pin_memory() if self.cuda else grown
+            self.fb_k, self._fb_k_owner = grown, owner
             self.fb_event += [None] * (n_slots - self.n_slots)
             self.n_slots = n_slots
 

@@ -21,7 +21,21 @@ from .statistics import STATS
 from .wrapper import CompactedTensor
 
 
+from .hostwords import HostWords
+
+# Environment switches of the executor (each one named in INTEGRATION.md with the measurement behind its default).  Everything else
+# that used to be a switch is a plain attribute of FusedRenderer for tests / tools to set.
 _GUARD_ALLOC = os.environ.get("LITEGS_GUARD_ALLOC", "0") == "1"
+_DEPTH_ORDER = {"global": 0, "tile": 1, "auto": 2}
+
+
+class LgFusedCtx(ctypes.Structure):
+    """include/litegs_hip.h: the executor's per-call context (the library keeps no process-wide executor state)"""
+    _fields_ = [("struct_bytes", ctypes.c_int32), ("depth_order", ctypes.c_int32), ("bound_margin_pct", ctypes.c_int32),
+                ("tile_scatter", ctypes.c_int32), ("grad_replicas", ctypes.c_int32), ("step_id", ctypes.c_int32),
+                ("debug_validate", ctypes.c_int32), ("tilesort_wg_radix", ctypes.c_int32),
+                ("hot_counter", ctypes.c_void_p), ("poison", ctypes.c_void_p), ("poison_host", ctypes.c_void_p),
+                ("applied_host", ctypes.c_void_p), ("debug_words", ctypes.c_void_p)]
 
 
 def _empty(shape, dtype, device, zero: bool = False, align: int = 16):
@@ -56,139 +70,215 @@ class CameraFrame:
         self.proj_ptr = self.proj_host.ctypes.data
 
 
-def _apply_env_options() -> None:
-    """LITEGS_DEPTH_ORDER=global|tile|auto: depth sort of all visible splats before the emission (the reference's structure), per-tile
-    depth sort after the tile sort (csrc/tilesort.hip: no sort over the splats), or (default) per frame by its size; same tables bit
-    for bit (csrc/fused.hip)"""
-    mode = os.environ.get("LITEGS_DEPTH_ORDER")
-    if mode is not None:
-        if mode not in ("tile", "global", "auto"):
-            raise ValueError("LITEGS_DEPTH_ORDER must be 'global', 'tile' or 'auto'")
-        check(lib().lg_fused_set_option(0, {"global": 0, "tile": 1, "auto": 2}[mode]), "set_option")
-    scatter = os.environ.get("LITEGS_TILE_SCATTER")       # 1: group by tile with counts + cursors in the per-tile mode; 0: stable tile radix sort
-    if scatter is not None:
-        check(lib().lg_fused_set_option(2, 1 if scatter != "0" else 0), "set_option")
+class _FrameState:
+    """what the executor remembers about one camera between two visits (sizing feedback lives in the pinned words)"""
+    __slots__ = ("sched_cur", "sched_valid", "order_valid", "margin", "clean_visits", "cooldown", "margin_written", "margin_emitted",
+                 "last_capacity", "visits", "full_total", "last_unculled")
+
+    def __init__(self, margin: int):
+        self.sched_cur = 0
+        self.visits = 0
+        self.reset(margin)
+
+    def reset(self, margin: int):
+        self.sched_valid = False          # the frame's depth-bound block of its previous visit is usable
+        self.order_valid = False          # ... and its heaviest-first tile schedule
+        self.margin = margin              # margin (percent) of the bounds this visit writes
+        self.clean_visits = 0
+        self.cooldown = 0
+        self.margin_written = margin      # margin of the bounds the frame's next visit will cull with
+        self.margin_emitted = margin      # margin of the bounds behind the frame's last emitted total (fb_total)
+        self.last_capacity = 0            # table capacity of the frame's last visit
+        self.full_total = 0               # full table length of the frame's last unculled visit
+        self.last_unculled = False
 
 
 class FusedRenderer:
+    """One per trainer / evaluator.  Owns every piece of state the C executor needs between calls -- the library itself is stateless
+    (LgFusedCtx) -- and the pinned words the device stores into (library arena: never unmapped, see hostwords.py)."""
+
     def __init__(self, n_frames: int, height: int, width: int, tile=(8, 16), cluster_size: int = 128):
-        _apply_env_options()
         self.H, self.W, self.TH, self.TW, self.S = height, width, tile[0], tile[1], cluster_size
-        self.fb_vis = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
-        self.fb_total = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
         self.Hp = (height + tile[0] - 1) // tile[0] * tile[0]
         self.Wp = (width + tile[1] - 1) // tile[1] * tile[1]
+        self.ntiles = (self.Hp // tile[0]) * (self.Wp // tile[1])
+        self.n_frames = n_frames
+        # GPU-driven sizing feedback, three pinned words per frame, written by device stores in visit k and read in visit k + 1:
+        # visible chunks | emitted table length | full table length when a gated fallback ran
+        self._words = HostWords(3 * n_frames)
+        self.fb_vis = self._words.a[0:n_frames]
+        self.fb_total = self._words.a[n_frames:2 * n_frames]
+        self.fb_full = self._words.a[2 * n_frames:3 * n_frames]
         self.last_sizes = (0, 0)
+        # ---- options (attributes; the environment only selects the first three)
+        mode = os.environ.get("LITEGS_DEPTH_ORDER", "auto")
+        if mode not in _DEPTH_ORDER:
+            raise ValueError("LITEGS_DEPTH_ORDER must be 'global', 'tile' or 'auto'")
+        self.depth_order = _DEPTH_ORDER[mode]          # csrc/fused.hip: how each tile's list gets its depth order
+        self.cull_enabled = os.environ.get("LITEGS_DEPTH_CULL", "1") != "0"
+        # after the first statistics epoch the reference rasterises along the statistics helper's cached tile list (render/__init__.py:75-79);
+        # 'always' follows it, 'stat' keeps the executor's own schedule + depth bounds outside statistics renders (same image)
+        self.stat_schedule_always = os.environ.get("LITEGS_STAT_TILE_SCHEDULE", "always") != "stat"
+        self.validate_tables = os.environ.get("LITEGS_VALIDATE_TABLES", "0") == "1"      # debugging aid (csrc/fused.hip "Table validators")
+        self.tile_scatter = True           # per-tile mode: group by tile with counts + cursors (False: stable tile radix sort); same tables
+        self.tilesort_wg_radix = os.environ.get("LITEGS_TILESORT_WG_RADIX", "0") == "1"
+        self.replicas_enabled = True       # gradient replicas (csrc/raster.hip) for renders whose records only the fused backward kernels consume
+        # a frame whose previous visit emitted more than this many instances per tile on average takes the splat sort + stable tile radix
+        # sort instead of tile scatter + per-tile sort (0 = never); automatic depth-order mode only
+        self.long_list_global = 0
         # Per frame: a heaviest-first tile schedule (csrc/raster.hip; a hint -- results do not depend on it -- recomputed on a frame's
         # first visit and then every `cull_refresh`-th) and two depth-bound blocks (csrc/lg_tilewalk.h) used alternately: every
         # visit's blend forward records per-tile saturation depths, and the next visit of the frame skips the splats no tile will
-        # reach (depth-bound culling, csrc/fused.hip); a gated fallback keeps the result exact.  Every `cull_refresh`-th visit of a
-        # frame runs unculled (fresh bounds from the complete lists, fresh full table size, fresh schedule).
-        self.ntiles = (self.Hp // tile[0]) * (self.Wp // tile[1])
-        self.n_frames = n_frames
-        self.sched = None
-        self.sched_cur = [0] * n_frames
-        self.sched_valid = [False] * n_frames
-        self.tile_order = None
-        self.tile_order_valid = [False] * n_frames
-        self.cull_enabled = os.environ.get("LITEGS_DEPTH_CULL", "1") != "0"
+        # reach (depth-bound culling, csrc/fused.hip); a gated fallback or the speculative replay keeps the result exact.  Every
+        # `cull_refresh`-th visit of a frame runs unculled (fresh bounds from the complete lists, fresh full table size, fresh schedule).
         self.cull_refresh = 16
-        # depth-order mode 'tile' only.  Measured (3 M @1080p): interleaving brings the queue kernel back to its depth-order time
-        # (35 -> 18 us) but slows the in-workgroup kernel (66 -> 72 us) and the now gathered scan (16 -> 26 us): no gain, off by default
-        self.interleave_emission = os.environ.get("LITEGS_EMISSION_ORDER", "ids") == "interleaved"
-        # margin of the depth bounds (csrc/raster.hip: percent of the splats walked beyond a tile's saturation point), per frame.  A
-        # fallback costs a whole second binning + blend (~0.4 ms at 3 M @1080p), a wider margin only a few more instances (~35 us per
-        # million): measured over 40 training steps of the bench scene, margin 50 % -> 12 fallbacks, 1.093 ms/step; 100 % -> 1 fallback,
-        # 0.986 ms; 200 % -> none, 1.026 ms (gpurun_out/margin_ab.log).  Base 100 %; the margin of a frame doubles when its previous
-        # visit fell back and decays back after clean visits.  LITEGS_CULL_MARGIN=<percent> pins it.
-        pin = os.environ.get("LITEGS_CULL_MARGIN")
-        self.margin_fixed = int(pin) if pin else 0
+        # margin of the depth bounds (percent of the splats walked beyond a tile's saturation point), per frame.  A fallback costs a whole
+        # second binning + blend (~0.4 ms at 3 M @1080p), a wider margin only a few more instances (~35 us per million): measured over 40
+        # training steps of the bench scene, margin 50 % -> 12 fallbacks, 1.093 ms/step; 100 % -> 1 fallback, 0.986 ms; 200 % -> none,
+        # 1.026 ms (profiles/r02_margin_ab.log).  Base 100 %; the margin of a frame doubles when its previous visit fell back and decays
+        # back after clean visits.  margin_fixed = <percent> pins it (tests / tools).
+        self.margin_fixed = 0
         self.margin_lo, self.margin_hi = 100, 400
-        self.margin = [self.margin_fixed or self.margin_lo] * n_frames
-        self.clean_visits = [0] * n_frames
-        # visits a frame renders unculled after one of its depth bounds was violated (0 = cull again at once, the measured default);
-        # LITEGS_CULL_COOLDOWN=<visits>: an unmeasured knob for many-camera runs, where a frame's bounds age 100+ steps between visits
-        self.cull_cooldown = int(os.environ.get("LITEGS_CULL_COOLDOWN", "0"))
-        self.cooldown = [0] * n_frames
-        self.margin_written = [self.margin[0]] * n_frames    # margin of the bounds a frame's next visit will cull with
-        self.margin_emitted = [self.margin[0]] * n_frames    # margin of the bounds behind the frame's last emitted total (fb_total)
-        self.fallbacks = 0                                   # visits that were re-run unculled (observed one visit later)
-        self.last_capacity = [0] * n_frames                  # table capacity a frame's last unculled visit ran with
-        self.truncated_visits = 0                            # unculled visits whose table turned out too short (observed one visit later)
-        self.visits = [0] * n_frames
-        self.full_total = [0] * n_frames                     # host copy of the full table length of a frame's last unculled visit
-        self.last_unculled = [False] * n_frames
-        self.fb_full = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()     # written by the device when a fallback ran
+        self.cull_cooldown = 0             # visits a frame renders unculled after one of its bounds was violated
+        self.frames = [_FrameState(self.margin_lo) for _ in range(n_frames)]
+        self.sched = None
+        self.tile_order = None
+        self.fallbacks = 0                 # visits that were re-run unculled (observed one visit later)
+        self.truncated_visits = 0          # unculled visits whose table turned out too short (observed one visit later)
         self.last_cull = False
         # fuse_optimizer: backward stops after the blend backward; FusedAdam.step() then runs the per-Gaussian backward fused
         # with the Adam update (csrc/fused.hip: project_backward_adam_kernel) -- parameter gradients never go to HBM.
-        # Only valid when nothing needs the gradients between backward and the optimizer step (no DP exchange).
+        # Only valid when nothing needs the gradients between backward and the optimizer step (no gradient-hook DP exchange).
         self.fuse_optimizer = False
+        # the records of this render are consumed ONLY by the fused backward kernels, which fold gradient replicas (set by the trainer:
+        # false for the data-parallel moment exchange, whose compaction reads the N regular lines only)
+        self.fold_only_consumer = True
         self.pending = None
         self.probe_events = None      # measurement hook (bench.py): a list that receives an event pair around every blend backward launch
         # data-parallel hook (dp.MomentExchange.begin): called with (visible_chunkid, visible_chunks_num) as soon as the culling is
         # enqueued, so that the union-of-visibility collective runs on RCCL's stream underneath the whole forward + blend backward
         self.after_cull = None
         self._cull_scratch, self._cull_chunks, self._cull_epoch = None, -1, 0
-        # speculative culling (csrc/fused.hip): set by FrameTrainer when it takes over the replay of failed steps
-        # gradient replicas (csrc/raster.hip): splats that cover many tiles get several gradient lines; on for renders whose records only
-        # the fused backward kernels consume (no statistics, no data-parallel exchange).  LITEGS_GRAD_REPLICAS=0 disables.
-        self.replicas_enabled = os.environ.get("LITEGS_GRAD_REPLICAS", "1") != "0"
-        self.stat_schedule_always = os.environ.get("LITEGS_STAT_TILE_SCHEDULE", "always") != "stat"
-        # Experimental, off by default (unmeasured): in the automatic depth-order mode, a frame whose previous visit emitted more than this
-        # many instances per tile on average takes the splat sort + stable tile radix sort (17 us per million instances + 75 us) instead of
-        # tile scatter + per-tile sort, whose long-list regimes cost 30-34 us per million (profiles/r03_tilesort_scaling.log).
-        self.long_list_global = int(os.environ.get("LITEGS_LONG_LIST_GLOBAL", "0"))
-        self.hot_counter = None
-        self.spec = None              # dict(poison=device int32[1], poison_host / applied_host = pinned int32[1])
+        self.hot_counter = None       # device int32[1]: replica line counter (persistent; reset by the step's last kernel)
+        # speculative culling (csrc/fused.hip): owned here, driven by FrameTrainer, which replays failed steps
+        self.spec_poison = None       # device int32[1], sticky
+        self.spec_words = None        # HostWords(2): [0] mirror of the poison word, [1] step number of the last fused Adam launch that ran
         self.spec_step = 0            # number of the training step being enqueued
         self.force_full = False       # the next render runs unculled (the first replayed step)
+        self._debug_words = None      # HostWords(8), validate_tables only
+        self._closed = False
 
+    # -- compatibility views of the per-frame records (tests, tools, bench.py read them) --------------------------------------------
+    @property
+    def margin(self):
+        return [f.margin for f in self.frames]
+
+    @property
+    def visits(self):
+        return [f.visits for f in self.frames]
+
+    @property
+    def full_total(self):
+        return [f.full_total for f in self.frames]
+
+    @property
+    def sched_cur(self):
+        return [f.sched_cur for f in self.frames]
+
+    # -- lifetime ---------------------------------------------------------------------------------------------------------------------
+    def close(self):
+        """Everything enqueued so far has finished before the renderer's device words and pinned words are released.  (The pinned words
+        would survive anyway -- the arena quarantines them -- but the device tensors go back to torch's allocator.)"""
+        if self._closed:
+            return
+        self._closed = True
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+        self.pending = None
+        for w in (self._words, self.spec_words, self._debug_words):
+            if w is not None:
+                w.close()
+        self.fb_vis = self.fb_total = self.fb_full = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- speculation ------------------------------------------------------------------------------------------------------------------
     def enable_speculation(self, device):
-        if self.spec is None:
-            self.spec = dict(poison=torch.zeros((1,), dtype=torch.int32, device=device),
-                             poison_host=torch.zeros((1,), dtype=torch.int32).pin_memory(),
-                             applied_host=torch.zeros((1,), dtype=torch.int32).pin_memory())
-        return self.spec
+        if self.spec_poison is None:
+            self.spec_poison = torch.zeros((1,), dtype=torch.int32, device=device)
+            self.spec_words = HostWords(2)
+        return self.spec_words
 
-    def speculation_args(self, active: bool):
-        """arguments of lg_fused_set_speculation for the coming call (all NULL: the gated repeat / an unconditional Adam)"""
-        if active and self.spec is not None:
-            sp = self.spec
-            return (sp["poison"].data_ptr(), sp["poison_host"].data_ptr(), sp["applied_host"].data_ptr(), int(self.spec_step))
-        return (None, None, None, 0)
+    def disable_speculation(self):
+        """back to the gated repeat.  The words are kept (a launch in flight may still store into them); only the mode changes."""
+        self.spec_step = 0
+
+    @property
+    def speculating(self) -> bool:
+        return self.spec_poison is not None and self.spec_step > 0
+
+    def poisoned(self) -> bool:
+        return self.spec_words is not None and int(self.spec_words.a[0]) != 0
+
+    def applied_step(self) -> int:
+        return int(self.spec_words.a[1]) if self.spec_words is not None else 0
+
+    def clear_poison(self):
+        self.spec_poison.zero_()
+        self.spec_words.a[0] = 0
+
+    def context(self, depth_order: int, replicas: bool, margin: int, speculate: bool) -> LgFusedCtx:
+        """the LgFusedCtx of one call; `speculate`: hand the poison words over (a culled render that a fused Adam step follows, and that step)"""
+        c = LgFusedCtx()
+        c.struct_bytes = ctypes.sizeof(LgFusedCtx)
+        c.depth_order = depth_order
+        c.bound_margin_pct = max(1, int(margin))
+        c.tile_scatter = 1 if self.tile_scatter else 0
+        c.grad_replicas = 1 if replicas else 0
+        c.tilesort_wg_radix = 1 if self.tilesort_wg_radix else 0
+        c.hot_counter = self.hot_counter.data_ptr() if self.hot_counter is not None else None
+        if speculate and self.speculating:
+            c.poison = self.spec_poison.data_ptr()
+            c.poison_host = self.spec_words.addr(0)
+            c.applied_host = self.spec_words.addr(1)
+            c.step_id = int(self.spec_step)
+        if self.validate_tables:
+            if self._debug_words is None:
+                self._debug_words = HostWords(8)
+            c.debug_validate = 1
+            c.debug_words = self._debug_words.addr(0)
+        return c
+
+    def check_tables(self):
+        """validate_tables: raise if a table check on the device found garbage since the last call (the run itself was kept alive)"""
+        if self._debug_words is not None and int(self._debug_words.a[0]) != 0:
+            rec = [int(x) for x in self._debug_words.a]
+            self._debug_words.a[0] = 0
+            what = {1: "tile key out of range in the emitted table", 2: "tile range ends beyond the valid entries", 3: "splat id out of range in the grouped table"}
+            raise RuntimeError(f"litegs_amd: table validator: {what.get(rec[0], 'code %d' % rec[0])}: where={rec[1]} value={rec[2]} bound={rec[3]} "
+                               f"valid_entries={rec[4]} reports_so_far={rec[7]}")
+
+    def note_fallback(self, k: int):
+        """frame k was re-run unculled (gated repeat observed, or a speculative step replayed): widen its margin, start its cool-down"""
+        F = self.frames[k]
+        self.fallbacks += 1
+        F.clean_visits = 0
+        F.cooldown = self.cull_cooldown
+        if not self.margin_fixed:
+            F.margin = min(F.margin * 2, self.margin_hi)
 
     def reset_feedback(self):
         """parameters were replaced / re-sorted: forget everything predicted from earlier visits (sizes, schedules, depth bounds)"""
-        self.fb_vis.zero_(); self.fb_total.zero_(); self.fb_full.zero_()
-        n = self.n_frames
-        self.sched_valid = [False] * n
-        self.tile_order_valid = [False] * n
-        self.full_total = [0] * n
-        self.last_unculled = [False] * n
-        self.last_capacity = [0] * n
-        self.margin = [self.margin_fixed or self.margin_lo] * n
-        self.clean_visits = [0] * n
-        self.cooldown = [0] * n
-        self.margin_written = [self.margin[0]] * n
-        self.margin_emitted = [self.margin[0]] * n
-
-    def emission_order(self, A: int, S: int, device):
-        """depth-order mode 'tile' only: slot j -> splat ((j mod A) * P mod A) * S + j div A with P coprime to A -- every group of 256
-        consecutive slots draws one splat from each of 256 chunks that lie far apart in the (Morton-ordered) cloud.  Cached per A."""
-        import math
-        cache = self.__dict__.setdefault("_emit_cache", {})
-        key = (A, S)
-        if key not in cache:
-            if len(cache) >= 16:
-                cache.pop(next(iter(cache)))
-            P = max(int(A * 0.6180339887) | 1, 1)
-            while math.gcd(P, A) != 1:
-                P += 2
-            j = np.arange(A * S, dtype=np.int64)
-            order = ((j % A) * P % A) * S + j // A
-            cache[key] = torch.from_numpy(order.astype(np.int32)).to(device)
-        return cache[key]
+        self.fb_vis[:] = 0; self.fb_total[:] = 0; self.fb_full[:] = 0
+        for f in self.frames:
+            f.reset(self.margin_fixed or self.margin_lo)
 
     def cull_scratch(self, chunks: int, device):
         """persistent look-back table of the multi-workgroup culling kernel (epoch-tagged: zeroed once, never cleared again)"""
@@ -227,19 +317,32 @@ class _RenderFn(torch.autograd.Function):
         dev = xyz.device
         chunks, S = xyz.shape[-2], xyz.shape[-1]
         k = frame.index
+        F = R.frames[k]
         s = _s()
+        needs_grad = any(ctx.needs_input_grad)
         visibility = _empty((chunks,), torch.bool, dev)
         vis_num = _empty((1,), torch.int32, dev)
         vis_ids = _empty((chunks,), torch.int64, dev)
-        fb_vis_ptr = R.fb_vis.data_ptr() + 4 * k
-        fb_tot_ptr = R.fb_total.data_ptr() + 4 * k
+        fb_vis_ptr = R._words.addr(k)
+        fb_tot_ptr = R._words.addr(R.n_frames + k)
+        fb_full_ptr = R._words.addr(2 * R.n_frames + k)
         common = (origin.data_ptr(), extend.data_ptr(), frame.planes.data_ptr(), chunks, frame.view_ptr, frame.proj_ptr, R.H, R.W, R.TH, R.TW,
                   int(degree), xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), sh_0.data_ptr(), sh_rest.data_ptr(), opacity.data_ptr(), S)
+        stat = STATS.active
+        replicas = bool(R.replicas_enabled and R.fuse_optimizer and R.fold_only_consumer and not stat and needs_grad)
+        if replicas and R.hot_counter is None:
+            R.hot_counter = _empty((1,), torch.int32, dev, zero=True)
         pred_vis = int(R.fb_vis[k])
+        pred_total = int(R.fb_total[k])
+        # per-frame depth-order mode: long lists (previous visit) go through the splat sort + stable tile radix sort
+        depth_order = R.depth_order
+        if R.long_list_global > 0 and depth_order == 2 and pred_total > R.long_list_global * R.ntiles:
+            depth_order = 0
         do_cull = 1
         if pred_vis <= 0:                                    # first visit: blocking count (GR/compact.cu:543-546)
-            check(L.lg_fused_stage1(*common, 1, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), 0, None, 0, fb_vis_ptr, None,
-                                    *R.cull_scratch(chunks, dev), None, None, s),
+            c0 = R.context(depth_order, False, F.margin, False)
+            check(L.lg_fused_stage1(ctypes.byref(c0), *common, 1, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), 0, None, 0,
+                                    fb_vis_ptr, None, *R.cull_scratch(chunks, dev), None, None, s),
                   "fused cull")
             A = int(vis_num.item())
             do_cull = 0
@@ -247,92 +350,72 @@ class _RenderFn(torch.autograd.Function):
             A = min(int(1.2 * pred_vis), chunks)
         A = max(A, 1)
         N = A * S
-        stat = STATS.active
-        replicas = bool(R.replicas_enabled and R.fuse_optimizer and R.after_cull is None and not stat and any(ctx.needs_input_grad))
-        if replicas and R.hot_counter is None:
-            R.hot_counter = _empty((1,), torch.int32, dev, zero=True)
-        if R.hot_counter is not None:
-            L.lg_fused_set_hot_counter(R.hot_counter.data_ptr())
-        L.lg_fused_set_option(3, 1 if replicas else 0)
-        if R.interleave_emission and L.lg_fused_get_option(0) != 0:
-            L.lg_fused_set_emission_order(R.emission_order(A, S, dev).data_ptr(), N)
         ws1_bytes = L.lg_fused_workspace1_bytes(N)
         ws1 = _empty((ws1_bytes,), torch.uint8, dev, align=64)            # 64-byte records read by 64-byte scalar loads
         # The reference rasterises along the statistics helper's cached heavy-first tile list whenever a frame has one, i.e. in every render
         # after the first statistics epoch (litegs/render/__init__.py:75-79), and so does the executor by default: from then on its own
         # schedule, depth bounds and speculative culling are idle.  The list is a permutation of ALL tiles -- a schedule, not a selection --
-        # so LITEGS_STAT_TILE_SCHEDULE=stat keeps the executor's own machinery outside statistics renders (same image,
-        # test_gpu_stats.py).  Measured over the first 4500 iterations of tests/convergence_3m.py (150 cameras: a frame is revisited
-        # after 150 steps of a fast-changing cloud, bounds are violated often): 1.66 ms / iteration against 1.49 with the reference's
-        # behaviour -- hence not the default.
+        # so stat_schedule_always = False keeps the executor's own machinery outside statistics renders (same image, test_gpu_stats.py).
         tiles = STATS.schedule_for_current_frame() if (stat or R.stat_schedule_always) else None
         # depth-bound culling: bookkeeping of the sizing feedback (the emitted total of a culled visit is not the full table length)
-        pred_total = int(R.fb_total[k])
-        if R.last_unculled[k] and pred_total > R.last_capacity[k] > 0:
+        if F.last_unculled and pred_total > F.last_capacity > 0:
             # the previous (unculled) visit needed more entries than its predicted table held: its tail was dropped, as in the reference
             # (GR/binning.cu:63, silent there).  Counted here, and this visit sizes its table exactly (the blocking first-visit path).
             R.truncated_visits += 1
             pred_total = 0
             R.fb_total[k] = 0
-        if R.last_unculled[k] and pred_total > 0:
-            R.full_total[k] = pred_total                      # the previous visit of this frame emitted everything
-        if int(R.fb_full[k]) > 0:                             # ... or a fallback re-ran it in full
-            if int(R.fb_full[k]) > R.last_capacity[k] > 0:    # ... into a table that was too short for it: same treatment
+        if F.last_unculled and pred_total > 0:
+            F.full_total = pred_total                         # the previous visit of this frame emitted everything
+        fb_full = int(R.fb_full[k])
+        if fb_full > 0:                                       # ... or a fallback re-ran it in full
+            if fb_full > F.last_capacity > 0:                 # ... into a table that was too short for it: same treatment
                 R.truncated_visits += 1
                 pred_total = 0
                 R.fb_total[k] = 0
-            R.full_total[k] = max(R.full_total[k], int(R.fb_full[k]))
+            F.full_total = max(F.full_total, fb_full)
             R.fb_full[k] = 0
-            R.fallbacks += 1
-            R.clean_visits[k] = 0
-            R.cooldown[k] = R.cull_cooldown
-            if not R.margin_fixed:
-                R.margin[k] = min(R.margin[k] * 2, R.margin_hi)
+            R.note_fallback(k)
         elif not R.margin_fixed:
-            R.clean_visits[k] += 1
-            if R.clean_visits[k] >= 6 and R.margin[k] > R.margin_lo:
-                R.margin[k] = max(R.margin_lo, (R.margin[k] * 3) // 4)
-                R.clean_visits[k] = 0
+            F.clean_visits += 1
+            if F.clean_visits >= 6 and F.margin > R.margin_lo:
+                F.margin = max(R.margin_lo, (F.margin * 3) // 4)
+                F.clean_visits = 0
         use_sched = not stat and tiles is None
         if use_sched and R.sched is None:
             R.sched = _empty((R.n_frames, 2, L.lg_sched_words(R.H, R.W, R.TH, R.TW)), torch.int32, dev)
             R.tile_order = _empty((R.n_frames, R.ntiles), torch.int32, dev)
         in_ptr = out_ptr = None
         if use_sched:
-            cur = R.sched_cur[k]
-            if R.sched_valid[k]:
-                in_ptr = R.sched[k, cur].data_ptr()
-            out_ptr = R.sched[k, 1 - cur].data_ptr()
-        refresh = R.visits[k] % R.cull_refresh == 0
-        cull = bool(R.cull_enabled and in_ptr is not None and R.full_total[k] > 0 and pred_total > 0 and not refresh and not R.force_full
-                    and R.cooldown[k] == 0)
-        if R.cooldown[k] > 0:
-            R.cooldown[k] -= 1
+            if F.sched_valid:
+                in_ptr = R.sched[k, F.sched_cur].data_ptr()
+            out_ptr = R.sched[k, 1 - F.sched_cur].data_ptr()
+        refresh = F.visits % R.cull_refresh == 0
+        cull = bool(R.cull_enabled and in_ptr is not None and F.full_total > 0 and pred_total > 0 and not refresh and not R.force_full
+                    and F.cooldown == 0)
+        if F.cooldown > 0:
+            F.cooldown -= 1
         R.force_full = False
         order_ptr = (R.tile_order.data_ptr() + 4 * R.ntiles * k) if use_sched else None
-        order_in = order_ptr if (use_sched and R.tile_order_valid[k]) else None
-        order_out = order_ptr if (use_sched and (refresh or not R.tile_order_valid[k])) else None
-        R.visits[k] += 1
-        # per-frame override of the depth-order mode (see long_list_global): the same value must hold for stage 1, stage 2 and the backward
-        mode_override = None
-        if R.long_list_global > 0 and pred_total > R.long_list_global * R.ntiles and L.lg_fused_get_option(0) == 2:
-            mode_override = 0
-            L.lg_fused_set_option(0, 0)
-        check(L.lg_fused_stage1(*common, do_cull, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), A, ws1.data_ptr(), ws1_bytes,
-                                fb_vis_ptr if do_cull else None, fb_tot_ptr, *(R.cull_scratch(chunks, dev) if do_cull else (None, 0)),
-                                in_ptr if cull else None, out_ptr, s), "fused stage1")
-        if R.after_cull is not None and any(ctx.needs_input_grad):
+        order_in = order_ptr if (use_sched and F.order_valid) else None
+        order_out = order_ptr if (use_sched and (refresh or not F.order_valid)) else None
+        F.visits += 1
+        # a culled render that a fused Adam step follows may run speculatively (no gated repeat); anything else keeps the repeat
+        cx = R.context(depth_order, replicas, F.margin, cull and R.fuse_optimizer and needs_grad)
+        check(L.lg_fused_stage1(ctypes.byref(cx), *common, do_cull, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), A,
+                                ws1.data_ptr(), ws1_bytes, fb_vis_ptr if do_cull else None, fb_tot_ptr,
+                                *(R.cull_scratch(chunks, dev) if do_cull else (None, 0)), in_ptr if cull else None, out_ptr, s), "fused stage1")
+        if R.after_cull is not None and needs_grad:
             R.after_cull(vis_ids, vis_num)
         if pred_total <= 0:                                  # first visit: blocking table size (GR/binning.cu:152-163)
             off = L.lg_fused_total_offset(N)
             table_len = int(ws1[off:off + 4].view(torch.int32).item())
         elif cull:
-            table_len = int(1.5 * R.full_total[k])           # capacity for the fallback's full table
+            table_len = int(1.5 * F.full_total)              # capacity for the fallback's full table
         else:
-            table_len = int(1.5 * max(pred_total, R.full_total[k]))
+            table_len = int(1.5 * max(pred_total, F.full_total))
         table_len = max(table_len, 1)
         # the emitted total was predicted under the margin of the visit before last: scale the culled table when the bounds got wider
-        grow = max(1.0, R.margin_written[k] / max(R.margin_emitted[k], 1))
+        grow = max(1.0, F.margin_written / max(F.margin_emitted, 1))
         len_cull = min(table_len, int(1.5 * grow * pred_total) + 65536) if cull else table_len
         ws2_bytes = L.lg_fused_workspace2_bytes(table_len, N, R.H, R.W, R.TH, R.TW)
         ws2 = _empty((ws2_bytes,), torch.uint8, dev)
@@ -353,37 +436,34 @@ class _RenderFn(torch.autograd.Function):
             img.zero_(); trans.fill_(1.0); last.zero_()
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
         pg_lines = L.lg_fused_grad_lines(N) if replicas else N
-        pg = _empty((pg_lines, L.lg_packed_grad_floats()), torch.float32, dev) if any(ctx.needs_input_grad) else None
-        L.lg_fused_set_option(1, int(R.margin[k]))
-        # a culled render that a fused Adam step follows may run speculatively (no gated repeat); anything else keeps the repeat
-        L.lg_fused_set_speculation(*R.speculation_args(cull and R.fuse_optimizer and any(ctx.needs_input_grad)))
-        check(L.lg_fused_stage2(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes, tp, K,
+        pg = _empty((pg_lines, L.lg_packed_grad_floats()), torch.float32, dev) if needs_grad else None
+        check(L.lg_fused_stage2(ctypes.byref(cx), A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes, tp, K,
                                 1 if stat else 0, img.data_ptr(), trans.data_ptr(), last.data_ptr(),
                                 fc.data_ptr() if stat else None, fw.data_ptr() if stat else None,
                                 pg.data_ptr() if pg is not None else None,
-                                order_in, order_out, in_ptr, out_ptr, 1 if cull else 0, len_cull, R.fb_full.data_ptr() + 4 * k,
+                                order_in, order_out, in_ptr, out_ptr, 1 if cull else 0, len_cull, fb_full_ptr,
                                 frame.view_ptr, frame.proj_ptr, int(degree), chunks,
                                 xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), sh_0.data_ptr(), sh_rest.data_ptr(), opacity.data_ptr(),
                                 vis_ids.data_ptr(), vis_num.data_ptr(), s), "fused stage2")
-        if mode_override is not None:
-            L.lg_fused_set_option(0, 2)
-        ctx.mode_override = mode_override
         if use_sched:
-            R.sched_cur[k] = 1 - R.sched_cur[k]
-            R.sched_valid[k] = True
-        R.last_unculled[k] = not cull
-        R.last_capacity[k] = table_len
+            F.sched_cur = 1 - F.sched_cur
+            F.sched_valid = True
+        F.last_unculled = not cull
+        F.last_capacity = table_len
         R.last_cull = cull
         if cull:
-            R.margin_emitted[k] = R.margin_written[k]
-        R.margin_written[k] = R.margin[k]
+            F.margin_emitted = F.margin_written
+        F.margin_written = F.margin
         R.last_ws1 = (ws1, N)                              # for tests: the fallback flag lives in workspace 1 (lg_fused_flags_offset)
         R.last_ws2 = (ws2, table_len, N)                   # for tools: the tile range table lives in workspace 2 (lg_fused_tile_start_offset)
+        R.last_ctx = cx                                    # ... at an offset that depends on the frame's depth-order mode
         if order_out is not None:
-            R.tile_order_valid[k] = True
-        ctx.order_ptr = order_ptr if (use_sched and R.tile_order_valid[k]) else None
+            F.order_valid = True
+        ctx.order_ptr = order_ptr if (use_sched and F.order_valid) else None
         ctx.pg = pg
         ctx.replicas = replicas
+        # the backward finds its lists where THIS frame's forward put them: same depth-order mode, same replica setting, no speculation
+        ctx.cx = R.context(depth_order, replicas, F.margin, False)
         if stat:
             STATS.update_tile_schedule(last, R.TH, R.TW)
         ctx.R, ctx.frame, ctx.meta = R, frame, (A, S, table_len, int(degree), chunks, sh_rest.shape[0], ws1_bytes, ws2_bytes, stat)
@@ -410,9 +490,7 @@ class _RenderFn(torch.autograd.Function):
         if pg is None:
             pg, pg_zero = _empty((L.lg_fused_grad_lines(N) if ctx.replicas else N, L.lg_packed_grad_floats()), torch.float32, dev), 0
         ctx.pg = None
-        L.lg_fused_set_option(3, 1 if ctx.replicas else 0)          # as it was for this frame's stage 1
-        if ctx.mode_override is not None:
-            L.lg_fused_set_option(0, ctx.mode_override)              # ... and so the depth-order mode (where the blend finds its lists)
+        cx = ctx.cx
         esq = _empty((1, 1, N), torch.float32, dev, zero=True) if stat else None
         tiles = ctx.tiles
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
@@ -420,14 +498,12 @@ class _RenderFn(torch.autograd.Function):
             if R.probe_events is not None:
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            check(L.lg_fused_backward(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes,
+            check(L.lg_fused_backward(ctypes.byref(cx), A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes,
                                       frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
                                       xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
                                       trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
                                       pg.data_ptr(), pg_zero, esq.data_ptr() if stat else None, None, None, None, None, None, None, ctx.order_ptr, _s()),
                   "fused blend backward")
-            if ctx.mode_override is not None:
-                L.lg_fused_set_option(0, 2)
             if R.probe_events is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
@@ -446,7 +522,7 @@ class _RenderFn(torch.autograd.Function):
         d_sh0 = _empty((3, A, S), torch.float32, dev)
         d_shr = _empty((Rr * 3, A, S), torch.float32, dev)
         d_opa = _empty((1, A, S), torch.float32, dev)
-        check(L.lg_fused_backward(A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes,
+        check(L.lg_fused_backward(ctypes.byref(cx), A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes,
                                   frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
                                   xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
                                   trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
@@ -454,8 +530,6 @@ class _RenderFn(torch.autograd.Function):
                                   d_pos.data_ptr(), d_scale.data_ptr(), d_rot.data_ptr(), d_sh0.data_ptr(), d_shr.data_ptr(), d_opa.data_ptr(),
                                   ctx.order_ptr, _s()),
               "fused backward")
-        if ctx.mode_override is not None:
-            L.lg_fused_set_option(0, 2)
         if stat:
             fc, fw = ctx.stat_bufs
             # d_opacity of the activated opacity = packed_grad slot 8 (rasterize_backward's 4th output)
@@ -481,7 +555,7 @@ class FusedAdam:
         self._farr = ctypes.c_float * G
         self._ready = False
         self.touched = None
-        self.skip_untouched = os.environ.get("LITEGS_ADAM_SKIP_UNTOUCHED", "1") != "0"
+        self.skip_untouched = True           # exact skip of no-op updates (csrc/fused.hip); False: every visible Gaussian is read and written
 
     def _init_state(self):
         for g in self.groups:
@@ -525,12 +599,11 @@ class FusedAdam:
         vs = [self.opt.state[p]["exp_avg_sq"] for p in ps]
         lr6 = (ctypes.c_float * 6)(*[float(self._by_name[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]])
         R, fr = self.renderer, pend["frame"]
-        lib().lg_fused_set_speculation(*R.speculation_args(True))
         hot = None
         if pend.get("replicas") and "ws1" in pend:
             hot = pend["ws1"].data_ptr() + lib().lg_fused_hot_offset(pend["A"] * pend["S"])
-        lib().lg_fused_set_hot_table(hot)
-        check(lib().lg_fused_backward_adam(pend["A"], pend["S"], R.H, R.W, fr.view_ptr, fr.proj_ptr, pend["degree"], pend["chunks"], pend["Rr"],
+        cx = R.context(R.depth_order, bool(pend.get("replicas")), 100, True)      # speculative mode: this launch honours / reports the poison word
+        check(lib().lg_fused_backward_adam(ctypes.byref(cx), hot, pend["A"], pend["S"], R.H, R.W, fr.view_ptr, fr.proj_ptr, pend["degree"], pend["chunks"], pend["Rr"],
                                            pend["vis_ids"].data_ptr(), pend["vis_num"].data_ptr(), pend["pg"].data_ptr(), None,
                                            *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms], *[v.data_ptr() for v in vs],
                                            lr6, 0.9, 0.999, float(self.groups[0]["eps"]),

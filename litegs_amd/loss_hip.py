@@ -76,6 +76,7 @@ class RasterL1SSIM(torch.autograd.Function):
         d_raw = torch.empty_like(raw)
         g = grad_out.contiguous()
         partial, loss = ctx.pending if ctx.pending is not None else (None, None)
+        ctx.pending = None              # breaks the cycle loss -> grad_fn -> ctx -> loss (one leaked step per iteration otherwise)
         check(lib().lg_l1_ssim_backward_raster_value(raw.data_ptr(), Hp, Wp, gt.data_ptr(), dmaps.data_ptr(), g.data_ptr(), B * C, H, W,
                                                      LAMBDA_DSSIM, d_raw.data_ptr(), partial.data_ptr() if partial is not None else None,
                                                      loss.data_ptr() if loss is not None else None, _s()), "l1_ssim_backward_raster")

@@ -46,9 +46,12 @@ class FrameTrainer:
         self.n_chunks, self.S = self.params[0].shape[-2], self.params[0].shape[-1]
         self.frames = frames
         n_frames = len(frames) + extra_slots
-        # Implicit synchronisation buffers: written in epoch N, read in epoch N+1 (litegs/data.py:238)
-        self.feedback_visible_chunks_num = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
-        self.feedback_binning_allocate_size = torch.zeros((n_frames,), dtype=torch.int32).pin_memory()
+        # Implicit synchronisation buffers of the operator path: written in epoch N, read in epoch N+1 (litegs/data.py:238).  Pinned words
+        # from the library's arena (hostwords.py): the device stores into them asynchronously, so they must never be unmapped under it
+        from .hostwords import HostWords
+        self._fb_words = HostWords(2 * n_frames)
+        self.feedback_visible_chunks_num = torch.from_numpy(self._fb_words.a[:n_frames])
+        self.feedback_binning_allocate_size = torch.from_numpy(self._fb_words.a[n_frames:])
         self.opt, self.sched = opt, sched
         with torch.no_grad():
             xyz, scale, rot = self.params[0], self.params[1], self.params[2]
@@ -110,11 +113,10 @@ class FrameTrainer:
             self._spec_ring.append((self._spec_next, frame_index, [float(g["lr"]) for g in self.opt.param_groups]))
             self._spec_next += 1
             if len(self._spec_ring) > 64:                 # steps whose Adam launch has reported in need no replay any more
-                done = int(self.renderer.spec["applied_host"][0])
+                done = self.renderer.applied_step()
                 self._spec_ring = [r for r in self._spec_ring if r[0] > done]
-        elif self.renderer.spec is not None:
-            self.renderer.spec_step = 0
-            self.renderer.spec = None
+        else:
+            self.renderer.disable_speculation()
         loss = self._step_body(frame_index, grad_hook, hook_slot, peer_frames)
         if spec:
             ev = torch.cuda.Event()
@@ -126,8 +128,7 @@ class FrameTrainer:
 
     # -- speculative culling: notice, replay ------------------------------------------------------------------------------------
     def _spec_poll(self):
-        sp = self.renderer.spec
-        if sp is not None and int(sp["poison_host"][0]) != 0:
+        if self.renderer.poisoned():
             self._spec_recover()
 
     def _spec_recover(self):
@@ -136,15 +137,13 @@ class FrameTrainer:
         R = self.renderer
         while True:
             torch.cuda.current_stream().synchronize()
-            sp = R.spec
-            if sp is None or int(sp["poison_host"][0]) == 0:
+            if not R.poisoned():
                 break
-            done = int(sp["applied_host"][0])
+            done = R.applied_step()
             todo = [r for r in self._spec_ring if r[0] > done]
             self._spec_ring = []
             self._spec_events = []
-            sp["poison"].zero_()
-            sp["poison_host"][0] = 0
+            R.clear_poison()
             torch.cuda.current_stream().synchronize()
             current = [float(g["lr"]) for g in self.opt.param_groups]
             for i, (no, frame_index, lrs) in enumerate(todo):
@@ -153,12 +152,7 @@ class FrameTrainer:
                 R.spec_step = no
                 R.force_full = (i == 0)
                 if i == 0:                                # the frame whose bounds were violated: what the gated repeat's bookkeeping does
-                    k = self.frames[frame_index % len(self.frames)].cam.index
-                    R.fallbacks += 1
-                    R.clean_visits[k] = 0
-                    R.cooldown[k] = R.cull_cooldown
-                    if not R.margin_fixed:
-                        R.margin[k] = min(R.margin[k] * 2, R.margin_hi)
+                    R.note_fallback(self.frames[frame_index % len(self.frames)].cam.index)
                 self._spec_ring.append((no, frame_index, lrs))
                 self._step_body(frame_index, None, 0, None)
                 self.spec_replays += 1
@@ -168,10 +162,11 @@ class FrameTrainer:
     def flush(self):
         """the parameters reflect every step enqueued so far (speculative mode: failed steps are replayed first); synchronises"""
         torch.cuda.current_stream().synchronize()
-        if self.renderer.spec is not None:
+        if self.renderer.spec_words is not None:
             self._spec_recover()
         self._spec_ring = []
         self._spec_events = []
+        self.renderer.check_tables()
 
     def _step_body(self, frame_index: int, grad_hook=None, hook_slot: int = 0, peer_frames=None):
         frame = self.frames[frame_index % len(self.frames)]
@@ -181,6 +176,9 @@ class FrameTrainer:
         # gradients are only materialised when something consumes them between backward and the optimizer (gradient-hook DP exchange)
         self.renderer.fuse_optimizer = self.fused and self.fuse_adam and (grad_hook is None or moments)
         self.renderer.after_cull = grad_hook.begin if (moments and hasattr(grad_hook, "begin")) else None
+        # gradient replicas only when the fused backward kernels are the records' sole consumer (the moment exchange's compaction reads
+        # the N regular lines only)
+        self.renderer.fold_only_consumer = grad_hook is None
         img, vis_id, vis_num, prim_vis = self.forward(frame, raw=self.raw_loss)
         if self.raw_loss:
             from . import loss_hip
@@ -203,6 +201,28 @@ class FrameTrainer:
         self.opt.zero_grad(set_to_none=True)
         self.last = dict(loss=loss.detach(), vis_num=vis_num)
         return loss
+
+    def close(self):
+        """everything enqueued has landed (failed speculative steps replayed) and the renderer's words are released; idempotent"""
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
+        try:
+            if torch.cuda.is_available():
+                self.flush()
+        finally:
+            self.renderer.close()
+            self._fb_words.close()
+
+    def __del__(self):
+        # no replay of failed speculative steps from a finaliser (that is close()'s / flush()'s job): only make sure nothing is in flight
+        try:
+            if not getattr(self, "_closed", False):
+                self._closed = True
+                self.renderer.close()
+                self._fb_words.close()
+        except Exception:
+            pass
 
     @torch.no_grad()
     def forward_only(self, frame_index: int):
@@ -314,9 +334,9 @@ def train(trainer: FrameTrainer, epochs: int, exchange=None, rank: int = 0, worl
                 hook = None if exchange is None else (exchange if moments else exchange.hook)
                 trainer.step(peers[rank], hook, k, peers)
                 step += 1
-        trainer.end_epoch(epoch)
         if moments:
-            exchange.check()
+            exchange.check()                             # before end_epoch: a re-bind (density control) resets the exchange's overflow words
+        trainer.end_epoch(epoch)
         if on_epoch is not None:
             on_epoch(epoch, trainer)
     return trainer

@@ -51,13 +51,30 @@ def _snapshot(path, tag, tr):
         os.fsync(f.fileno())
 
 
-def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify, log):
+def save_state(path, tr, epoch):
+    """the student cloud + its Adam moments at an epoch boundary (tools/late_phase.py replays steps on it under a profiler)"""
+    by = {g["name"]: g["params"][0] for g in tr.opt.param_groups}
+    order = ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]
+    st = dict(epoch=epoch, degree=tr.degree, params=[by[n].detach().cpu() for n in order],
+              exp_avg=[tr.opt.state[by[n]].get("exp_avg", torch.zeros_like(by[n])).cpu() for n in order],
+              exp_avg_sq=[tr.opt.state[by[n]].get("exp_avg_sq", torch.zeros_like(by[n])).cpu() for n in order],
+              lr={g["name"]: float(g["lr"]) for g in tr.opt.param_groups})
+    torch.save(st, path)
+
+
+def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify, log, settings=None):
     from litegs_amd import densify as D
     from litegs_amd.statistics import STATS
     tr = SyntheticTrainer(cfg["n"], cfg["W"], cfg["H"], cfg["focal"], n_frames=cfg["frames"], seed=cfg["seed"], scene=student, fused=fused, noise_targets=False)
     for k, t in enumerate(targets):
         tr.frames[k].gt = t
     tr.speculative = fused                                   # the executor's speculative culling, as bench.py and training.start run it
+    for key, val in (settings or {}).items():                # A/B runs: attributes of the executor (litegs_amd/fast.py FusedRenderer)
+        if not hasattr(tr.renderer, key):
+            raise AttributeError(f"FusedRenderer has no option '{key}'")
+        setattr(tr.renderer, key, val)
+    save_at = os.environ.get("LITEGS_CONV_SAVE")             # "<file>:<epoch>"
+    epoch_ms, epoch_inst = [], []
     ctl = tr.enable_densify(D.DensifyParams(**densify), total_epochs=epochs, seed=cfg["seed"]) if densify else None
 
     def evaluate():
@@ -69,6 +86,7 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
     t0 = time.time()
     rng = np.random.default_rng(cfg["seed"] + 7)
     for epoch in range(epochs):
+        te = time.time()
         tr.degree = min(epoch // 5, 3)                       # trainer.py:111
         order = rng.permutation(cfg["frames"])               # the reference's DataLoader shuffles
         if ctl is not None:
@@ -79,6 +97,12 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
         else:
             for k in order:
                 tr.step(int(k))
+        torch.cuda.synchronize()
+        epoch_ms.append((time.time() - te) / cfg["frames"] * 1e3)
+        if fused:
+            epoch_inst.append(float(np.mean(tr.renderer.fb_total)))
+        if save_at and fused and epoch + 1 == int(save_at.rsplit(":", 1)[1]) and not os.path.exists(save_at.rsplit(":", 1)[0]):
+            save_state(save_at.rsplit(":", 1)[0], tr, epoch + 1)
         if os.environ.get("LITEGS_CONV_SNAPSHOT"):
             _snapshot(os.environ["LITEGS_CONV_SNAPSHOT"], f"{'executor' if fused else 'operator'} epoch {epoch}", tr)
         if os.environ.get("LITEGS_CONV_VERBOSE"):
@@ -90,17 +114,20 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
     secs = time.time() - t0
     rd = tr.renderer
     info = dict(psnr=curve, size=sizes, iterations=at, seconds=secs, ms_per_iteration=secs / (epochs * cfg["frames"]) * 1e3,
-                unculled_reruns=int(rd.fallbacks), replayed_steps=int(tr.spec_replays), truncated=int(rd.truncated_visits), finite=all(bool(torch.isfinite(p).all()) for p in tr.params))
+                unculled_reruns=int(rd.fallbacks), replayed_steps=int(tr.spec_replays), truncated=int(rd.truncated_visits), finite=all(bool(torch.isfinite(p).all()) for p in tr.params),
+                epoch_ms=epoch_ms, epoch_instances=epoch_inst)
     if ctl is not None:
         STATS.reset(1, 1, enabled_for_epoch=lambda e: False, device="cuda")
         STATS.tile_schedule.clear(); STATS.tile_blend_count.clear()
+    tr.close()
     del tr
     torch.cuda.empty_cache()
     log(f"{'executor' if fused else 'operator'}: {curve[0]:.3f} -> {curve[-1]:.3f} dB, {sizes[-1]} points, {secs:.1f} s ({info['ms_per_iteration']:.3f} ms / iteration)")
     return info
 
 
-def run(iterations=30000, frames=150, n=3_000_000, W=1920, H=1080, focal=1200.0, seed=0, runs=3, eval_every=10, log=lambda *a: print(*a, flush=True)):
+def run(iterations=30000, frames=150, n=3_000_000, W=1920, H=1080, focal=1200.0, seed=0, runs=3, eval_every=10, log=lambda *a: print(*a, flush=True),
+        settings=None):
     cfg = dict(n=n, W=W, H=H, focal=focal, frames=frames, seed=seed)
     epochs = iterations // frames
     t0 = time.time()
@@ -112,11 +139,11 @@ def run(iterations=30000, frames=150, n=3_000_000, W=1920, H=1080, focal=1200.0,
     torch.cuda.empty_cache()
     eval_frames = list(range(0, frames, max(1, frames // 16)))[:16]
     densify = dict(target_primitives=int(1.1 * n))                       # the reference's defaults otherwise (arguments.py:95-110)
-    out = dict(config=cfg, iterations=iterations, epochs=epochs, densify=densify, eval_frames=eval_frames)
+    out = dict(config=cfg, iterations=iterations, epochs=epochs, densify=densify, eval_frames=eval_frames, settings=settings or {})
     log(f"targets rendered ({frames} frames {W}x{H}), {epochs} epochs; {time.time() - t0:.0f} s")
     out["executor"] = []
     for _ in range(runs):
-        out["executor"].append(train(student, targets, cfg, True, epochs, eval_frames, eval_every, densify, log))
+        out["executor"].append(train(student, targets, cfg, True, epochs, eval_frames, eval_every, densify, log, settings))
         if os.environ.get("LITEGS_CONV_PARTIAL"):                       # completed curves survive a later failure
             with open(os.environ["LITEGS_CONV_PARTIAL"], "w") as f:
                 json.dump(out, f)
@@ -156,6 +183,16 @@ def to_markdown(out):
           f"| steps replayed by the speculative executor (the failed step and those enqueued behind it) | {', '.join(str(r.get('replayed_steps', 0)) for r in ex)} |",
           f"| truncated tables observed | {', '.join(str(r['truncated']) for r in ex)} |",
           f"| parameters finite at the end | {all(r['finite'] for r in ex) and op['finite']} |"]
+    if ex and ex[0].get("epoch_ms"):
+        L += ["", "Cost per iteration over the run (executor run 1; plain epochs and statistics / density-control epochs alike; wall clock per epoch / frames):", "",
+              "| epoch | ms / iteration | mean emitted instances per frame (M) |", "|---:|---:|---:|"]
+        em, ei = ex[0]["epoch_ms"], ex[0].get("epoch_instances", [])
+        for e in list(range(0, len(em), 10)) + [len(em) - 1]:
+            lo, hi = e, min(e + 10, len(em))
+            inst = f"{np.mean(ei[lo:hi]) / 1e6:.1f}" if ei else ""
+            L.append(f"| {lo}-{hi - 1} | {np.mean(em[lo:hi]):.3f} | {inst} |")
+    if out.get("settings"):
+        L += ["", f"Executor options of this run: {out['settings']}"]
     return "\n".join(x for x in L if x != "") + "\n"
 
 
@@ -169,8 +206,15 @@ if __name__ == "__main__":
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--runs", type=int, default=3)
     ap.add_argument("--eval-every", type=int, default=10)
+    ap.add_argument("--set", default="", help="executor options for an A/B run: attr=value[,attr=value...] (FusedRenderer attributes)")
     a = ap.parse_args()
-    res = run(iterations=a.iterations, frames=a.frames, n=a.n, W=a.width, H=a.height, runs=a.runs, eval_every=a.eval_every)
+    settings = {}
+    for kv in filter(None, a.set.split(",")):
+        key, val = kv.split("=")
+        settings[key] = {"true": True, "false": False}.get(val.lower(), None)
+        if settings[key] is None:
+            settings[key] = int(val)
+    res = run(iterations=a.iterations, frames=a.frames, n=a.n, W=a.width, H=a.height, runs=a.runs, eval_every=a.eval_every, settings=settings)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out, "w") as f:
         f.write(to_markdown(res))

@@ -78,4 +78,10 @@ def test_c_abi_rejects_missing_required_buffers():
     assert L.lg_depth_sort_keys(None, 16, None, None, None) == 1
     assert L.lg_depth_sort_keys(None, 0, None, None, None) == 0
     assert L.lg_tile_range(None, 1, 0, 8, None, None) == 1                                          # the range table itself is always required
-    assert L.lg_fused_set_option(99, 0) != 0
+    # the executor's context is validated the same way: a struct of another size (a caller built against another header) is refused
+    import ctypes
+    from litegs_amd.fast import LgFusedCtx
+    bad = LgFusedCtx()
+    bad.struct_bytes = ctypes.sizeof(LgFusedCtx) - 4
+    assert L.lg_fused_sorted_points_offset(ctypes.byref(bad), 16, 128, 32, 32, 8, 16) == -1
+    assert L.lg_fused_sorted_points_offset(None, 16, 128, 32, 32, 8, 16) >= 0                      # NULL context = defaults

@@ -16,7 +16,7 @@ def _apply(tr, pend, ps, ms, vs, touched):
     by = {g["name"]: g for g in tr.opt.param_groups}
     lr6 = (ctypes.c_float * 6)(*[float(by[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]])
     R, fr = tr.renderer, pend["frame"]
-    check(lib().lg_fused_backward_adam(pend["A"], pend["S"], R.H, R.W, fr.view_ptr, fr.proj_ptr, pend["degree"], pend["chunks"], pend["Rr"],
+    check(lib().lg_fused_backward_adam(None, None, pend["A"], pend["S"], R.H, R.W, fr.view_ptr, fr.proj_ptr, pend["degree"], pend["chunks"], pend["Rr"],
                                        pend["vis_ids"].data_ptr(), pend["vis_num"].data_ptr(), pend["pg"].data_ptr(), None,
                                        *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms], *[v.data_ptr() for v in vs],
                                        lr6, 0.9, 0.999, float(tr.opt.param_groups[0]["eps"]),

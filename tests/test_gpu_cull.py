@@ -48,7 +48,7 @@ def test_culled_visit_is_bit_identical_and_emits_less(depth_order_mode):
     from litegs_amd import fast
     params, cam, origin, extend, H, W = _scene()
     w = torch.from_numpy(np.random.default_rng(2).standard_normal((1, 3, H, W)).astype(np.float32)).cuda()
-    rd = fast.FusedRenderer(1, H, W)
+    rd = depth_order_mode(fast.FusedRenderer(1, H, W))
     rd.margin_fixed = 50                       # short lists at this scene size: the default 100 % margin reaches most of them
     rd.reset_feedback()
     img0 = _render(rd, cam, origin, extend, params, w)
@@ -74,19 +74,18 @@ def test_culled_visit_is_bit_identical_and_emits_less(depth_order_mode):
 def depth_order_mode(request):
     """the three ways the executor builds the tile lists (csrc/fused.hip): depth sort of the splats + stable tile sort; per-tile depth sort
     behind the tile scatter (no sort over the instances); per-tile depth sort behind the stable tile radix sort"""
-    from litegs_amd._lib import lib
-    L = lib()
-    prev = (L.lg_fused_get_option(0), L.lg_fused_get_option(2))
-    mode, scatter = {"global": (0, 1), "tile+scatter": (1, 1), "tile+radix": (1, 0)}[request.param]
-    assert L.lg_fused_set_option(0, mode) == 0 and L.lg_fused_set_option(2, scatter) == 0
-    yield request.param
-    L.lg_fused_set_option(0, prev[0]); L.lg_fused_set_option(2, prev[1])
+    mode, scatter = {"global": (0, True), "tile+scatter": (1, True), "tile+radix": (1, False)}[request.param]
+
+    def apply(rd):
+        rd.depth_order, rd.tile_scatter = mode, scatter
+        return rd
+    return apply
 
 
 def test_violated_bounds_take_the_gated_fallback(depth_order_mode):
     from litegs_amd import fast
     params, cam, origin, extend, H, W = _scene()
-    rd = fast.FusedRenderer(1, H, W)
+    rd = depth_order_mode(fast.FusedRenderer(1, H, W))
     img0 = _render(rd, cam, origin, extend, params)
     full = int(rd.fb_total[0])
     _bounds(rd, H, W).mul_(0.2)                 # bounds far too tight: most tiles cannot saturate inside them
@@ -105,14 +104,14 @@ def test_scene_change_between_visits_stays_exact(depth_order_mode):
     the one a fresh, unculled renderer produces"""
     from litegs_amd import fast
     params, cam, origin, extend, H, W = _scene()
-    rd = fast.FusedRenderer(1, H, W)
+    rd = depth_order_mode(fast.FusedRenderer(1, H, W))
     _render(rd, cam, origin, extend, params)
     for shift in (0.3, 1.0, 3.0):
         with torch.no_grad():
             params[5].sub_(shift)              # raw opacity (pre-sigmoid)
         img_c = _render(rd, cam, origin, extend, params)
         assert rd.last_cull
-        ref = fast.FusedRenderer(1, H, W)
+        ref = depth_order_mode(fast.FusedRenderer(1, H, W))
         ref.cull_enabled = False
         img_r = _render(ref, cam, origin, extend, params)
         assert torch.equal(img_c, img_r), f"shift {shift}: culled visit differs (fallback flag {_flags(rd)[0]})"
@@ -148,9 +147,9 @@ def test_speculative_culling_replays_failed_steps():
     tb, lb = run(True)
     assert ta.renderer.fallbacks >= 1                        # the gated repeat really ran in the reference run
     assert tb.spec_replays >= 2, tb.spec_replays             # the failed step and at least the one enqueued behind it
-    sp = tb.renderer.spec
-    assert int(sp["poison_host"][0]) == 0 and int(sp["poison"].item()) == 0
-    assert int(sp["applied_host"][0]) == 14                  # every step's Adam launch has run, the last one being step 14
+    rb = tb.renderer
+    assert not rb.poisoned() and int(rb.spec_poison.item()) == 0
+    assert rb.applied_step() == 14                           # every step's Adam launch has run, the last one being step 14
     for pa, pa2, pb in zip(ta.params, ta2.params, tb.params):
         assert torch.isfinite(pb).all()
         noise = (pa.detach() - pa2.detach()).abs().max().item()

@@ -188,50 +188,45 @@ def test_underpredicted_table_in_per_tile_depth_mode(oracle):
     c, params, view, proj, planes, origin, extend = _setup(name)
     res = oracle_forward(name)
     H, W = c["H"], c["W"]
-    L = lib()
-    prev = L.lg_fused_get_option(0)
-    try:
-        assert L.lg_fused_set_option(0, 1) == 0
-        rd = fast.FusedRenderer(1, H, W)
-        cam = fast.CameraFrame(view, proj, planes, 0)
-        with torch.no_grad():
-            rd.render(cam, origin, extend, *params, c["degree"])
-            torch.cuda.synchronize()
-            total = int(rd.fb_total[0])
-            assert total == res.n_instances
-            rd.fb_total[0] = int(0.3 * total)
-            img, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
-            torch.cuda.synchronize()
-        want = int(1.5 * int(0.3 * total))
-        assert rd.last_sizes[1] == want and int(rd.fb_total[0]) == total
-        op = res.act[4]
-        N = res.alloc.shape[1]
-        ident = np.arange(N, dtype=np.int64)[None]
-        prefix_id = np.cumsum(res.alloc, axis=-1, dtype=np.int64).astype(np.int32)
-        ks, vs, _, _ = oracle.create_table(res.ndc, res.inv_cov, op, prefix_id, ident, H, W, 8, 16, table_len=want)
-        depth = np.ascontiguousarray(res.view_pos[:, 2, :])
-        u = depth[0].view(np.uint32).astype(np.uint64)
-        dkey = np.where((u & 0x80000000) != 0, (~u) & 0xFFFFFFFF, u | 0x80000000)
-        bounds = np.flatnonzero(np.diff(ks[0])) + 1
-        vs = vs.copy()
-        for a, b in zip(np.r_[0, bounds], np.r_[bounds, ks.shape[1]]):
-            if ks[0, a] != 0:
-                ids = vs[0, a:b]
-                vs[0, a:b] = ids[np.lexsort((ids, dkey[ids]))]
-        ntiles = ((H + 7) // 8) * ((W + 15) // 16)
-        ts = oracle.tile_range(ks, ntiles)
-        ref_img, *_ = oracle.raster_forward(vs, ts, res.packed, H, W, 8, 16)
-        ref_img = np.clip(ref_img[..., :H, :W], 0, 1)
-        full_img = np.clip(res.img[..., :H, :W], 0, 1)
-        assert np.abs(ref_img - full_img).max() > 0.05
-        assert_close(img.cpu().numpy(), ref_img, **IMG_FLIP, name="truncated img (tile mode)")
-        with torch.no_grad():
-            img3, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
-            torch.cuda.synchronize()
-        assert rd.truncated_visits == 1 and rd.last_sizes[1] == total
-        assert_close(img3.cpu().numpy(), full_img, **IMG_FLIP, name="healed img (tile mode)")
-    finally:
-        L.lg_fused_set_option(0, prev)
+    rd = fast.FusedRenderer(1, H, W)
+    rd.depth_order = 1
+    cam = fast.CameraFrame(view, proj, planes, 0)
+    with torch.no_grad():
+        rd.render(cam, origin, extend, *params, c["degree"])
+        torch.cuda.synchronize()
+        total = int(rd.fb_total[0])
+        assert total == res.n_instances
+        rd.fb_total[0] = int(0.3 * total)
+        img, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
+        torch.cuda.synchronize()
+    want = int(1.5 * int(0.3 * total))
+    assert rd.last_sizes[1] == want and int(rd.fb_total[0]) == total
+    op = res.act[4]
+    N = res.alloc.shape[1]
+    ident = np.arange(N, dtype=np.int64)[None]
+    prefix_id = np.cumsum(res.alloc, axis=-1, dtype=np.int64).astype(np.int32)
+    ks, vs, _, _ = oracle.create_table(res.ndc, res.inv_cov, op, prefix_id, ident, H, W, 8, 16, table_len=want)
+    depth = np.ascontiguousarray(res.view_pos[:, 2, :])
+    u = depth[0].view(np.uint32).astype(np.uint64)
+    dkey = np.where((u & 0x80000000) != 0, (~u) & 0xFFFFFFFF, u | 0x80000000)
+    bounds = np.flatnonzero(np.diff(ks[0])) + 1
+    vs = vs.copy()
+    for a, b in zip(np.r_[0, bounds], np.r_[bounds, ks.shape[1]]):
+        if ks[0, a] != 0:
+            ids = vs[0, a:b]
+            vs[0, a:b] = ids[np.lexsort((ids, dkey[ids]))]
+    ntiles = ((H + 7) // 8) * ((W + 15) // 16)
+    ts = oracle.tile_range(ks, ntiles)
+    ref_img, *_ = oracle.raster_forward(vs, ts, res.packed, H, W, 8, 16)
+    ref_img = np.clip(ref_img[..., :H, :W], 0, 1)
+    full_img = np.clip(res.img[..., :H, :W], 0, 1)
+    assert np.abs(ref_img - full_img).max() > 0.05
+    assert_close(img.cpu().numpy(), ref_img, **IMG_FLIP, name="truncated img (tile mode)")
+    with torch.no_grad():
+        img3, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
+        torch.cuda.synchronize()
+    assert rd.truncated_visits == 1 and rd.last_sizes[1] == total
+    assert_close(img3.cpu().numpy(), full_img, **IMG_FLIP, name="healed img (tile mode)")
 
 
 def test_gradient_replicas_do_not_change_the_update():

@@ -80,20 +80,14 @@ def _render_all(tr, frames, visits):
 
 def test_executor_is_bit_identical_with_and_without_the_splat_sort():
     """first visits (unculled, blocking sizes), culled revisits and the 16th-visit refresh: same images bit for bit in both modes"""
-    from litegs_amd._lib import lib
     from litegs_amd.trainer import SyntheticTrainer
-    L = lib()
-    previous = L.lg_fused_get_option(0)
     imgs = {}
-    try:
-        for mode in (1, 0):
-            assert L.lg_fused_set_option(0, mode) == 0
-            tr = SyntheticTrainer(60000, 640, 360, 500.0, n_frames=3, seed=5)
-            imgs[mode] = _render_all(tr, range(3), 18)
-            if mode == 1:
-                assert tr.renderer.last_cull                          # the revisits really ran culled
-    finally:
-        L.lg_fused_set_option(0, previous)
+    for mode in (1, 0):
+        tr = SyntheticTrainer(60000, 640, 360, 500.0, n_frames=3, seed=5)
+        tr.renderer.depth_order = mode
+        imgs[mode] = _render_all(tr, range(3), 18)
+        if mode == 1:
+            assert tr.renderer.last_cull                          # the revisits really ran culled
     assert len(imgs[0]) == len(imgs[1]) == 54
     for a, b in zip(imgs[0], imgs[1]):
         assert torch.equal(a, b)
@@ -102,20 +96,14 @@ def test_executor_is_bit_identical_with_and_without_the_splat_sort():
 def test_training_steps_agree_between_the_two_modes():
     """a few optimisation steps (forward, loss, blend backward, fused backward + Adam) with both orders: the blend backward's float
     atomics make parameters differ in the last bits run to run, so this is a tolerance check on top of the bit-exact forward test"""
-    from litegs_amd._lib import lib
     from litegs_amd.trainer import SyntheticTrainer
-    L = lib()
-    previous = L.lg_fused_get_option(0)
     res = {}
-    try:
-        for mode in (1, 0):
-            L.lg_fused_set_option(0, mode)
-            tr = SyntheticTrainer(30000, 480, 270, 400.0, n_frames=2, seed=9)
-            losses = [float(tr.step(i % 2).detach()) for i in range(12)]
-            torch.cuda.synchronize()
-            res[mode] = (losses, [p.detach().clone() for p in tr.params])
-    finally:
-        L.lg_fused_set_option(0, previous)
+    for mode in (1, 0):
+        tr = SyntheticTrainer(30000, 480, 270, 400.0, n_frames=2, seed=9)
+        tr.renderer.depth_order = mode
+        losses = [float(tr.step(i % 2).detach()) for i in range(12)]
+        torch.cuda.synchronize()
+        res[mode] = (losses, [p.detach().clone() for p in tr.params])
     # losses of the first steps agree closely; later steps (and the parameters) drift apart like any two runs of the SAME mode do, because
     # the blend backward's float atomics reorder the sums (tests/test_gpu_convergence.py measures that spread)
     np.testing.assert_allclose(res[0][0][:4], res[1][0][:4], rtol=2e-4)
@@ -184,33 +172,28 @@ def test_executor_tables_match_the_oracle_with_the_tile_scatter(oracle):
     params = [torch.from_numpy(p).cuda() for p in c["params"]]
     view, proj, planes = [torch.from_numpy(x).cuda() for x in (c["view"], c["proj"], c["planes"])]
     origin, extend = R.get_cluster_AABB(params[0], params[1].exp(), torch.nn.functional.normalize(params[2], dim=0))
-    prev = (L.lg_fused_get_option(0), L.lg_fused_get_option(2))
-    try:
-        for scatter in (1, 0):
-            assert L.lg_fused_set_option(0, 1) == 0 and L.lg_fused_set_option(2, scatter) == 0
-            rd = fast.FusedRenderer(1, H, W)
-            cam = fast.CameraFrame(view, proj, planes, 0)
-            with torch.no_grad():
-                rd.render(cam, origin, extend, *params, c["degree"])
-            torch.cuda.synchronize()
-            ws2, table_len, N = rd.last_ws2
-            o_pts = L.lg_fused_sorted_points_offset(table_len, N, H, W, 8, 16)
-            o_ts = L.lg_fused_tile_start_offset(table_len, N, H, W, 8, 16)
-            ntiles = res.tile_start.shape[1] - 2
-            ts = ws2[o_ts:o_ts + 4 * (ntiles + 2)].view(torch.int32).cpu().numpy()
-            pts = ws2[o_pts:o_pts + 4 * res.n_instances].view(torch.int32).cpu().numpy()
-            np.testing.assert_array_equal(ts, res.tile_start[0], err_msg=f"scatter={scatter}")
-            np.testing.assert_array_equal(pts, res.sorted_point[0], err_msg=f"scatter={scatter}")
-    finally:
-        L.lg_fused_set_option(0, prev[0]); L.lg_fused_set_option(2, prev[1])
+    import ctypes
+    for scatter, validate in ((True, False), (False, False), (True, True), (False, True)):
+        rd = fast.FusedRenderer(1, H, W)
+        rd.depth_order, rd.tile_scatter, rd.validate_tables = 1, scatter, validate     # validate: the table checks find nothing to report
+        cam = fast.CameraFrame(view, proj, planes, 0)
+        with torch.no_grad():
+            rd.render(cam, origin, extend, *params, c["degree"])
+        torch.cuda.synchronize()
+        rd.check_tables()
+        ws2, table_len, N = rd.last_ws2
+        o_pts = L.lg_fused_sorted_points_offset(ctypes.byref(rd.last_ctx), table_len, N, H, W, 8, 16)
+        o_ts = L.lg_fused_tile_start_offset(table_len, N, H, W, 8, 16)
+        ntiles = res.tile_start.shape[1] - 2
+        ts = ws2[o_ts:o_ts + 4 * (ntiles + 2)].view(torch.int32).cpu().numpy()
+        pts = ws2[o_pts:o_pts + 4 * res.n_instances].view(torch.int32).cpu().numpy()
+        np.testing.assert_array_equal(ts, res.tile_start[0], err_msg=f"scatter={scatter}")
+        np.testing.assert_array_equal(pts, res.sorted_point[0], err_msg=f"scatter={scatter}")
 
 
-@pytest.mark.skipif(__import__("os").environ.get("LITEGS_TEST_REGIME_W") != "1",
-                    reason="regime W of the per-tile sort (workgroup radix sort, lists of 1025..4096) is host-emulated only so far "
-                           "(tests/host/bitonic_check.cpp); set LITEGS_TEST_REGIME_W=1 to run it on the device")
 @pytest.mark.parametrize("ties", [False, True])
 def test_regime_w_of_the_tile_sort_matches_stable_sorts(ties):
-    """lists of 1025 .. 4096 entries through the workgroup radix sort (lg_tile_depth_sort_set_regime_w), id-ordered and arbitrary
+    """lists of 1025 .. 4096 entries through the workgroup radix sort (lg_tile_depth_sort_ex, wg_radix = 1), id-ordered and arbitrary
     arrival: by (depth key, id), exactly as the bitonic regimes leave them"""
     from litegs_amd import fused
     from litegs_amd._lib import check, lib
@@ -228,18 +211,14 @@ def test_regime_w_of_the_tile_sort_matches_stable_sorts(ties):
     pk = torch.from_numpy(depth[None].copy()).to(dev)
     start = fused.tileRange(torch.from_numpy(keys[None]).to(dev), ntiles)
     s = torch.cuda.current_stream().cuda_stream
-    try:
-        check(L_.lg_tile_depth_sort_set_regime_w(1), "set")
-        for any_order in (False, True):
-            vals = np.concatenate([rng.permutation(l) if any_order else l for l in lists])
-            tv = torch.from_numpy(vals[None].copy()).to(dev)
-            scratch = torch.empty((1, len(vals)), dtype=torch.int32, device=dev)
-            fn = L_.lg_tile_depth_sort_unordered if any_order else L_.lg_tile_depth_sort
-            check(fn(tv.data_ptr(), start.data_ptr(), pk.data_ptr(), 1, len(vals), N, ntiles, scratch.data_ptr(), s), "sort")
-            got, off = tv.cpu().numpy()[0], 0
-            for t, ids in enumerate(lists[:-1]):                      # the last run has no closing entry (tileRange): not a list
-                want = ids[np.lexsort((ids, _depth_key(depth[ids])))]
-                np.testing.assert_array_equal(got[off:off + len(ids)], want, err_msg=f"list {t} n={len(ids)} any_order={any_order}")
-                off += len(ids)
-    finally:
-        L_.lg_tile_depth_sort_set_regime_w(0)
+    for any_order in (False, True):
+        vals = np.concatenate([rng.permutation(l) if any_order else l for l in lists])
+        tv = torch.from_numpy(vals[None].copy()).to(dev)
+        scratch = torch.empty((1, len(vals)), dtype=torch.int32, device=dev)
+        check(L_.lg_tile_depth_sort_ex(tv.data_ptr(), start.data_ptr(), pk.data_ptr(), 1, len(vals), N, ntiles, scratch.data_ptr(),
+                                       1 if any_order else 0, 1, s), "sort")
+        got, off = tv.cpu().numpy()[0], 0
+        for t, ids in enumerate(lists[:-1]):                      # the last run has no closing entry (tileRange): not a list
+            want = ids[np.lexsort((ids, _depth_key(depth[ids])))]
+            np.testing.assert_array_equal(got[off:off + len(ids)], want, err_msg=f"list {t} n={len(ids)} any_order={any_order}")
+            off += len(ids)

@@ -43,11 +43,6 @@ def ab(state):
     for v, name in ((0, "generic"), (1, "fast"), (0, "generic"), (1, "fast")):
         L.lg_set_tuning(5, v)
         measure(f"{state}: {name} kernel")
-    # measurement only (lr is zero here: nothing is trained on the wrong gradients): no atomics / uncontended private lines / one dword per record
-    for v, name in ((1, "atomics off"), (2, "atomics to private lines"), (3, "one-dword atomics"), (0, "normal")):
-        L.lg_set_tuning(6, v)
-        measure(f"{state}: fast kernel, {name}")
-    L.lg_set_tuning(6, 0)
     for v, name in ((0, "generic"), (1, "packed"), (0, "generic"), (1, "packed")):      # blend forward: generic loop vs the packed 8x16 loop
         L.lg_set_tuning(7, v)
         for i in range(8):

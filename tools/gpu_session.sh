@@ -1,0 +1,86 @@
+#!/bin/bash
+# One parameterised GPU-box script (replaces the per-session tools/gpu_rNN_*.sh of earlier rounds).
+#   usage: tools/gpu_session.sh TAG STAGE [STAGE ...]      (run from the repository root on the GPU box; output under gpurun_out/)
+# stages:
+#   tests        the whole -m gpu suite (flip counts collected)           tests:<pytest args>  a targeted run
+#   smoke        __graft_entry__.smoke()
+#   bench        the default bench line                                     bench10m / bench500k  the other BASELINE sizes
+#   benchdp2     bench.py --gpus 2 with both ranks on this GPU over gloo (control-flow check of the N>1 path)
+#   trace        rocprofv3 --kernel-trace --stats of the default bench -> step timeline + kernel stats
+#   sq           SQ counters (VALU / SALU / LDS bank conflicts) of the bench workload, fresh and trained state
+#   conv:<runs>  tests/convergence_3m.py with <runs> executor trainers in ONE process (operator curve taken from profiles/), allocator
+#                snapshots on, late-phase state saved to /tmp/late.pt at epoch 120 by the first trainer
+#   late         tools/late_phase.py ab + parity on /tmp/late.pt            latetrace  kernel trace + LDS counters of late-phase steps
+#   dpglue       tools/dp_glue_bench.py on the trained-state cloud
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for STAGE in "$@"; do
+  echo "=== $STAGE"
+  case $STAGE in
+    tests)
+      rm -f gpurun_out/flip_counts.jsonl
+      LITEGS_COLLECT_FLIPS=1 timeout -s KILL 900 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/pytest_$TAG.log 2>&1
+      grep -E "passed|failed" gpurun_out/pytest_$TAG.log | tail -1; grep -E "^FAILED|^ERROR" gpurun_out/pytest_$TAG.log | head -20; grep -E "^E  " gpurun_out/pytest_$TAG.log | head -20 ;;
+    tests:*)
+      timeout -s KILL 600 python -m pytest ${STAGE#tests:} -m gpu -x -q > gpurun_out/pytest_quick_$TAG.log 2>&1
+      grep -E "passed|failed|error" gpurun_out/pytest_quick_$TAG.log | tail -2; grep -E "^E  " gpurun_out/pytest_quick_$TAG.log | head -20 ;;
+    smoke)
+      timeout -s KILL 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; tail -1 gpurun_out/smoke_$TAG.log ;;
+    bench)
+      timeout -s KILL 600 python bench.py > gpurun_out/bench_$TAG.log 2>&1; tail -1 gpurun_out/bench_$TAG.log | cut -c1-900 ;;
+    bench10m)
+      timeout -s KILL 300 python bench.py --config 10m_1600x1200 --frames 4 --no-cpu-baseline --no-operator-path --no-pmc > gpurun_out/bench_10m_$TAG.log 2>&1; tail -1 gpurun_out/bench_10m_$TAG.log | cut -c1-300 ;;
+    bench500k)
+      timeout -s KILL 200 python bench.py --config 500k_1080p --no-cpu-baseline --no-operator-path --no-pmc --soak-steps 0 > gpurun_out/bench_500k_$TAG.log 2>&1; tail -1 gpurun_out/bench_500k_$TAG.log | cut -c1-300 ;;
+    benchdp2)
+      LITEGS_BENCH_ONE_GPU=1 timeout -s KILL 400 python bench.py --gpus 2 --steps 10 --warmup 4 --no-cpu-baseline --no-operator-path --no-pmc > gpurun_out/bench_dp2_$TAG.log 2>&1; grep '^{' gpurun_out/bench_dp2_$TAG.log | cut -c1-600; tail -3 gpurun_out/bench_dp2_$TAG.log | cut -c1-300 ;;
+    trace)
+      (cd /tmp && timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o trace -- python $R/bench.py --no-cpu-baseline --no-operator-path --no-pmc --no-training-state > $R/gpurun_out/rocprof_$TAG.log 2>&1)
+      T=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
+      python tools/profile_r03.py $T > gpurun_out/step_timeline_$TAG.md 2> gpurun_out/step_timeline_$TAG.err; sed -n 3,32p gpurun_out/step_timeline_$TAG.md; tail -3 gpurun_out/step_timeline_$TAG.err
+      S=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); cp $S gpurun_out/kernel_stats_$TAG.csv
+      rm -rf gpurun_out/prof_$TAG ;;
+    sq)
+      timeout -s KILL 300 python tools/soaked_probe.py save /tmp/soaked.npz 1000 > gpurun_out/soaked_save_$TAG.log 2>&1; tail -1 gpurun_out/soaked_save_$TAG.log
+      for STATE in fresh trained; do
+        if [ $STATE = fresh ]; then CMD="python $R/bench.py --pmc-child --steps 8 --warmup 0"; else CMD="python $R/tools/soaked_probe.py run /tmp/soaked.npz 8"; fi
+        for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"; do
+          NAME=$(echo $SET | cut -d' ' -f1)
+          (cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $R/gpurun_out/pmc_${STATE}_${NAME}_$TAG -o pmc -- $CMD > $R/gpurun_out/pmc_${STATE}_${NAME}_$TAG.log 2>&1)
+          C=$(find gpurun_out/pmc_${STATE}_${NAME}_$TAG -name "*counter_collection.csv" | head -1)
+          python tools/sq_summary.py $C "$STATE cloud, $NAME set" > gpurun_out/sq_${STATE}_${NAME}_$TAG.md 2>> gpurun_out/sq_$TAG.err; sed -n 5,16p gpurun_out/sq_${STATE}_${NAME}_$TAG.md
+          rm -rf gpurun_out/pmc_${STATE}_${NAME}_$TAG
+        done
+      done ;;
+    conv:*)
+      RUNS=${STAGE#conv:}
+      rm -f /tmp/late.pt gpurun_out/conv_snap_$TAG.jsonl
+      LITEGS_CONV_SAVE=/tmp/late.pt:120 LITEGS_CONV_SNAPSHOT=/tmp/conv_snap_$TAG.jsonl LITEGS_CONV_PARTIAL=gpurun_out/convergence_3m_${TAG}_partial.json \
+        LITEGS_CONV_SKIP_OPERATOR=profiles/r03_convergence_3m.json timeout -s KILL 2400 python -X faulthandler tests/convergence_3m.py --runs $RUNS $CONV_ARGS \
+        --out gpurun_out/convergence_3m_$TAG.md > gpurun_out/convergence_3m_$TAG.log 2>&1
+      echo "exit $?"; grep -E "executor:|fault|Error|error" gpurun_out/convergence_3m_$TAG.log | head -20
+      tail -c 20000000 /tmp/conv_snap_$TAG.jsonl | tail -n 3 > gpurun_out/conv_snap_tail_$TAG.jsonl ;;
+    late)
+      timeout -s KILL 900 python tools/late_phase.py ab /tmp/late.pt > gpurun_out/late_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/late_ab_$TAG.log | tail -14
+      timeout -s KILL 600 python tools/late_phase.py parity /tmp/late.pt > gpurun_out/late_parity_$TAG.log 2>&1; grep -E "parity|PARITY" gpurun_out/late_parity_$TAG.log | tail -12 ;;
+    latetrace)
+      for V in default stat_epoch; do
+        (cd /tmp && timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_late_${V}_$TAG -o trace -- python $R/tools/late_phase.py trace /tmp/late.pt $V > $R/gpurun_out/late_trace_${V}_$TAG.log 2>&1)
+        T=$(find gpurun_out/prof_late_${V}_$TAG -name "*kernel_trace.csv" | head -1)
+        python tools/late_timeline.py $T 8 > gpurun_out/late_timeline_${V}_$TAG.md 2>> gpurun_out/late_timeline_$TAG.err; head -40 gpurun_out/late_timeline_${V}_$TAG.md
+        rm -rf gpurun_out/prof_late_${V}_$TAG
+      done
+      for SET in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU"; do
+        (cd /tmp && LATE_TRACE_STEPS=4 timeout -s KILL 600 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $R/gpurun_out/pmc_late_$TAG -o pmc -- python $R/tools/late_phase.py trace /tmp/late.pt default > $R/gpurun_out/pmc_late_$TAG.log 2>&1)
+        C=$(find gpurun_out/pmc_late_$TAG -name "*counter_collection.csv" | head -1)
+        python tools/sq_summary.py $C "late-phase cloud, LDS set" > gpurun_out/sq_late_lds_$TAG.md 2>> gpurun_out/late_timeline_$TAG.err; sed -n 5,20p gpurun_out/sq_late_lds_$TAG.md
+        rm -rf gpurun_out/pmc_late_$TAG
+      done ;;
+    dpglue)
+      timeout -s KILL 400 python tools/dp_glue_bench.py > gpurun_out/dp_glue_$TAG.log 2>&1; tail -12 gpurun_out/dp_glue_$TAG.log ;;
+    *) echo "unknown stage $STAGE" ;;
+  esac
+done
