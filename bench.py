@@ -2,9 +2,10 @@
 """bench.py -- headline benchmark of the LiteGS render hot path on MI355X.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched through
-``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).  W untimed warm-up steps,
-then exactly K timed steps bracketed by barrier + synchronize on both sides, MAX over ranks; rank 0 prints
-ONE JSON line.
+``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL) -- or, when started without a launcher
+(WORLD_SIZE unset), it re-executes itself through that launcher; a world size that differs from --gpus is an error, never a silent
+one-GPU run.  W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize on both sides, MAX over ranks;
+rank 0 prints ONE JSON line.
 
 Workload = BASELINE.json configs[2]: 3M synthetic Gaussians (SURVEY.md 8d distribution, seed 0), SH degree 3,
 1920x1080, one camera frame per GPU per step, full training iteration (render_preprocess + render + L1/SSIM loss +
@@ -43,6 +44,9 @@ def parse_args():
                          "(not the headline configuration; single GPU only)")
     ap.add_argument("--soak-steps", type=int, default=1000,
                     help="training steps between the timed region and the steady_state measurement (0 = skip steady_state)")
+    ap.add_argument("--no-training-state", action="store_true", help="skip the training_state leg (teacher -> student run with density control)")
+    ap.add_argument("--training-epochs", type=int, default=60,
+                    help="epochs of the training_state leg's teacher -> student run (reference schedule over the bench's cameras)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the process rocprofv3 wraps: a few training steps, no report
     ap.add_argument("--cpu-tile-stride", type=int, default=0,
@@ -220,6 +224,77 @@ def steady_state(tr, args, n_frames):
     return out
 
 
+def training_state(args, n, W, H, focal, scene, n_frames):
+    """The state `training.start` with density control is in (reference loop: litegs/training/trainer.py:108-195), reached by a
+    deterministic recipe on the bench's own scene: the bench cloud is the teacher, its renders from the bench cameras are the targets, a
+    perturbed copy is trained with the reference's schedule -- SH degree min(epoch // 5, 3), statistics epochs + density control every 5
+    epochs from epoch 3, opacity decay every 10, Morton re-sort after every densification, position-lr decay -- for --training-epochs
+    epochs over the cameras.  Opacity decay keeps tiles from saturating, lists are walked to their ends, every frame carries the statistics
+    helper's cached tile list (render/__init__.py:75-79): the executor's depth-bound culling is idle and the step costs what it costs in
+    a real run (profiles/r04_convergence_3m.md: 4.0 ms per plain step from iteration 6000 on at 150 cameras).  Measured in that state:
+    plain steps and statistics-epoch steps (events per step), forward only, instances, and the dominant kernel's roofline."""
+    from litegs_amd import densify as D
+    from litegs_amd import synthetic as S
+    from litegs_amd.statistics import STATS
+    from litegs_amd.trainer import SyntheticTrainer
+    teacher = SyntheticTrainer(n, W, H, focal, n_frames=n_frames, scene=scene, noise_targets=False)
+    targets = [teacher.forward_only(k).clamp(0, 1).clone() for k in range(n_frames)]
+    teacher.close()
+    del teacher
+    torch.cuda.empty_cache()
+    tr = SyntheticTrainer(n, W, H, focal, n_frames=n_frames, scene=S.perturb(scene, 1, amount=0.5), noise_targets=False)
+    for k in range(n_frames):
+        tr.frames[k].gt = targets[k]
+    tr.speculative = True
+    epochs = args.training_epochs
+    tr.enable_densify(D.DensifyParams(target_primitives=int(1.1 * n)), total_epochs=max(epochs, 200), seed=0)
+    rng = np.random.default_rng(7)
+    t0 = time.perf_counter()
+    for epoch in range(epochs):
+        tr.degree = min(epoch // 5, 3)
+        with tr.begin_epoch(epoch):
+            for k in rng.permutation(n_frames):
+                tr.step(int(k))
+        tr.end_epoch(epoch)
+    tr.flush()
+    torch.cuda.synchronize()
+    run_s = time.perf_counter() - t0
+    rd = tr.renderer
+    # plain steps (between two statistics epochs), then statistics-epoch steps, both on the final cloud; lr stays live (this is training)
+    for k in range(n_frames):
+        tr.step(k)
+    ms = timed_steps(lambda i: tr.step(i % n_frames), 64, tr.flush)
+    STATS.active = True
+    try:
+        for k in range(n_frames):
+            tr.step(k)
+        ms_stat = timed_steps(lambda i: tr.step(i % n_frames), 16, tr.flush)
+    finally:
+        STATS.active = False
+    for k in range(n_frames):
+        tr.step(k)
+    tr.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(16):
+        tr.forward_only(i % n_frames)
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - t0) / 16 * 1e3
+    inst = float(np.mean([rd.fb_total[k] for k in range(n_frames)]))
+    out = {"recipe": f"teacher = the bench cloud, student = perturbed copy, reference schedule (SH degree epoch//5, density control every 5 epochs from 3, "
+                     f"opacity decay every 10, Morton re-sort) for {epochs} epochs over the {n_frames} bench cameras = {epochs * n_frames} iterations",
+           "run_s": round(run_s, 2), "gaussians": int(tr.n_chunks * tr.S), "sh_degree": int(tr.degree),
+           "ms_per_step": round(sum(ms) / len(ms), 4), **percentiles(ms), "frames_per_s": round(1e3 / (sum(ms) / len(ms)), 2),
+           "statistics_epoch_ms_per_step": round(sum(ms_stat) / len(ms_stat), 4),
+           "fwd_ms": round(fwd_ms, 4), "instances_emitted_per_frame": int(inst), "instances_per_tile": round(inst / rd.ntiles, 1),
+           "depth_order": "splat sort + tile radix sort (long lists)" if inst > rd.long_list_global * rd.ntiles > 0 else "tile scatter + per-tile sort",
+           "unculled_reruns": int(rd.fallbacks), "replayed_steps": int(tr.spec_replays), "truncated_tables": int(rd.truncated_visits)}
+    out["roofline"] = roofline_probe(tr, list(range(n_frames)))
+    out["finite"] = all(bool(torch.isfinite(p).all()) for p in tr.params)
+    tr.close()
+    return out
+
+
 def operator_path_ms(n, W, H, focal, scene, frames, steps=16):
     """ms per training iteration when the SAME iteration is driven operator by operator through the drop-in `litegs_fused` surface
     (what the reference's unmodified trainer calls; the compiled binding when it is built) instead of the native executor --
@@ -313,9 +388,28 @@ def _cpu_model():
     return "unknown"
 
 
+def relaunch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run (what the driver's command line does)
+    and hand its exit code back.  One rank per GPU over RCCL; LITEGS_BENCH_ONE_GPU=1 (test hook) puts every rank on cuda:0 over gloo."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not args.pmc_child:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a number for the wrong job size")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -419,6 +513,37 @@ def main():
         dp_diag["phase_ms"] = hook.timing()
         hook.profile = False
         hook.check()
+        if args.soak_steps > 0:
+            # the exchange in the TRAINED state (most visible Gaussians carry gradients: records per rank grow from ~10^4 to ~10^6): soak,
+            # then the same barrier-bracketed timing and the same phase split
+            soak = min(args.soak_steps, 400)
+            for i in range(soak):
+                tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
+                step_no += 1
+            hook.check()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
+                step_no += 1
+            torch.cuda.synchronize()
+            dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
+            if one_gpu:
+                tt = tt.cpu()
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            hook.profile = True
+            for i in range(16):
+                tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
+                step_no += 1
+            phase = hook.timing()
+            hook.profile = False
+            hook.check()
+            dp_diag["steady_state"] = {"after_steps": soak, "ms_per_step": round(float(tt.item()) / args.steps * 1e3, 4),
+                                       "frames_per_s": round(world * args.steps / float(tt.item()), 2),
+                                       "bytes_received_per_rank_per_step": int(hook.bytes_last), "record_capacity": int(hook.last_cap),
+                                       "records_per_rank_bytes_each": 40, "phase_ms": phase}
         sums = torch.stack([p.detach().view(torch.int32).to(torch.int64).sum() for p in tr.params])
         if one_gpu:
             sums = sums.cpu()                         # gloo (the one-GPU test hook) gathers host tensors
@@ -455,7 +580,7 @@ def main():
                 # exact skip of no-op Adam updates (csrc/fused.hip): Gaussians of the visible chunks that never received a gradient
                 result["adam_noop_skip"] = {"enabled": True, "gaussians_with_history": int(fa.touched.sum().item()),
                                             "gaussians_total": int(fa.touched.numel()),
-                                            "note": "bit-exact: zero moments + zero gradient = unchanged parameter; LITEGS_ADAM_SKIP_UNTOUCHED=0 disables"}
+                                            "note": "bit-exact: zero moments + zero gradient = unchanged parameter"}
             else:
                 result["adam_noop_skip"] = {"enabled": False}
         if world == 1 and not args.operator_path:
@@ -467,6 +592,8 @@ def main():
             result["operator_path_ms"] = operator_path_ms(n, W, H, focal, scene, args.frames)
         if world == 1 and not args.operator_path and args.soak_steps > 0:
             result["steady_state"] = steady_state(tr, args, len(tr.frames))
+        if world == 1 and not args.operator_path and not args.no_training_state:
+            result["training_state"] = training_state(args, n, W, H, focal, scene, args.frames)
         if world == 1 and not args.operator_path:
             if args.no_pmc:
                 result["roofline"]["traffic_note"] = "PMC passes skipped (--no-pmc)"

@@ -165,10 +165,6 @@ int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const float* de
 int lg_tile_group(const int32_t* keys, const int32_t* vals, long long L, int max_tile, int32_t* tile_start, int32_t* out_vals, void* temp, void* stream);
 int lg_tile_depth_sort_unordered(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
                                  uint32_t* scratch, void* stream);
-/* the same with wg_radix = 1: lists of 1025 .. 4096 entries are sorted by the four waves of a workgroup with the wave regime's radix sort
- * instead of the bitonic network (identical tables); any_order = 1: the lists arrive in arbitrary order (lg_tile_group) */
-int lg_tile_depth_sort_ex(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
-                          uint32_t* scratch, int any_order, int wg_radix, void* stream);
 int lg_memset_async(void* ptr, int value, long long bytes, void* stream);
 
 /* ---- raster.hip : GR/raster.h --------------------------------------------------------------- */
@@ -255,7 +251,7 @@ typedef struct LgFusedCtx {
     int32_t grad_replicas;
     int32_t step_id;
     int32_t debug_validate;     /* 1: lg_fused_stage2 checks the grouped table on the device before anything indexes with it (debug_words) */
-    int32_t tilesort_wg_radix;  /* [0] per-tile sort: lists of 1025 .. 4096 entries through the workgroup radix sort instead of the bitonic regimes */
+    int32_t reserved;
     int* hot_counter;           /* device int32[1] */
     int* poison;                /* device int32[1] */
     int* poison_host;           /* pinned int32[1] */

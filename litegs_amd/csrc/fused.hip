@@ -63,12 +63,12 @@ __host__ __device__ static inline long long hot_capacity(long long N) { return N
 //    the one the gated repeat would have produced.  Renders that are not followed by a fused Adam step (evaluation, gradient-hook data
 //    parallelism) keep the gated repeat.
 struct Exec {
-    int depth_order, margin_pct, tile_scatter, replicas, step_id, validate, wg_radix;
+    int depth_order, margin_pct, tile_scatter, replicas, step_id, validate;
     int *hot_counter, *poison, *poison_host, *applied_host, *debug_words;
 };
 static int resolve_ctx(const LgFusedCtx* c, Exec& x)
 {
-    x = Exec{ LG_DEPTH_ORDER_AUTO, 100, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr };
+    x = Exec{ LG_DEPTH_ORDER_AUTO, 100, 1, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr };
     if (c == nullptr) return 0;
     if (c->struct_bytes != (int32_t)sizeof(LgFusedCtx)) return (int)hipErrorInvalidValue;          // caller built against another header
     if (c->depth_order < 0 || c->depth_order > 2 || c->bound_margin_pct < 1 || c->bound_margin_pct > 100000) return (int)hipErrorInvalidValue;
@@ -76,7 +76,7 @@ static int resolve_ctx(const LgFusedCtx* c, Exec& x)
     if (c->poison != nullptr && (c->poison_host == nullptr || c->applied_host == nullptr)) return (int)hipErrorInvalidValue;
     if (c->debug_validate && c->debug_words == nullptr) return (int)hipErrorInvalidValue;
     x.depth_order = c->depth_order; x.margin_pct = c->bound_margin_pct; x.tile_scatter = c->tile_scatter ? 1 : 0;
-    x.replicas = c->grad_replicas ? 1 : 0; x.step_id = c->step_id; x.validate = c->debug_validate ? 1 : 0; x.wg_radix = c->tilesort_wg_radix ? 1 : 0;
+    x.replicas = c->grad_replicas ? 1 : 0; x.step_id = c->step_id; x.validate = c->debug_validate ? 1 : 0;
     x.hot_counter = c->hot_counter; x.poison = c->poison; x.poison_host = c->poison_host; x.applied_host = c->applied_host;
     x.debug_words = c->debug_words;
     return 0;
@@ -710,7 +710,7 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
         if (rc) return rc;
         if (x.validate) { rc = validate_table(x, (int32_t*)(w + f.tv_b), (int32_t*)(w + f.tile_start), Ls, total_dev, ntiles, (int)N, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
         rc = lg_tile_depth_sort_gated((int32_t*)(w + f.tv_b), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L, (int)N, ntiles,
-                                      (uint32_t*)(w + f.tk_b), 1, x.wg_radix, gate, s);
+                                      (uint32_t*)(w + f.tk_b), 1, gate, s);
         if (rc) return rc;
     } else {
     // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
@@ -733,7 +733,7 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     if (x.validate) { rc = validate_table(x, (int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (int32_t*)(w + f.tile_start), Ls, total_dev, ntiles, (int)N, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
     if (tile_mode) {      // depth order inside every tile; scratch for lists beyond 2048: the key buffer the tile sort did not end in
         rc = lg_tile_depth_sort_gated((int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L,
-                                      (int)N, ntiles, (uint32_t*)(w + (odd ? f.tk_a : f.tk_b)), 0, x.wg_radix, gate, s);
+                                      (int)N, ntiles, (uint32_t*)(w + (odd ? f.tk_a : f.tk_b)), 0, gate, s);
         if (rc) return rc;
     }
     }

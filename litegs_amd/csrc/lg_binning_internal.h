@@ -60,7 +60,7 @@ int lg_gather_scan_gated(const int32_t* src, const int32_t* idx, long long n, in
 // per-tile depth sort of the tile-sorted value table (tilesort.hip); gate as above
 // any_order: the lists do not arrive in ascending id order (tile scatter): ties in depth are ordered by id explicitly
 int lg_tile_depth_sort_gated(int32_t* vals, const int32_t* tile_start, const float* depth /*[V,N] view depths*/, int V, long long L, int N, int ntiles,
-                             uint32_t* scratch, int any_order, int wg_radix /*lists of 1025..4096 entries through the workgroup radix sort*/, const int* gate, void* stream);
+                             uint32_t* scratch, int any_order, const int* gate, void* stream);
 
 // tileRange on a table whose output was pre-filled with -1
 int lg_tile_range_prefilled(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream);

@@ -413,245 +413,3 @@ TS_FN void ts_radix_sort_tile(int* v, int n, uint32_t* exch /*[TS_RADIX_MAX]*/, 
     else if (n <= 512) ts_radix_sort_tile_n<BALLOT, 8, ANY_ORDER>(v, n, exch, cnt, depth_bits TS_TID_PASS);
     else ts_radix_sort_tile_n<BALLOT, TS_RCHUNKS, ANY_ORDER>(v, n, exch, cnt, depth_bits TS_TID_PASS);
 }
-
-// ---------------------------------------------------------------------------------------------
-// Regime W: the four waves of a workgroup sort ONE list of up to TS_WG_MAX entries with the same stable LSD radix sort.  Wave w owns the
-// w-th quarter of the list (Q = C * 64 consecutive positions, C chunks per wave in registers), ranks its elements against wave-private
-// digit counters exactly as regime R does, and the destination of an element is
-//     (keys with a smaller digit, all waves) + (keys with the same digit in the waves in front of this one) + (its rank in its wave),
-// which keeps the pass stable across the wave boundaries.  Keys and ids travel through one exchange buffer shared by the workgroup.
-// LDS: TS_WG_MAX words (exchange) + 4 * 256 (counters) + 16 (reductions) -- the 20 KB of the kernel.  Measured motive
-// (profiles/r03_tilesort_scaling.log): the bitonic regimes cost 30-34 us per million instances, regime R 8-12.
-// ---------------------------------------------------------------------------------------------
-#define TS_WG_MAX 4096
-#define TS_WG_CHUNKS (TS_WG_MAX / 256)
-#ifdef LG_TILESORT_HOST
-#define TS_LOCAL_WG(type, name, n) type name[256][n]
-#else
-#define TS_LOCAL_WG(type, name, n) type name[n]
-#endif
-
-template <bool BALLOT, bool ANY_ORDER, class DepthBits>
-TS_FN void ts_radix_sort_tile_wg(int* v, int n, uint32_t* exch /*[TS_WG_MAX]*/, int* cnt /*[4 * 256]*/, int* red /*[16]*/, DepthBits depth_bits TS_TID_ARG)
-{
-    constexpr int RCH = TS_WG_CHUNKS;
-    const int C = (n + 255) >> 8;                 // chunks of 64 per wave
-    const int Q = C * 64;                         // positions per wave
-    TS_LOCAL_WG(uint32_t, key, RCH);
-    TS_LOCAL_WG(int, id, RCH);
-    TS_LOCAL_WG(int, pos, RCH);
-#define TS_WG_E(c, tid) (((tid) >> 6) * Q + (c) * 64 + ((tid) & 63))
-    TS_PHASE(tid, 256) {
-        uint32_t o = 0u, a = 0xffffffffu;
-#pragma unroll
-        for (int c = 0; c < RCH; c++) {
-            const int e = TS_WG_E(c, tid);
-            TS_L(id, c) = v[(c < C && e < n) ? e : n - 1];
-        }
-#pragma unroll
-        for (int c = 0; c < RCH; c++) TS_L(key, c) = ts_depth_key(depth_bits(TS_L(id, c)));
-#pragma unroll
-        for (int c = 0; c < RCH; c++)
-            if (c < C && TS_WG_E(c, tid) < n) { o |= TS_L(key, c); a &= TS_L(key, c); }
-#ifdef LG_TILESORT_HOST
-        if (tid == 0) { red[0] = 0; red[1] = -1; }
-        red[0] |= (int)o; red[1] &= (int)a;
-#else
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { o |= (uint32_t)__shfl_xor((int)o, off); a &= (uint32_t)__shfl_xor((int)a, off); }
-        if ((tid & 63) == 0) { red[2 + (tid >> 6)] = (int)o; red[6 + (tid >> 6)] = (int)a; }
-#endif
-    }
-    TS_SYNC(false);
-#ifdef LG_TILESORT_HOST
-    const uint32_t or_all = (uint32_t)red[0], and_all = (uint32_t)red[1];
-#else
-    const uint32_t or_all = (uint32_t)(red[2] | red[3] | red[4] | red[5]), and_all = (uint32_t)(red[6] & red[7] & red[8] & red[9]);
-#endif
-    const uint32_t varies = or_all ^ and_all;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 8 * pass;
-        if (((varies >> shift) & 255u) == 0u) continue;
-        TS_PHASE(tid, 256) {
-            cnt[4 * tid] = 0; cnt[4 * tid + 1] = 0; cnt[4 * tid + 2] = 0; cnt[4 * tid + 3] = 0;
-        }
-        TS_SYNC(false);
-        // rank inside (wave, digit): chunks in order, lanes in order -- wave-private counters, so the waves do not interact here
-#pragma unroll
-        for (int c = 0; c < RCH; c++) {
-            if (c < C) {
-                TS_PHASE(tid, 256) {
-                    const int lane = tid & 63;
-                    int* wc = cnt + (tid >> 6) * 256;
-                    const bool ok = TS_WG_E(c, tid) < n;
-                    const uint32_t d = ok ? ((TS_L(key, c) >> shift) & 255u) : 0u;
-#ifdef LG_TILESORT_HOST
-                    (void)lane;
-                    if (ok) { TS_L(pos, c) = wc[d]; wc[d] += 1; }
-#else
-                    if constexpr (!BALLOT) {
-                        if (ok) TS_L(pos, c) = atomicAdd(&wc[d], 1);
-                    } else {
-                        unsigned long long same = __ballot(ok);
-#pragma unroll
-                        for (int b = 0; b < 8; b++) {
-                            const unsigned long long bal = __ballot((d >> b) & 1u);
-                            same &= ((d >> b) & 1u) ? bal : ~bal;
-                        }
-                        if (ok) {
-                            const int leader = __ffsll((long long)same) - 1;
-                            int base = 0;
-                            if (lane == leader) { base = wc[d]; wc[d] = base + __popcll(same); }
-                            base = __shfl(base, leader);
-                            TS_L(pos, c) = base + __popcll(same & ((1ull << lane) - 1ull));
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    }
-#endif
-                }
-            }
-        }
-        TS_SYNC(false);
-        // thread d: the four waves' counts of digit d -> exclusive scan over the digits -> first destination per (wave, digit)
-#ifdef LG_TILESORT_HOST
-        {
-            int tot[256], run = 0;
-            for (int d = 0; d < 256; d++) tot[d] = cnt[d] + cnt[256 + d] + cnt[512 + d] + cnt[768 + d];
-            for (int d = 0; d < 256; d++) {
-                const int c0 = cnt[d], c1 = cnt[256 + d], c2 = cnt[512 + d];
-                cnt[d] = run; cnt[256 + d] = run + c0; cnt[512 + d] = run + c0 + c1; cnt[768 + d] = run + c0 + c1 + c2;
-                run += tot[d];
-            }
-        }
-#else
-        TS_PHASE(tid, 256) {
-            const int c0 = cnt[tid], c1 = cnt[256 + tid], c2 = cnt[512 + tid], c3 = cnt[768 + tid];
-            const int tot = c0 + c1 + c2 + c3;
-            int incl = tot;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int nb = __shfl_up(incl, off);
-                if ((tid & 63) >= off) incl += nb;
-            }
-            if ((tid & 63) == 63) red[10 + (tid >> 6)] = incl;
-            __syncthreads();
-            int base = incl - tot;
-            for (int w = 0; w < (tid >> 6); w++) base += red[10 + w];
-            cnt[tid] = base; cnt[256 + tid] = base + c0; cnt[512 + tid] = base + c0 + c1; cnt[768 + tid] = base + c0 + c1 + c2;
-        }
-#endif
-        TS_SYNC(false);
-        TS_PHASE(tid, 256) {
-            const int* wc = cnt + (tid >> 6) * 256;
-#pragma unroll
-            for (int c = 0; c < RCH; c++)
-                if (c < C && TS_WG_E(c, tid) < n) {
-                    TS_L(pos, c) += wc[(TS_L(key, c) >> shift) & 255u];
-                    exch[TS_L(pos, c)] = TS_L(key, c);
-                }
-        }
-        TS_SYNC(false);
-        TS_PHASE(tid, 256) {
-#pragma unroll
-            for (int c = 0; c < RCH; c++)
-                if (c < C && TS_WG_E(c, tid) < n) TS_L(key, c) = exch[TS_WG_E(c, tid)];
-        }
-        TS_SYNC(false);
-        TS_PHASE(tid, 256) {
-#pragma unroll
-            for (int c = 0; c < RCH; c++)
-                if (c < C && TS_WG_E(c, tid) < n) exch[TS_L(pos, c)] = (uint32_t)TS_L(id, c);
-        }
-        TS_SYNC(false);
-        TS_PHASE(tid, 256) {
-#pragma unroll
-            for (int c = 0; c < RCH; c++)
-                if (c < C && TS_WG_E(c, tid) < n) TS_L(id, c) = (int)exch[TS_WG_E(c, tid)];
-        }
-        TS_SYNC(false);
-    }
-    if (ANY_ORDER) {
-        // as in regime R: keys are final, runs of equal keys are put into ascending id order by an odd-even transposition on the ids
-        TS_LOCAL_WG(bool, eq, RCH);
-        TS_PHASE(tid, 256) {
-#pragma unroll
-            for (int c = 0; c < RCH; c++)
-                if (c < C && TS_WG_E(c, tid) < n) exch[TS_WG_E(c, tid)] = TS_L(key, c);
-        }
-        TS_SYNC(false);
-        TS_PHASE(tid, 256) {
-            bool t = false;
-#pragma unroll
-            for (int c = 0; c < RCH; c++) {
-                const int e = TS_WG_E(c, tid);
-                TS_L(eq, c) = (c < C && e + 1 < n) && exch[e + 1] == TS_L(key, c);
-                t |= TS_L(eq, c);
-            }
-#ifdef LG_TILESORT_HOST
-            if (tid == 0) red[0] = 0;
-            red[0] |= t ? 1 : 0;
-#else
-            if (tid < 4) red[2 + tid] = 0;
-            __syncthreads();
-            if (__any(t) && (tid & 63) == 0) red[2 + (tid >> 6)] = 1;
-#endif
-        }
-        TS_SYNC(false);
-#ifdef LG_TILESORT_HOST
-        const bool any_tie = red[0] != 0;
-#else
-        const bool any_tie = (red[2] | red[3] | red[4] | red[5]) != 0;
-#endif
-        if (any_tie) {
-            TS_SYNC(false);
-            TS_PHASE(tid, 256) {
-#pragma unroll
-                for (int c = 0; c < RCH; c++)
-                    if (c < C && TS_WG_E(c, tid) < n) exch[TS_WG_E(c, tid)] = (uint32_t)TS_L(id, c);
-            }
-            TS_SYNC(false);
-            for (int sweep = 0; sweep < 2 * n + 2; sweep++) {
-                bool swapped = false;
-                for (int parity = 0; parity < 2; parity++) {
-#ifdef LG_TILESORT_HOST
-                    bool sw_any = false;
-#endif
-                    TS_PHASE(tid, 256) {
-                        bool sw = false;
-#pragma unroll
-                        for (int c = 0; c < RCH; c++) {
-                            const int e = TS_WG_E(c, tid);
-                            if (c < C && (e & 1) == parity && TS_L(eq, c)) {
-                                const uint32_t a = exch[e], b = exch[e + 1];
-                                if (a > b) { exch[e] = b; exch[e + 1] = a; sw = true; }
-                            }
-                        }
-#ifdef LG_TILESORT_HOST
-                        sw_any |= sw;
-#else
-                        swapped |= (__syncthreads_or(sw ? 1 : 0) != 0);      // also the barrier between the two parities
-#endif
-                    }
-#ifdef LG_TILESORT_HOST
-                    swapped |= sw_any;
-#endif
-                }
-                if (!swapped) break;
-            }
-            TS_PHASE(tid, 256) {
-#pragma unroll
-                for (int c = 0; c < RCH; c++)
-                    if (c < C && TS_WG_E(c, tid) < n) TS_L(id, c) = (int)exch[TS_WG_E(c, tid)];
-            }
-        }
-    }
-    TS_PHASE(tid, 256) {
-#pragma unroll
-        for (int c = 0; c < RCH; c++)
-            if (c < C && TS_WG_E(c, tid) < n) v[TS_WG_E(c, tid)] = TS_L(id, c);
-    }
-    TS_SYNC(false);
-#undef TS_WG_E
-}

@@ -13,9 +13,6 @@
 //   regime R  2 <= n <= 1024  : one wave per tile (four tiles per workgroup): stable LSD radix sort on the 32-bit depth key with the elements
 //                               in registers, 5 KB of LDS per wave (digit counters + a 4-byte exchange buffer), no workgroup barriers;
 //                               ties keep the ascending id order the list arrives in (lg_tilesort_body.h)
-//   regime W  n <= 4096       : (optional, wg_radix; a second launch) the workgroup's four waves together on ONE list with the radix sort of regime R: wave-private ranking, destinations chained
-//                               across the waves (lg_tilesort_body.h).  Motive: the bitonic regimes below cost 4x more per instance than
-//                               regime R (profiles/r03_tilesort_scaling.log)
 //   regime M  n <= 2048       : the workgroup's four waves together, bitonic network on (depth key, id) in 16 KB of LDS
 //   regime L  n  > 2048       : depth keys in global scratch; 2048-element chunks sorted in LDS, merge stages with the large strides on
 //                               global memory (one workgroup per tile: workgroup-scope visibility) and the small strides per chunk in LDS
@@ -32,7 +29,7 @@
 template <bool BALLOT, bool ANY_ORDER>
 __global__ void __launch_bounds__(256) tile_depth_sort_kernel(int* __restrict__ vals, const int* __restrict__ tile_start,
                                                               const float* __restrict__ depth, int ntiles, long long L, int N,
-                                                              uint32_t* __restrict__ scratch, const int* __restrict__ gate, int regime_w)
+                                                              uint32_t* __restrict__ scratch, const int* __restrict__ gate)
 {
     if (gate != nullptr && *gate == 0) return;              // fallback launch of the depth-bound culling that is not needed
     __shared__ uint64_t lds[(4 * TS_WAVE_WORDS * 4) / 8];   // 20 KB
@@ -64,61 +61,30 @@ __global__ void __launch_bounds__(256) tile_depth_sort_kernel(int* __restrict__ 
         if (tile > ntiles) break;
         const int start = ts[tile], end = ts[tile + 1];
         const int n = (start >= 0 && end > start) ? end - start : 0;
-        if (n > TS_RADIX_MAX && !(regime_w && n <= TS_WG_MAX)) {      // regime W lists are left to tile_depth_sort_wg_kernel
+        if (n > TS_RADIX_MAX) {
             __syncthreads();                                // the wave-private regions / the previous long list are free
             ts_sort_tile(v + start, n, lds, scratch ? scratch + (size_t)view * L + start : (uint32_t*)nullptr, depth_bits, 256, false, (int)threadIdx.x);
         }
     }
 }
 
-// Regime W as a kernel of its own (one workgroup per tile; tiles outside 1025 .. TS_WG_MAX entries leave at once): inside the kernel
-// above its register arrays would cost the common regimes a quarter of their occupancy (106 -> 150 VGPRs).
-template <bool BALLOT, bool ANY_ORDER>
-__global__ void __launch_bounds__(256) tile_depth_sort_wg_kernel(int* __restrict__ vals, const int* __restrict__ tile_start,
-                                                                 const float* __restrict__ depth, int ntiles, long long L, int N,
-                                                                 const int* __restrict__ gate)
-{
-    if (gate != nullptr && *gate == 0) return;
-    __shared__ uint32_t exch[TS_WG_MAX];
-    __shared__ int cnt[4 * 256];
-    __shared__ int red[16];
-    const int view = blockIdx.y, tile = blockIdx.x + 1;
-    const int* __restrict__ ts = tile_start + (size_t)view * (ntiles + 2);
-    const int start = ts[tile], end = ts[tile + 1];
-    const int n = (start >= 0 && end > start) ? end - start : 0;
-    if (n <= TS_RADIX_MAX || n > TS_WG_MAX) return;
-    const float* __restrict__ dz = depth + (size_t)view * N;
-    auto depth_bits = [dz](int id) -> uint32_t { return __float_as_uint(dz[id]); };
-    ts_radix_sort_tile_wg<BALLOT, ANY_ORDER>(vals + (size_t)view * L + start, n, exch, cnt, red, depth_bits, (int)threadIdx.x);
-}
-
 // vals [V, L] int32 splat ids grouped by tile (ascending id inside a tile unless any_order), tile_start [V, ntiles + 2] (lg_tile_range), depth [V, N] view depths.
 // scratch [V, L] uint32 (any content; only touched for lists longer than 2048 -- nullable only if such lists cannot occur).
 // gate (nullable device int): nothing runs unless *gate != 0.
 int lg_tile_depth_sort_gated(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
-                             uint32_t* scratch, int any_order, int wg_radix, const int* gate, void* stream)
+                             uint32_t* scratch, int any_order, const int* gate, void* stream)
 {
     if (ntiles <= 0 || L <= 0 || V <= 0) return 0;
-    const int g_regime_w = wg_radix ? 1 : 0;
     // ranking inside a digit: the verified lane-ordered LDS add, or the ballot ranking when the device self-test says otherwise (binning.hip)
     const bool ballot = lg_radix_rank_mode() != 0;
     const dim3 grid(lg_cdiv(ntiles, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_TDS(B_, A_) hipLaunchKernelGGL((tile_depth_sort_kernel<B_, A_>), grid, block, 0, s, vals, tile_start, depth, ntiles, L, N, scratch, gate, g_regime_w)
+#define LAUNCH_TDS(B_, A_) hipLaunchKernelGGL((tile_depth_sort_kernel<B_, A_>), grid, block, 0, s, vals, tile_start, depth, ntiles, L, N, scratch, gate)
     if (!ballot && !any_order) LAUNCH_TDS(false, false);
     else if (!ballot) LAUNCH_TDS(false, true);
     else if (!any_order) LAUNCH_TDS(true, false);
     else LAUNCH_TDS(true, true);
 #undef LAUNCH_TDS
-    if (g_regime_w) {
-        const dim3 grid_w(ntiles, V);
-#define LAUNCH_TDW(B_, A_) hipLaunchKernelGGL((tile_depth_sort_wg_kernel<B_, A_>), grid_w, block, 0, s, vals, tile_start, depth, ntiles, L, N, gate)
-        if (!ballot && !any_order) LAUNCH_TDW(false, false);
-        else if (!ballot) LAUNCH_TDW(false, true);
-        else if (!any_order) LAUNCH_TDW(true, false);
-        else LAUNCH_TDW(true, true);
-#undef LAUNCH_TDW
-    }
     LG_RETURN_LAST();
 }
 
@@ -126,7 +92,7 @@ LG_API int lg_tile_depth_sort(int32_t* vals, const int32_t* tile_start, const fl
                               uint32_t* scratch, void* stream)
 {
     if (vals == nullptr || tile_start == nullptr || depth == nullptr || scratch == nullptr) return (int)hipErrorInvalidValue;
-    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 0, 0, nullptr, stream);
+    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 0, nullptr, stream);
 }
 
 // the same for lists that arrive in arbitrary order (lg_tile_group): equal depths are ordered by id explicitly
@@ -134,12 +100,5 @@ LG_API int lg_tile_depth_sort_unordered(int32_t* vals, const int32_t* tile_start
                                         uint32_t* scratch, void* stream)
 {
     if (vals == nullptr || tile_start == nullptr || depth == nullptr || scratch == nullptr) return (int)hipErrorInvalidValue;
-    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 1, 0, nullptr, stream);
-}
-
-LG_API int lg_tile_depth_sort_ex(int32_t* vals, const int32_t* tile_start, const float* depth, int V, long long L, int N, int ntiles,
-                                 uint32_t* scratch, int any_order, int wg_radix, void* stream)
-{
-    if (vals == nullptr || tile_start == nullptr || depth == nullptr || scratch == nullptr) return (int)hipErrorInvalidValue;
-    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, any_order, wg_radix, nullptr, stream);
+    return lg_tile_depth_sort_gated(vals, tile_start, depth, V, L, N, ntiles, scratch, 1, nullptr, stream);
 }

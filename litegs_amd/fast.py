@@ -33,7 +33,7 @@ class LgFusedCtx(ctypes.Structure):
     """include/litegs_hip.h: the executor's per-call context (the library keeps no process-wide executor state)"""
     _fields_ = [("struct_bytes", ctypes.c_int32), ("depth_order", ctypes.c_int32), ("bound_margin_pct", ctypes.c_int32),
                 ("tile_scatter", ctypes.c_int32), ("grad_replicas", ctypes.c_int32), ("step_id", ctypes.c_int32),
-                ("debug_validate", ctypes.c_int32), ("tilesort_wg_radix", ctypes.c_int32),
+                ("debug_validate", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("hot_counter", ctypes.c_void_p), ("poison", ctypes.c_void_p), ("poison_host", ctypes.c_void_p),
                 ("applied_host", ctypes.c_void_p), ("debug_words", ctypes.c_void_p)]
 
@@ -121,11 +121,14 @@ class FusedRenderer:
         self.stat_schedule_always = os.environ.get("LITEGS_STAT_TILE_SCHEDULE", "always") != "stat"
         self.validate_tables = os.environ.get("LITEGS_VALIDATE_TABLES", "0") == "1"      # debugging aid (csrc/fused.hip "Table validators")
         self.tile_scatter = True           # per-tile mode: group by tile with counts + cursors (False: stable tile radix sort); same tables
-        self.tilesort_wg_radix = os.environ.get("LITEGS_TILESORT_WG_RADIX", "0") == "1"
         self.replicas_enabled = True       # gradient replicas (csrc/raster.hip) for renders whose records only the fused backward kernels consume
-        # a frame whose previous visit emitted more than this many instances per tile on average takes the splat sort + stable tile radix
-        # sort instead of tile scatter + per-tile sort (0 = never); automatic depth-order mode only
-        self.long_list_global = 0
+        # Automatic depth-order mode: a frame whose previous visit emitted more than this many instances per tile on average takes the splat
+        # sort + stable tile radix sort instead of tile scatter + per-tile sort (0 = never).  The per-tile sort is a one-wave register radix
+        # sort up to 1024 entries (8-12 us per million instances) and falls back to bitonic networks beyond (30-34 us per million); late in
+        # a density-control run lists average 1200-2500 entries (19-24 M instances per 1080p frame) and the per-tile sort alone is 0.76 ms of
+        # a 4.0 ms step, the global route 0.49 ms cheaper in total (profiles/r04_late_phase_ab_tile_vs_global_vs_regime_w.log).  At the
+        # bench's clouds (170-720 per tile) the per-tile route wins.
+        self.long_list_global = 640
         # Per frame: a heaviest-first tile schedule (csrc/raster.hip; a hint -- results do not depend on it -- recomputed on a frame's
         # first visit and then every `cull_refresh`-th) and two depth-bound blocks (csrc/lg_tilewalk.h) used alternately: every
         # visit's blend forward records per-tile saturation depths, and the next visit of the frame skips the splats no tile will
@@ -242,7 +245,6 @@ class FusedRenderer:
         c.bound_margin_pct = max(1, int(margin))
         c.tile_scatter = 1 if self.tile_scatter else 0
         c.grad_replicas = 1 if replicas else 0
-        c.tilesort_wg_radix = 1 if self.tilesort_wg_radix else 0
         c.hot_counter = self.hot_counter.data_ptr() if self.hot_counter is not None else None
         if speculate and self.speculating:
             c.poison = self.spec_poison.data_ptr()

@@ -57,6 +57,20 @@ def make_scene(n: int, seed: int = 0, sh_degree: int = 3, radius: float = 4.0, c
     return tuple(out)
 
 
+def perturb(scene, seed: int, amount: float = 1.0):
+    """student = teacher + seeded noise in raw parameter space (positions 2 % of the radius, 25 % axis lengths, colours, opacity; the SH
+    rest starts at zero) -- the start of the teacher -> student training runs (tests/convergence*.py, bench.py's training_state)."""
+    rng = np.random.default_rng(seed)
+    xyz, scale, rot, sh0, shr, opa = [np.array(a, copy=True) for a in scene]
+    xyz += amount * 0.08 * rng.standard_normal(xyz.shape).astype(np.float32)
+    scale += amount * 0.25 * rng.standard_normal(scale.shape).astype(np.float32)
+    rot += amount * 0.2 * rng.standard_normal(rot.shape).astype(np.float32)
+    sh0 += amount * 0.4 * rng.standard_normal(sh0.shape).astype(np.float32)
+    shr = shr * 0.0
+    opa += amount * 0.7 * rng.standard_normal(opa.shape).astype(np.float32)
+    return xyz, scale, rot, sh0, shr.astype(np.float32), opa
+
+
 def quat_to_rot(q):
     w, x, y, z = q
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],

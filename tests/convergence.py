@@ -33,17 +33,7 @@ from litegs_amd import synthetic as S             # noqa: E402
 from litegs_amd.trainer import SyntheticTrainer   # noqa: E402
 
 
-def perturb(scene, seed, amount=1.0):
-    """student = teacher + seeded noise in raw parameter space (positions 2 % of the radius, 25 % axis lengths, colours, opacity)."""
-    rng = np.random.default_rng(seed)
-    xyz, scale, rot, sh0, shr, opa = [np.array(a, copy=True) for a in scene]
-    xyz += amount * 0.08 * rng.standard_normal(xyz.shape).astype(np.float32)
-    scale += amount * 0.25 * rng.standard_normal(scale.shape).astype(np.float32)
-    rot += amount * 0.2 * rng.standard_normal(rot.shape).astype(np.float32)
-    sh0 += amount * 0.4 * rng.standard_normal(sh0.shape).astype(np.float32)
-    shr = shr * 0.0
-    opa += amount * 0.7 * rng.standard_normal(opa.shape).astype(np.float32)
-    return xyz, scale, rot, sh0, shr.astype(np.float32), opa
+perturb = S.perturb          # the student's start (litegs_amd/synthetic.py)
 
 
 def make_trainer(scene, cfg, fused):

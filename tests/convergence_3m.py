@@ -101,8 +101,10 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
         epoch_ms.append((time.time() - te) / cfg["frames"] * 1e3)
         if fused:
             epoch_inst.append(float(np.mean(tr.renderer.fb_total)))
-        if save_at and fused and epoch + 1 == int(save_at.rsplit(":", 1)[1]) and not os.path.exists(save_at.rsplit(":", 1)[0]):
-            save_state(save_at.rsplit(":", 1)[0], tr, epoch + 1)
+        for spec in filter(None, (save_at or "").split(",")):          # "<file>:<epoch>[,<file>:<epoch>...]"
+            path, at = spec.rsplit(":", 1)
+            if fused and epoch + 1 == int(at) and not os.path.exists(path):
+                save_state(path, tr, epoch + 1)
         if os.environ.get("LITEGS_CONV_SNAPSHOT"):
             _snapshot(os.environ["LITEGS_CONV_SNAPSHOT"], f"{'executor' if fused else 'operator'} epoch {epoch}", tr)
         if os.environ.get("LITEGS_CONV_VERBOSE"):

@@ -10,7 +10,7 @@
 #include <vector>
 #include "lg_tilesort_body.h"
 
-static int check(int n, int n_splats, int distinct_depths, std::mt19937& rng, bool radix = false, bool any_order = false, bool wg = false)
+static int check(int n, int n_splats, int distinct_depths, std::mt19937& rng, bool radix = false, bool any_order = false)
 {
     std::vector<float> depth(n_splats);
     std::uniform_real_distribution<float> ud(0.01f, 40.0f);
@@ -31,12 +31,7 @@ static int check(int n, int n_splats, int distinct_depths, std::mt19937& rng, bo
     std::vector<uint64_t> sk(TS_CHUNK);
     std::vector<uint32_t> dk(n);
     const bool small = n <= TS_SMALL;
-    if (wg) {                // regime W: the four waves of a workgroup on one list of 1025 .. TS_WG_MAX entries
-        std::vector<uint32_t> exch(TS_WG_MAX);
-        std::vector<int> cnt(4 * 256), red(16);
-        if (any_order) ts_radix_sort_tile_wg<false, true>(v.data(), n, exch.data(), cnt.data(), red.data(), bits);
-        else ts_radix_sort_tile_wg<false, false>(v.data(), n, exch.data(), cnt.data(), red.data(), bits);
-    } else if (radix) {
+    if (radix) {
         std::vector<uint32_t> exch(TS_RADIX_MAX);
         std::vector<int> cnt(256);
         if (any_order) ts_radix_sort_tile<false, true>(v.data(), n, exch.data(), cnt.data(), bits);
@@ -80,19 +75,6 @@ int main()
     }
     // regimes M / L sort by the 64-bit key (depth, id): any arrival order
     for (int n : {1025, 2048, 2049, 5000, 9000}) { if (bad) break; bad |= check(n, n + 5, 3, rng, false, true); bad |= check(n, n + 5, 0, rng, false, true); cases += 2; }
-    // regime W (workgroup radix sort): lengths across its whole range (it also has to be right below 1025: the mapping is general),
-    // id-ordered and arbitrary arrival, random depths, long / short runs of ties, one depth
-    for (int n : {2, 3, 63, 64, 65, 255, 256, 257, 1000, 1024, 1025, 1026, 1279, 1280, 1281, 1500, 2047, 2048, 2049, 2303, 2304, 2305, 3000, 3583, 3584, 3585, 4000, 4094, 4095, 4096}) {
-        if (bad) break;
-        for (int any = 0; any < 2 && !bad; any++) {
-            bad |= check(n, n + 9, 0, rng, true, any != 0, true); cases++;
-            bad |= check(n, n + 5, 3, rng, true, any != 0, true); cases++;
-            bad |= check(n, n + 5, 1, rng, true, any != 0, true); cases++;
-            bad |= check(n, n + 5, 200, rng, true, any != 0, true); cases++;
-            bad |= check(n, n + 5, n / 2 + 1, rng, true, any != 0, true); cases++;
-        }
-    }
-    for (int n = 1025; n <= TS_WG_MAX && !bad; n += 37) { bad |= check(n, n + 11, 0, rng, true, (n & 1) != 0, true); cases++; }
     // the flip/step pair generators enumerate disjoint pairs covering [0, P)
     for (int lp = 1; lp <= 12 && !bad; lp++) {
         const int P = 1 << lp;

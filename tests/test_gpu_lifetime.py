@@ -104,9 +104,9 @@ def test_executor_context_is_per_call():
     view, proj, planes = [torch.from_numpy(x).cuda() for x in (c["view"], c["proj"], c["planes"])]
     origin, extend = R.get_cluster_AABB(params[0], params[1].exp(), torch.nn.functional.normalize(params[2], dim=0))
     rds = []
-    for mode, scatter, wg in ((0, True, False), (1, True, True), (1, False, False)):
+    for mode, scatter in ((0, True), (1, True), (1, False)):
         rd = fast.FusedRenderer(1, H, W)
-        rd.depth_order, rd.tile_scatter, rd.tilesort_wg_radix = mode, scatter, wg
+        rd.depth_order, rd.tile_scatter = mode, scatter
         rds.append(rd)
     cam = fast.CameraFrame(view, proj, planes, 0)
     imgs = []

@@ -189,36 +189,3 @@ def test_executor_tables_match_the_oracle_with_the_tile_scatter(oracle):
         pts = ws2[o_pts:o_pts + 4 * res.n_instances].view(torch.int32).cpu().numpy()
         np.testing.assert_array_equal(ts, res.tile_start[0], err_msg=f"scatter={scatter}")
         np.testing.assert_array_equal(pts, res.sorted_point[0], err_msg=f"scatter={scatter}")
-
-
-@pytest.mark.parametrize("ties", [False, True])
-def test_regime_w_of_the_tile_sort_matches_stable_sorts(ties):
-    """lists of 1025 .. 4096 entries through the workgroup radix sort (lg_tile_depth_sort_ex, wg_radix = 1), id-ordered and arbitrary
-    arrival: by (depth key, id), exactly as the bitonic regimes leave them"""
-    from litegs_amd import fused
-    from litegs_amd._lib import check, lib
-    L_ = lib()
-    rng = np.random.default_rng(7 + int(ties))
-    lengths = [1025, 1026, 1500, 2047, 2048, 2049, 3000, 4095, 4096, 700, 4097, 1300, 2]
-    ntiles = len(lengths) + 2
-    N = 60000
-    depth = rng.uniform(0.01, 50.0, size=N).astype(np.float32)
-    if ties:
-        depth = rng.choice(rng.uniform(0.5, 9.0, size=300).astype(np.float32), size=N)
-    keys = np.concatenate([np.full((n,), t + 1, np.int32) for t, n in enumerate(lengths)])
-    lists = [np.sort(rng.choice(N, size=n, replace=False)).astype(np.int32) for n in lengths]
-    dev = torch.device("cuda", 0)
-    pk = torch.from_numpy(depth[None].copy()).to(dev)
-    start = fused.tileRange(torch.from_numpy(keys[None]).to(dev), ntiles)
-    s = torch.cuda.current_stream().cuda_stream
-    for any_order in (False, True):
-        vals = np.concatenate([rng.permutation(l) if any_order else l for l in lists])
-        tv = torch.from_numpy(vals[None].copy()).to(dev)
-        scratch = torch.empty((1, len(vals)), dtype=torch.int32, device=dev)
-        check(L_.lg_tile_depth_sort_ex(tv.data_ptr(), start.data_ptr(), pk.data_ptr(), 1, len(vals), N, ntiles, scratch.data_ptr(),
-                                       1 if any_order else 0, 1, s), "sort")
-        got, off = tv.cpu().numpy()[0], 0
-        for t, ids in enumerate(lists[:-1]):                      # the last run has no closing entry (tileRange): not a list
-            want = ids[np.lexsort((ids, _depth_key(depth[ids])))]
-            np.testing.assert_array_equal(got[off:off + len(ids)], want, err_msg=f"list {t} n={len(ids)} any_order={any_order}")
-            off += len(ids)

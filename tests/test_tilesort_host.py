@@ -1,7 +1,7 @@
 """The per-tile depth sort's network and its three list-length regimes, emulated on the host: litegs_amd/csrc/lg_tilesort_body.h is
 written so that the same text compiles as device code (tilesort.hip) and as a sequential C++ program (tests/host/bitonic_check.cpp),
-which compares it with std::stable_sort for ≈2500 lists (every length 2..700, chunk edges up to 20 000, duplicate-heavy depths, the
-wave radix regime at every length, arbitrary arrival orders, and the workgroup radix regime W across 2..4096)."""
+which compares it with std::stable_sort for ≈2100 lists (every length 2..700, chunk edges up to 20 000, duplicate-heavy depths, the
+wave radix regime at every length, arbitrary arrival orders)."""
 import os
 import shutil
 import subprocess

@@ -1,5 +1,8 @@
 """Developer tool: cost of the data-parallel exchange glue on ONE GPU (single-rank RCCL group: the collectives degenerate to copies, what
-remains is the compaction / map / accumulation work every rank does per step).  Frozen parameters (lr 0): the workload does not drift."""
+remains is the compaction / map / accumulation work every rank does per step).  Frozen parameters (lr 0): the workload does not drift.
+    python tools/dp_glue_bench.py [--outside] [--trained <steps>] [modes...]
+--trained N: first train the cloud for N steps (noise targets, as bench.py's steady_state): most visible Gaussians then carry gradients and
+Adam history, and the moment records per rank grow from ~10^4 to ~10^6 -- the state the exchange has to be sized for."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,11 +16,19 @@ cfg = "3m_1080p"
 n, W, H, f = S.CONFIGS[cfg]
 outside = "--outside" in sys.argv                      # camera outside the cloud: a frame touches ~10x more Gaussians
 tr = SyntheticTrainer(n, W, H, f, n_frames=4, cam_radius_frac=(1.6 if outside else 0.5))
+trained = int(sys.argv[sys.argv.index("--trained") + 1]) if "--trained" in sys.argv else 0
+if trained:
+    tr.speculative = True
+    for i in range(trained):
+        tr.step(i % 4)
+    tr.flush()
+    tr.speculative = False
 for g in tr.opt.param_groups:
     g["lr"] = 0.0
 tr.sched.step = lambda: None
 out = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "dp_glue.log"), "a")
-modes = [a for a in sys.argv[1:] if not a.startswith("--")] or ["none", "moments", "sparse"]
+modes = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()] or ["none", "moments", "sparse"]
+label = ("outside " if outside else "") + (f"trained {trained} steps " if trained else "")
 for mode in modes:
     ex = None if mode == "none" else (dp.MomentExchange(tr.params, 1) if mode == "moments" else dp.GradientExchange(tr.params, 1, mode=mode))
     hook = None if ex is None else (ex if mode == "moments" else ex.hook)
@@ -34,5 +45,7 @@ for mode in modes:
         extra = f", record capacity {ex.last_cap}, block bytes {(1 + ex.last_cap) * 40}"
     elif ex is not None:
         extra = f", last K = {ex.last_k}"
-    print(f"{'outside ' if outside else ''}{mode}: {(time.perf_counter() - t) / K * 1e3:.3f} ms/step (world 1){extra}", file=out, flush=True)
+    line = f"{label}{mode}: {(time.perf_counter() - t) / K * 1e3:.3f} ms/step (world 1){extra}"
+    print(line, file=out, flush=True)
+    print(line, flush=True)
 dist.destroy_process_group()

@@ -57,14 +57,15 @@ for STAGE in "$@"; do
       done ;;
     conv:*)
       RUNS=${STAGE#conv:}
-      rm -f /tmp/late.pt gpurun_out/conv_snap_$TAG.jsonl
-      LITEGS_CONV_SAVE=/tmp/late.pt:120 LITEGS_CONV_SNAPSHOT=/tmp/conv_snap_$TAG.jsonl LITEGS_CONV_PARTIAL=gpurun_out/convergence_3m_${TAG}_partial.json \
+      rm -f /tmp/late.pt /tmp/mid.pt gpurun_out/conv_snap_$TAG.jsonl
+      LITEGS_CONV_SAVE=/tmp/late.pt:120,/tmp/mid.pt:27 LITEGS_CONV_SNAPSHOT=/tmp/conv_snap_$TAG.jsonl LITEGS_CONV_PARTIAL=gpurun_out/convergence_3m_${TAG}_partial.json \
         LITEGS_CONV_SKIP_OPERATOR=profiles/r03_convergence_3m.json timeout -s KILL 2400 python -X faulthandler tests/convergence_3m.py --runs $RUNS $CONV_ARGS \
         --out gpurun_out/convergence_3m_$TAG.md > gpurun_out/convergence_3m_$TAG.log 2>&1
       echo "exit $?"; grep -E "executor:|fault|Error|error" gpurun_out/convergence_3m_$TAG.log | head -20
       tail -c 20000000 /tmp/conv_snap_$TAG.jsonl | tail -n 3 > gpurun_out/conv_snap_tail_$TAG.jsonl ;;
     late)
       timeout -s KILL 900 python tools/late_phase.py ab /tmp/late.pt > gpurun_out/late_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/late_ab_$TAG.log | tail -14
+      if [ -f /tmp/mid.pt ]; then timeout -s KILL 600 python tools/late_phase.py ab /tmp/mid.pt default,global,own_schedule > gpurun_out/mid_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/mid_ab_$TAG.log | tail -8; fi
       timeout -s KILL 600 python tools/late_phase.py parity /tmp/late.pt > gpurun_out/late_parity_$TAG.log 2>&1; grep -E "parity|PARITY" gpurun_out/late_parity_$TAG.log | tail -12 ;;
     latetrace)
       for V in default stat_epoch; do
@@ -80,7 +81,14 @@ for STAGE in "$@"; do
         rm -rf gpurun_out/pmc_late_$TAG
       done ;;
     dpglue)
-      timeout -s KILL 400 python tools/dp_glue_bench.py > gpurun_out/dp_glue_$TAG.log 2>&1; tail -12 gpurun_out/dp_glue_$TAG.log ;;
+      rm -f gpurun_out/dp_glue.log
+      timeout -s KILL 300 python tools/dp_glue_bench.py > gpurun_out/dp_glue_$TAG.log 2>&1
+      timeout -s KILL 400 python tools/dp_glue_bench.py --trained 1000 >> gpurun_out/dp_glue_$TAG.log 2>&1; grep "ms/step" gpurun_out/dp_glue_$TAG.log ;;
+    spec)
+      timeout -s KILL 400 python tools/spec_noise.py 3 > gpurun_out/spec_noise_$TAG.log 2>&1; grep -v amdgpu.ids gpurun_out/spec_noise_$TAG.log | cut -c1-220 ;;
+    conv8)
+      LITEGS_CONV_SKIP_OPERATOR=profiles/r03_convergence_3m.json timeout -s KILL 600 python tests/convergence_3m.py --runs 1 --frames 8 --iterations 1600 --eval-every 20 \
+        --out gpurun_out/conv8_$TAG.md > gpurun_out/conv8_$TAG.log 2>&1; grep -E "executor:" gpurun_out/conv8_$TAG.log; grep -A30 "Cost per iteration" gpurun_out/conv8_$TAG.md | tail -26 ;;
     *) echo "unknown stage $STAGE" ;;
   esac
 done

@@ -9,8 +9,6 @@ import torch
 from litegs_amd._lib import lib, check
 
 L_ = lib()
-WG = 1 if os.environ.get("LITEGS_TILESORT_WG_RADIX") == "1" else 0          # A/B: lists of 1025..4096 through the workgroup radix sort
-print("workgroup radix regime", "on" if WG else "off")
 ntiles, N = 16200, 1_200_000
 lengths = [int(x) for x in sys.argv[1:]] or [250, 700, 1000, 1500, 2500, 4000]
 dev = torch.device("cuda", 0)
@@ -28,7 +26,7 @@ for n in lengths:
         vals = base.clone()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        check(L_.lg_tile_depth_sort_ex(vals.data_ptr(), ts.data_ptr(), depth.data_ptr(), 1, total, N, ntiles, scratch.data_ptr(), 1, WG, s), "sort")
+        check(L_.lg_tile_depth_sort_unordered(vals.data_ptr(), ts.data_ptr(), depth.data_ptr(), 1, total, N, ntiles, scratch.data_ptr(), s), "sort")
         b.record(); torch.cuda.synchronize()
         ms.append(a.elapsed_time(b))
     d = depth[vals[: n].long()]
