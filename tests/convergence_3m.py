@@ -102,8 +102,8 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
         if fused:
             epoch_inst.append(float(np.mean(tr.renderer.fb_total)))
         for spec in filter(None, (save_at or "").split(",")):          # "<file>:<epoch>[,<file>:<epoch>...]"
-            path, at = spec.rsplit(":", 1)
-            if fused and epoch + 1 == int(at) and not os.path.exists(path):
+            path, at_epoch = spec.rsplit(":", 1)
+            if fused and epoch + 1 == int(at_epoch) and not os.path.exists(path):
                 save_state(path, tr, epoch + 1)
         if os.environ.get("LITEGS_CONV_SNAPSHOT"):
             _snapshot(os.environ["LITEGS_CONV_SNAPSHOT"], f"{'executor' if fused else 'operator'} epoch {epoch}", tr)

@@ -150,13 +150,16 @@ def test_speculative_culling_replays_failed_steps():
     rb = tb.renderer
     assert not rb.poisoned() and int(rb.spec_poison.item()) == 0
     assert rb.applied_step() == 14                           # every step's Adam launch has run, the last one being step 14
+    # Adam turns a last-bit gradient difference of a Gaussian with a near-zero gradient into a +-lr step, so the MAXIMUM difference between
+    # two runs of the SAME mode is already of the order of the parameter change (tools/spec_noise.py: opacity 0.15-0.30 between two gated
+    # runs); the MEAN absolute difference is what separates the two cases -- most Gaussians agree to the last bits between two correct runs,
+    # while a lost or doubled Adam step moves every visible Gaussian by about one learning-rate step
     for pa, pa2, pb in zip(ta.params, ta2.params, tb.params):
         assert torch.isfinite(pb).all()
-        noise = (pa.detach() - pa2.detach()).abs().max().item()
-        d = (pa.detach() - pb.detach()).abs().max().item()
-        # Adam turns last-bit gradient differences into +-lr steps, so two runs of the SAME mode differ already; a lost or doubled step
-        # would show up as a difference of the order of the parameter change itself
-        assert d <= 4.0 * noise + 1e-6, (d, noise)
+        noise = (pa.detach() - pa2.detach()).abs().mean().item()
+        d = (pa.detach() - pb.detach()).abs().mean().item()
+        assert d <= 3.0 * noise + 1e-7, (d, noise)
+    np.testing.assert_allclose(la, lb, rtol=2e-4)             # the loss of every step: what each step saw is what the gated run saw
     moved = max((p.detach() - torch.from_numpy(q).cuda()).abs().max().item() for p, q in zip(tb.params, S.make_scene(150_000, seed=5)))
     assert moved > 1e-2                                      # the 14 steps really changed the parameters
     np.testing.assert_allclose(la[:6], lb[:6], rtol=1e-4)    # before the first sabotage the two runs are the same computation
