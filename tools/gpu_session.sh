@@ -55,6 +55,12 @@ for STAGE in "$@"; do
           rm -rf gpurun_out/pmc_${STATE}_${NAME}_$TAG
         done
       done ;;
+    convown:*)       # whole-run A/B: the executor keeps its own schedule + depth-bound culling after the first statistics epoch
+      RUNS=${STAGE#convown:}
+      LITEGS_CONV_SNAPSHOT=/tmp/conv_snap_own_$TAG.jsonl LITEGS_CONV_PARTIAL=gpurun_out/convergence_3m_own_${TAG}_partial.json \
+        LITEGS_CONV_SKIP_OPERATOR=profiles/r03_convergence_3m.json timeout -s KILL 2400 python -X faulthandler tests/convergence_3m.py --runs $RUNS --set stat_schedule_always=false$CONV_OWN_EXTRA \
+        --out gpurun_out/convergence_3m_own_$TAG.md > gpurun_out/convergence_3m_own_$TAG.log 2>&1
+      echo "exit $?"; grep -E "executor:|fault|Error|error" gpurun_out/convergence_3m_own_$TAG.log | head -20 ;;
     conv:*)
       RUNS=${STAGE#conv:}
       rm -f /tmp/late.pt /tmp/mid.pt gpurun_out/conv_snap_$TAG.jsonl
