@@ -106,6 +106,19 @@ __device__ __forceinline__ float wave_sum(float v)
     v += xor_dpp1(v); v += xor_dpp2(v); v += xor_swz4(v); v += xor_swz8(v); v += xor_swz16(v); v += xor_32(v);
     return v;
 }
+// Sum over the wave, total in lane 63, on the DPP path alone (no LDS crossbar, no bpermute): in-row prefix by row_shr 1, 2, 4, 8 (lane 15
+// of every row holds its row total), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Six add-with-DPP slots.
+#define DPP_ADD(v, ctrl, row_mask, bank_mask) ((v) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, row_mask, bank_mask, false)))
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = DPP_ADD(v, 0x111, 0xF, 0xF);       // row_shr:1  (lanes shifted in from outside the row contribute the `old` operand: 0)
+    v = DPP_ADD(v, 0x112, 0xF, 0xF);       // row_shr:2
+    v = DPP_ADD(v, 0x114, 0xF, 0xF);       // row_shr:4
+    v = DPP_ADD(v, 0x118, 0xF, 0xF);       // row_shr:8
+    v = DPP_ADD(v, 0x142, 0xA, 0xF);       // row_bcast:15 -> rows 1, 3
+    v = DPP_ADD(v, 0x143, 0xC, 0xF);       // row_bcast:31 -> rows 2, 3
+    return v;
+}
 __device__ __forceinline__ int wave_max_i(int v)
 {
 #pragma unroll
@@ -272,7 +285,10 @@ __device__ __forceinline__ float min_where(float a, float b, unsigned long long 
     asm("v_min_f32 %0, %1, %2\n\tv_cndmask_b32_e64 %0, 0, %0, %3" : "=&v"(r) : "v"(a), "v"(b), "s"(mask));
     return r;
 }
-__device__ __forceinline__ bool fwd_splat_fast(FwdFast& st, const f32x16& rec)
+// STAT (statistic epochs, GR/raster.cu:283-302): fragment count and weight sum of the splat.  The count is the popcount of the two validity
+// masks (scalar unit), the weight sum one DPP reduction; one lane issues the two atomics.
+template <bool STAT>
+__device__ __forceinline__ bool fwd_splat_fast(FwdFast& st, const f32x16& rec, unsigned id, int lane, int* __restrict__ frag_count, float* __restrict__ frag_weight)
 {
     const unsigned long long act0 = __builtin_amdgcn_ballot_w64(st.T.x > 1.0f / 8192), act1 = __builtin_amdgcn_ballot_w64(st.T.y > 1.0f / 8192);
     if ((act0 | act1) == 0ull) return false;         // checked BEFORE blending, as the reference does
@@ -294,6 +310,14 @@ __device__ __forceinline__ bool fwd_splat_fast(FwdFast& st, const f32x16& rec)
     st.Cg = rec[R_CG] * w + st.Cg;
     st.Cb = rec[R_CB] * w + st.Cb;
     st.T = st.T - w;                                 // T * (1 - alpha)
+    if constexpr (STAT) {
+        const int fct = __popcll(val0) + __popcll(val1);           // s_bcnt1: no vector instruction
+        const float wst = wave_sum_to_lane63(w.x + w.y);
+        if (lane == 63) {
+            atomicAdd(&frag_count[id], fct);
+            unsafeAtomicAdd(&frag_weight[id], wst);
+        }
+    }
     return true;
 }
 
@@ -340,7 +364,7 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     bool live = true;
     const int n = (start >= 0 && end > start) ? end - start : 0;
     const int* __restrict__ sp = sorted_points + (size_t)view * L + (start >= 0 ? start : 0);
-    if constexpr (PPL == 2 && !STAT) {
+    if constexpr (PPL == 2) {
         if (n > 0 && fast) {
             FwdFast f;
             f.X = st.X; f.Y = v2f{ st.Y[0], st.Y[1] }; f.T = v2f{ 1.0f, 1.0f };
@@ -356,16 +380,17 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
             rec_request(ra, pk, (unsigned)id_a << 6);
             rec_wait(ra);
             for (int pos = 0; pos < n; pos += 2) {                            // `ra` holds position pos
+                const unsigned cur_a = (unsigned)id_a, cur_b = (unsigned)id_b;  // splat ids of `ra` / `rb` (statistics)
                 rec_request(rb, pk, (unsigned)id_b << 6);
                 id_request(id_a, sp, (unsigned)min(pos + 2, n - 1) << 2);
-                live = fwd_splat_fast(f, ra);
+                live = fwd_splat_fast<STAT>(f, ra, cur_a, lane, frag_count, frag_weight);
                 rec_id_wait(rb, id_a);
                 if (!live) break;
                 visited = pos + 1;
                 if (pos + 1 >= n) break;                                       // odd tail: the list ends here
                 rec_request(ra, pk, (unsigned)id_a << 6);
                 id_request(id_b, sp, (unsigned)min(pos + 3, n - 1) << 2);
-                live = fwd_splat_fast(f, rb);
+                live = fwd_splat_fast<STAT>(f, rb, cur_b, lane, frag_count, frag_weight);
                 rec_id_wait(ra, id_b);
                 if (!live) break;
                 visited = pos + 2;
@@ -873,9 +898,12 @@ struct BwdFast {
     int lc0, lc1;
 };
 
-template <bool TRANS, bool CHECK>
+// STAT (statistic epochs): the per-splat sum of squares of the running d_opacity of GR/raster.cu:781-783 -- per lane, after its first pixel
+// (m0 / opacity)^2 and after its second ((m0 + m1) / opacity)^2, the second term only if some pixel of the wave takes the splat in that
+// pixel row group (the reference's per-row-group gate, raster.cu:753) -- reduced on the DPP path and added by one lane.
+template <bool TRANS, bool CHECK, bool STAT>
 __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, int pos, unsigned pid_off, unsigned slot_off,
-                                               unsigned long long writers, float* __restrict__ pg)
+                                               unsigned long long writers, float* __restrict__ pg, float* __restrict__ err_square_sum, int lane)
 {
     const float dx = rec[R_PX] - st.X;
     const float t1 = rec[R_B2] * dx;
@@ -916,14 +944,21 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     asm volatile("s_mov_b64 exec, %2\n\t"
                  "global_atomic_add_f32 %0, %1, %3\n\t"
                  "s_mov_b64 exec, -1" : : "v"(slot_off), "v"(tot), "s"(writers), "s"(base) : "memory");
+    if constexpr (STAT) {
+        const float inv_o = __builtin_amdgcn_rcpf(rec[R_O]);
+        const float vo0 = m.x * inv_o, vo1 = s0 * inv_o;
+        const float esq = wave_sum_to_lane63(__builtin_fmaf(vo0, vo0, __any(val1) ? vo1 * vo1 : 0.0f));
+        if (lane == 63) unsafeAtomicAdd(&err_square_sum[pid_off >> 6], esq);
+    }
 }
 
-template <bool TRANS>
+template <bool TRANS, bool STAT>
 __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
                                                                    const float* __restrict__ packed, const int* __restrict__ tiles, int K,
                                                                    const float* __restrict__ final_T, const short* __restrict__ last,
                                                                    const float* __restrict__ d_img, const float* __restrict__ d_trans,
-                                                                   float* __restrict__ packed_grad, const int* __restrict__ order,
+                                                                   float* __restrict__ packed_grad, float* __restrict__ err_square_sum /*STAT*/,
+                                                                   const int* __restrict__ order,
                                                                    int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode,
                                                                    const int* __restrict__ hot_of)
 {
@@ -944,6 +979,7 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     const int* __restrict__ sp = sorted_points + (size_t)view * L + start;
     const float* __restrict__ pk = packed + (size_t)view * N * REC;
     float* __restrict__ pg = packed_grad + (size_t)view * N * GREC;
+    if (STAT) err_square_sum += (size_t)view * N;
 
     const int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
     const int x = tx * TW + lane % TW;
@@ -999,13 +1035,13 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
         rec_request(rb, pk, off_b);                                                                           \
         id_request(hot_b, hot, hot_on ? off_b >> 4 : 0u);                                                     \
         id_request(id_a, sp, (unsigned)max(pos - 2, 0) << 2);                                                 \
-        bwd_splat_fast<TRANS, CHK>(st, ra, pos, HOT_TARGET(hot_a, off_a), slot_off, writers, pg);              \
+        bwd_splat_fast<TRANS, CHK, STAT>(st, ra, pos, HOT_TARGET(hot_a, off_a), slot_off, writers, pg, err_square_sum, lane);  \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rb), "+s"(id_a), "+s"(hot_b));                             \
         off_a = (unsigned)id_a << 6;                                                                          \
         rec_request(ra, pk, off_a);                                                                           \
         id_request(hot_a, hot, hot_on ? off_a >> 4 : 0u);                                                     \
         id_request(id_b, sp, (unsigned)max(pos - 3, 0) << 2);                                                 \
-        bwd_splat_fast<TRANS, CHK>(st, rb, pos - 1, HOT_TARGET(hot_b, off_b), slot_off, writers, pg);          \
+        bwd_splat_fast<TRANS, CHK, STAT>(st, rb, pos - 1, HOT_TARGET(hot_b, off_b), slot_off, writers, pg, err_square_sum, lane);  \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(id_b), "+s"(hot_a));                             \
         off_b = (unsigned)id_b << 6;                                                                          \
         pos -= 2;                                                                                             \
@@ -1068,11 +1104,12 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
         if (TH != 8 || TW != 16 || enable_stat || d_trans) return (int)hipErrorInvalidValue;
         LAUNCH_RB(8, 16, false, false, true);
     }
-    else if (TH == 8 && TW == 16 && !enable_stat && g_bwd_fast) {
-        if (d_trans) hipLaunchKernelGGL((raster_backward_fast_kernel<true>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
-                                        d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, hot_of);
-        else hipLaunchKernelGGL((raster_backward_fast_kernel<false>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
-                                d_img, d_trans, packed_grad, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, hot_of);
+    else if (TH == 8 && TW == 16 && g_bwd_fast && !(enable_stat && (err_square_sum == nullptr || hot_of != nullptr))) {
+#define LAUNCH_RBF(T_, S_) hipLaunchKernelGGL((raster_backward_fast_kernel<T_, S_>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last, \
+                                              d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, hot_of)
+        if (enable_stat) { if (d_trans) LAUNCH_RBF(true, true); else LAUNCH_RBF(false, true); }
+        else { if (d_trans) LAUNCH_RBF(true, false); else LAUNCH_RBF(false, false); }
+#undef LAUNCH_RBF
     }
     else if (TH == 8 && TW == 16) DISPATCH_RB(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RB(16, 16);

@@ -72,7 +72,7 @@ class CameraFrame:
 
 class _FrameState:
     """what the executor remembers about one camera between two visits (sizing feedback lives in the pinned words)"""
-    __slots__ = ("sched_cur", "sched_valid", "order_valid", "margin", "clean_visits", "cooldown", "margin_written", "margin_emitted",
+    __slots__ = ("sched_cur", "sched_valid", "order_valid", "margin", "clean_visits", "margin_written", "margin_emitted",
                  "last_capacity", "visits", "full_total", "last_unculled")
 
     def __init__(self, margin: int):
@@ -85,7 +85,6 @@ class _FrameState:
         self.order_valid = False          # ... and its heaviest-first tile schedule
         self.margin = margin              # margin (percent) of the bounds this visit writes
         self.clean_visits = 0
-        self.cooldown = 0
         self.margin_written = margin      # margin of the bounds the frame's next visit will cull with
         self.margin_emitted = margin      # margin of the bounds behind the frame's last emitted total (fb_total)
         self.last_capacity = 0            # table capacity of the frame's last visit
@@ -116,9 +115,13 @@ class FusedRenderer:
             raise ValueError("LITEGS_DEPTH_ORDER must be 'global', 'tile' or 'auto'")
         self.depth_order = _DEPTH_ORDER[mode]          # csrc/fused.hip: how each tile's list gets its depth order
         self.cull_enabled = os.environ.get("LITEGS_DEPTH_CULL", "1") != "0"
-        # after the first statistics epoch the reference rasterises along the statistics helper's cached tile list (render/__init__.py:75-79);
-        # 'always' follows it, 'stat' keeps the executor's own schedule + depth bounds outside statistics renders (same image)
-        self.stat_schedule_always = os.environ.get("LITEGS_STAT_TILE_SCHEDULE", "always") != "stat"
+        # After the first statistics epoch the reference rasterises along the statistics helper's cached tile list (render/__init__.py:75-79).
+        # True follows it (the executor's own schedule, depth bounds and speculative culling are then idle); False keeps the executor's
+        # machinery outside statistics renders -- same image (test_gpu_stats.py).  Whole-run A/B at 3 M / 150 cameras / 30 000 iterations
+        # (profiles/r04_convergence_3m_own_schedule.md vs r04_convergence_3m.md): 3.63-3.65 ms per iteration against 3.57-3.66 -- 1230-1300
+        # violated bounds per run (a frame is revisited after 150 steps of a moving cloud) eat what the culling saves, except in the last
+        # 40 epochs (3.32 vs 3.49).  Depth-bound culling is a few-camera / converged-cloud feature: the reference's behaviour stays the default.
+        self.stat_schedule_always = True
         self.validate_tables = os.environ.get("LITEGS_VALIDATE_TABLES", "0") == "1"      # debugging aid (csrc/fused.hip "Table validators")
         self.tile_scatter = True           # per-tile mode: group by tile with counts + cursors (False: stable tile radix sort); same tables
         self.replicas_enabled = True       # gradient replicas (csrc/raster.hip) for renders whose records only the fused backward kernels consume
@@ -142,7 +145,6 @@ class FusedRenderer:
         # back after clean visits.  margin_fixed = <percent> pins it (tests / tools).
         self.margin_fixed = 0
         self.margin_lo, self.margin_hi = 100, 400
-        self.cull_cooldown = 0             # visits a frame renders unculled after one of its bounds was violated
         self.frames = [_FrameState(self.margin_lo) for _ in range(n_frames)]
         self.sched = None
         self.tile_order = None
@@ -272,7 +274,6 @@ class FusedRenderer:
         F = self.frames[k]
         self.fallbacks += 1
         F.clean_visits = 0
-        F.cooldown = self.cull_cooldown
         if not self.margin_fixed:
             F.margin = min(F.margin * 2, self.margin_hi)
 
@@ -392,10 +393,7 @@ class _RenderFn(torch.autograd.Function):
                 in_ptr = R.sched[k, F.sched_cur].data_ptr()
             out_ptr = R.sched[k, 1 - F.sched_cur].data_ptr()
         refresh = F.visits % R.cull_refresh == 0
-        cull = bool(R.cull_enabled and in_ptr is not None and F.full_total > 0 and pred_total > 0 and not refresh and not R.force_full
-                    and F.cooldown == 0)
-        if F.cooldown > 0:
-            F.cooldown -= 1
+        cull = bool(R.cull_enabled and in_ptr is not None and F.full_total > 0 and pred_total > 0 and not refresh and not R.force_full)
         R.force_full = False
         order_ptr = (R.tile_order.data_ptr() + 4 * R.ntiles * k) if use_sched else None
         order_in = order_ptr if (use_sched and F.order_valid) else None

@@ -41,7 +41,6 @@ VARIANTS = {
     "global": (dict(depth_order=0), False),                                # splat sort + stable tile radix sort
     "own_schedule": (dict(stat_schedule_always=False), False),             # default list building, executor's schedule + depth-bound culling
     "own_schedule_tile": (dict(stat_schedule_always=False, long_list_global=0), False),
-    "own_schedule_cooldown4": (dict(stat_schedule_always=False, cull_cooldown=4), False),
     "stat_epoch": (dict(), True),
     "stat_epoch_tile": (dict(long_list_global=0), True),
 }
@@ -97,7 +96,7 @@ def stat_pass(tr, pick):
 
 def configure(tr, attrs):
     rd = tr.renderer
-    base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], cull_cooldown=0)
+    base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"])
     base.update(attrs)
     for k, v in base.items():
         setattr(rd, k, v)
