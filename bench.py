@@ -224,18 +224,10 @@ def steady_state(tr, args, n_frames):
     return out
 
 
-def training_state(args, n, W, H, focal, scene, n_frames):
-    """The state `training.start` with density control is in (reference loop: litegs/training/trainer.py:108-195), reached by a
-    deterministic recipe on the bench's own scene: the bench cloud is the teacher, its renders from the bench cameras are the targets, a
-    perturbed copy is trained with the reference's schedule -- SH degree min(epoch // 5, 3), statistics epochs + density control every 5
-    epochs from epoch 3, opacity decay every 10, Morton re-sort after every densification, position-lr decay -- for --training-epochs
-    epochs over the cameras.  Opacity decay keeps tiles from saturating, lists are walked to their ends, every frame carries the statistics
-    helper's cached tile list (render/__init__.py:75-79): the executor's depth-bound culling is idle and the step costs what it costs in
-    a real run (profiles/r04_convergence_3m.md: 4.0 ms per plain step from iteration 6000 on at 150 cameras).  Measured in that state:
-    plain steps and statistics-epoch steps (events per step), forward only, instances, and the dominant kernel's roofline."""
+def build_training_state(n, W, H, focal, scene, n_frames, epochs):
+    """the recipe of training_state(): -> (trainer in that state, seconds the run took)"""
     from litegs_amd import densify as D
     from litegs_amd import synthetic as S
-    from litegs_amd.statistics import STATS
     from litegs_amd.trainer import SyntheticTrainer
     teacher = SyntheticTrainer(n, W, H, focal, n_frames=n_frames, scene=scene, noise_targets=False)
     targets = [teacher.forward_only(k).clamp(0, 1).clone() for k in range(n_frames)]
@@ -246,7 +238,6 @@ def training_state(args, n, W, H, focal, scene, n_frames):
     for k in range(n_frames):
         tr.frames[k].gt = targets[k]
     tr.speculative = True
-    epochs = args.training_epochs
     tr.enable_densify(D.DensifyParams(target_primitives=int(1.1 * n)), total_epochs=max(epochs, 200), seed=0)
     rng = np.random.default_rng(7)
     t0 = time.perf_counter()
@@ -258,7 +249,21 @@ def training_state(args, n, W, H, focal, scene, n_frames):
         tr.end_epoch(epoch)
     tr.flush()
     torch.cuda.synchronize()
-    run_s = time.perf_counter() - t0
+    return tr, time.perf_counter() - t0
+
+
+def training_state(args, n, W, H, focal, scene, n_frames):
+    """The state `training.start` with density control is in (reference loop: litegs/training/trainer.py:108-195), reached by a
+    deterministic recipe on the bench's own scene: the bench cloud is the teacher, its renders from the bench cameras are the targets, a
+    perturbed copy is trained with the reference's schedule -- SH degree min(epoch // 5, 3), statistics epochs + density control every 5
+    epochs from epoch 3, opacity decay every 10, Morton re-sort after every densification, position-lr decay -- for --training-epochs
+    epochs over the cameras.  Opacity decay keeps tiles from saturating, lists are walked to their ends, every frame carries the statistics
+    helper's cached tile list (render/__init__.py:75-79): the executor's depth-bound culling is idle and the step costs what it costs in
+    a real run (profiles/r04_convergence_3m.md: 4.0 ms per plain step from iteration 6000 on at 150 cameras).  Measured in that state:
+    plain steps and statistics-epoch steps (events per step), forward only, instances, and the dominant kernel's roofline."""
+    from litegs_amd.statistics import STATS
+    epochs = args.training_epochs
+    tr, run_s = build_training_state(n, W, H, focal, scene, n_frames, epochs)
     rd = tr.renderer
     # plain steps (between two statistics epochs), then statistics-epoch steps, both on the final cloud; lr stays live (this is training)
     for k in range(n_frames):

@@ -49,7 +49,34 @@ VARIANTS = {
 DEFAULTS = {}
 
 
+def load_recipe():
+    """path == "recipe": the state bench.py's training_state leg reaches (teacher -> student on the bench scene and its 8 cameras, 60 epochs
+    of the reference schedule: 1.6 s) instead of a stored cloud of the 150-camera run -- the same regime (23 M instances per frame)"""
+    global RUN_FRAMES
+    from bench import build_training_state
+    n, W_, H_, f_ = S.CONFIGS["3m_1080p"]
+    RUN_FRAMES = 8
+    tr, _ = build_training_state(n, W_, H_, f_, S.make_scene(n, seed=0), 8, int(os.environ.get("LATE_RECIPE_EPOCHS", "60")))
+    pick = list(range(8))
+    order = ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]
+    by = {g["name"]: g["params"][0] for g in tr.opt.param_groups}
+    moments = [(tr.opt.state[by[nme]]["exp_avg"].clone(), tr.opt.state[by[nme]]["exp_avg_sq"].clone()) for nme in order]
+
+    def restore():
+        for i, nme in enumerate(order):
+            tr.opt.state[by[nme]]["exp_avg"].copy_(moments[i][0])
+            tr.opt.state[by[nme]]["exp_avg_sq"].copy_(moments[i][1])
+        tr.fadam.touched = None
+    for g in tr.opt.param_groups:
+        g["lr"] = 0.0
+    tr.sched.step = lambda: None
+    DEFAULTS.update(long_list_global=tr.renderer.long_list_global, stat_schedule_always=tr.renderer.stat_schedule_always)
+    return tr, pick, restore, dict(epoch=60, degree=tr.degree)
+
+
 def load(path):
+    if path == "recipe":
+        return load_recipe()
     st = torch.load(path, map_location="cpu")
     scene = [p.numpy() for p in st["params"]]
     n = scene[0].shape[-2] * scene[0].shape[-1]
