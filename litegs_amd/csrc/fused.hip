@@ -737,8 +737,10 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
         if (rc) return rc;
     }
     }
+    // statistic epochs: the executor's blend backward accumulates the per-splat statistics inside the gradient record (raster.hip, STAT == 2);
+    // the forward then is the plain one (frag_count == NULL).  A caller that wants the forward's own counters passes the two arrays.
     return lg_raster_forward_bounds(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
-                                    enable_stat, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order, tiles ? nullptr : tile_work,
+                                    (enable_stat && frag_count != nullptr && frag_weight != nullptr) ? 1 : 0, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order, tiles ? nullptr : tile_work,
                                     tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, (zb_check & 1) | (x.margin_pct << 8), fail_flag, fail_host, gate, s);
 }
 

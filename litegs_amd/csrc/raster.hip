@@ -900,8 +900,18 @@ struct BwdFast {
 
 // STAT (statistic epochs): the per-splat sum of squares of the running d_opacity of GR/raster.cu:781-783 -- per lane, after its first pixel
 // (m0 / opacity)^2 and after its second ((m0 + m1) / opacity)^2, the second term only if some pixel of the wave takes the splat in that
-// pixel row group (the reference's per-row-group gate, raster.cu:753) -- reduced on the DPP path and added by one lane.
-template <bool TRANS, bool CHECK, bool STAT>
+// pixel row group (the reference's per-row-group gate, raster.cu:753).
+//   STAT == 1 (operator surface: rasterize_backward's err_square_sum output): reduced on the DPP path, added by one lane to the array.
+//   STAT == 2 (executor): the three per-splat statistics of an epoch -- fragment count and fragment weight sum (what the reference's forward
+//     accumulates, raster.cu:283-302: the backward sees the same validity mask and recovers the same weights) and err_square -- are reduced
+//     by one small transposing butterfly and travel in slots 9, 10, 11 of the splat's gradient record, inside the ONE atomic instruction
+//     the nine moments already cost.  Measured motive (profiles/r04_stat_epoch_timeline.md): every additional per-splat atomic instruction
+//     costs ~0.4 ms per 1080p frame of the late-phase cloud (9.8 M contributing (tile, splat) pairs, same-line contention), the three of the
+//     separate-array form 1.2 ms.
+#define STAT_SLOT_COUNT 9
+#define STAT_SLOT_WEIGHT 10
+#define STAT_SLOT_ERRSQ 11
+template <bool TRANS, bool CHECK, int STAT>
 __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, int pos, unsigned pid_off, unsigned slot_off,
                                                unsigned long long writers, float* __restrict__ pg, float* __restrict__ err_square_sum, int lane)
 {
@@ -938,13 +948,28 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     const float s2 = __builtin_fmaf(my.x, dyv.x, my.y * dyv.y);
     const float mx = dx * s0;
     // order: (Mx My Mxx Mxy Myy dr DB DG M0) -- dg / db swapped against the record, see wave_slot_fast
-    const float tot = reduce9_pk(mx, s1, dx * mx, dx * s1, s2, crg.x, v_b, crg.y, s0);
-    // ONE atomic instruction from the nine lanes that hold a total: scalar base = the splat's gradient record
+    float tot = reduce9_pk(mx, s1, dx * mx, dx * s1, s2, crg.x, v_b, crg.y, s0);
+    if constexpr (STAT == 2) {
+        const float inv_o = __builtin_amdgcn_rcpf(rec[R_O]);
+        const float vo0 = m.x * inv_o, vo1 = s0 * inv_o;
+        float a = (val0 ? 1.0f : 0.0f) + (val1 ? 1.0f : 0.0f);                                   // fragments of this lane
+        float b = w.x + w.y;                                                                     // their blend weights
+        float c = __builtin_fmaf(vo0, vo0, __any(val1) ? vo1 * vo1 : 0.0f), d = 0.0f;
+        // transposing butterfly of four values: rows 0 / 1 / 2 / 3 end up with the 16 partial sums of a / c / b / d, lane 15 of each row
+        // with the row's total (lanes 15, 31, 47: the writers of slots 9, 11, 10 -- stat_lane_slot())
+        swap32(a, b); swap32(c, d);
+        a += b; c += d;
+        swap16(a, c);
+        a += c;
+        a = DPP_ADD(a, 0x111, 0xF, 0xF); a = DPP_ADD(a, 0x112, 0xF, 0xF); a = DPP_ADD(a, 0x114, 0xF, 0xF); a = DPP_ADD(a, 0x118, 0xF, 0xF);
+        tot = ((lane & 15) == 15) ? a : tot;
+    }
+    // ONE atomic instruction from the lanes that hold a total: scalar base = the splat's gradient record
     const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pg) + pid_off);
     asm volatile("s_mov_b64 exec, %2\n\t"
                  "global_atomic_add_f32 %0, %1, %3\n\t"
                  "s_mov_b64 exec, -1" : : "v"(slot_off), "v"(tot), "s"(writers), "s"(base) : "memory");
-    if constexpr (STAT) {
+    if constexpr (STAT == 1) {
         const float inv_o = __builtin_amdgcn_rcpf(rec[R_O]);
         const float vo0 = m.x * inv_o, vo1 = s0 * inv_o;
         const float esq = wave_sum_to_lane63(__builtin_fmaf(vo0, vo0, __any(val1) ? vo1 * vo1 : 0.0f));
@@ -952,7 +977,13 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     }
 }
 
-template <bool TRANS, bool STAT>
+// record slot of the statistics total that lane 15 / 31 / 47 holds after the four-value butterfly of bwd_splat_fast<.., 2> (-1: none)
+__device__ __forceinline__ int stat_lane_slot(int lane)
+{
+    return lane == 15 ? STAT_SLOT_COUNT : (lane == 31 ? STAT_SLOT_ERRSQ : (lane == 47 ? STAT_SLOT_WEIGHT : -1));
+}
+
+template <bool TRANS, int STAT>
 __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
                                                                    const float* __restrict__ packed, const int* __restrict__ tiles, int K,
                                                                    const float* __restrict__ final_T, const short* __restrict__ last,
@@ -979,7 +1010,7 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     const int* __restrict__ sp = sorted_points + (size_t)view * L + start;
     const float* __restrict__ pk = packed + (size_t)view * N * REC;
     float* __restrict__ pg = packed_grad + (size_t)view * N * GREC;
-    if (STAT) err_square_sum += (size_t)view * N;
+    if (STAT == 1) err_square_sum += (size_t)view * N;
 
     const int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
     const int x = tx * TW + lane % TW;
@@ -1007,6 +1038,7 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     if (n <= 0) return;
     int myslot = wave_slot(lane);
     myslot = myslot == 6 ? 7 : (myslot == 7 ? 6 : myslot);       // reduce9_pk is fed (.., dr, db, dg, ..)
+    if (STAT == 2 && stat_lane_slot(lane) >= 0) myslot = stat_lane_slot(lane);
     const unsigned long long writers = __ballot(myslot >= 0);
     const unsigned slot_off = (unsigned)max(myslot, 0) * 4u;
     // An even number of iterations (two per trip over a ping-pong pair of record registers): if n is odd the walk starts one
@@ -1104,11 +1136,14 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
         if (TH != 8 || TW != 16 || enable_stat || d_trans) return (int)hipErrorInvalidValue;
         LAUNCH_RB(8, 16, false, false, true);
     }
-    else if (TH == 8 && TW == 16 && g_bwd_fast && !(enable_stat && (err_square_sum == nullptr || hot_of != nullptr))) {
+    else if (enable_stat && err_square_sum == nullptr && !(TH == 8 && TW == 16 && g_bwd_fast && hot_of == nullptr))
+        return (int)hipErrorInvalidValue;          // statistics inside the gradient record exist in the 8x16 moment-form kernel only
+    else if (TH == 8 && TW == 16 && g_bwd_fast && !(enable_stat && hot_of != nullptr)) {
 #define LAUNCH_RBF(T_, S_) hipLaunchKernelGGL((raster_backward_fast_kernel<T_, S_>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last, \
                                               d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, hot_of)
-        if (enable_stat) { if (d_trans) LAUNCH_RBF(true, true); else LAUNCH_RBF(false, true); }
-        else { if (d_trans) LAUNCH_RBF(true, false); else LAUNCH_RBF(false, false); }
+        if (enable_stat && err_square_sum == nullptr) { if (d_trans) LAUNCH_RBF(true, 2); else LAUNCH_RBF(false, 2); }       // executor: statistics in the record
+        else if (enable_stat) { if (d_trans) LAUNCH_RBF(true, 1); else LAUNCH_RBF(false, 1); }
+        else { if (d_trans) LAUNCH_RBF(true, 0); else LAUNCH_RBF(false, 0); }
 #undef LAUNCH_RBF
     }
     else if (TH == 8 && TW == 16) DISPATCH_RB(8, 16);

@@ -313,6 +313,13 @@ def _d_opacity(pg, ws1, N):
     return torch.where(o > 0, pg[:, 8] / o, torch.zeros_like(o)).reshape(1, 1, N)
 
 
+def _record_statistics(pg, N):
+    """statistic epochs: (fragment_count int32, fragment_weight_sum, err_square_sum), each [1,1,N], from slots 9 / 10 / 11 of the gradient
+    records (csrc/raster.hip STAT_SLOT_*; the count is a sum of small integers in fp32: exact below 2^24)"""
+    st = pg[:N, 9:12]
+    return (st[:, 0].round().to(torch.int32).reshape(1, 1, N), st[:, 1].reshape(1, 1, N).contiguous(), st[:, 2].reshape(1, 1, N).contiguous())
+
+
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, R: FusedRenderer, frame: CameraFrame, origin, extend, degree, xyz, scale, rot, sh_0, sh_rest, opacity):
@@ -424,9 +431,13 @@ class _RenderFn(torch.autograd.Function):
         last = _empty((1, 1, R.Hp, R.Wp), torch.int16, dev)
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
         fc = fw = None
+        # statistic epochs, 8x16 tiles: fragment count / weight / err_square travel in slots 9-11 of the blend backward's gradient record
+        # (csrc/raster.hip, STAT == 2: no per-splat atomics of their own); other tile shapes keep the forward's two counter arrays
+        stat_in_record = stat and (R.TH, R.TW) == (8, 16)
         if stat:
-            fc = _empty((1, 1, N), torch.int32, dev, zero=True)
-            fw = _empty((1, 1, N), torch.float32, dev, zero=True)
+            if not stat_in_record:
+                fc = _empty((1, 1, N), torch.int32, dev, zero=True)
+                fw = _empty((1, 1, N), torch.float32, dev, zero=True)
             STATS.set_compaction(vis_ids[:A], vis_num)
             a_off = L.lg_fused_alloc_offset(N)                # b_visible = allocate_size != 0 (wrapper.py:733-736)
             STATS.add_visible((ws1[a_off:a_off + 4 * N].view(torch.int32) != 0).view(1, N))
@@ -439,7 +450,7 @@ class _RenderFn(torch.autograd.Function):
         pg = _empty((pg_lines, L.lg_packed_grad_floats()), torch.float32, dev) if needs_grad else None
         check(L.lg_fused_stage2(ctypes.byref(cx), A, S, table_len, R.H, R.W, R.TH, R.TW, ws1.data_ptr(), ws1_bytes, ws2.data_ptr(), ws2_bytes, tp, K,
                                 1 if stat else 0, img.data_ptr(), trans.data_ptr(), last.data_ptr(),
-                                fc.data_ptr() if stat else None, fw.data_ptr() if stat else None,
+                                fc.data_ptr() if fc is not None else None, fw.data_ptr() if fw is not None else None,
                                 pg.data_ptr() if pg is not None else None,
                                 order_in, order_out, in_ptr, out_ptr, 1 if cull else 0, len_cull, fb_full_ptr,
                                 frame.view_ptr, frame.proj_ptr, int(degree), chunks,
@@ -468,7 +479,7 @@ class _RenderFn(torch.autograd.Function):
             STATS.update_tile_schedule(last, R.TH, R.TW)
         ctx.R, ctx.frame, ctx.meta = R, frame, (A, S, table_len, int(degree), chunks, sh_rest.shape[0], ws1_bytes, ws2_bytes, stat)
         ctx.tiles = tiles
-        ctx.stat_bufs = (fc, fw)
+        ctx.stat_bufs = (fc, fw, stat_in_record)
         ctx.save_for_backward(ws1, ws2, vis_ids, vis_num, trans, last, xyz, scale, rot, sh_0, sh_rest, opacity)
         ctx.mark_non_differentiable(vis_ids, vis_num)
         ctx.set_materialize_grads(False)          # no zero-filled gradients for the two index outputs
@@ -491,7 +502,8 @@ class _RenderFn(torch.autograd.Function):
             pg, pg_zero = _empty((L.lg_fused_grad_lines(N) if ctx.replicas else N, L.lg_packed_grad_floats()), torch.float32, dev), 0
         ctx.pg = None
         cx = ctx.cx
-        esq = _empty((1, 1, N), torch.float32, dev, zero=True) if stat else None
+        fc, fw, stat_in_record = ctx.stat_bufs
+        esq = _empty((1, 1, N), torch.float32, dev, zero=True) if (stat and not stat_in_record) else None
         tiles = ctx.tiles
         K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
         if R.fuse_optimizer:
@@ -502,14 +514,15 @@ class _RenderFn(torch.autograd.Function):
                                       frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
                                       xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
                                       trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
-                                      pg.data_ptr(), pg_zero, esq.data_ptr() if stat else None, None, None, None, None, None, None, ctx.order_ptr, _s()),
+                                      pg.data_ptr(), pg_zero, esq.data_ptr() if esq is not None else None, None, None, None, None, None, None, ctx.order_ptr, _s()),
                   "fused blend backward")
             if R.probe_events is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
                 R.probe_events.append((ev0, ev1))
             if stat:
-                fc, fw = ctx.stat_bufs
+                if stat_in_record:
+                    fc, fw, esq = _record_statistics(pg, N)
                 STATS.add_moments("fragment_weight", fw, fw * fw, fc)
                 STATS.add_moments("fragment_err", _d_opacity(pg, ws1, N), esq, fc)
             # ws1 rides along: its tile counts tell the fused backward + Adam which gradient records can only be zero
@@ -526,12 +539,13 @@ class _RenderFn(torch.autograd.Function):
                                   frame.view_ptr, frame.proj_ptr, degree, chunks, Rr, vis_ids.data_ptr(), vis_num.data_ptr(),
                                   xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), opacity.data_ptr(), tp, K,
                                   trans.data_ptr(), last.data_ptr(), g_img.data_ptr(), None, None, 1 if stat else 0,
-                                  pg.data_ptr(), pg_zero, esq.data_ptr() if stat else None,
+                                  pg.data_ptr(), pg_zero, esq.data_ptr() if esq is not None else None,
                                   d_pos.data_ptr(), d_scale.data_ptr(), d_rot.data_ptr(), d_sh0.data_ptr(), d_shr.data_ptr(), d_opa.data_ptr(),
                                   ctx.order_ptr, _s()),
               "fused backward")
         if stat:
-            fc, fw = ctx.stat_bufs
+            if stat_in_record:
+                fc, fw, esq = _record_statistics(pg, N)
             # d_opacity of the activated opacity = packed_grad slot 8 (rasterize_backward's 4th output)
             d_op_act = _d_opacity(pg, ws1, N)
             STATS.add_moments("fragment_weight", fw, fw * fw, fc)
