@@ -93,6 +93,20 @@ for STAGE in "$@"; do
         python tools/sq_summary.py $C "late-phase cloud, LDS set" > gpurun_out/sq_late_lds_$TAG.md 2>> gpurun_out/late_timeline_$TAG.err; sed -n 5,20p gpurun_out/sq_late_lds_$TAG.md
         rm -rf gpurun_out/pmc_late_$TAG
       done ;;
+    optrace)         # the operator surface (what the unmodified reference trainer drives): kernel time per step against wall time per step
+      (cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_op_$TAG -o trace -- python $R/bench.py --operator-path --steps 32 --warmup 8 --no-cpu-baseline --no-pmc --soak-steps 0 --no-training-state > $R/gpurun_out/optrace_$TAG.log 2>&1)
+      tail -1 gpurun_out/optrace_$TAG.log | cut -c1-200
+      S=$(find gpurun_out/prof_op_$TAG -name "*kernel_stats.csv" | head -1); cp $S gpurun_out/kernel_stats_operator_$TAG.csv
+      python - <<PY
+import csv
+rows = list(csv.DictReader(open("gpurun_out/kernel_stats_operator_$TAG.csv")))
+steps = 8 + 8 + 32 + 32          # setup + warm-up + timed + forward-only (forward kernels run in all of them)
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"all kernels: {tot / 1e6:.1f} ms over the process")
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:28]:
+    print(f'{r["Name"][:90]:90s} calls {int(r["Calls"]):6d}  total {float(r["TotalDurationNs"]) / 1e3:10.0f} us  avg {float(r["AverageNs"]) / 1e3:8.1f} us')
+PY
+      rm -rf gpurun_out/prof_op_$TAG ;;
     dpglue)
       rm -f gpurun_out/dp_glue.log
       timeout -s KILL 300 python tools/dp_glue_bench.py > gpurun_out/dp_glue_$TAG.log 2>&1
