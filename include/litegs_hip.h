@@ -324,7 +324,8 @@ int lg_adam_update_multi(int ngroups, void* const* param, const void* const* gra
 /* ---- dp.hip : data-parallel gradient exchange on the device (the reference is single-GPU only).  The ranks exchange the
  * blend backward's moment records (global Gaussian index + 9 floats per touched Gaussian) instead of parameter gradients; every rank
  * replays the per-Gaussian chain backward of every rank's records with that rank's camera, averages and applies Adam in one kernel.
- * A block is float[(1 + cap) * lg_dp_record_floats()]: row 0 = header (word 0 = number of touched Gaussians, int bits), then records. */
+ * A block is float[(1 + cap) * lg_dp_record_floats()]: a header of lg_dp_record_floats() words (word 0 = number of touched Gaussians, int bits)
+ * followed by lg_dp_record_floats() rows of cap words: row 0 the global Gaussian indices (int bits), rows 1..9 the nine moments. */
 int lg_dp_record_floats(void);
 int lg_dp_compact_moments(const float* packed_grad /*[A*S,16] of lg_fused_backward*/, const int64_t* vis_ids, const int* vis_num, int A, int S,
                           int cap, float* block, void* stream);

@@ -8,8 +8,12 @@
 // (deterministic: replicas stay bit-identical), scales by 1/W and applies Adam in the same kernel.  The parameter gradients never
 // exist in HBM, on any rank; backward + Adam stay fused exactly as on one GPU.
 //
-//   lg_dp_compact_moments : packed_grad [N,16] -> block [1 + cap][10]: row 0 = header (word 0: number of touched Gaussians K),
-//                           row 1 + k = { global Gaussian index (int bits), 9 moments }.  Unordered (one atomic per wave).
+//   lg_dp_compact_moments : packed_grad [N,16] -> block of (1 + cap) * 10 words: a 10-word header (word 0: number of touched Gaussians K)
+//                           followed by ten ROWS of cap words -- row 0 the global Gaussian indices (int bits), rows 1..9 the nine moments
+//                           (structure of arrays: the compaction's stores and the consumer's loads are coalesced 4-byte streams; the
+//                           first version's 40-byte records cost ten 2.5 KB-strided stores / loads per wave).  Unordered; one returning
+//                           atomic per 1024 records (one per wave serialised 16 k atomics on the header word: 140 us in the trained
+//                           state, profiles/r04_dp_glue.log).
 //   (RCCL all_gather of the W blocks -- torch.distributed, litegs_amd/dp.py)
 //   lg_dp_build_slotmap   : for every rank r and record k: slot[r][gid] = k + 1; also the job's largest K to a pinned host word
 //                           (sizes the next visit's blocks) and an overflow flag if some K exceeded the capacity.
@@ -26,37 +30,58 @@
 #define DP_MAX_WORLD 8
 
 // ---------------------------------------------------------------------------------------------
+#define DP_BATCH 1024          // records per workgroup: one returning atomic on the header word per batch
 __global__ void __launch_bounds__(256) dp_compact_kernel(const float4* __restrict__ packed_grad, const int64_t* __restrict__ vis_ids,
                                                          const int* __restrict__ vis_num, int A, int S, int cap, float* __restrict__ block)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long N = (long long)A * S;
-    bool nz = false;
-    float mom[9];
-    long long gid = 0;
-    if (i < N) {
-        const int a = (int)(i / S), t = (int)(i % S);
-        if (a < vis_num[0]) {
-            load_moments(packed_grad, (size_t)i, mom);
+    const long long i0 = (long long)blockIdx.x * DP_BATCH;
+    const int nvis = vis_num[0];
+    // thread t takes records i0 + j * 256 + t, j = 0..3: every wave instruction reads 64 consecutive 64-byte lines
+    float mom[4][9];
+    int gid[4];
+    bool nz[4];
+    int mine = 0;
 #pragma unroll
-            for (int k = 0; k < 9; k++) nz |= (__float_as_uint(mom[k]) & 0x7fffffffu) != 0u;     // +-0 adds nothing to a sum; NaN/inf travel
-            gid = vis_ids[a] * S + t;
+    for (int j = 0; j < 4; j++) {
+        const long long i = i0 + (long long)j * 256 + tid;
+        nz[j] = false; gid[j] = 0;
+        if (i < N) {
+            const int a = (int)(i / S), t = (int)(i % S);
+            if (a < nvis) {
+                load_moments(packed_grad, (size_t)i, mom[j]);
+#pragma unroll
+                for (int k = 0; k < 9; k++) nz[j] |= (__float_as_uint(mom[j][k]) & 0x7fffffffu) != 0u;     // +-0 adds nothing to a sum; NaN/inf travel
+                gid[j] = (int)(vis_ids[a] * S + t);
+            }
         }
+        mine += nz[j] ? 1 : 0;
     }
-    const unsigned long long m = __ballot(nz);
-    if (m == 0ull) return;
-    int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(reinterpret_cast<int*>(block), __popcll(m));     // header word 0 = K
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (nz) {
-        const int k = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (k < cap) {                                       // beyond the capacity: dropped, the header still counts it (overflow)
-            float* __restrict__ r = block + (size_t)(1 + k) * DP_REC;
-            r[0] = __int_as_float((int)gid);
+    // exclusive scan of the per-thread counts over the workgroup (order inside a batch: thread-major; across batches: arrival)
+    int incl = mine;
 #pragma unroll
-            for (int q = 0; q < 9; q++) r[1 + q] = mom[q];
+    for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(incl, o); if (lane >= o) incl += nb; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (total == 0) return;
+    if (tid == 0) base_s = atomicAdd(reinterpret_cast<int*>(block), total);          // header word 0 = K
+    __syncthreads();
+    int k = base_s + incl - mine;
+    for (int w = 0; w < wave; w++) k += wsum[w];
+    float* __restrict__ rows = block + DP_REC;                // row q: rows + q * cap
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!nz[j]) continue;
+        if (k < cap) {                                        // beyond the capacity: dropped, the header still counts it (overflow)
+            rows[k] = __int_as_float(gid[j]);
+#pragma unroll
+            for (int q = 0; q < 9; q++) rows[(size_t)(1 + q) * cap + k] = mom[j][q];
         }
+        k++;
     }
 }
 
@@ -70,7 +95,7 @@ LG_API int lg_dp_compact_moments(const float* packed_grad, const int64_t* vis_id
     hipError_t e = hipMemsetAsync(block, 0, sizeof(float) * DP_REC, s);          // the header row
     if (e != hipSuccess) return (int)e;
     const long long N = (long long)A * S;
-    hipLaunchKernelGGL(dp_compact_kernel, dim3(lg_cdiv(N, 256)), dim3(256), 0, s, (const float4*)packed_grad, vis_ids, vis_num, A, S, cap, block);
+    hipLaunchKernelGGL(dp_compact_kernel, dim3(lg_cdiv(N, DP_BATCH)), dim3(256), 0, s, (const float4*)packed_grad, vis_ids, vis_num, A, S, cap, block);
     LG_RETURN_LAST();
 }
 
@@ -84,7 +109,7 @@ __global__ void __launch_bounds__(256) dp_slotmap_kernel(const float* __restrict
     const int ktrue = __float_as_int(blk[0]);
     const int kr = ktrue < cap ? ktrue : cap;
     if (k < kr) {
-        const int gid = __float_as_int(blk[(size_t)(1 + k) * DP_REC]);
+        const int gid = __float_as_int(blk[DP_REC + k]);               // row 0 of the block: the global indices
         if (gid >= 0 && gid < total) slot[(size_t)r * total + gid] = k + 1;
     }
     if (r == 0 && k == 0) {
@@ -149,10 +174,10 @@ __global__ void dp_backward_adam_kernel(const int64_t* __restrict__ union_ids, c
         const int k1 = *sp;
         if (k1 == 0) continue;
         *sp = 0;                                            // leave the map clean for the next step
-        const float* __restrict__ rec = gathered + ((size_t)r * (1 + cap) + k1) * DP_REC + 1;
+        const float* __restrict__ rec = gathered + (size_t)r * (1 + cap) * DP_REC + DP_REC + (k1 - 1);     // rank r's block, column k1 - 1
         float mom[9];
 #pragma unroll
-        for (int q = 0; q < 9; q++) mom[q] = rec[q];
+        for (int q = 0; q < 9; q++) mom[q] = rec[(size_t)(1 + q) * cap];
         GaussGrads G;
         gaussian_backward<DEG>(cams.c[r], mom, 1.0f, px, py, pz, s0, s1, s2, rw, rx, ry, rz, oraw, G);
 #pragma unroll

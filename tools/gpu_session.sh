@@ -107,6 +107,21 @@ for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:28]:
     print(f'{r["Name"][:90]:90s} calls {int(r["Calls"]):6d}  total {float(r["TotalDurationNs"]) / 1e3:10.0f} us  avg {float(r["AverageNs"]) / 1e3:8.1f} us')
 PY
       rm -rf gpurun_out/prof_op_$TAG ;;
+    dptrace)         # kernel stats of the data-parallel step's glue (single-rank RCCL group), fresh and trained state
+      for ST in fresh trained; do
+        if [ $ST = fresh ]; then EXTRA=""; else EXTRA="--trained 1000"; fi
+        (cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dp_${ST}_$TAG -o trace -- python $R/tools/dp_glue_bench.py $EXTRA moments > $R/gpurun_out/dptrace_${ST}_$TAG.log 2>&1)
+        S=$(find gpurun_out/prof_dp_${ST}_$TAG -name "*kernel_stats.csv" | head -1); cp $S gpurun_out/kernel_stats_dp_${ST}_$TAG.csv
+        grep "ms/step" gpurun_out/dptrace_${ST}_$TAG.log
+        python - <<PY
+import csv
+rows = list(csv.DictReader(open("gpurun_out/kernel_stats_dp_${ST}_$TAG.csv")))
+for r in sorted(rows, key=lambda r: -float(r["AverageNs"])):
+    if any(k in r["Name"] for k in ("dp_", "compact", "mark", "slot", "Memset", "fill", "copyBuffer", "nccl", "rccl", "project_backward")):
+        print(f'{r["Name"][:100]:100s} calls {int(r["Calls"]):6d}  avg {float(r["AverageNs"]) / 1e3:8.1f} us')
+PY
+        rm -rf gpurun_out/prof_dp_${ST}_$TAG
+      done ;;
     dpglue)
       rm -f gpurun_out/dp_glue.log
       timeout -s KILL 300 python tools/dp_glue_bench.py > gpurun_out/dp_glue_$TAG.log 2>&1
