@@ -327,8 +327,10 @@ int lg_adam_update_multi(int ngroups, void* const* param, const void* const* gra
  * A block is float[(1 + cap) * lg_dp_record_floats()]: a header of lg_dp_record_floats() words (word 0 = number of touched Gaussians, int bits)
  * followed by lg_dp_record_floats() rows of cap words: row 0 the global Gaussian indices (int bits), rows 1..9 the nine moments. */
 int lg_dp_record_floats(void);
-int lg_dp_compact_moments(const float* packed_grad /*[A*S,16] of lg_fused_backward*/, const int64_t* vis_ids, const int* vis_num, int A, int S,
-                          int cap, float* block, void* stream);
+int lg_dp_compact_moments(const float* packed_grad /*[A*S,16] of lg_fused_backward (+ replica lines when hot_of is given)*/, const int64_t* vis_ids,
+                          const int* vis_num, int A, int S, int cap, float* block,
+                          const int* hot_of /*nullable: the frame's replica assignment (workspace 1 + lg_fused_hot_offset): folded into the records*/,
+                          int* hot_counter /*required with hot_of: the renderer's replica line counter, reset here for the next frame*/, void* stream);
 int lg_dp_build_slotmap(const float* gathered /*[W] blocks*/, int W, int cap, long long total /*chunks*S*/, int* slot /*[W][total], zero*/,
                         int* host_max_k /*nullable pinned int[2]: {largest count of the job, the same count if it exceeded cap (records were dropped) else 0}*/, int* overflow /*nullable device flag*/, void* stream);
 int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count, int chunks, int S, int H, int W_img,

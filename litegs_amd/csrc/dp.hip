@@ -32,19 +32,21 @@
 // ---------------------------------------------------------------------------------------------
 #define DP_BATCH 1024          // records per workgroup: one returning atomic on the header word per batch
 __global__ void __launch_bounds__(256) dp_compact_kernel(const float4* __restrict__ packed_grad, const int64_t* __restrict__ vis_ids,
-                                                         const int* __restrict__ vis_num, int A, int S, int cap, float* __restrict__ block)
+                                                         const int* __restrict__ vis_num, int A, int S, int cap, float* __restrict__ block,
+                                                         const int* __restrict__ hot_of /*nullable: gradient replicas to fold (raster.hip)*/,
+                                                         int* __restrict__ hot_counter /*nullable: reset for the next frame's projection*/)
 {
-    __shared__ int wsum[4];
+    __shared__ int cnt[4][4];          // [j][wave]: touched records of round j in that wave
     __shared__ int base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long N = (long long)A * S;
     const long long i0 = (long long)blockIdx.x * DP_BATCH;
     const int nvis = vis_num[0];
+    if (hot_counter != nullptr && blockIdx.x == 0 && tid == 0) *hot_counter = 0;
     // thread t takes records i0 + j * 256 + t, j = 0..3: every wave instruction reads 64 consecutive 64-byte lines
     float mom[4][9];
-    int gid[4];
+    int gid[4], rank[4];
     bool nz[4];
-    int mine = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const long long i = i0 + (long long)j * 256 + tid;
@@ -52,50 +54,53 @@ __global__ void __launch_bounds__(256) dp_compact_kernel(const float4* __restric
         if (i < N) {
             const int a = (int)(i / S), t = (int)(i % S);
             if (a < nvis) {
-                load_moments(packed_grad, (size_t)i, mom[j]);
+                load_moments_folded(packed_grad, (size_t)i, N, hot_of, mom[j]);
 #pragma unroll
                 for (int k = 0; k < 9; k++) nz[j] |= (__float_as_uint(mom[j][k]) & 0x7fffffffu) != 0u;     // +-0 adds nothing to a sum; NaN/inf travel
                 gid[j] = (int)(vis_ids[a] * S + t);
             }
         }
-        mine += nz[j] ? 1 : 0;
+        const unsigned long long m = __ballot(nz[j]);
+        rank[j] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) cnt[j][wave] = __popcll(m);
     }
-    // exclusive scan of the per-thread counts over the workgroup (order inside a batch: thread-major; across batches: arrival)
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(incl, o); if (lane >= o) incl += nb; }
-    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // Records leave in ASCENDING index order inside a batch (round-major, then wave, then lane): the consumer's workgroup -- one chunk of
+    // S consecutive Gaussians -- then reads consecutive columns of the block (coalesced); batches arrive in any order.
+    int total = 0, before[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w == wave) before[j] = total;
+            total += cnt[j][w];
+        }
     if (total == 0) return;
     if (tid == 0) base_s = atomicAdd(reinterpret_cast<int*>(block), total);          // header word 0 = K
     __syncthreads();
-    int k = base_s + incl - mine;
-    for (int w = 0; w < wave; w++) k += wsum[w];
     float* __restrict__ rows = block + DP_REC;                // row q: rows + q * cap
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        if (!nz[j]) continue;
-        if (k < cap) {                                        // beyond the capacity: dropped, the header still counts it (overflow)
+        const int k = base_s + before[j] + rank[j];
+        if (nz[j] && k < cap) {                               // beyond the capacity: dropped, the header still counts it (overflow)
             rows[k] = __int_as_float(gid[j]);
 #pragma unroll
             for (int q = 0; q < 9; q++) rows[(size_t)(1 + q) * cap + k] = mom[j][q];
         }
-        k++;
     }
 }
 
 LG_API int lg_dp_record_floats(void) { return DP_REC; }
 
 LG_API int lg_dp_compact_moments(const float* packed_grad, const int64_t* vis_ids, const int* vis_num, int A, int S, int cap,
-                                 float* block /*[(1 + cap) * 10]*/, void* stream)
+                                 float* block /*[(1 + cap) * 10]*/, const int* hot_of, int* hot_counter, void* stream)
 {
-    if (A <= 0 || cap <= 0) return (int)hipErrorInvalidValue;
+    if (A <= 0 || cap <= 0 || (hot_of != nullptr && hot_counter == nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(block, 0, sizeof(float) * DP_REC, s);          // the header row
     if (e != hipSuccess) return (int)e;
     const long long N = (long long)A * S;
-    hipLaunchKernelGGL(dp_compact_kernel, dim3(lg_cdiv(N, DP_BATCH)), dim3(256), 0, s, (const float4*)packed_grad, vis_ids, vis_num, A, S, cap, block);
+    hipLaunchKernelGGL(dp_compact_kernel, dim3(lg_cdiv(N, DP_BATCH)), dim3(256), 0, s, (const float4*)packed_grad, vis_ids, vis_num, A, S, cap, block, hot_of, hot_counter);
     LG_RETURN_LAST();
 }
 

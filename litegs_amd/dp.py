@@ -241,9 +241,10 @@ class HipMomentOps:
     """Device primitives of the moment exchange on the HIP kernels (no CPU path)."""
 
     @staticmethod
-    def compact_moments(pg, vis_ids, vis_num, A, S, cap, block):
+    def compact_moments(pg, vis_ids, vis_num, A, S, cap, block, hot_of=None, hot_counter=None):
+        """hot_of / hot_counter (device addresses, optional): the frame's gradient replicas (csrc/raster.hip) are folded into the records"""
         from ._lib import check, lib
-        check(lib().lg_dp_compact_moments(pg.data_ptr(), vis_ids.data_ptr(), vis_num.data_ptr(), A, S, cap, block.data_ptr(),
+        check(lib().lg_dp_compact_moments(pg.data_ptr(), vis_ids.data_ptr(), vis_num.data_ptr(), A, S, cap, block.data_ptr(), hot_of, hot_counter,
                                           torch.cuda.current_stream().cuda_stream), "dp_compact_moments")
 
     @staticmethod
@@ -409,6 +410,9 @@ class MomentExchange:
         self.steps += 1
         self._raise_if_dropped(self.steps - 2)           # steps older than the previous one: their words have landed
         dev = pg.device
+        hot = {}                                         # gradient replicas of this frame (litegs_amd/fast.py): folded by the compaction
+        if pending.get("replicas"):
+            hot = dict(hot_of=pending["hot_of"], hot_counter=pending["hot_counter"])
         nrec = self.ops.record_floats() if hasattr(self.ops, "record_floats") else 10
         self._mark("start")
         # union of visibility (device-side list + count): already in flight if begin() was called for this step
@@ -428,7 +432,7 @@ class MomentExchange:
         pred = int(self.fb_k[slot, 0])
         if pred <= 0:                                    # first visit of the slot: blocking count
             probe = torch.empty(((1 + A * S) * nrec,), dtype=torch.int32, device=dev)
-            self.ops.compact_moments(pg, vis_ids, vis_num, A, S, A * S, probe)
+            self.ops.compact_moments(pg, vis_ids, vis_num, A, S, A * S, probe, **hot)
             k = probe[:1].clone()
             dist.all_reduce(k, op=dist.ReduceOp.MAX, group=self.group)
             pred = max(int(k.item()), 1)
@@ -436,7 +440,7 @@ class MomentExchange:
         self.last_cap = cap
         # wire container: int32 words (record = index word + nine float bit patterns) -- an integer collective can only copy
         block = torch.empty(((1 + cap) * nrec,), dtype=torch.int32, device=dev)
-        self.ops.compact_moments(pg, vis_ids, vis_num, A, S, cap, block)
+        self.ops.compact_moments(pg, vis_ids, vis_num, A, S, cap, block, **hot)
         self._mark("compact_ms")
         gathered = torch.empty((W * (1 + cap) * nrec,), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(gathered, block, group=self.group)

@@ -155,8 +155,8 @@ class FusedRenderer:
         # with the Adam update (csrc/fused.hip: project_backward_adam_kernel) -- parameter gradients never go to HBM.
         # Only valid when nothing needs the gradients between backward and the optimizer step (no gradient-hook DP exchange).
         self.fuse_optimizer = False
-        # the records of this render are consumed ONLY by the fused backward kernels, which fold gradient replicas (set by the trainer:
-        # false for the data-parallel moment exchange, whose compaction reads the N regular lines only)
+        # every consumer of this render's gradient records folds gradient replicas: true for the fused backward + Adam and for the
+        # data-parallel moment compaction (csrc/dp.hip); the trainer clears it for anything else that reads the records
         self.fold_only_consumer = True
         self.pending = None
         self.probe_events = None      # measurement hook (bench.py): a list that receives an event pair around every blend backward launch
@@ -528,6 +528,9 @@ class _RenderFn(torch.autograd.Function):
             # ws1 rides along: its tile counts tell the fused backward + Adam which gradient records can only be zero
             R.pending = dict(pg=pg, A=A, S=S, frame=frame, degree=degree, chunks=chunks, Rr=Rr, vis_ids=vis_ids, vis_num=vis_num, ws1=ws1,
                              replicas=ctx.replicas)
+            if ctx.replicas:                              # for consumers other than FusedAdam (the data-parallel compaction folds them too)
+                R.pending["hot_of"] = ws1.data_ptr() + L.lg_fused_hot_offset(N)
+                R.pending["hot_counter"] = R.hot_counter.data_ptr()
             return (None,) * 11
         d_pos = _empty((3, A, S), torch.float32, dev)
         d_scale = _empty((3, A, S), torch.float32, dev)

@@ -176,9 +176,9 @@ class FrameTrainer:
         # gradients are only materialised when something consumes them between backward and the optimizer (gradient-hook DP exchange)
         self.renderer.fuse_optimizer = self.fused and self.fuse_adam and (grad_hook is None or moments)
         self.renderer.after_cull = grad_hook.begin if (moments and hasattr(grad_hook, "begin")) else None
-        # gradient replicas only when the fused backward kernels are the records' sole consumer (the moment exchange's compaction reads
-        # the N regular lines only)
-        self.renderer.fold_only_consumer = grad_hook is None
+        # gradient replicas whenever every consumer of the records folds them: the fused backward + Adam and the moment exchange's
+        # compaction (csrc/dp.hip) do
+        self.renderer.fold_only_consumer = grad_hook is None or moments
         img, vis_id, vis_num, prim_vis = self.forward(frame, raw=self.raw_loss)
         if self.raw_loss:
             from . import loss_hip
