@@ -367,6 +367,11 @@ class _RenderFn(torch.autograd.Function):
         # schedule, depth bounds and speculative culling are idle.  The list is a permutation of ALL tiles -- a schedule, not a selection --
         # so stat_schedule_always = False keeps the executor's own machinery outside statistics renders (same image, test_gpu_stats.py).
         tiles = STATS.schedule_for_current_frame() if (stat or R.stat_schedule_always) else None
+        if tiles is not None and (tiles.shape[1] != R.ntiles or tiles.device != dev):
+            # the statistics helper is a process-wide singleton keyed by frame index (as the reference's, statistic_helper.py:14): a list
+            # cached by another trainer at another resolution is not this frame's schedule.  (A foreign list of the right length is a
+            # permutation of all tiles -- a schedule, harmless.)
+            tiles = None
         # depth-bound culling: bookkeeping of the sizing feedback (the emitted total of a culled visit is not the full table length)
         if F.last_unculled and pred_total > F.last_capacity > 0:
             # the previous (unculled) visit needed more entries than its predicted table held: its tail was dropped, as in the reference
@@ -441,10 +446,6 @@ class _RenderFn(torch.autograd.Function):
             STATS.set_compaction(vis_ids[:A], vis_num)
             a_off = L.lg_fused_alloc_offset(N)                # b_visible = allocate_size != 0 (wrapper.py:733-736)
             STATS.add_visible((ws1[a_off:a_off + 4 * N].view(torch.int32) != 0).view(1, N))
-        if tiles is not None and tiles.shape[1] != R.ntiles:
-            # a partial tile list leaves the other tiles' pixels at "nothing blended".  The statistics helper's cached list is a permutation
-            # of all tiles (statistics.py update_tile_schedule: the argsort of the per-tile blend counts): every pixel is written, no fills
-            img.zero_(); trans.fill_(1.0); last.zero_()
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
         pg_lines = L.lg_fused_grad_lines(N) if replicas else N
         pg = _empty((pg_lines, L.lg_packed_grad_floats()), torch.float32, dev) if needs_grad else None

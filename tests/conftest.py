@@ -17,3 +17,16 @@ def oracle():
     from oracle import oracle as O
     O.build()
     return O
+
+
+@pytest.fixture(autouse=True)
+def _statistics_singleton_is_left_clean(request):
+    """litegs_amd.statistics.STATS is a process-wide singleton (as the reference's StatisticsHelper): a test that ran a statistics epoch must
+    not hand its cached per-frame tile lists to the next test's renderers."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    from litegs_amd.statistics import STATS
+    STATS.active = False
+    STATS.tile_schedule.clear()
+    STATS.tile_blend_count.clear()

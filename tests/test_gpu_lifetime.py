@@ -122,3 +122,27 @@ def test_executor_context_is_per_call():
                 np.testing.assert_array_equal(pts, res.sorted_point[0])
     for img in imgs[1:]:
         assert torch.equal(img, imgs[0])
+
+
+def test_a_foreign_cached_tile_list_is_not_this_frames_schedule():
+    """the statistics helper's per-frame tile lists are keyed by frame index in a process-wide singleton: a renderer at another resolution
+    must ignore a list another trainer cached under the same index (it used to rasterise along it: most tiles never written)"""
+    from litegs_amd import fast, render as R
+    from litegs_amd.statistics import STATS
+    from tests.util import case
+    c = case("small")
+    H, W = c["H"], c["W"]
+    params = [torch.from_numpy(p).cuda() for p in c["params"]]
+    view, proj, planes = [torch.from_numpy(x).cuda() for x in (c["view"], c["proj"], c["planes"])]
+    origin, extend = R.get_cluster_AABB(params[0], params[1].exp(), torch.nn.functional.normalize(params[2], dim=0))
+    cam = fast.CameraFrame(view, proj, planes, 0)
+    with torch.no_grad():
+        ref = fast.FusedRenderer(1, H, W).render(cam, origin, extend, *params, c["degree"])[0].clone()
+    STATS.current_frame = 0
+    STATS.tile_schedule[0] = torch.arange(1, 41, dtype=torch.int32, device="cuda")          # 40 tiles of some other image
+    try:
+        with torch.no_grad():
+            img = fast.FusedRenderer(1, H, W).render(cam, origin, extend, *params, c["degree"])[0]
+        assert torch.equal(img, ref)
+    finally:
+        STATS.tile_schedule.clear()
