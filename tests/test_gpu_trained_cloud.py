@@ -2,7 +2,8 @@
 (clone / split / prune, opacity decay, Morton re-sort -- the reference's loop, litegs/training/trainer.py:108-195), then every way the
 executor builds its tile lists must reproduce, bit for bit, what the oracle's binning (get_allocate_size -> stable depth order ->
 create_table -> tile_range) makes of the executor's OWN per-splat records, and the oracle's blend of that table must give the executor's
-image.  tools/late_phase.py runs the same check on the epoch-120 cloud of the 3 M / 150-camera run (profiles/r04_late_phase_parity.log)."""
+image (flip pins of this file are set by hand to 60: the trained cloud differs run to run -- float atomics -- so the observed count, 0-3
+of 230 k pixels, is not a constant of the build).  tools/late_phase.py runs the same check on the epoch-120 cloud of the 3 M / 150-camera run (profiles/r04_late_phase_parity.log)."""
 import ctypes
 
 import numpy as np
