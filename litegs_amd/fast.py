@@ -339,15 +339,18 @@ class _RenderFn(torch.autograd.Function):
         common = (origin.data_ptr(), extend.data_ptr(), frame.planes.data_ptr(), chunks, frame.view_ptr, frame.proj_ptr, R.H, R.W, R.TH, R.TW,
                   int(degree), xyz.data_ptr(), scale.data_ptr(), rot.data_ptr(), sh_0.data_ptr(), sh_rest.data_ptr(), opacity.data_ptr(), S)
         stat = STATS.active
-        replicas = bool(R.replicas_enabled and R.fuse_optimizer and R.fold_only_consumer and not stat and needs_grad)
-        if replicas and R.hot_counter is None:
-            R.hot_counter = _empty((1,), torch.int32, dev, zero=True)
         pred_vis = int(R.fb_vis[k])
         pred_total = int(R.fb_total[k])
-        # per-frame depth-order mode: long lists (previous visit) go through the splat sort + stable tile radix sort
+        # frames with long lists (previous visit): the splat sort + stable tile radix sort builds them, and gradient replicas are off --
+        # with 1450 instances per tile the blend backward gains nothing from them (1196 us either way) while assigning the lines costs the
+        # projection 49 us (one counter, thousands of atomics) and folding them the backward + Adam 134 us (profiles/r04_replicas_training_state.md)
+        long_lists = R.long_list_global > 0 and pred_total > R.long_list_global * R.ntiles
         depth_order = R.depth_order
-        if R.long_list_global > 0 and depth_order == 2 and pred_total > R.long_list_global * R.ntiles:
+        if long_lists and depth_order == 2:
             depth_order = 0
+        replicas = bool(R.replicas_enabled and R.fuse_optimizer and R.fold_only_consumer and not stat and needs_grad and not long_lists)
+        if replicas and R.hot_counter is None:
+            R.hot_counter = _empty((1,), torch.int32, dev, zero=True)
         do_cull = 1
         if pred_vis <= 0:                                    # first visit: blocking count (GR/compact.cu:543-546)
             c0 = R.context(depth_order, False, F.margin, False)

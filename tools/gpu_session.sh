@@ -73,6 +73,14 @@ for STAGE in "$@"; do
       timeout -s KILL 900 python tools/late_phase.py ab /tmp/late.pt > gpurun_out/late_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/late_ab_$TAG.log | tail -14
       if [ -f /tmp/mid.pt ]; then timeout -s KILL 600 python tools/late_phase.py ab /tmp/mid.pt default,global,own_schedule > gpurun_out/mid_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/mid_ab_$TAG.log | tail -8; fi
       timeout -s KILL 600 python tools/late_phase.py parity /tmp/late.pt > gpurun_out/late_parity_$TAG.log 2>&1; grep -E "parity|PARITY" gpurun_out/late_parity_$TAG.log | tail -12 ;;
+    recipeab:*)      # step / forward time of chosen variants on the training_state recipe
+      timeout -s KILL 600 python tools/late_phase.py ab recipe ${STAGE#recipeab:} > gpurun_out/recipe_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/recipe_ab_$TAG.log | tail -12 ;;
+    recipetrace:*)   # kernel trace of one named variant on the recipe state
+      V=${STAGE#recipetrace:}
+      (cd /tmp && timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_rec_${V}_$TAG -o trace -- python $R/tools/late_phase.py trace recipe $V > $R/gpurun_out/recipe_trace_${V}_$TAG.log 2>&1)
+      T=$(find gpurun_out/prof_rec_${V}_$TAG -name "*kernel_trace.csv" | head -1)
+      python tools/late_timeline.py $T 8 > gpurun_out/recipe_timeline_${V}_$TAG.md 2>> gpurun_out/recipe_timeline_$TAG.err; grep -v "rocprim\|at::native" gpurun_out/recipe_timeline_${V}_$TAG.md | head -32
+      rm -rf gpurun_out/prof_rec_${V}_$TAG ;;
     recipetrace)     # the same traces on the bench's training_state recipe (no stored cloud needed: 1.6 s to reach the state)
       for V in default stat_epoch; do
         (cd /tmp && timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_rec_${V}_$TAG -o trace -- python $R/tools/late_phase.py trace recipe $V > $R/gpurun_out/recipe_trace_${V}_$TAG.log 2>&1)

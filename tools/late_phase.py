@@ -41,6 +41,7 @@ VARIANTS = {
     "global": (dict(depth_order=0), False),                                # splat sort + stable tile radix sort
     "own_schedule": (dict(stat_schedule_always=False), False),             # default list building, executor's schedule + depth-bound culling
     "own_schedule_tile": (dict(stat_schedule_always=False, long_list_global=0), False),
+    "no_replicas": (dict(replicas_enabled=False), False),                  # gradient replicas off (blend backward contends, nothing to fold)
     "stat_epoch": (dict(), True),
     "stat_epoch_tile": (dict(long_list_global=0), True),
 }
@@ -123,7 +124,7 @@ def stat_pass(tr, pick):
 
 def configure(tr, attrs):
     rd = tr.renderer
-    base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"])
+    base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
     base.update(attrs)
     for k, v in base.items():
         setattr(rd, k, v)
