@@ -73,6 +73,8 @@ for STAGE in "$@"; do
       timeout -s KILL 900 python tools/late_phase.py ab /tmp/late.pt > gpurun_out/late_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/late_ab_$TAG.log | tail -14
       if [ -f /tmp/mid.pt ]; then timeout -s KILL 600 python tools/late_phase.py ab /tmp/mid.pt default,global,own_schedule > gpurun_out/mid_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/mid_ab_$TAG.log | tail -8; fi
       timeout -s KILL 600 python tools/late_phase.py parity /tmp/late.pt > gpurun_out/late_parity_$TAG.log 2>&1; grep -E "parity|PARITY" gpurun_out/late_parity_$TAG.log | tail -12 ;;
+    critical)        # blend kernels: whole frame against the heaviest tiles alone (is the launch a critical path?)
+      timeout -s KILL 300 python tools/late_phase.py critical recipe > gpurun_out/critical_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/critical_$TAG.log | tail -12 ;;
     recipeab:*)      # step / forward time of chosen variants on the training_state recipe
       timeout -s KILL 600 python tools/late_phase.py ab recipe ${STAGE#recipeab:} > gpurun_out/recipe_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/recipe_ab_$TAG.log | tail -12 ;;
     recipetrace:*)   # kernel trace of one named variant on the recipe state

@@ -211,6 +211,63 @@ def main():
             inst = float(np.mean([rd.fb_total[k] for k in pick]))
             print(f"{name:24s} step {ms:7.3f} ms   forward only {fw:7.3f} ms   emitted instances / frame {inst / 1e6:6.2f} M   culled last: {rd.last_cull}   "
                   f"unculled re-runs {rd.fallbacks - fb0}  replayed steps {tr.spec_replays - rp0}", flush=True)
+    elif mode == "critical":
+        # Is the blend bound by throughput or by its longest tile?  The whole frame's forward / backward against the same kernels on the K
+        # heaviest tiles only (the `tiles` argument of the C ABI): if the heaviest tile alone takes most of the frame's time, the launch is
+        # a critical path, not a throughput problem.
+        import ctypes
+        from litegs_amd._lib import check, lib
+        L = lib()
+        configure(tr, {})
+        k = pick[0]
+        with torch.no_grad():
+            tr.forward_only(k); tr.forward_only(k)
+        torch.cuda.synchronize()
+        ws1, N = rd.last_ws1
+        ws2, tl, _ = rd.last_ws2
+        o_ts = L.lg_fused_tile_start_offset(tl, N, H, W, 8, 16)
+        o_pts = L.lg_fused_sorted_points_offset(ctypes.byref(rd.last_ctx), tl, N, H, W, 8, 16)
+        ts = ws2[o_ts:o_ts + 4 * (rd.ntiles + 2)].view(torch.int32)
+        pts = ws2[o_pts:o_pts + 4 * tl].view(torch.int32)
+        packed = ws1[L.lg_fused_packed_offset(N):][:4 * N * 16].view(torch.float32)
+        dev = ts.device
+        img = torch.empty((1, 3, rd.Hp, rd.Wp), device=dev); trans = torch.empty((1, 1, rd.Hp, rd.Wp), device=dev)
+        last = torch.empty((1, 1, rd.Hp, rd.Wp), dtype=torch.int16, device=dev)
+        work = torch.zeros((rd.ntiles + 1,), dtype=torch.int32, device=dev)
+        sm = torch.cuda.current_stream().cuda_stream
+
+        def fwd(tiles):
+            K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
+            check(L.lg_raster_forward(pts.data_ptr(), ts.data_ptr(), packed.data_ptr(), tp, K, 1, tl, N, H, W, 8, 16, 0, img.data_ptr(), trans.data_ptr(),
+                                      last.data_ptr(), None, None, None, work.data_ptr() if tiles is None else None, sm), "fwd")
+        d_img = torch.rand((1, 3, rd.Hp, rd.Wp), device=dev) - 0.5
+        pg = torch.zeros((N, 16), device=dev)
+
+        def bwd(tiles):
+            K, tp = (tiles.shape[1], tiles.data_ptr()) if tiles is not None else (0, None)
+            check(L.lg_raster_backward(pts.data_ptr(), ts.data_ptr(), packed.data_ptr(), tp, K, trans.data_ptr(), last.data_ptr(), d_img.data_ptr(), None,
+                                       1, tl, N, H, W, 8, 16, 0, pg.data_ptr(), None, None, None, sm), "bwd")
+
+        def timeit(fn, arg, reps=5):
+            fn(arg); torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); fn(arg); b.record(); torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b))
+            return best
+        fwd(None); torch.cuda.synchronize()
+        walked = work[1:].cpu().numpy()
+        order = np.argsort(-walked)
+        q = np.percentile(walked, [50, 90, 99, 99.9])
+        print(f"splats walked per tile (forward, camera {k}): sum {int(walked.sum())}  mean {walked.mean():.0f}  p50 {q[0]:.0f}  p90 {q[1]:.0f}  p99 {q[2]:.0f}  p99.9 {q[3]:.0f}  max {walked.max()}", flush=True)
+        t_all_f, t_all_b = timeit(fwd, None), timeit(bwd, None)
+        print(f"whole frame: forward {t_all_f * 1e3:8.1f} us   backward {t_all_b * 1e3:8.1f} us", flush=True)
+        for K in (1, 4, 16, 64, 256, 1024, 4096):
+            tl_ = torch.from_numpy((order[:K] + 1).astype(np.int32)[None].copy()).to(dev)
+            print(f"{K:5d} heaviest tiles ({int(walked[order[:K]].sum()):9d} entries walked, heaviest {int(walked[order[0]])}): forward {timeit(fwd, tl_) * 1e3:8.1f} us   "
+                  f"backward {timeit(bwd, tl_) * 1e3:8.1f} us", flush=True)
+        fwd(None)
     elif mode == "trace":
         name = sys.argv[3] if len(sys.argv) > 3 else "default"
         attrs, stat = VARIANTS[name]
