@@ -283,6 +283,16 @@ class FusedRenderer:
         for f in self.frames:
             f.reset(self.margin_fixed or self.margin_lo)
 
+    def parameters_replaced(self):
+        """Density control / a Morton re-sort replaced the parameters.  Depth bounds and tile schedules describe the old cloud: dropped.  The
+        SIZE predictions (visible chunks, table length) are kept -- the reference never resets its feedback buffers either (litegs/data.py:
+        236-241): a densification adds a few percent of points, inside the 1.2x / 1.5x allocation margins, and an under-predicted table
+        is noticed and sized exactly on the frame's next visit.  Resetting them made every frame's next visit a blocking first visit that
+        also mispredicts the list route: epochs after a densification cost 3.9-4.3 ms per iteration against 3.3-3.5 for the others at 3 M /
+        150 cameras (profiles/r04_convergence_3m_final.md, cost by position in the densification cycle)."""
+        for f in self.frames:
+            f.reset(self.margin_fixed or self.margin_lo)
+
     def cull_scratch(self, chunks: int, device):
         """persistent look-back table of the multi-workgroup culling kernel (epoch-tagged: zeroed once, never cleared again)"""
         if self._cull_scratch is None or self._cull_chunks != chunks or self._cull_epoch > 1_000_000:

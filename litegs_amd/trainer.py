@@ -233,8 +233,8 @@ class FrameTrainer:
 
     # -- epoch-boundary callers of the path (trainer.py:111-118, 195): Morton re-sort, density control ---------------------------
     def _rebind(self):
-        """parameters were replaced / re-sorted: refresh everything derived from them (chunk AABBs, cached pointers, the per-frame
-        size predictions of the GPU-driven protocol -- a first-visit blocking read is cheaper than a truncated table)."""
+        """parameters were replaced / re-sorted: refresh everything derived from them (chunk AABBs, cached pointers, depth bounds and tile
+        schedules).  The per-frame SIZE predictions of the GPU-driven protocol are kept, as in the reference."""
         if self._spec_ring:
             self.flush()
         by_name = {g["name"]: g["params"][0] for g in self.opt.param_groups}
@@ -246,11 +246,9 @@ class FrameTrainer:
         self.fadam._ready = False
         self.renderer.pending = None
         torch.cuda.current_stream().synchronize()               # pinned feedback words may still be in flight
-        self.renderer.reset_feedback()
+        self.renderer.parameters_replaced()                     # bounds and schedules dropped, size predictions kept (as the reference does)
         if getattr(self, "exchange", None) is not None:
             self.exchange.rebind(self.params)
-        self.feedback_visible_chunks_num.zero_()
-        self.feedback_binning_allocate_size.zero_()
 
     def enable_densify(self, params=None, total_epochs: int = 100, screen_extent: float = 1.0, seed: int = 0, group=None,
                        init_points_num: Optional[int] = None):
