@@ -239,6 +239,7 @@ class FrameTrainer:
             self.flush()
         by_name = {g["name"]: g["params"][0] for g in self.opt.param_groups}
         self.params = [by_name[n] for n in ("xyz", "scale", "rot", "sh_0", "sh_rest", "opacity")]
+        old_chunks = self.n_chunks
         self.n_chunks, self.S = self.params[0].shape[-2], self.params[0].shape[-1]
         with torch.no_grad():
             xyz, scale, rot = self.params[0], self.params[1], self.params[2]
@@ -246,7 +247,8 @@ class FrameTrainer:
         self.fadam._ready = False
         self.renderer.pending = None
         torch.cuda.current_stream().synchronize()               # pinned feedback words may still be in flight
-        self.renderer.parameters_replaced()                     # bounds and schedules dropped, size predictions kept (as the reference does)
+        # bounds and schedules dropped; size predictions of the frames in use kept and scaled by the cloud's growth (as the reference does)
+        self.renderer.parameters_replaced(self.n_chunks / max(old_chunks, 1))
         if getattr(self, "exchange", None) is not None:
             self.exchange.rebind(self.params)
 
