@@ -308,15 +308,12 @@ class MomentExchange:
         self.slot = torch.zeros((self.world, self.chunks * self.S), dtype=torch.int32, device=dev)
         self.overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
         # per slot: {largest count of the job, overflow marker}, written by the device (csrc/dp.hip: dp_slotmap_kernel)
-        old = getattr(self, "fb_k", None)
+        # per-slot record counts start over (a blocking first visit per slot): a dropped record is an error here, never a silent truncation,
+        # and density control can double a small cloud -- the renderer's table sizes, whose overflow self-heals, are kept instead (fast.py)
         self.fb_k = torch.zeros((self.n_slots, 2), dtype=torch.int32)
         if self.cuda:                                    # library arena: never unmapped under a launch in flight (hostwords.py)
             from .hostwords import pinned_int32
             self.fb_k, self._fb_k_owner = pinned_int32((self.n_slots, 2))
-        if old is not None and old.shape == self.fb_k.shape:
-            # the record-count predictions survive a re-bind (same value on every rank: each derived it from the same gathered headers):
-            # density control changes the counts by a few percent, inside the capacity factor -- and a first visit is a blocking collective
-            self.fb_k[:, 0] = old[:, 0]
         self.fb_event = [None] * self.n_slots            # recorded behind the kernel that writes fb_k[slot]
         self.in_flight = []                              # (step number, slot) of steps whose overflow word has not been read yet
         self.steps = 0
