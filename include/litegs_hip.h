@@ -65,6 +65,14 @@ int lg_adam_update_primitive(float* param, const float* grad, float* exp_avg, fl
 int lg_sparse_scatter(void* A_, const void* B, const int64_t* chunk_ids, const int* valid_count,
                       int E, int chunks, int alloc, int S, int dtype, int op, void* stream);
 
+/* Statistic epochs of the native executor: visible_count and the moments "fragment_weight" / "fragment_err" of the statistics helper
+ * (litegs/utils/statistic_helper.py) accumulated in one pass over the frame's gradient records [A*S,16] (slots 8-11: M0, fragment count,
+ * fragment weight sum, err_square; lg_fused_backward in statistic mode), the packed splat records (opacity) and the tile counts: the
+ * scatters gpu_driven_pipeline_sparse_op would perform, without the torch glue in between.  All destinations are [chunks, S]. */
+int lg_stat_accumulate(const float* packed_grad, const float* packed, const int* alloc, const int64_t* chunk_ids, const int* valid_count,
+                       int A, int chunks, int S, int* visible_count, float* w_sum, float* w_sq, int* w_cnt,
+                       float* e_sum, float* e_sq, int* e_cnt, void* stream);
+
 /* data-parallel helpers (new: the reference has no multi-GPU path): mask[ids[i]]=1 for i<*count; ordered compaction of an
  * int32 mask into (count, ids) with the output contract of lg_frustum_culling_aabb */
 int lg_mark_chunks(const int64_t* ids, const int* count, int A, int* mask, void* stream);

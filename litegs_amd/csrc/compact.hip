@@ -625,6 +625,48 @@ LG_API int lg_sparse_scatter(void* A, const void* B, const int64_t* chunk_ids, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Statistic epochs of the executor: everything the statistics helper accumulates per frame (litegs/utils/statistic_helper.py:
+// visible_count, the moments "fragment_weight" and "fragment_err") in ONE pass over the frame's gradient records, instead of ~15 torch
+// elementwise / scatter launches around the blend kernels.  Per compacted Gaussian i of visible chunk a:
+//   visible += (tile count != 0)                                        wrapper.py:733-736 (b_visible = allocate_size != 0)
+//   fragment_weight: sum += w, square_sum += w * w, count += n          n = fragment count (record slot 9), w = weight sum (slot 10)
+//   fragment_err:    sum += M0 / opacity, square_sum += e2, count += n  M0 = record slot 8, e2 = err_square (slot 11)
+// The adds are per-frame scatters into [chunks, S] arrays exactly as gpu_driven_pipeline_sparse_op performs them (one writer per word).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) stat_accumulate_kernel(const float4* __restrict__ packed_grad, const float4* __restrict__ packed,
+                                                              const int* __restrict__ alloc, const int64_t* __restrict__ chunk_ids,
+                                                              const int* __restrict__ valid_count, int chunks, int S,
+                                                              int* __restrict__ visible_count,
+                                                              float* __restrict__ w_sum, float* __restrict__ w_sq, int* __restrict__ w_cnt,
+                                                              float* __restrict__ e_sum, float* __restrict__ e_sq, int* __restrict__ e_cnt)
+{
+    const int a = blockIdx.x;
+    if (a >= valid_count[0]) return;
+    const size_t dstc = (size_t)chunk_ids[a];
+    if (dstc >= (size_t)chunks) return;
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        const size_t i = (size_t)a * S + t, d = dstc * S + t;
+        const float4 g2 = packed_grad[i * 4 + 2];                 // slots 8 (M0), 9 (count), 10 (weight), 11 (err_square)
+        const float o = packed[i * 4 + 1].y;                      // record dword 5: activated opacity
+        const int n = (int)__builtin_rintf(g2.y);
+        if (alloc[i] != 0) visible_count[d] += 1;
+        w_sum[d] += g2.z; w_sq[d] += g2.z * g2.z; w_cnt[d] += n;
+        e_sum[d] += (o > 0.0f) ? g2.x / o : 0.0f; e_sq[d] += g2.w; e_cnt[d] += n;
+    }
+}
+
+LG_API int lg_stat_accumulate(const float* packed_grad, const float* packed, const int* alloc, const int64_t* chunk_ids, const int* valid_count,
+                              int A, int chunks, int S, int* visible_count, float* w_sum, float* w_sq, int* w_cnt,
+                              float* e_sum, float* e_sq, int* e_cnt, void* stream)
+{
+    if (A <= 0 || S <= 0) return 0;
+    LG_REQUIRE(packed_grad, packed, alloc, chunk_ids, valid_count, visible_count, w_sum, w_sq, w_cnt, e_sum, e_sq, e_cnt);
+    hipLaunchKernelGGL(stat_accumulate_kernel, dim3(A), dim3(128), 0, (hipStream_t)stream, (const float4*)packed_grad, (const float4*)packed, alloc,
+                       chunk_ids, valid_count, chunks, S, visible_count, w_sum, w_sq, w_cnt, e_sum, e_sq, e_cnt);
+    LG_RETURN_LAST();
+}
+
 // 4-byte device -> pinned-host feedback copy on the caller's stream (GR/compact.cu:538, GR/binning.cu:148)
 LG_API int lg_feedback_d2h(int* host_dst, const int* device_src, void* stream)
 {

@@ -904,7 +904,7 @@ struct BwdFast {
 //   STAT == 1 (operator surface: rasterize_backward's err_square_sum output): reduced on the DPP path, added by one lane to the array.
 //   STAT == 2 (executor): the three per-splat statistics of an epoch -- fragment count and fragment weight sum (what the reference's forward
 //     accumulates, raster.cu:283-302: the backward sees the same validity mask and recovers the same weights) and err_square -- are reduced
-//     by one small transposing butterfly and travel in slots 9, 10, 11 of the splat's gradient record, inside the ONE atomic instruction
+//     (the count on the scalar unit, the two sums by one swap and five DPP adds) and travel in slots 9, 10, 11 of the splat's gradient record, inside the ONE atomic instruction
 //     the nine moments already cost.  Measured motive (profiles/r04_stat_epoch_timeline.md): every additional per-splat atomic instruction
 //     costs ~0.4 ms per 1080p frame of the late-phase cloud (9.8 M contributing (tile, splat) pairs, same-line contention), the three of the
 //     separate-array form 1.2 ms.
@@ -952,17 +952,17 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     if constexpr (STAT == 2) {
         const float inv_o = __builtin_amdgcn_rcpf(rec[R_O]);
         const float vo0 = m.x * inv_o, vo1 = s0 * inv_o;
-        float a = (val0 ? 1.0f : 0.0f) + (val1 ? 1.0f : 0.0f);                                   // fragments of this lane
-        float b = w.x + w.y;                                                                     // their blend weights
-        float c = __builtin_fmaf(vo0, vo0, __any(val1) ? vo1 * vo1 : 0.0f), d = 0.0f;
-        // transposing butterfly of four values: rows 0 / 1 / 2 / 3 end up with the 16 partial sums of a / c / b / d, lane 15 of each row
-        // with the row's total (lanes 15, 31, 47: the writers of slots 9, 11, 10 -- stat_lane_slot())
-        swap32(a, b); swap32(c, d);
-        a += b; c += d;
-        swap16(a, c);
-        a += c;
-        a = DPP_ADD(a, 0x111, 0xF, 0xF); a = DPP_ADD(a, 0x112, 0xF, 0xF); a = DPP_ADD(a, 0x114, 0xF, 0xF); a = DPP_ADD(a, 0x118, 0xF, 0xF);
-        tot = ((lane & 15) == 15) ? a : tot;
+        float b = w.x + w.y;                                                                     // blend weights of this lane's fragments
+        float c = __builtin_fmaf(vo0, vo0, __any(val1) ? vo1 * vo1 : 0.0f);
+        // the fragment COUNT is the popcount of the two validity masks: scalar unit, no reduction.  Weight and err_square: one
+        // permlane32 swap puts the b partials into lanes 0-31 and the c partials into lanes 32-63, four row_shr adds leave every row's
+        // total in its lane 15, one row_bcast:15 adds rows 0 / 2 into rows 1 / 3: lane 31 holds the weight sum, lane 63 err_square
+        const float fcount = (float)(__popcll(__ballot(val0)) + __popcll(__ballot(val1)));
+        swap32(b, c);
+        b += c;
+        b = DPP_ADD(b, 0x111, 0xF, 0xF); b = DPP_ADD(b, 0x112, 0xF, 0xF); b = DPP_ADD(b, 0x114, 0xF, 0xF); b = DPP_ADD(b, 0x118, 0xF, 0xF);
+        b = DPP_ADD(b, 0x142, 0xA, 0xF);
+        tot = (lane == 15) ? fcount : (((lane & 31) == 31) ? b : tot);
     }
     // ONE atomic instruction from the lanes that hold a total: scalar base = the splat's gradient record
     const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pg) + pid_off);
@@ -977,10 +977,10 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     }
 }
 
-// record slot of the statistics total that lane 15 / 31 / 47 holds after the four-value butterfly of bwd_splat_fast<.., 2> (-1: none)
+// record slot of the statistics total that lane 15 / 31 / 63 holds at the end of bwd_splat_fast<.., 2> (-1: none)
 __device__ __forceinline__ int stat_lane_slot(int lane)
 {
-    return lane == 15 ? STAT_SLOT_COUNT : (lane == 31 ? STAT_SLOT_ERRSQ : (lane == 47 ? STAT_SLOT_WEIGHT : -1));
+    return lane == 15 ? STAT_SLOT_COUNT : (lane == 31 ? STAT_SLOT_WEIGHT : (lane == 63 ? STAT_SLOT_ERRSQ : -1));
 }
 
 template <bool TRANS, int STAT>

@@ -336,13 +336,6 @@ def _d_opacity(pg, ws1, N):
     return torch.where(o > 0, pg[:, 8] / o, torch.zeros_like(o)).reshape(1, 1, N)
 
 
-def _record_statistics(pg, N):
-    """statistic epochs: (fragment_count int32, fragment_weight_sum, err_square_sum), each [1,1,N], from slots 9 / 10 / 11 of the gradient
-    records (csrc/raster.hip STAT_SLOT_*; the count is a sum of small integers in fp32: exact below 2^24)"""
-    st = pg[:N, 9:12]
-    return (st[:, 0].round().to(torch.int32).reshape(1, 1, N), st[:, 1].reshape(1, 1, N).contiguous(), st[:, 2].reshape(1, 1, N).contiguous())
-
-
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, R: FusedRenderer, frame: CameraFrame, origin, extend, degree, xyz, scale, rot, sh_0, sh_rest, opacity):
@@ -470,8 +463,9 @@ class _RenderFn(torch.autograd.Function):
                 fc = _empty((1, 1, N), torch.int32, dev, zero=True)
                 fw = _empty((1, 1, N), torch.float32, dev, zero=True)
             STATS.set_compaction(vis_ids[:A], vis_num)
-            a_off = L.lg_fused_alloc_offset(N)                # b_visible = allocate_size != 0 (wrapper.py:733-736)
-            STATS.add_visible((ws1[a_off:a_off + 4 * N].view(torch.int32) != 0).view(1, N))
+            if not (stat_in_record and needs_grad):          # (with the statistics in the record the backward counts the visible ones too)
+                a_off = L.lg_fused_alloc_offset(N)            # b_visible = allocate_size != 0 (wrapper.py:733-736)
+                STATS.add_visible((ws1[a_off:a_off + 4 * N].view(torch.int32) != 0).view(1, N))
         # gradient accumulator of the blend backward: allocated here so that stage 2 can clear it on the side (no memset launch later)
         pg_lines = L.lg_fused_grad_lines(N) if replicas else N
         pg = _empty((pg_lines, L.lg_packed_grad_floats()), torch.float32, dev) if needs_grad else None
@@ -547,9 +541,10 @@ class _RenderFn(torch.autograd.Function):
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
                 R.probe_events.append((ev0, ev1))
-            if stat:
-                if stat_in_record:
-                    fc, fw, esq = _record_statistics(pg, N)
+            if stat and stat_in_record:
+                STATS.set_compaction(vis_ids[:A], vis_num)
+                STATS.accumulate_records(pg, ws1.data_ptr() + L.lg_fused_packed_offset(N), ws1.data_ptr() + L.lg_fused_alloc_offset(N), A)
+            elif stat:
                 STATS.add_moments("fragment_weight", fw, fw * fw, fc)
                 STATS.add_moments("fragment_err", _d_opacity(pg, ws1, N), esq, fc)
             # ws1 rides along: its tile counts tell the fused backward + Adam which gradient records can only be zero
@@ -573,9 +568,10 @@ class _RenderFn(torch.autograd.Function):
                                   d_pos.data_ptr(), d_scale.data_ptr(), d_rot.data_ptr(), d_sh0.data_ptr(), d_shr.data_ptr(), d_opa.data_ptr(),
                                   ctx.order_ptr, _s()),
               "fused backward")
-        if stat:
-            if stat_in_record:
-                fc, fw, esq = _record_statistics(pg, N)
+        if stat and stat_in_record:
+            STATS.set_compaction(vis_ids[:A], vis_num)
+            STATS.accumulate_records(pg, ws1.data_ptr() + L.lg_fused_packed_offset(N), ws1.data_ptr() + L.lg_fused_alloc_offset(N), A)
+        elif stat:
             # d_opacity of the activated opacity = packed_grad slot 8 (rasterize_backward's 4th output)
             d_op_act = _d_opacity(pg, ws1, N)
             STATS.add_moments("fragment_weight", fw, fw * fw, fc)

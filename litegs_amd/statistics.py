@@ -79,6 +79,22 @@ class Statistics:
                                             self.compact_ids, self.compact_count, "add")
 
     @torch.no_grad()
+    def accumulate_records(self, packed_grad: torch.Tensor, packed_ptr: int, alloc_ptr: int, A: int):
+        """native executor, statistic epochs: visible_count and the moments "fragment_weight" / "fragment_err" of one frame in one pass over
+        its gradient records (csrc/compact.hip stat_accumulate_kernel) -- what add_visible + two add_moments calls accumulate, without the
+        dozen elementwise / scatter launches in between.  set_compaction() must have been called for the frame."""
+        from ._lib import check, lib
+        for key in ("fragment_weight", "fragment_err"):
+            if key not in self.moments:
+                self.moments[key] = _Moments((1, 1), self.chunks, self.S, packed_grad.device)
+        w, e = self.moments["fragment_weight"], self.moments["fragment_err"]
+        check(lib().lg_stat_accumulate(packed_grad.data_ptr(), packed_ptr, alloc_ptr, self.compact_ids.data_ptr(), self.compact_count.data_ptr(),
+                                       int(A), self.chunks, self.S, self.visible_count.data_ptr(),
+                                       w.sum.data_ptr(), w.square_sum.data_ptr(), w.count.data_ptr(),
+                                       e.sum.data_ptr(), e.square_sum.data_ptr(), e.count.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "stat_accumulate")
+
+    @torch.no_grad()
     def update_tile_schedule(self, last_contributor: torch.Tensor, th: int, tw: int):
         """Per-tile max blend depth -> heavy-first tile order for the next time this frame is rendered
         (statistic_helper.py:68-79)."""
