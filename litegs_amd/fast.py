@@ -73,12 +73,13 @@ class CameraFrame:
 class _FrameState:
     """what the executor remembers about one camera between two visits (sizing feedback lives in the pinned words)"""
     __slots__ = ("sched_cur", "sched_valid", "order_valid", "margin", "clean_visits", "margin_written", "margin_emitted",
-                 "last_capacity", "visits", "full_total", "last_unculled", "visits_at_replace")
+                 "last_capacity", "visits", "full_total", "last_unculled", "visits_at_replace", "idle_replacements")
 
     def __init__(self, margin: int):
         self.sched_cur = 0
         self.visits = 0
         self.visits_at_replace = 0
+        self.idle_replacements = 0
         self.reset(margin)
 
     def reset(self, margin: int):
@@ -286,17 +287,19 @@ class FusedRenderer:
 
     def parameters_replaced(self, growth: float = 1.0):
         """Density control / a Morton re-sort replaced the parameters (`growth` = new / old point count).  Depth bounds and tile schedules
-        describe the old cloud: dropped.  The SIZE predictions (visible chunks, table length) of the frames visited since the previous
-        replacement are kept, scaled by the growth -- the reference never resets its feedback buffers (litegs/data.py:236-241,
-        GR/compact.cu:527-546): a densification adds a few percent of points, inside the 1.2x / 1.5x allocation margins, and an
-        under-predicted table is noticed and sized exactly on the frame's next visit.  Frames NOT visited since (evaluation frames: their
-        predictions are many densifications old) start over with an exact, blocking first visit -- the reference would truncate them
-        silently.  Resetting everything made every training frame's next visit a blocking first visit that also mispredicts the list
+        describe the old cloud: dropped.  The SIZE predictions (visible chunks, table length) of the frames in use are kept, scaled by the
+        growth -- the reference never resets its feedback buffers (litegs/data.py:236-241, GR/compact.cu:527-546): a densification adds a
+        few percent of points, inside the 1.2x / 1.5x allocation margins, and an under-predicted table is noticed and sized exactly on the
+        frame's next visit.  Frames out of use (evaluation frames: their predictions are many densifications old) start over with an
+        exact, blocking first visit -- the reference would truncate them silently.  Resetting everything made every training frame's next visit a blocking first visit that also mispredicts the list
         route: epochs after a densification cost 3.9-4.3 ms per iteration against 3.3-3.5 for the others at 3 M / 150 cameras
         (profiles/r04_convergence_3m_runs_11_13.md, cost by position in the densification cycle)."""
         g = max(1.0, float(growth))
         for k, f in enumerate(self.frames):
-            fresh = f.visits > f.visits_at_replace
+            # a densification is TWO replacements with no visit in between (density control at the end of an epoch, the Morton re-sort at
+            # the start of the next): a frame is out of use when it sat out two replacements in a row
+            f.idle_replacements = 0 if f.visits > f.visits_at_replace else f.idle_replacements + 1
+            fresh = f.idle_replacements < 2
             f.reset(self.margin_fixed or self.margin_lo)
             f.visits_at_replace = f.visits
             if fresh:

@@ -201,6 +201,7 @@ def main():
         except Exception as e:                               # measurement aid only
             print("units: not available:", repr(e), flush=True)
         names = sys.argv[3].split(",") if len(sys.argv) > 3 else list(VARIANTS)
+        restore(); configure(tr, {}); timed(tr, pick, 1, False)      # discarded: the first timing of a process has come out 1.6 ms per step slow
         for name in names:
             attrs, stat = VARIANTS[name]
             restore()
