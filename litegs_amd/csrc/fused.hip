@@ -517,6 +517,8 @@ static Camera make_camera(const float* view_host, const float* proj_host, int H,
 // sum, emission, sort, ranges, blend -- that is always enqueued but exits at once while the flag is clear, redoes the frame in
 // full.  No host decision, no synchronisation; the common case pays seven empty launches.
 // ---------------------------------------------------------------------------------------------
+static int validate_chunk_ids(const struct Exec& x, int64_t* vis_ids, const int* vis_num, int A, int chunks, int* lock, hipStream_t s);
+
 struct Scene {            // what the projection kernel reads (raw parameters + the frame's visible chunks)
     const float *pos, *scale, *rot, *sh0, *shr, *opa;
     const int64_t* vis_ids;
@@ -590,6 +592,9 @@ LG_API int lg_fused_stage1(const LgFusedCtx* ctx, const float* aabb_origin, cons
     char* w = (char*)ws1;
     Camera cam = make_camera(view_host, proj_host, H, W);
     Scene sc = { pos, scale, rot, sh0, shr, opa, vis_ids, vis_num, chunks, S, A, degree };
+    if (x.validate) {      // (the lock word lives in the scratch the projection clears: taken from the previous frame's state of this workspace)
+        rc = validate_chunk_ids(x, vis_ids, vis_num, A, chunks, nullptr, s); if (rc) return rc;
+    }
     rc = launch_projection(sc, cam, TH, TW, w, f, true, sched_cull, sched_out, nullptr, s, x.replicas ? x.hot_counter : nullptr); if (rc) return rc;
     if (use_tile_order(x, N)) {
         // no splat sort: instances are emitted in splat-id order and every tile's list is depth-sorted after the tile sort
@@ -666,6 +671,37 @@ __global__ void __launch_bounds__(256) validate_table_kernel(int32_t* __restrict
         const int id = vals[i];
         if ((unsigned)id >= (unsigned)N) { validate_report(lock, dbg, 3, (int)i, id, N, (int)n); vals[i] = 0; }
     }
+}
+
+// code 4: visible_chunk_id[where] = value outside 0..chunks-1 for a position the kernels will use (where < min(A, visible count))
+__global__ void __launch_bounds__(256) validate_chunk_ids_kernel(int64_t* __restrict__ vis_ids, const int* __restrict__ vis_num, int A, int chunks,
+                                                                 int* __restrict__ dbg)
+{
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    const int n = vis_num[0];
+    if (a >= A || a >= n) return;
+    const int64_t id = vis_ids[a];
+    if (id < 0 || id >= (int64_t)chunks) {
+        const int seen = __hip_atomic_load(dbg + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dbg + 1, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dbg + 2, (int)id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dbg + 3, chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dbg + 4, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dbg + 7, seen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dbg + 0, 4, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        vis_ids[a] = 0;
+    }
+    if (a == 0 && (n < 0 || n > chunks)) {
+        __hip_atomic_store(dbg + 1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dbg + 2, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dbg + 3, chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dbg + 0, 5, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+static int validate_chunk_ids(const Exec& x, int64_t* vis_ids, const int* vis_num, int A, int chunks, int* /*lock*/, hipStream_t s)
+{
+    hipLaunchKernelGGL(validate_chunk_ids_kernel, dim3((A + 255) / 256), dim3(256), 0, s, vis_ids, vis_num, A, chunks, x.debug_words);
+    return (int)hipGetLastError();
 }
 
 #define LG_VALIDATE_LOCK_WORD 8            // int index inside Layout1::flags (cleared with the frame's scratch by the projection)

@@ -267,7 +267,8 @@ class FusedRenderer:
         if self._debug_words is not None and int(self._debug_words.a[0]) != 0:
             rec = [int(x) for x in self._debug_words.a]
             self._debug_words.a[0] = 0
-            what = {1: "tile key out of range in the emitted table", 2: "tile range ends beyond the valid entries", 3: "splat id out of range in the grouped table"}
+            what = {1: "tile key out of range in the emitted table", 2: "tile range ends beyond the valid entries", 3: "splat id out of range in the grouped table",
+                    4: "visible chunk id out of range", 5: "visible chunk count out of range"}
             raise RuntimeError(f"litegs_amd: table validator: {what.get(rec[0], 'code %d' % rec[0])}: where={rec[1]} value={rec[2]} bound={rec[3]} "
                                f"valid_entries={rec[4]} reports_so_far={rec[7]}")
 
