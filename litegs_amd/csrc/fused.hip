@@ -62,6 +62,40 @@ __host__ __device__ static inline long long hot_capacity(long long N) { return N
 //    later, synchronises, and replays the steps after `applied` in order, the first of them unculled: the parameter sequence is exactly
 //    the one the gated repeat would have produced.  Renders that are not followed by a fused Adam step (evaluation, gradient-hook data
 //    parallelism) keep the gated repeat.
+// Breadcrumbs for fault hunting (LITEGS_CRUMBS=1, with HIP_LAUNCH_BLOCKING=1): the name of the launch group a stage call is in and the sizes
+// it runs with, printed from a SIGABRT handler -- a GPU memory access fault aborts the process from the runtime's own thread, and with
+// blocking launches the group on record is the one that faulted.  Debugging aid; costs one getenv per process.
+#include <csignal>
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
+namespace {
+char g_crumb[512] = "(none)";
+char g_crumb_ctx[512] = "";
+int g_crumbs_on = -1;
+void (*g_prev_abort)(int) = nullptr;
+void crumb_abort_handler(int sig)
+{
+    const char* head = "\n[litegs crumbs] last launch group: ";
+    (void)!write(2, head, strlen(head)); (void)!write(2, g_crumb, strlen(g_crumb));
+    (void)!write(2, "\n[litegs crumbs] ", 18); (void)!write(2, g_crumb_ctx, strlen(g_crumb_ctx)); (void)!write(2, "\n", 1);
+    if (g_prev_abort != nullptr && g_prev_abort != SIG_DFL && g_prev_abort != SIG_IGN) g_prev_abort(sig);
+    signal(SIGABRT, SIG_DFL);
+    abort();
+}
+bool crumbs_on()
+{
+    if (g_crumbs_on < 0) {
+        const char* e = getenv("LITEGS_CRUMBS");
+        g_crumbs_on = (e != nullptr && e[0] == '1') ? 1 : 0;
+        if (g_crumbs_on) g_prev_abort = signal(SIGABRT, crumb_abort_handler);
+    }
+    return g_crumbs_on == 1;
+}
+}
+#define CRUMB(name) do { if (crumbs_on()) snprintf(g_crumb, sizeof(g_crumb), "%s", name); } while (0)
+
 struct Exec {
     int depth_order, margin_pct, tile_scatter, replicas, step_id, validate;
     int *hot_counter, *poison, *poison_host, *applied_host, *debug_words;
@@ -731,9 +765,13 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     const int bits = tile_key_bits(ntiles);
     const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(x, f, N, ntiles));
     int rc;
+    if (crumbs_on())
+        snprintf(g_crumb_ctx, sizeof(g_crumb_ctx), "stage2: N=%lld L=%lld Ls=%lld ntiles=%d tile_mode=%d scatter=%d replicas=%d stat=%d tiles=%p K=%d gate=%p ws1=%p ws2=%p ws2_bytes=%zu",
+                 N, L, Ls, ntiles, (int)tile_mode, (int)use_tile_scatter(x, N, ntiles), x.replicas, enable_stat, (const void*)tiles, K, (const void*)gate, (void*)w1, (void*)w, f.total);
     if (use_tile_scatter(x, N, ntiles)) {
         // TILE mode without a sort: the emitted keys are counted per key (LDS-aggregated), one workgroup turns the counts into the range
         // table and write cursors, one pass drops the values at their cursors, and the per-tile sort orders every list by (depth, id)
+        CRUMB("tile route: key emission (dup_small + dup_big)");
         rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
                                (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
                                qcount, (uint32_t*)(w + f.dup_entries), nullptr, 0, bits, nullptr, nullptr, 0,
@@ -741,10 +779,12 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
                                (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
         if (rc) return rc;
         if (x.validate) { rc = validate_keys(x, (int32_t*)(w + f.tk_a), Ls, total_dev, ntiles, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
+        CRUMB("tile route: count + offsets + scatter");
         rc = lg_tile_scatter_gated((const int32_t*)(w + f.tk_a), (const int32_t*)(w + f.tv_a), Ls, total_dev, ntiles, tcount, 1, (int*)(w + f.tile_cursor),
                                    (int32_t*)(w + f.tile_start), (int32_t*)(w + f.tv_b), gate, s);
         if (rc) return rc;
         if (x.validate) { rc = validate_table(x, (int32_t*)(w + f.tv_b), (int32_t*)(w + f.tile_start), Ls, total_dev, ntiles, (int)N, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
+        CRUMB("tile route: per-tile depth sort");
         rc = lg_tile_depth_sort_gated((int32_t*)(w + f.tv_b), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L, (int)N, ntiles,
                                       (uint32_t*)(w + f.tk_b), 1, gate, s);
         if (rc) return rc;
@@ -752,6 +792,7 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     // key/value emission; on the side it counts the tile sort's radix digits (into the header the projection kernel cleared) and
     // clears the sort's look-back table.  No table memset: the bounded sort only reads the first prefix[N-1] entries, and a
     // truncated table (Ls < total) gets its tail zeroed by the first splat that does not fit.
+    CRUMB("global route: key emission (dup_small + dup_big)");
     rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
                                (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
                                qcount, (uint32_t*)(w + f.dup_entries), tsort_hdr, 0, bits, nullptr, (uint32_t*)(w + f.tsort_table),
@@ -760,12 +801,15 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
                                (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
     if (rc) return rc;
     // instance count on the device: only that many entries are sorted and range-scanned
+    CRUMB("global route: tile radix sort");
     rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
                                 total_dev, 0, bits, tsort_hdr, (uint32_t*)(w + f.tsort_table), nullptr, nullptr, s);
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
+    CRUMB("global route: tile ranges");
     rc = lg_tile_range_prefilled(sorted_keys, 1, Ls, total_dev, ntiles, (int32_t*)(w + f.tile_start), s); if (rc) return rc;
+    CRUMB("global route: validators / per-tile sort");
     if (x.validate) { rc = validate_table(x, (int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (int32_t*)(w + f.tile_start), Ls, total_dev, ntiles, (int)N, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
     if (tile_mode) {      // depth order inside every tile; scratch for lists beyond 2048: the key buffer the tile sort did not end in
         rc = lg_tile_depth_sort_gated((int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (const int32_t*)(w + f.tile_start), (const float*)(w1 + f1.view_z), 1, L,
@@ -773,6 +817,7 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
         if (rc) return rc;
     }
     }
+    CRUMB("blend forward");
     // statistic epochs: the executor's blend backward accumulates the per-splat statistics inside the gradient record (raster.hip, STAT == 2);
     // the forward then is the plain one (frag_count == NULL).  A caller that wants the forward's own counters passes the two arrays.
     return lg_raster_forward_bounds(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
