@@ -103,62 +103,7 @@ __host__ __device__ static inline long long dup_queue_cap(long long N, long long
     return ((N + TPB - 1) / TPB + DUP_NQ - 1) / DUP_NQ * TPB + (L + DUP_PART - 1) / DUP_PART + TPB;
 }
 
-struct WalkFrame {          // per-splat constants of the (u,v) walk, derivable from SplatExtent
-    bool isY;
-    float BLOCK_U, BLOCK_V, bmin_u, bmax_u, bmin_v, bmax_v, argmin_v, argmax_v;
-    int rect_min_u, rect_max_u, rect_min_v, rect_max_v;
-};
-
-template <int TH, int TW>
-__device__ __forceinline__ WalkFrame walk_frame(const SplatExtent& e)
-{
-    WalkFrame f;
-    const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
-    f.isY = ys < xs;
-    f.BLOCK_U = f.isY ? (float)TH : (float)TW;
-    f.BLOCK_V = f.isY ? (float)TW : (float)TH;
-    f.rect_min_u = f.isY ? e.rminy : e.rminx; f.rect_max_u = f.isY ? e.rmaxy : e.rmaxx;
-    f.rect_min_v = f.isY ? e.rminx : e.rminy; f.rect_max_v = f.isY ? e.rmaxx : e.rmaxy;
-    f.bmin_u = f.isY ? e.bbox_min_y : e.bbox_min_x; f.bmin_v = f.isY ? e.bbox_min_x : e.bbox_min_y;
-    f.bmax_u = f.isY ? e.bbox_max_y : e.bbox_max_x; f.bmax_v = f.isY ? e.bbox_max_x : e.bbox_max_y;
-    f.argmin_v = f.isY ? e.argmin_x : e.argmin_y;
-    f.argmax_v = f.isY ? e.argmax_x : e.argmax_y;
-    return f;
-}
-
-// The serial walk carries intersect_max_line from slice to slice: it is cut(max_line_i) while max_line_i <= bmax_u and
-// then sticks at the last such cut (or at the sentinel if there is none).  Lines are (rect_min_u + i) * BLOCK_U exactly
-// (small integers), so "intersection at the upper line of slice i" is a pure function of i and K, where K = number of
-// slices whose upper line is <= bmax_u (a prefix).  Same for the lower line (= upper line of slice i-1, or the special
-// first-slice rule).  => each slice can be evaluated independently and still match the serial walk bit for bit.
-__device__ __forceinline__ void upper_cut(const SplatExtent& e, const WalkFrame& f, int i, int K, float& lo, float& hi)
-{
-    // intersect_max_line after processing slice i (i >= 0); i == -1 -> sentinel
-    int j = (i < K) ? i : (K - 1);
-    if (j < 0) { lo = f.bmax_v; hi = f.bmin_v; return; }
-    ellipse_cut(e, f.isY, (float)(f.rect_min_u + j + 1) * f.BLOCK_U, lo, hi);
-}
-
-__device__ __forceinline__ void slice_bounds(const SplatExtent& e, const WalkFrame& f, int i, int K, int& min_tile_v, int& max_tile_v)
-{
-    const float min_line = (float)(f.rect_min_u + i) * f.BLOCK_U;
-    const float max_line = min_line + f.BLOCK_U;
-    float imin_lo, imin_hi, imax_lo, imax_hi;
-    if (i == 0) {
-        if (f.bmin_u <= min_line) ellipse_cut(e, f.isY, (float)f.rect_min_u * f.BLOCK_U, imin_lo, imin_hi);
-        else { imin_lo = f.bmax_v; imin_hi = f.bmin_v; }
-    } else {
-        upper_cut(e, f, i - 1, K, imin_lo, imin_hi);
-    }
-    upper_cut(e, f, i, K, imax_lo, imax_hi);
-    float ellipse_min, ellipse_max;
-    if (min_line <= f.argmin_v && f.argmin_v < max_line) ellipse_min = f.bmin_v;
-    else ellipse_min = fminf(imin_lo, imax_lo);
-    if (min_line <= f.argmax_v && f.argmax_v < max_line) ellipse_max = f.bmax_v;
-    else ellipse_max = fmaxf(imin_hi, imax_hi);
-    min_tile_v = max(f.rect_min_v, min(f.rect_max_v, lg_f2i(ellipse_min / f.BLOCK_V)));
-    max_tile_v = min(f.rect_max_v, max(f.rect_min_v, lg_f2i(ellipse_max / f.BLOCK_V + 1)));
-}
+// (WalkFrame / walk_frame / slice_bounds: lg_tilewalk.h)
 
 // ---- helpers shared by the producers that feed the radix sort -------------------------------------------------
 // Radix digit counts of the keys a kernel emits, accumulated in an LDS table h[passes][RADIX] (flushed to the sort's `totals` at
@@ -226,6 +171,16 @@ __device__ __forceinline__ void load_splat(const SplatSrc& src, size_t b, int N,
     }
 }
 
+// debug_words[5] = emission slots whose walk disagreed with the projection's count, [6] = the last one's (walked - counted); word 0
+// is left to the table validators (fused.hip).  dbg nullable (product runs): the emission pads / drops silently.
+__device__ __forceinline__ void dup_report_mismatch(int* __restrict__ dbg, int slot, int walked, int counted)
+{
+    if (dbg == nullptr) return;
+    __hip_atomic_fetch_add(dbg + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 6, walked - counted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    (void)slot;
+}
+
 // Kernel 1 of duplicate_with_keys: one thread per depth slot.  Small splats are walked serially into a compacted LDS buffer of
 // keys and streamed out coalesced; big splats (> DUP_SMALL tiles) are only QUEUED for kernel 2.
 // LdsKeyT: uint16_t when every tile id + 1 fits 16 bits (anything up to ~8 MPixel at 8x16 tiles) -- halves the staging buffer, one
@@ -240,7 +195,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
                                                         uint32_t* __restrict__ zero_ptr, long long zero_words,
                                                         uint32_t* __restrict__ ones_ptr, long long ones_words,
                                                         uint32_t* __restrict__ zero2_ptr, long long zero2_words,
-                                                        const int* __restrict__ gate, int* __restrict__ trunc_flag)
+                                                        const int* __restrict__ gate, int* __restrict__ trunc_flag, int* __restrict__ dbg)
 {
     if (gate != nullptr && *gate == 0) return;            // fallback launch of the depth-bound culling that is not needed (fused.hip)
     __shared__ LdsKeyT buf[DUP_LDS_ENTRIES];              // 16/32 KiB: compacted keys of the small splats
@@ -386,7 +341,18 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     if (tid == 0) t_loff[TPB] = total_small;
     if (small) {
         t_stride[tid] = ((e.rmaxy - e.rminy) < (e.rmaxx - e.rminx)) ? 1 : gx;       // walk_tiles' isY rule
-        walk_tiles<TH, TW, true, LdsKeyT>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf, reinterpret_cast<unsigned int*>(sstarts));
+        // the slot owns buf[loff, loff + cnt): cnt is the projection's count of the same walk over the same six floats.  The walk is
+        // nevertheless bounded by it, and the stream-out below writes exactly cnt entries per slot, so the table is fully written and
+        // nothing outside the slot's range is touched even if the two counts ever disagree (reported through dbg when validating).
+        const int walked = (int)walk_tiles<TH, TW, true, LdsKeyT>(e, gx, idx, loff, (int32_t*)nullptr, (int32_t*)nullptr, buf,
+                                                                  reinterpret_cast<unsigned int*>(sstarts), (long long)loff + cnt);
+        if (walked != cnt) {
+            if (walked <= 0) {                            // no slice start of its own: the slot becomes padding (key 0 = "no tile")
+                buf[loff] = (LdsKeyT)0; t_stride[tid] = 0;
+                atomicOr(reinterpret_cast<unsigned int*>(sstarts) + (loff >> 5), 1u << (loff & 31));
+            }
+            dup_report_mismatch(dbg, j, walked, cnt);
+        }
     }
     __syncthreads();
     int sbase = 0;                                        // set bits below position p0
@@ -415,6 +381,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             const unsigned long long sm = sword & ((2ull << lane) - 1ull);
             const int ps = sm ? p0 + wave * 64 + 63 - __clzll(sm) : sprev;
             key = (int32_t)buf[ps] + (p - ps) * t_stride[t];
+            if ((unsigned)key > (unsigned)(gx * gy)) key = 0;              // cannot happen while walk and count agree; a key is an index downstream
             const int g = t_goff[t] + (p - t_loff[t]);
             kout[g] = key;
             vout[g] = t_idx[t];
@@ -444,7 +411,8 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                                                       const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                       long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
                                                       const int* __restrict__ qcount, const uint32_t* __restrict__ qentries,
-                                                      int* __restrict__ totals, DigitSpec ds, int* __restrict__ tile_counts, const int* __restrict__ gate)
+                                                      int* __restrict__ totals, DigitSpec ds, int* __restrict__ tile_counts, const int* __restrict__ gate,
+                                                      int* __restrict__ dbg)
 {
     if (gate != nullptr && *gate == 0) return;
     __shared__ int w_minv[TPB / 64][DUP_MAX_SLICES];      // per-wave slice scratch
@@ -483,7 +451,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
         const int left = (nq - gw - r0 * nwaves + nwaves - 1) / nwaves;          // entries of this wave from slot r0 on
         const int nb = left < DUP_BATCH ? left : DUP_BATCH;
         SplatExtent e;
-        int my_off = 0, my_idx = 0, my_part = 0;
+        int my_off = 0, my_idx = 0, my_part = 0, my_cnt = 0;
         if (lane < nb) {
             const int t = (r0 + lane) * nwaves + gw;               // flat entry -> (sub-queue, position)
             int lo = 0, hi = DUP_NQ - 1;
@@ -495,6 +463,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             const int j = (int)(ent >> 8);
             my_part = (int)(ent & 255u);
             my_off = (j == 0) ? 0 : pf[j - 1];
+            my_cnt = pf[j] - my_off;                               // the slot's share of the table (what dup_small sized the parts by)
             my_idx = sorted_id ? (int)sorted_id[(size_t)b * N + j] : j;
             float nx, ny, a, bb, cc, o;
             load_splat<PACKED>(src, b, N, my_idx, nx, ny, a, bb, cc, o);
@@ -512,6 +481,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             const int sidx = bcast_i(my_idx, srcl);
             const int sgoff = bcast_i(my_off, srcl);
             const int part = bcast_i(my_part, srcl);
+            const int scnt = bcast_i(my_cnt, srcl);
             const WalkFrame f = walk_frame<TH, TW>(s);
             const int nsl = f.rect_max_u - f.rect_min_u;                   // <= min(grid.x, grid.y) slices
             if (nsl > DUP_MAX_SLICES) {                                    // > 4K-class images: the owner lane walks serially
@@ -581,23 +551,34 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                 }
                 continue;
             }
-            // this wave's part of the output range (whole splat when it has DUP_PART outputs or fewer)
-            const int nparts = dup_num_parts(run);
+            // this wave's part of the output range (whole splat when it has DUP_PART outputs or fewer).  Parts and range follow the
+            // slot's share of the table (scnt, from the prefix sums -- the projection's count), not the count of this kernel's own walk:
+            // the two are the same function of the same six floats, but every entry of [off, off + scnt) is written whatever happens
+            // (tiles beyond scnt dropped, entries beyond run padded with key 0 = "no tile"), because an entry left unwritten is stale
+            // memory that the sort carries to the range scan, and a word of garbage there is a wild store.
+            if (run != scnt && part == 0 && lane == 0) dup_report_mismatch(dbg, -1 - sidx, run, scnt);
+            const int nparts = dup_num_parts(scnt);
             const int k_begin = part * DUP_PART;
-            const int k_end = (part == nparts - 1) ? run : (k_begin + DUP_PART < run ? k_begin + DUP_PART : run);
+            const int k_end = (part == nparts - 1) ? scnt : (k_begin + DUP_PART < scnt ? k_begin + DUP_PART : scnt);
             int before = 0;                       // non-empty slices that start before k_begin
             if (k_begin > 0) {
-                for (int wq = lane; wq < (k_begin >> 5); wq += 64) before += __popc(bitmap[wave][wq]);
+                const int kb = k_begin < run ? k_begin : run;
+                for (int wq = lane; wq < (kb >> 5); wq += 64) before += __popc(bitmap[wave][wq]);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
             }
             for (int k0 = k_begin; k0 < k_end; k0 += 64) {
                 const int k = k0 + lane;
                 const bool act = k < k_end;
-                const uint32_t wlo = bitmap[wave][(k0 >> 5)], whi = bitmap[wave][(k0 >> 5) + 1];
+                const int bw = (k0 < run ? k0 : run) >> 5;         // (run <= DUP_MAX_RUN here: inside the bitmap)
+                const uint32_t wlo = bitmap[wave][bw], whi = bitmap[wave][bw + 1];
                 const unsigned long long word = ((unsigned long long)whi << 32) | wlo;
                 int32_t key = 0;
-                if (act) {
+                if (act && k >= run) {                             // padding (only if the counts disagree)
+                    kout[sgoff + k] = 0;
+                    vout[sgoff + k] = 0;
+                    if (tile_counts) atomicAdd(&tile_counts[(size_t)b * (gx * gy + 2)], 1);
+                } else if (act) {
                     const int r = before + __popcll(word & ((2ull << lane) - 1ull)) - 1;
                     const int sl = c_idx[wave][r];
                     const int u = f.rect_min_u + sl;
@@ -632,7 +613,7 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
 {
     return lg_dup_emit_gated(ndc, inv_cov, opacity, packed, prefix, sorted_id, sorted_id_is_int64, V, N, H, W, TH, TW, table_len, keys, values,
                              qcount, qentries, totals, begin_bit, end_bit, nullptr, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words,
-                             nullptr, nullptr, stream);
+                             nullptr, nullptr, nullptr, stream);
 }
 
 int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
@@ -640,7 +621,7 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
                       int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, int* tile_counts,
                       uint32_t* zero_ptr, long long zero_words,
                       uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words,
-                      const int* gate, int* trunc_flag, void* stream)
+                      const int* gate, int* trunc_flag, int* dbg, void* stream)
 {
     if (N <= 0) return 0;
     if (packed && sorted_id_is_int64) return (int)hipErrorInvalidValue;     // packed records: fused executor only (int32 order)
@@ -661,12 +642,12 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
     do {                                                                                                                                   \
         if (gx * gy + 1 <= 0xffff)                                                                                                         \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg); \
         else                                                                                                                               \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,   \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg); \
         hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
-                           N, H, W, gx, gy, table_len, keys, values, (const int*)qcount, (const uint32_t*)qentries, totals, ds, tile_counts, gate); \
+                           N, H, W, gx, gy, table_len, keys, values, (const int*)qcount, (const uint32_t*)qentries, totals, ds, tile_counts, gate, dbg); \
     } while (0)
 #define DISPATCH_DUP(A_, B_)                                              \
     do {                                                                  \
@@ -1624,15 +1605,17 @@ __global__ void __launch_bounds__(TPB) tile_range_kernel(const int32_t* __restri
 #pragma unroll
         for (int j = 0; j < 5; j++) key[j] = (i0 + j < L) ? k[i0 + j] : 0;
     }
-    if (i0 == 0) o[key[0]] = 0;
+    // A key outside 0..max_tile cannot come out of a correct table; if one does (an entry the emission left unwritten, DESIGN.md section 9
+    // "memory access fault"), it must not become a store address: such boundaries are skipped, the tile keeps "empty".
+    if (i0 == 0 && (unsigned)key[0] <= (unsigned)max_tile) o[key[0]] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const long long i = i0 + j;
         if (i == L - 1) o[max_tile + 1] = (int32_t)L;
         if (i < L - 1) {
             const int cur = key[j], nxt = key[j + 1];
-            if (cur != nxt) {
-                if (cur + 1 < nxt) o[cur + 1] = (int32_t)(i + 1);
+            if (cur != nxt && (unsigned)nxt <= (unsigned)max_tile) {
+                if (cur + 1 < nxt && cur >= -1) o[cur + 1] = (int32_t)(i + 1);
                 o[nxt] = (int32_t)(i + 1);
             }
         }
@@ -1754,7 +1737,7 @@ __device__ __forceinline__ void tg_load(const int32_t* __restrict__ src, long lo
 }
 
 __global__ void __launch_bounds__(TPB) tile_count_lds_kernel(const int32_t* __restrict__ keys, long long L, const int* __restrict__ n_dev,
-                                                             int* __restrict__ counts, const int* __restrict__ gate)
+                                                             int* __restrict__ counts, const int* __restrict__ gate, int max_tile)
 {
     if (gate != nullptr && *gate == 0) return;
     __shared__ unsigned int hist[TG_BINS / 2];
@@ -1767,7 +1750,7 @@ __global__ void __launch_bounds__(TPB) tile_count_lds_kernel(const int32_t* __re
     tg_load(keys, i0, n, k, -1);
 #pragma unroll
     for (int j = 0; j < TG_PER_THREAD; j++)
-        if (k[j] >= 0) atomicAdd(&hist[k[j] >> 1], 1u << ((k[j] & 1) * 16));
+        if ((unsigned)k[j] <= (unsigned)max_tile) atomicAdd(&hist[k[j] >> 1], 1u << ((k[j] & 1) * 16));      // (a key is an index: range-checked)
     __syncthreads();
     for (int w = threadIdx.x; w < TG_BINS / 2; w += TPB) {
         const unsigned int c = hist[w];
@@ -1778,7 +1761,7 @@ __global__ void __launch_bounds__(TPB) tile_count_lds_kernel(const int32_t* __re
 
 __global__ void __launch_bounds__(TPB) tile_scatter_lds_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals, long long L,
                                                                const int* __restrict__ n_dev, int* __restrict__ cursor, int32_t* __restrict__ out_vals,
-                                                               const int* __restrict__ gate)
+                                                               const int* __restrict__ gate, int max_tile)
 {
     if (gate != nullptr && *gate == 0) return;
     __shared__ unsigned int hist[TG_BINS / 2];     // per key: first the workgroup's count, then the index of the key's entry in base[]
@@ -1796,6 +1779,7 @@ __global__ void __launch_bounds__(TPB) tile_scatter_lds_kernel(const int32_t* __
 #pragma unroll
     for (int j = 0; j < TG_PER_THREAD; j++) {
         rank[j] = 0;
+        if ((unsigned)k[j] > (unsigned)max_tile) k[j] = -1;        // a key is an index (LDS bin, cursor): outside 0..max_tile it is dropped
         if (k[j] >= 0) {
             const int sh = (k[j] & 1) * 16;
             rank[j] = (int)((atomicAdd(&hist[k[j] >> 1], 1u << sh) >> sh) & 0xffffu);       // position inside the workgroup's run of this key
@@ -1838,7 +1822,7 @@ __global__ void __launch_bounds__(TPB) tile_scatter_lds_kernel(const int32_t* __
 
 __global__ void __launch_bounds__(TPB) tile_scatter_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals, long long L,
                                                            const int* __restrict__ n_dev, int* __restrict__ cursor, int32_t* __restrict__ out_vals,
-                                                           const int* __restrict__ gate)
+                                                           const int* __restrict__ gate, int max_tile)
 {
     if (gate != nullptr && *gate == 0) return;
     const long long i0 = ((long long)blockIdx.x * TPB + threadIdx.x) * 4;
@@ -1854,7 +1838,7 @@ __global__ void __launch_bounds__(TPB) tile_scatter_kernel(const int32_t* __rest
     }
     int pos[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) pos[j] = k[j] >= 0 ? atomicAdd(&cursor[k[j]], 1) : -1;       // four independent returning atomics in flight
+    for (int j = 0; j < 4; j++) pos[j] = (unsigned)k[j] <= (unsigned)max_tile ? atomicAdd(&cursor[k[j]], 1) : -1;       // four independent returning atomics in flight
 #pragma unroll
     for (int j = 0; j < 4; j++) if (pos[j] >= 0) out_vals[pos[j]] = v[j];
 }
@@ -1862,11 +1846,11 @@ __global__ void __launch_bounds__(TPB) tile_scatter_kernel(const int32_t* __rest
 // counts [max_tile + 2] (filled by the emission), cursor [max_tile + 2] scratch, tile_start [max_tile + 2] pre-filled with -1;
 // keys / vals: the emitted table (capacity L, valid entries min(L, *n_dev)); out_vals: values grouped by tile (any order inside a tile)
 __global__ void __launch_bounds__(TPB) tile_count_kernel(const int32_t* __restrict__ keys, long long L, const int* __restrict__ n_dev,
-                                                         int* __restrict__ counts, const int* __restrict__ gate)
+                                                         int* __restrict__ counts, const int* __restrict__ gate, int max_tile)
 {
     if (gate != nullptr && *gate == 0) return;
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (i < bounded_n(L, n_dev)) atomicAdd(&counts[keys[i]], 1);
+    if (i < bounded_n(L, n_dev) && (unsigned)keys[i] <= (unsigned)max_tile) atomicAdd(&counts[keys[i]], 1);
 }
 
 // counts [max_tile + 2] zero on entry when count_keys != 0 (then counted here from the emitted keys, in LDS-aggregated form), else filled by
@@ -1879,12 +1863,12 @@ int lg_tile_scatter_gated(const int32_t* keys, const int32_t* vals, long long L,
     hipStream_t s = (hipStream_t)stream;
     const bool lds = max_tile + 1 <= TG_BINS;
     if (count_keys) {
-        if (lds) hipLaunchKernelGGL(tile_count_lds_kernel, dim3(lg_cdiv(L, TG_ITEMS)), dim3(TPB), 0, s, keys, L, n_dev, counts, gate);
-        else hipLaunchKernelGGL(tile_count_kernel, dim3(lg_cdiv(L, TPB)), dim3(TPB), 0, s, keys, L, n_dev, counts, gate);
+        if (lds) hipLaunchKernelGGL(tile_count_lds_kernel, dim3(lg_cdiv(L, TG_ITEMS)), dim3(TPB), 0, s, keys, L, n_dev, counts, gate, max_tile);
+        else hipLaunchKernelGGL(tile_count_kernel, dim3(lg_cdiv(L, TPB)), dim3(TPB), 0, s, keys, L, n_dev, counts, gate, max_tile);
     }
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, max_tile, n_dev, L, cursor, tile_start, gate);
-    if (lds) hipLaunchKernelGGL(tile_scatter_lds_kernel, dim3(lg_cdiv(L, TG_ITEMS)), dim3(TPB), 0, s, keys, vals, L, n_dev, cursor, out_vals, gate);
-    else hipLaunchKernelGGL(tile_scatter_kernel, dim3(lg_cdiv(L, TPB * 4)), dim3(TPB), 0, s, keys, vals, L, n_dev, cursor, out_vals, gate);
+    if (lds) hipLaunchKernelGGL(tile_scatter_lds_kernel, dim3(lg_cdiv(L, TG_ITEMS)), dim3(TPB), 0, s, keys, vals, L, n_dev, cursor, out_vals, gate, max_tile);
+    else hipLaunchKernelGGL(tile_scatter_kernel, dim3(lg_cdiv(L, TPB * 4)), dim3(TPB), 0, s, keys, vals, L, n_dev, cursor, out_vals, gate, max_tile);
     LG_RETURN_LAST();
 }
 

@@ -678,14 +678,14 @@ __device__ __forceinline__ void validate_report(int* __restrict__ lock, int* __r
 }
 
 __global__ void __launch_bounds__(256) validate_keys_kernel(int32_t* __restrict__ keys, long long L, const int* __restrict__ n_dev, int ntiles,
-                                                            int* __restrict__ lock, int* __restrict__ dbg, const int* __restrict__ gate)
+                                                            int* __restrict__ lock, int* __restrict__ dbg, const int* __restrict__ gate, int code)
 {
     if (gate != nullptr && *gate == 0) return;
     long long n = L;
     if (n_dev != nullptr && (long long)*n_dev < n) n = *n_dev;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int k = keys[i];
-        if (k < 0 || k > ntiles) { validate_report(lock, dbg, 1, (int)i, k, ntiles, (int)n); keys[i] = 0; }
+        if (k < 0 || k > ntiles) { validate_report(lock, dbg, code, (int)i, k, ntiles, (int)n); keys[i] = 0; }
     }
 }
 
@@ -739,9 +739,33 @@ static int validate_chunk_ids(const Exec& x, int64_t* vis_ids, const int* vis_nu
 }
 
 #define LG_VALIDATE_LOCK_WORD 8            // int index inside Layout1::flags (cleared with the frame's scratch by the projection)
-static int validate_keys(const Exec& x, int32_t* keys, long long L, const int* n_dev, int ntiles, int* lock, const int* gate, hipStream_t s)
+static int validate_keys(const Exec& x, int32_t* keys, long long L, const int* n_dev, int ntiles, int* lock, const int* gate, hipStream_t s, int code = 1)
 {
-    hipLaunchKernelGGL(validate_keys_kernel, dim3(2048), dim3(256), 0, s, keys, L, n_dev, ntiles, lock, x.debug_words, gate);
+    hipLaunchKernelGGL(validate_keys_kernel, dim3(2048), dim3(256), 0, s, keys, L, n_dev, ntiles, lock, x.debug_words, gate, code);
+    return (int)hipGetLastError();
+}
+// code 7: the radix digit totals the emission counted for pass `where` add up to `value`, not to the `bound` entries the sort will move
+__global__ void __launch_bounds__(256) validate_totals_kernel(const int* __restrict__ totals, int passes, long long L, const int* __restrict__ n_dev,
+                                                              int* __restrict__ lock, int* __restrict__ dbg, const int* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    long long n = L;
+    if (n_dev != nullptr && (long long)*n_dev < n) n = *n_dev;
+    __shared__ long long part[4];
+    for (int p = 0; p < passes; p++) {
+        long long v = totals[p * 256 + threadIdx.x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        const long long sum = part[0] + part[1] + part[2] + part[3];
+        if (threadIdx.x == 0 && sum != n) validate_report(lock, dbg, 7, p, (int)sum, (int)n, (int)n);
+        __syncthreads();
+    }
+}
+static int validate_totals(const Exec& x, const int* totals, int passes, long long L, const int* n_dev, int* lock, const int* gate, hipStream_t s)
+{
+    hipLaunchKernelGGL(validate_totals_kernel, dim3(1), dim3(256), 0, s, totals, passes, L, n_dev, lock, x.debug_words, gate);
     return (int)hipGetLastError();
 }
 static int validate_table(const Exec& x, int32_t* vals, int32_t* tile_start, long long L, const int* n_dev, int ntiles, int N, int* lock, const int* gate, hipStream_t s)
@@ -772,11 +796,13 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
         // TILE mode without a sort: the emitted keys are counted per key (LDS-aggregated), one workgroup turns the counts into the range
         // table and write cursors, one pass drops the values at their cursors, and the per-tile sort orders every list by (depth, id)
         CRUMB("tile route: key emission (dup_small + dup_big)");
+        if (x.validate) { rc = (int)hipMemsetAsync(w + f.tk_a, 0xff, sizeof(int32_t) * (size_t)Ls, s); if (rc) return rc; }      // an entry the emission leaves out reads -1
         rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
                                (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
                                qcount, (uint32_t*)(w + f.dup_entries), nullptr, 0, bits, nullptr, nullptr, 0,
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
-                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag,
+                               x.validate ? x.debug_words : nullptr, s);
         if (rc) return rc;
         if (x.validate) { rc = validate_keys(x, (int32_t*)(w + f.tk_a), Ls, total_dev, ntiles, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
         CRUMB("tile route: count + offsets + scatter");
@@ -793,13 +819,20 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     // clears the sort's look-back table.  No table memset: the bounded sort only reads the first prefix[N-1] entries, and a
     // truncated table (Ls < total) gets its tail zeroed by the first splat that does not fit.
     CRUMB("global route: key emission (dup_small + dup_big)");
+    if (x.validate) { rc = (int)hipMemsetAsync(w + f.tk_a, 0xff, sizeof(int32_t) * (size_t)Ls, s); if (rc) return rc; }          // an entry the emission leaves out reads -1
     rc = lg_dup_emit_gated(nullptr, nullptr, nullptr, (const float*)(w1 + f1.packed),
                                (const int32_t*)(w1 + f1.prefix), depth_order, 0, 1, (int)N, H, W, TH, TW, Ls, (int32_t*)(w + f.tk_a), (int32_t*)(w + f.tv_a),
                                qcount, (uint32_t*)(w + f.dup_entries), tsort_hdr, 0, bits, nullptr, (uint32_t*)(w + f.tsort_table),
                                (long long)lg_radix_table_words(Ls, lg_radix_sort_num_passes(0, bits)),
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
-                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag, s);
+                               (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag,
+                               x.validate ? x.debug_words : nullptr, s);
     if (rc) return rc;
+    if (x.validate) {           // emitted keys (code 1: value -1 = never written) and the digit totals counted on the side (code 7)
+        int* lock = (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD;
+        rc = validate_keys(x, (int32_t*)(w + f.tk_a), Ls, total_dev, ntiles, lock, gate, s); if (rc) return rc;
+        rc = validate_totals(x, tsort_hdr, lg_radix_sort_num_passes(0, bits), Ls, total_dev, lock, gate, s); if (rc) return rc;
+    }
     // instance count on the device: only that many entries are sorted and range-scanned
     CRUMB("global route: tile radix sort");
     rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
@@ -807,6 +840,10 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
+    if (x.validate) {           // code 6: a key outside 0..tiles in the SORTED table (the sort moved stale memory)
+        rc = validate_keys(x, (int32_t*)(w + (odd ? f.tk_b : f.tk_a)), Ls, total_dev, ntiles, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s, 6);
+        if (rc) return rc;
+    }
     CRUMB("global route: tile ranges");
     rc = lg_tile_range_prefilled(sorted_keys, 1, Ls, total_dev, ntiles, (int32_t*)(w + f.tile_start), s); if (rc) return rc;
     CRUMB("global route: validators / per-tile sort");

@@ -41,7 +41,9 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
                       int* tile_counts /*nullable [V][tiles + 2], zero on entry: instances per key, for lg_tile_scatter_gated*/,
                       uint32_t* zero_ptr, long long zero_words,
                       uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words,
-                      const int* gate, int* trunc_flag, void* stream);
+                      const int* gate, int* trunc_flag,
+                      int* dbg /*nullable pinned debug words: [5] += slots whose walk disagreed with the prefix sums, [6] = last difference*/,
+                      void* stream);
 
 // grouping by tile without a sort (binning.hip "Tile scatter"): per-key counts -> range table + cursors -> values dropped at their
 // tile's cursor.  Order inside a tile is arbitrary: follow with lg_tile_depth_sort_gated(any_order = 1).

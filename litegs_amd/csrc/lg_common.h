@@ -1,6 +1,8 @@
 // Shared device/host helpers for the litegs_amd HIP kernels (gfx950 / CDNA4 only).
 #pragma once
+#ifndef LG_HOST_CHECK          // tests/host/*.cpp compile the exact-arithmetic headers as sequential C++ with their own shims
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #define LG_API extern "C" __attribute__((visibility("default")))

@@ -61,7 +61,7 @@ __device__ __forceinline__ void splat_extent(float ndcx, float ndcy, float ic00,
 template <int TH, int TW, bool EMIT, typename LdsKeyT = int32_t>
 __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int32_t idx, long long off,
                                                int32_t* __restrict__ keys, int32_t* __restrict__ values, LdsKeyT* lds_keys = nullptr,
-                                               unsigned int* lds_slice_starts = nullptr)
+                                               unsigned int* lds_slice_starts = nullptr, long long lds_limit = 0x7fffffffffffffffLL)
 {
     const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
     const bool isY = ys < xs;
@@ -94,7 +94,7 @@ __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int
         int max_tile_v = min(rect_max_v, max(rect_min_v, lg_f2i(ellipse_max / BLOCK_V + 1)));
         count += (uint32_t)(max_tile_v - min_tile_v);
         if (EMIT && lds_slice_starts) {
-            if (max_tile_v > min_tile_v) {
+            if (max_tile_v > min_tile_v && off < lds_limit) {     // (lds_limit: end of the caller's share of the LDS buffer)
                 const uint32_t key = isY ? (uint32_t)(u * gx + min_tile_v) : (uint32_t)(min_tile_v * gx + u);
                 lds_keys[off] = (LdsKeyT)(key + 1);
                 atomicOr(lds_slice_starts + (off >> 5), 1u << (off & 31));
@@ -133,6 +133,64 @@ __device__ __forceinline__ int lg_tile_count(float nx, float ny, float view_z, f
     if ((e.rmaxy - e.rminy) * (e.rmaxx - e.rminx) <= 0) return 0;
     if (rect) { rect[0] = e.rminx; rect[1] = e.rmaxx; rect[2] = e.rminy; rect[3] = e.rmaxy; }
     return (int)walk_tiles<TH, TW, false>(e, gx, 0, 0, nullptr, nullptr);
+}
+
+// ---- the same walk, one slice at a time (binning.hip dup_big_kernel: one lane per slice) ----
+struct WalkFrame {          // per-splat constants of the (u,v) walk, derivable from SplatExtent
+    bool isY;
+    float BLOCK_U, BLOCK_V, bmin_u, bmax_u, bmin_v, bmax_v, argmin_v, argmax_v;
+    int rect_min_u, rect_max_u, rect_min_v, rect_max_v;
+};
+
+template <int TH, int TW>
+__device__ __forceinline__ WalkFrame walk_frame(const SplatExtent& e)
+{
+    WalkFrame f;
+    const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
+    f.isY = ys < xs;
+    f.BLOCK_U = f.isY ? (float)TH : (float)TW;
+    f.BLOCK_V = f.isY ? (float)TW : (float)TH;
+    f.rect_min_u = f.isY ? e.rminy : e.rminx; f.rect_max_u = f.isY ? e.rmaxy : e.rmaxx;
+    f.rect_min_v = f.isY ? e.rminx : e.rminy; f.rect_max_v = f.isY ? e.rmaxx : e.rmaxy;
+    f.bmin_u = f.isY ? e.bbox_min_y : e.bbox_min_x; f.bmin_v = f.isY ? e.bbox_min_x : e.bbox_min_y;
+    f.bmax_u = f.isY ? e.bbox_max_y : e.bbox_max_x; f.bmax_v = f.isY ? e.bbox_max_x : e.bbox_max_y;
+    f.argmin_v = f.isY ? e.argmin_x : e.argmin_y;
+    f.argmax_v = f.isY ? e.argmax_x : e.argmax_y;
+    return f;
+}
+
+// The serial walk carries intersect_max_line from slice to slice: it is cut(max_line_i) while max_line_i <= bmax_u and
+// then sticks at the last such cut (or at the sentinel if there is none).  Lines are (rect_min_u + i) * BLOCK_U exactly
+// (small integers), so "intersection at the upper line of slice i" is a pure function of i and K, where K = number of
+// slices whose upper line is <= bmax_u (a prefix).  Same for the lower line (= upper line of slice i-1, or the special
+// first-slice rule).  => each slice can be evaluated independently and still match the serial walk bit for bit.
+__device__ __forceinline__ void upper_cut(const SplatExtent& e, const WalkFrame& f, int i, int K, float& lo, float& hi)
+{
+    // intersect_max_line after processing slice i (i >= 0); i == -1 -> sentinel
+    int j = (i < K) ? i : (K - 1);
+    if (j < 0) { lo = f.bmax_v; hi = f.bmin_v; return; }
+    ellipse_cut(e, f.isY, (float)(f.rect_min_u + j + 1) * f.BLOCK_U, lo, hi);
+}
+
+__device__ __forceinline__ void slice_bounds(const SplatExtent& e, const WalkFrame& f, int i, int K, int& min_tile_v, int& max_tile_v)
+{
+    const float min_line = (float)(f.rect_min_u + i) * f.BLOCK_U;
+    const float max_line = min_line + f.BLOCK_U;
+    float imin_lo, imin_hi, imax_lo, imax_hi;
+    if (i == 0) {
+        if (f.bmin_u <= min_line) ellipse_cut(e, f.isY, (float)f.rect_min_u * f.BLOCK_U, imin_lo, imin_hi);
+        else { imin_lo = f.bmax_v; imin_hi = f.bmin_v; }
+    } else {
+        upper_cut(e, f, i - 1, K, imin_lo, imin_hi);
+    }
+    upper_cut(e, f, i, K, imax_lo, imax_hi);
+    float ellipse_min, ellipse_max;
+    if (min_line <= f.argmin_v && f.argmin_v < max_line) ellipse_min = f.bmin_v;
+    else ellipse_min = fminf(imin_lo, imax_lo);
+    if (min_line <= f.argmax_v && f.argmax_v < max_line) ellipse_max = f.bmax_v;
+    else ellipse_max = fmaxf(imin_hi, imax_hi);
+    min_tile_v = max(f.rect_min_v, min(f.rect_max_v, lg_f2i(ellipse_min / f.BLOCK_V)));
+    max_tile_v = min(f.rect_max_v, max(f.rect_min_v, lg_f2i(ellipse_max / f.BLOCK_V + 1)));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -161,6 +161,9 @@ __device__ __forceinline__ void rec_request(f32x16& rec, const float* __restrict
     asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(rec) : "s"(pk), "s"(byte_off));
 }
 __device__ __forceinline__ void rec_wait(f32x16& rec) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rec)); }
+// byte offset of a splat's 64-byte record.  An id outside 0..N-1 cannot come out of a correct table; if one does (an entry the binning left
+// unwritten), it must not become a load / atomic address: clamped (one scalar min per splat; the scalar unit has the slack).
+__device__ __forceinline__ unsigned rec_off(int id, int N) { return min((unsigned)id, (unsigned)(N - 1)) << 6; }
 
 // the id of a list position through the scalar path as well (one s_load_dword, two splats ahead of its use): no vector load of the
 // list, no v_readlane per splat
@@ -232,11 +235,11 @@ __device__ __forceinline__ bool fwd_splat(FwdState<PPL>& st, const f32x16& rec, 
 // the blend loop of the generic kernel (any tile shape, statistics): ids 64 at a time in a VGPR, handed out by v_readlane
 template <int PPL, bool STAT>
 __device__ __forceinline__ void fwd_generic_loop(FwdState<PPL>& st, const int* __restrict__ sp, const float* __restrict__ pk, int n, int lane,
-                                                 int* __restrict__ frag_count, float* __restrict__ frag_weight, int& visited, bool& live)
+                                                 int* __restrict__ frag_count, float* __restrict__ frag_weight, int& visited, bool& live, int N)
 {
     // ids of the list, 64 at a time: lane l of `nxt` holds the id at position c0 + l + 1, i.e. the splat to REQUEST while
     // position c0 + l is blended (clamped at the list end: the surplus request is never used)
-    unsigned off_a = (unsigned)rfl(sp[0]) << 6, off_b = 0;
+    unsigned off_a = rec_off(rfl(sp[0]), N), off_b = 0;
     f32x16 ra, rb;
     rec_request(ra, pk, off_a);
     int nxt = sp[min(lane + 1, n - 1)];
@@ -245,14 +248,14 @@ __device__ __forceinline__ void fwd_generic_loop(FwdState<PPL>& st, const int* _
         const int cnt = min(64, n - c0);                            // positions c0 .. c0 + cnt - 1 in this chunk
         const int nxt_next = sp[min(c0 + 64 + lane + 1, n - 1)];    // next chunk's ids, in flight while this chunk is blended
         for (int j = 0; j < cnt; j += 2) {                          // cnt is even except possibly in the last chunk
-            off_b = (unsigned)__builtin_amdgcn_readlane(nxt, j) << 6;
+            off_b = rec_off(__builtin_amdgcn_readlane(nxt, j), N);
             rec_request(rb, pk, off_b);
             live = fwd_splat<PPL, STAT>(st, ra, c0 + j + 1, lane, off_a, frag_count, frag_weight);
             rec_wait(rb);
             if (!live) break;
             visited = c0 + j + 1;
             if (j + 1 >= cnt) break;                                // odd tail: the list ends here
-            off_a = (unsigned)__builtin_amdgcn_readlane(nxt, j + 1) << 6;
+            off_a = rec_off(__builtin_amdgcn_readlane(nxt, j + 1), N);
             rec_request(ra, pk, off_a);
             live = fwd_splat<PPL, STAT>(st, rb, c0 + j + 2, lane, off_b, frag_count, frag_weight);
             rec_wait(ra);
@@ -377,18 +380,18 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
             id_request(id_a, sp, 0u);
             id_request(id_b, sp, (unsigned)min(1, n - 1) << 2);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id_a), "+s"(id_b));
-            rec_request(ra, pk, (unsigned)id_a << 6);
+            rec_request(ra, pk, rec_off(id_a, N));
             rec_wait(ra);
             for (int pos = 0; pos < n; pos += 2) {                            // `ra` holds position pos
-                const unsigned cur_a = (unsigned)id_a, cur_b = (unsigned)id_b;  // splat ids of `ra` / `rb` (statistics)
-                rec_request(rb, pk, (unsigned)id_b << 6);
+                const unsigned cur_a = rec_off(id_a, N) >> 6, cur_b = rec_off(id_b, N) >> 6;  // splat ids of `ra` / `rb` (statistics)
+                rec_request(rb, pk, rec_off(id_b, N));
                 id_request(id_a, sp, (unsigned)min(pos + 2, n - 1) << 2);
                 live = fwd_splat_fast<STAT>(f, ra, cur_a, lane, frag_count, frag_weight);
                 rec_id_wait(rb, id_a);
                 if (!live) break;
                 visited = pos + 1;
                 if (pos + 1 >= n) break;                                       // odd tail: the list ends here
-                rec_request(ra, pk, (unsigned)id_a << 6);
+                rec_request(ra, pk, rec_off(id_a, N));
                 id_request(id_b, sp, (unsigned)min(pos + 3, n - 1) << 2);
                 live = fwd_splat_fast<STAT>(f, rb, cur_b, lane, frag_count, frag_weight);
                 rec_id_wait(ra, id_b);
@@ -399,10 +402,10 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
             st.Cr[0] = f.Cr.x; st.Cr[1] = f.Cr.y; st.Cg[0] = f.Cg.x; st.Cg[1] = f.Cg.y; st.Cb[0] = f.Cb.x; st.Cb[1] = f.Cb.y;
             st.lc[0] = f.lc0; st.lc[1] = f.lc1;
         } else if (n > 0) {
-            fwd_generic_loop<PPL, STAT>(st, sp, pk, n, lane, frag_count, frag_weight, visited, live);
+            fwd_generic_loop<PPL, STAT>(st, sp, pk, n, lane, frag_count, frag_weight, visited, live, N);
         }
     } else if (n > 0) {
-        fwd_generic_loop<PPL, STAT>(st, sp, pk, n, lane, frag_count, frag_weight, visited, live);
+        fwd_generic_loop<PPL, STAT>(st, sp, pk, n, lane, frag_count, frag_weight, visited, live, N);
     }
     // work done for this tile (splats walked before every pixel saturated): the schedule key of the backward and of the next visit
     if (tile_work != nullptr && lane == 0) tile_work[(size_t)view * (ntiles + 1) + tile] = visited;
@@ -428,11 +431,11 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
         float znew = INF;
         bool ok = !(zused < INF);
         if (sat && visited > 0) {
-            const float stop_z = pk[(size_t)rfl(sp[visited - 1]) * REC + 12];
+            const float stop_z = pk[(size_t)(rec_off(rfl(sp[visited - 1]), N) >> 6) * REC + 12];
             ok = stop_z <= zused;
             const int p = visited - 1 + max(16, (int)(((long long)visited * margin_pct) / 100));
-            if (p <= n - 1) znew = pk[(size_t)rfl(sp[p]) * REC + 12];
-            else if (zused < INF) znew = fmaxf(zused, pk[(size_t)rfl(sp[n - 1]) * REC + 12]) * 1.25f;
+            if (p <= n - 1) znew = pk[(size_t)(rec_off(rfl(sp[p]), N) >> 6) * REC + 12];
+            else if (zused < INF) znew = fmaxf(zused, pk[(size_t)(rec_off(rfl(sp[n - 1]), N) >> 6) * REC + 12]) * 1.25f;
         }
         if (lane == 0) {
             reinterpret_cast<float*>(sched_out)[lg_sched_level_offset(gx, gy, 0) + tile - 1] = znew;
@@ -824,7 +827,7 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
         int c0 = (top - 1) & ~63;                                    // first position of the current 64-chunk
         // lane l of `prv` holds the id at position c0 + l - 1: the splat to REQUEST while position c0 + l is processed
         int prv = sp[min(max(c0 + lane - 1, 0), n - 1)];
-        unsigned off_a = (unsigned)rfl(sp[min(top - 1, n - 1)]) << 6, off_b = 0;
+        unsigned off_a = rec_off(rfl(sp[min(top - 1, n - 1)]), N), off_b = 0;
         f32x16 ra, rb;
         rec_request(ra, pk, off_a);
         rec_wait(ra);
@@ -833,11 +836,11 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
 #pragma unroll
             for (int k = 0; k < PPL; k++) st.lcrel[k] = lc[k] - c0;
             for (int j = min(63, top - 1 - c0); j >= 1; j -= 2) {          // j is odd here: positions c0 + j and c0 + j - 1
-                off_b = (unsigned)__builtin_amdgcn_readlane(prv, j) << 6;
+                off_b = rec_off(__builtin_amdgcn_readlane(prv, j), N);
                 rec_request(rb, pk, off_b);
                 bwd_splat<PPL, STAT, TRANS, COUNT>(st, ra, j, off_a, slot_off, writers, pg, err_square_sum, lane, contributing);
                 rec_wait(rb);
-                off_a = (unsigned)__builtin_amdgcn_readlane(prv, j - 1) << 6;
+                off_a = rec_off(__builtin_amdgcn_readlane(prv, j - 1), N);
                 rec_request(ra, pk, off_a);
                 bwd_splat<PPL, STAT, TRANS, COUNT>(st, rb, j - 1, off_b, slot_off, writers, pg, err_square_sum, lane, contributing);
                 rec_wait(ra);
@@ -1050,7 +1053,7 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     id_request(id_a, sp, (unsigned)min(pos, n - 1) << 2);
     id_request(id_b, sp, (unsigned)(pos - 1) << 2);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id_a), "+s"(id_b));
-    unsigned off_a = (unsigned)id_a << 6, off_b = (unsigned)id_b << 6;
+    unsigned off_a = rec_off(id_a, N), off_b = rec_off(id_b, N);
     // replicas: a splat that covers many tiles has R = 2^k gradient lines behind the N regular ones (hot_of: first line << 6 | k, -1: none;
     // assigned by the projection, fused.hip); this tile adds into replica (tile mod R) -- same-line contention at the memory-side atomic
     // units was 70-80 % of what the atomics cost (profiles/r03_bwd_ab.log).  The word travels with the splat's record (scalar path).
@@ -1058,7 +1061,7 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     const unsigned hot_on = hot_of != nullptr ? 1u : 0u;
     int hot_a = -1, hot_b = -1;
     rec_request(ra, pk, off_a);
-    id_request(hot_a, hot, hot_on ? (unsigned)id_a << 2 : 0u);
+    id_request(hot_a, hot, hot_on ? off_a >> 4 : 0u);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(hot_a));
     // phase 1: positions that some pixel of the tile had already stopped before (pos >= minlast): per-pixel last_contributor test
 #define HOT_TARGET(h, off) ((hot_on && (h) >= 0) ? (((unsigned)N + ((unsigned)(h) >> 6) + ((unsigned)tile & ((1u << ((h) & 63)) - 1u))) << 6) : (off))
@@ -1069,13 +1072,13 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
         id_request(id_a, sp, (unsigned)max(pos - 2, 0) << 2);                                                 \
         bwd_splat_fast<TRANS, CHK, STAT>(st, ra, pos, HOT_TARGET(hot_a, off_a), slot_off, writers, pg, err_square_sum, lane);  \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rb), "+s"(id_a), "+s"(hot_b));                             \
-        off_a = (unsigned)id_a << 6;                                                                          \
+        off_a = rec_off(id_a, N);                                                                          \
         rec_request(ra, pk, off_a);                                                                           \
         id_request(hot_a, hot, hot_on ? off_a >> 4 : 0u);                                                     \
         id_request(id_b, sp, (unsigned)max(pos - 3, 0) << 2);                                                 \
         bwd_splat_fast<TRANS, CHK, STAT>(st, rb, pos - 1, HOT_TARGET(hot_b, off_b), slot_off, writers, pg, err_square_sum, lane);  \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(id_b), "+s"(hot_a));                             \
-        off_b = (unsigned)id_b << 6;                                                                          \
+        off_b = rec_off(id_b, N);                                                                          \
         pos -= 2;                                                                                             \
     }
     for (; pos >= 1 && pos >= minlast; ) BWD_PAIR(true)

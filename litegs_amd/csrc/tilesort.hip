@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(256) tile_depth_sort_kernel(int* __restrict__ 
     // the depth of a splat comes from the SoA array (4 B x N: 3.5 MB at 0.9 M visible splats, resident in every XCD's L2), not from
     // word 12 of its 64-byte record: 4 M random reads of whole record lines (56 MB of records: L2 misses) cost more than the sort itself
     const float* __restrict__ dz = depth + (size_t)view * N;
-    auto depth_bits = [dz](int id) -> uint32_t { return __float_as_uint(dz[id]); };
+    // (an id outside 0..N-1 cannot come out of a correct table; it must not become a gather address: clamped, the blend clamps the same way)
+    auto depth_bits = [dz, N](int id) -> uint32_t { return __float_as_uint(dz[min((unsigned)id, (unsigned)(N - 1))]); };
 
     {   // regime R: every wave its own tile
         const int tile = t0 + wave + 1;

@@ -173,6 +173,7 @@ class FusedRenderer:
         self.spec_step = 0            # number of the training step being enqueued
         self.force_full = False       # the next render runs unculled (the first replayed step)
         self._debug_words = None      # HostWords(8), validate_tables only
+        self.emission_mismatches = 0  # validate_tables: slots whose emission walk disagreed with the projection's tile count
         self._closed = False
 
     # -- compatibility views of the per-frame records (tests, tools, bench.py read them) --------------------------------------------
@@ -264,13 +265,23 @@ class FusedRenderer:
 
     def check_tables(self):
         """validate_tables: raise if a table check on the device found garbage since the last call (the run itself was kept alive)"""
+        if self._debug_words is not None and int(self._debug_words.a[5]) != 0:
+            # the key emission walked a splat to another tile count than the projection counted for it: padded / dropped on the device (the
+            # table stays fully written), reported here because the two are meant to be the same function of the same floats
+            import sys
+            n, d = int(self._debug_words.a[5]), int(self._debug_words.a[6])
+            self._debug_words.a[5] = 0
+            self.emission_mismatches += n
+            print(f"[litegs_amd validate] key emission: {n} slot(s) walked to a different tile count than the prefix sums hold "
+                  f"(last: walked - counted = {d})", file=sys.stderr, flush=True)
         if self._debug_words is not None and int(self._debug_words.a[0]) != 0:
             rec = [int(x) for x in self._debug_words.a]
             self._debug_words.a[0] = 0
             what = {1: "tile key out of range in the emitted table", 2: "tile range ends beyond the valid entries", 3: "splat id out of range in the grouped table",
-                    4: "visible chunk id out of range", 5: "visible chunk count out of range"}
+                    4: "visible chunk id out of range", 5: "visible chunk count out of range",
+                    6: "tile key out of range in the SORTED table", 7: "radix digit totals of the emission do not add up to the table length"}
             raise RuntimeError(f"litegs_amd: table validator: {what.get(rec[0], 'code %d' % rec[0])}: where={rec[1]} value={rec[2]} bound={rec[3]} "
-                               f"valid_entries={rec[4]} reports_so_far={rec[7]}")
+                               f"valid_entries={rec[4]} reports_so_far={rec[7]} emission_count_mismatches={rec[5]} (last walked-counted={rec[6]})")
 
     def note_fallback(self, k: int):
         """frame k was re-run unculled (gated repeat observed, or a speculative step replayed): widen its margin, start its cool-down"""
