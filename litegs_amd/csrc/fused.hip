@@ -753,7 +753,8 @@ __global__ void __launch_bounds__(256) validate_totals_kernel(const int* __restr
     if (n_dev != nullptr && (long long)*n_dev < n) n = *n_dev;
     __shared__ long long part[4];
     for (int p = 0; p < passes; p++) {
-        long long v = totals[p * 256 + threadIdx.x];
+        long long v = 0;                                  // (the totals live in LG_SORT_TOTALS_COPIES interleaved copies, lg_binning_internal.h)
+        for (int c = 0; c < LG_SORT_TOTALS_COPIES; c++) v += totals[c * LG_SORT_TOTALS_STRIDE + p * 256 + threadIdx.x];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
