@@ -152,6 +152,7 @@ class FusedRenderer:
         self.tile_order = None
         self.fallbacks = 0                 # visits that were re-run unculled (observed one visit later)
         self.truncated_visits = 0          # unculled visits whose table turned out too short (observed one visit later)
+        self.keep_size_predictions = False  # across a densification / re-sort (parameters_replaced): measured gain 1-3 %, see there
         self.last_cull = False
         # fuse_optimizer: backward stops after the blend backward; FusedAdam.step() then runs the per-Gaussian backward fused
         # with the Adam update (csrc/fused.hip: project_backward_adam_kernel) -- parameter gradients never go to HBM.
@@ -299,22 +300,26 @@ class FusedRenderer:
 
     def parameters_replaced(self, growth: float = 1.0):
         """Density control / a Morton re-sort replaced the parameters (`growth` = new / old point count).  Depth bounds and tile schedules
-        describe the old cloud: dropped.  The SIZE predictions (visible chunks, table length) of the frames in use are kept, scaled by the
-        growth -- the reference never resets its feedback buffers (litegs/data.py:236-241, GR/compact.cu:527-546): a densification adds a
-        few percent of points, inside the 1.2x / 1.5x allocation margins, and an under-predicted table is noticed and sized exactly on the
-        frame's next visit.  Frames out of use (evaluation frames: their predictions are many densifications old) start over with an
-        exact, blocking first visit -- the reference would truncate them silently.  Resetting everything made every training frame's next visit a blocking first visit that also mispredicts the list
-        route: epochs after a densification cost 3.9-4.3 ms per iteration against 3.3-3.5 for the others at 3 M / 150 cameras
-        (profiles/r04_convergence_3m_runs_11_13.md, cost by position in the densification cycle)."""
+        describe the old cloud: dropped.  The SIZE predictions (visible chunks, table length) are dropped too by default: every frame's
+        next visit is an exact, blocking first visit (GR/compact.cu:543-546, GR/binning.cu:152-163).
+
+        keep_size_predictions = True keeps them for the frames in use, scaled by the growth, as the reference does (it never resets its
+        feedback buffers, litegs/data.py:236-241): a densification adds a few percent of points, inside the 1.2x / 1.5x allocation
+        margins, and an under-predicted table is truncated (GR/binning.cu:63), noticed, and sized exactly on the frame's next visit;
+        frames out of use (evaluation frames) still start over.  Measured at 3 M / 150 cameras: epochs right after a densification cost
+        3.9-4.3 ms per iteration with the reset against 3.3-3.5 for the others (profiles/r04_convergence_3m_runs_11_13.md), the whole run
+        3.21 against 3.24-3.30 ms per iteration.  It is NOT the default because the three long runs that had it on lost their second
+        trainer to a memory access fault that is attributed but not root-caused (profiles/r04_fault_attribution.md); the runs without
+        it: 19 trainers, none lost."""
         g = max(1.0, float(growth))
         for k, f in enumerate(self.frames):
             # a densification is TWO replacements with no visit in between (density control at the end of an epoch, the Morton re-sort at
             # the start of the next): a frame is out of use when it sat out two replacements in a row
             f.idle_replacements = 0 if f.visits > f.visits_at_replace else f.idle_replacements + 1
-            fresh = f.idle_replacements < 2
+            keep = self.keep_size_predictions and f.idle_replacements < 2
             f.reset(self.margin_fixed or self.margin_lo)
             f.visits_at_replace = f.visits
-            if fresh:
+            if keep:
                 self.fb_vis[k] = int(np.ceil(g * int(self.fb_vis[k])))
                 self.fb_total[k] = int(min(np.ceil(g * int(self.fb_total[k])), 2**31 - 1))
             else:
