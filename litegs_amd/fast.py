@@ -26,6 +26,7 @@ from .hostwords import HostWords
 # Environment switches of the executor (each one named in INTEGRATION.md with the measurement behind its default).  Everything else
 # that used to be a switch is a plain attribute of FusedRenderer for tests / tools to set.
 _GUARD_ALLOC = os.environ.get("LITEGS_GUARD_ALLOC", "0") == "1"
+_POISON_ALLOC = os.environ.get("LITEGS_GUARD_ALLOC", "0") == "poison"     # module attribute: tools may set it after import
 _DEPTH_ORDER = {"global": 0, "tile": 1, "auto": 2}
 
 
@@ -43,6 +44,13 @@ def _empty(shape, dtype, device, zero: bool = False, align: int = 16):
     PYTORCH_NO_CUDA_MEMORY_CACHING=1 so that every tensor is a device mapping of its own): the tensor is placed so that it ENDS where its
     page-granular allocation ends (`align`-byte granularity), which turns a read or write past the end of a buffer into an immediate
     memory access fault instead of a silent access to a neighbour."""
+    if _POISON_ALLOC and not zero:
+        # LITEGS_GUARD_ALLOC=poison (debugging aid, works with the caching allocator): every per-frame buffer starts as 0xC1 bytes -- as int32
+        # a large negative number, as float -24.2 -- so that a word no kernel of this frame wrote is out of range wherever it is used as a
+        # key, an id or a position, in a process's FIRST trainer as well; pair it with LITEGS_VALIDATE_TABLES=1 (profiles/r04_fault_attribution.md)
+        t = torch.empty(shape, dtype=dtype, device=device)
+        t.view(-1).view(torch.uint8).fill_(0xC1)
+        return t
     if not _GUARD_ALLOC:
         return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
     n = 1
