@@ -579,7 +579,11 @@ def main():
                                              "margin_pct": sorted(set(int(m) for m in rd.margin)),
                                              "unculled_reruns_observed": int(rd.fallbacks), "truncated_tables_observed": int(rd.truncated_visits),
                                              "visits": int(sum(rd.visits)),
-                                             "full_instances": int(rd.full_total[frame_of(0)])}
+                                             "full_instances": int(rd.full_total[frame_of(0)]),
+                                             # every violated bound so far: step number (0 = first setup step; the timed region is steps
+                                             # [frames + warmup, frames + warmup + steps)), frame, that frame's visit count, steps replayed
+                                             "timed_region_steps": [n_slots + args.warmup, n_slots + args.warmup + args.steps],
+                                             "violations": [{"step": a, "frame": b, "visit": c, "steps_replayed": d} for a, b, c, d in tr.spec_log[:16]]}
             fa = tr.fadam
             if fa.skip_untouched and fa.touched is not None:
                 # exact skip of no-op Adam updates (csrc/fused.hip): Gaussians of the visible chunks that never received a gradient

@@ -77,6 +77,7 @@ class FrameTrainer:
         self._spec_events = []        # one event behind every speculative step still in flight
         self.spec_depth = 2           # steps the host may run ahead of the device in speculative mode
         self.spec_replays = 0
+        self.spec_log = []                # (step number, frame, visits of that frame so far, steps replayed) per violated bound
 
     # -------------------------------------------------------------------------------------------
     def forward(self, frame: Frame, raw: bool = False):
@@ -152,7 +153,10 @@ class FrameTrainer:
                 R.spec_step = no
                 R.force_full = (i == 0)
                 if i == 0:                                # the frame whose bounds were violated: what the gated repeat's bookkeeping does
-                    R.note_fallback(self.frames[frame_index % len(self.frames)].cam.index)
+                    k = self.frames[frame_index % len(self.frames)].cam.index
+                    if len(self.spec_log) < 64:
+                        self.spec_log.append((int(no), int(k), int(R.frames[k].visits), len(todo)))
+                    R.note_fallback(k)
                 self._spec_ring.append((no, frame_index, lrs))
                 self._step_body(frame_index, None, 0, None)
                 self.spec_replays += 1
