@@ -8,6 +8,7 @@
 #   benchdp2     bench.py --gpus 2 with both ranks on this GPU over gloo (control-flow check of the N>1 path)
 #   trace        rocprofv3 --kernel-trace --stats of the default bench -> step timeline + kernel stats
 #   sq           SQ counters (VALU / SALU / LDS bank conflicts) of the bench workload, fresh and trained state
+#   poison       short scenarios plain vs with poisoned per-frame buffers + validators (tools/poison_probe.py): must be indistinguishable
 #   hunt:<runs>  the same loop in the configuration that faulted, with poisoned buffers + validators + breadcrumbs (see the stage)
 #   conv:<runs>  tests/convergence_3m.py with <runs> executor trainers in ONE process (operator curve taken from profiles/), allocator
 #                snapshots on, late-phase state saved to /tmp/late.pt at epoch 120 by the first trainer
@@ -62,6 +63,9 @@ for STAGE in "$@"; do
         LITEGS_CONV_SKIP_OPERATOR=profiles/r03_convergence_3m.json timeout -s KILL 2400 python -X faulthandler tests/convergence_3m.py --runs $RUNS --set stat_schedule_always=false$CONV_OWN_EXTRA \
         --out gpurun_out/convergence_3m_own_$TAG.md > gpurun_out/convergence_3m_own_$TAG.log 2>&1
       echo "exit $?"; grep -E "executor:|fault|Error|error" gpurun_out/convergence_3m_own_$TAG.log | head -20 ;;
+    poison)          # tools/poison_probe.py through its test: plain vs poisoned-buffer runs of short scenarios; findings print as XFAIL lines
+      LITEGS_POISON_PROBE=1 timeout -s KILL 600 python -m pytest tests/test_zz_gpu_poison.py -m gpu -q > gpurun_out/poison_$TAG.log 2>&1
+      tail -5 gpurun_out/poison_$TAG.log | cut -c1-3000 ;;
     hunt:*)          # the fault hunt of profiles/r04_fault_attribution.md: <runs> trainers in one process with size predictions kept across
                      # densifications (the configuration that faulted), per-frame buffers poisoned (a word no kernel wrote is out of range
                      # wherever it is used), every table validator on, launch breadcrumbs on.  A validator report names the stage.
