@@ -293,7 +293,7 @@ class FusedRenderer:
                                f"valid_entries={rec[4]} reports_so_far={rec[7]} emission_count_mismatches={rec[5]} (last walked-counted={rec[6]})")
 
     def note_fallback(self, k: int):
-        """frame k was re-run unculled (gated repeat observed, or a speculative step replayed): widen its margin, start its cool-down"""
+        """frame k was re-run unculled (gated repeat observed, or a speculative step replayed): widen its margin"""
         F = self.frames[k]
         self.fallbacks += 1
         F.clean_visits = 0
