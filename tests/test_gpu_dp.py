@@ -256,6 +256,7 @@ def _two_rank_epochs_worker(rank, world, port, mode, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.stochastic
 @pytest.mark.parametrize("mode", ["moments", "sparse"])
 def test_two_ranks_epochs_with_density_control_stay_identical(mode):
     """six epochs of the data-parallel loop on two ranks (one GPU, gloo transport): statistic epochs, density control (append + prune +

@@ -15,6 +15,7 @@ def _steps(tr, n, start=0):
     return [float(tr.step((start + i) % len(tr.frames)).detach()) for i in range(n)]
 
 
+@pytest.mark.stochastic
 def test_two_trainers_and_an_evaluator_interleaved_across_empty_cache():
     """Trainer A (speculative culling, gradient replicas), trainer B (the same) and an evaluation renderer (no gradients, gated repeat) take
     turns; A is dropped WITHOUT a flush while its last steps are in flight, the caches are emptied, B and the evaluator go on and a third

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.util import noise_log
+
 pytestmark = pytest.mark.gpu
 
 
@@ -93,6 +95,7 @@ def test_executor_is_bit_identical_with_and_without_the_splat_sort():
         assert torch.equal(a, b)
 
 
+@pytest.mark.stochastic
 def test_training_steps_agree_between_the_two_modes():
     """a few optimisation steps (forward, loss, blend backward, fused backward + Adam) with both orders: the blend backward's float
     atomics make parameters differ in the last bits run to run, so this is a tolerance check on top of the bit-exact forward test"""
@@ -106,8 +109,11 @@ def test_training_steps_agree_between_the_two_modes():
         res[mode] = (losses, [p.detach().clone() for p in tr.params])
     # losses of the first steps agree closely; later steps (and the parameters) drift apart like any two runs of the SAME mode do, because
     # the blend backward's float atomics reorder the sums (tests/test_gpu_convergence.py measures that spread)
-    np.testing.assert_allclose(res[0][0][:4], res[1][0][:4], rtol=2e-4)
-    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-2)
+    a, b = np.asarray(res[0][0]), np.asarray(res[1][0])
+    noise_log(what="loss, tile vs global order", rel_first4=float((np.abs(a - b) / np.abs(b))[:4].max()), rel_all=float((np.abs(a - b) / np.abs(b)).max()),
+              bound_first4=2e-4, bound_all=2e-2)
+    np.testing.assert_allclose(a[:4], b[:4], rtol=2e-4)
+    np.testing.assert_allclose(a, b, rtol=2e-2)
 
 
 @pytest.mark.parametrize("case", ["mixed", "ties"])

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.util import noise_log
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -32,6 +34,7 @@ def _args(scene, model, iterations, **kw):
     return lp, op, pp, dp
 
 
+@pytest.mark.stochastic
 def test_start_trains_a_colmap_scene_and_writes_the_outputs(tmp_path):
     from litegs_amd import training
     from litegs_amd.io import load_ply
@@ -60,6 +63,7 @@ def test_start_trains_a_colmap_scene_and_writes_the_outputs(tmp_path):
     assert hist2[-1]["psnr_train"] > hist[0]["psnr_train"] + 1.0
 
 
+@pytest.mark.stochastic
 def test_operator_path_runs_the_same_loop(tmp_path):
     from litegs_amd import training
     scene = _scene(str(tmp_path), points=2048, frames=8)
@@ -67,6 +71,7 @@ def test_operator_path_runs_the_same_loop(tmp_path):
     _, h_exec = training.start(lp, op, pp, dp, test_epochs=[5], log=lambda *a: None)
     lp, op, pp, dp = _args(scene, str(tmp_path / "m_ops"), 7 * 6)
     _, h_ops = training.start(lp, op, pp, dp, test_epochs=[5], fused=False, log=lambda *a: None)
+    noise_log(what="training.start executor vs operator, psnr_train after 6 epochs", d=abs(h_exec[-1]["psnr_train"] - h_ops[-1]["psnr_train"]), bound=0.75)
     assert abs(h_exec[-1]["psnr_train"] - h_ops[-1]["psnr_train"]) < 0.75, (h_exec[-1], h_ops[-1])
     assert h_exec[-1]["points_after"] == h_ops[-1]["points_after"]
 
@@ -104,6 +109,7 @@ def _dp_worker(rank, world, port, scene, model, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.stochastic
 def test_two_ranks_train_the_scene_data_parallel(tmp_path):
     import torch.multiprocessing as mp
     from litegs_amd import training

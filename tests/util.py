@@ -62,6 +62,20 @@ def pinned_count(name, count, size, ceiling, max_err=0.0, atol=ATOL):
         assert count <= pin, f"{key}: {count} flipped elements, pinned at {pin}"
 
 
+def noise_log(**values):
+    """Stochastic tests (pytest.mark.stochastic) record the statistic they bound -- one JSON line per assertion in gpurun_out/noise_stats.jsonl --
+    so that every bound in the suite can be read against the spread actually observed over repeated runs (tools/gpu_session.sh `stochastic:<reps>`
+    repeats them in one session; profiles/r05_noise_calibration.md is the summary)."""
+    rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]}
+    rec.update({k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in values.items()})
+    try:
+        os.makedirs(os.path.dirname(_FLIP_LOG), exist_ok=True)
+        with open(os.path.join(os.path.dirname(_FLIP_LOG), "noise_stats.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
 def assert_close(got, ref, atol=ATOL, flip_frac=0.0, flip_atol=FLIP_ATOL, normalize=False, name="", flip_max=None):
     """|got - ref| <= atol everywhere, except for at most min(ceil(flip_frac * size), flip_max) "flipped" elements, which must still be
     within flip_atol.  Whenever an allowance is given, the OBSERVED count is logged (gpurun_out/flip_counts.jsonl, and printed) and must not

@@ -3,6 +3,7 @@
 #   usage: tools/gpu_session.sh TAG STAGE [STAGE ...]      (run from the repository root on the GPU box; output under gpurun_out/)
 # stages:
 #   tests        the whole -m gpu suite (flip counts collected)           tests:<pytest args>  a targeted run
+#   stochastic:<reps>  the noise-bounded tests repeated in one session (calibration of their bounds)
 #   smoke        __graft_entry__.smoke()
 #   bench        the default bench line                                     bench10m / bench500k  the other BASELINE sizes
 #   benchdp2     bench.py --gpus 2 with both ranks on this GPU over gloo (control-flow check of the N>1 path)
@@ -29,6 +30,14 @@ for STAGE in "$@"; do
     tests:*)
       timeout -s KILL 600 python -m pytest ${STAGE#tests:} -m gpu -x -q > gpurun_out/pytest_quick_$TAG.log 2>&1
       grep -E "passed|failed|error" gpurun_out/pytest_quick_$TAG.log | tail -2; grep -E "^E  " gpurun_out/pytest_quick_$TAG.log | head -20 ;;
+    stochastic:*)    # every noise-bounded test (pytest.mark.stochastic) <reps> times in this one session; the statistic each bounds goes to noise_stats.jsonl
+      REPS=${STAGE#stochastic:}
+      rm -f gpurun_out/noise_stats.jsonl
+      for i in $(seq 1 $REPS); do
+        timeout -s KILL 600 python -m pytest tests -m "gpu and stochastic" -q -p no:cacheprovider > gpurun_out/pytest_stochastic_${TAG}_$i.log 2>&1
+        echo "rep $i: $(grep -E 'passed|failed' gpurun_out/pytest_stochastic_${TAG}_$i.log | tail -1)"; grep -E "^FAILED|^E  " gpurun_out/pytest_stochastic_${TAG}_$i.log | head -8
+      done
+      cp gpurun_out/noise_stats.jsonl gpurun_out/noise_stats_$TAG.jsonl 2>/dev/null ;;
     smoke)
       timeout -s KILL 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; tail -1 gpurun_out/smoke_$TAG.log ;;
     bench)
