@@ -297,6 +297,8 @@ def training_state(args, n, W, H, focal, scene, n_frames):
     out["roofline"] = roofline_probe(tr, list(range(n_frames)))
     out["finite"] = all(bool(torch.isfinite(p).all()) for p in tr.params)
     tr.close()
+    out["keep_size_predictions"] = bool(rd.keep_size_predictions)
+    out["sanitised"] = dict(tr.sanitised)                  # csrc/lg_sanity.h: garbage table words neutralised during this leg ({} = none)
     return out
 
 
@@ -396,13 +398,10 @@ def _cpu_model():
 def relaunch(args):
     """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run (what the driver's command line does)
     and hand its exit code back.  One rank per GPU over RCCL; LITEGS_BENCH_ONE_GPU=1 (test hook) puts every rank on cuda:0 over gloo."""
-    import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous on a port it binds itself (no bind-then-close race with other launches)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
@@ -480,11 +479,16 @@ def main():
     step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step event pairs
     t0 = time.perf_counter()
     step_events[0].record()
+    replays_seen, with_replay = tr.spec_replays, []
     for i in range(args.steps):
         tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
         step_no += 1
         step_events[i + 1].record()
+        if tr.spec_replays != replays_seen:               # a failed speculative step was noticed and replayed inside this step's interval
+            replays_seen = tr.spec_replays
+            with_replay.append(i)
     tr.flush()
+    replays_in_flush = tr.spec_replays - replays_seen
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -564,7 +568,10 @@ def main():
             "metric": "train iters/s (camera frames trained per second, whole job) + fwd Msplats/s, "
                       + ("3M Gaussians @1080p" if args.config == "3m_1080p" else f"{args.config} (not the BASELINE headline config)"),
             "value": round(world * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), **{k: v for k, v in percentiles(step_ms).items() if k != "samples"}, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), **{k: v for k, v in percentiles(step_ms).items() if k != "samples"},
+            # mean over the steps whose event interval holds no speculative replay (`value` and ms_per_step include every replay)
+            "ms_per_step_excl_replays": round(float(np.mean([m for i, m in enumerate(step_ms) if i not in set(with_replay)] or [0.0])), 4),
+            "steps_with_replay": with_replay, "steps_replayed_in_final_flush": int(replays_in_flush), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} Gaussians SH3, {W}x{H}, 1 camera frame per GPU per step, full training iteration "
                                    "(render_preprocess+render+L1/SSIM loss+backward+sparse Adam), seed 0 (SURVEY 8d)",
@@ -584,6 +591,10 @@ def main():
                                              # [frames + warmup, frames + warmup + steps)), frame, that frame's visit count, steps replayed
                                              "timed_region_steps": [n_slots + args.warmup, n_slots + args.warmup + args.steps],
                                              "violations": [{"step": a, "frame": b, "visit": c, "steps_replayed": d} for a, b, c, d in tr.spec_log[:16]]}
+            # sizing protocol (litegs/data.py:236-241): are the per-frame size predictions kept across a parameter replacement
+            result["keep_size_predictions"] = bool(rd.keep_size_predictions)
+            # always-on counters of garbage table words neutralised by a kernel (csrc/lg_sanity.h): {} = none since the process started
+            result["sanitised"] = dict(tr.sanitised)
             fa = tr.fadam
             if fa.skip_untouched and fa.touched is not None:
                 # exact skip of no-op Adam updates (csrc/fused.hip): Gaussians of the visible chunks that never received a gradient

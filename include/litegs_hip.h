@@ -206,6 +206,7 @@ int lg_unpack_gradient(const float* packed_grad, const float* packed /*[V,N,16] 
  * key 0: tiles per workgroup of the blend backward (1, 2, 4); key 1 / 2: workgroup -> tile map of the backward / forward
  * (0 = one band per XCD, 1 = identity, C >= 2 = runs of C workgroups interleaved over the XCDs). */
 int lg_set_tuning(int key, int value);
+int lg_stat_in_record_supported(int TH, int TW);   /* 1: statistic renders of this tile shape carry their three statistics in gradient-record slots 9-11 (raster.hip) */
 
 /* ---- loss.hip : fused_ssim.fused_l1_ssim_loss (litegs/training/trainer.py:145; un-vendored submodule, formula in
  * litegs_amd/loss.py).  planes = B*C image planes of H x W.  dmaps [3,planes,H,W] carries dS/dmu1, dS/dE[x^2], dS/dE[xy]
@@ -271,6 +272,12 @@ typedef struct LgFusedCtx {
  * memory that is still there, and a freed word is handed out again only after a device synchronisation.  n int32 words, zeroed. */
 int* lg_host_words_alloc(int n);
 void lg_host_words_free(int* words, int n);
+/* Always-on counters of table words that a consumer had to neutralise instead of indexing with them (csrc/lg_sanity.h; a correct table
+ * never takes those branches).  out[8] receives the counts since the last reset, summed over the library's kernels: [0] emission key out
+ * of range, [1] emission walk != prefix sums, [2] tile_range boundary key skipped, [3] tile count / scatter key dropped, [4] radix sort
+ * scatter position outside [0, n), [5] per-tile sort id clamped, [6] truncated tables (not an error: GR/binning.cu:63), [7] unused.
+ * Blocking (device memcpy on the null stream): call at a synchronisation point.  No reference counterpart (the reference faults). */
+int lg_sanitised_counts(int* out, int reset);
 long long lg_fused_hot_offset(long long N);
 long long lg_fused_grad_lines(long long N);
 long long lg_fused_workspace1_bytes(long long N);

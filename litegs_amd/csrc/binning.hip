@@ -9,6 +9,9 @@
 #include <stdlib.h>
 #include "lg_tilewalk.h"
 #include "lg_binning_internal.h"
+#include "lg_sanity.h"
+
+LG_DEFINE_SANITY_COLLECT(binning)
 
 #define TPB 256
 
@@ -175,6 +178,7 @@ __device__ __forceinline__ void load_splat(const SplatSrc& src, size_t b, int N,
 // is left to the table validators (fused.hip).  dbg nullable (product runs): the emission pads / drops silently.
 __device__ __forceinline__ void dup_report_mismatch(int* __restrict__ dbg, int slot, int walked, int counted)
 {
+    lg_note_sanitised(LG_SITE_EMIT_COUNT);
     if (dbg == nullptr) return;
     __hip_atomic_fetch_add(dbg + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(dbg + 6, walked - counted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -252,6 +256,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             // are counted into the sort's digit totals (digit 0 of every pass) -- the sort then handles exactly table_len keys.
             for (long long q = off; q < table_len; q++) { kout[q] = 0; vout[q] = 0; }
             if (trunc_flag) atomicOr(trunc_flag, 1);          // the table was under-predicted: the culled run asks for the fallback
+            lg_note_sanitised(LG_SITE_TRUNCATED);             // (counted, not an error: the reference truncates silently)
             if (totals)
                 for (int p = 0; p < ds.passes; p++) atomicAdd(&totals[p * 256], (int)(table_len - off));
             if (tile_counts) atomicAdd(&tile_counts[(size_t)b * (gx * gy + 2)], (int)(table_len - off));
@@ -381,7 +386,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             const unsigned long long sm = sword & ((2ull << lane) - 1ull);
             const int ps = sm ? p0 + wave * 64 + 63 - __clzll(sm) : sprev;
             key = (int32_t)buf[ps] + (p - ps) * t_stride[t];
-            if ((unsigned)key > (unsigned)(gx * gy)) key = 0;              // cannot happen while walk and count agree; a key is an index downstream
+            if ((unsigned)key > (unsigned)(gx * gy)) { key = 0; lg_note_sanitised(LG_SITE_EMIT_KEY); }   // cannot happen while walk and count agree; a key is an index downstream
             const int g = t_goff[t] + (p - t_loff[t]);
             kout[g] = key;
             vout[g] = t_idx[t];
@@ -870,6 +875,7 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
             const uint32_t k = lds_k[p];
             const uint32_t d = (k >> shift) & mask;
             const int g = global_base[d] + (p - digit_run[d]);
+            if ((unsigned long long)(long long)g >= (unsigned long long)n) { lg_note_sanitised(LG_SITE_RADIX_INDEX); continue; }
             keys_out[g] = k;
             vals_out[g] = lds_v[p];
         }
@@ -1045,6 +1051,10 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
             const uint32_t d = (k >> shift) & mask;
             const int g = global_base[d] + (p - digit_base[d]);
             const uint32_t v = lds_v[p];
+            // g is built from the producer's digit totals and the predecessors' look-back words: if either is inconsistent with the keys
+            // (a total that over-counts, a status word that was not zero on entry) g leaves [0, n) -- or lands on another key's slot,
+            // which leaves a hole of stale memory elsewhere.  The first is caught here and counted; never a wild store.
+            if ((unsigned long long)(long long)g >= (unsigned long long)n) { lg_note_sanitised(LG_SITE_RADIX_INDEX); continue; }
             keys_out[g] = k;
             vals_out[g] = v;
             if (aux_in) aux_out[g] = aux_in[v];          // last pass of the depth sort: tile counts gathered into depth order on the way out
@@ -1607,7 +1617,7 @@ __global__ void __launch_bounds__(TPB) tile_range_kernel(const int32_t* __restri
     }
     // A key outside 0..max_tile cannot come out of a correct table; if one does (an entry the emission left unwritten, DESIGN.md section 9
     // "memory access fault"), it must not become a store address: such boundaries are skipped, the tile keeps "empty".
-    if (i0 == 0 && (unsigned)key[0] <= (unsigned)max_tile) o[key[0]] = 0;
+    if (i0 == 0) { if ((unsigned)key[0] <= (unsigned)max_tile) o[key[0]] = 0; else lg_note_sanitised(LG_SITE_RANGE_KEY); }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const long long i = i0 + j;
@@ -1617,7 +1627,7 @@ __global__ void __launch_bounds__(TPB) tile_range_kernel(const int32_t* __restri
             if (cur != nxt && (unsigned)nxt <= (unsigned)max_tile) {
                 if (cur + 1 < nxt && cur >= -1) o[cur + 1] = (int32_t)(i + 1);
                 o[nxt] = (int32_t)(i + 1);
-            }
+            } else if (cur != nxt) lg_note_sanitised(LG_SITE_RANGE_KEY);
         }
     }
 }
@@ -1751,6 +1761,7 @@ __global__ void __launch_bounds__(TPB) tile_count_lds_kernel(const int32_t* __re
 #pragma unroll
     for (int j = 0; j < TG_PER_THREAD; j++)
         if ((unsigned)k[j] <= (unsigned)max_tile) atomicAdd(&hist[k[j] >> 1], 1u << ((k[j] & 1) * 16));      // (a key is an index: range-checked)
+        else if (i0 + (long long)(j >> 2) * (TPB * 4) + (long long)threadIdx.x * 4 + (j & 3) < n) lg_note_sanitised(LG_SITE_SCATTER_KEY);
     __syncthreads();
     for (int w = threadIdx.x; w < TG_BINS / 2; w += TPB) {
         const unsigned int c = hist[w];

@@ -129,19 +129,35 @@ static bool use_tile_scatter(const Exec& x, long long N, int ntiles) { return x.
 // ---------------------------------------------------------------------------------------------
 #include <mutex>
 #include <vector>
+#include <unordered_map>
 namespace {
-struct HostRange { int* p; int n; };
+struct HostRange { int* p; int n; int dev; };      // dev: the device that was current when the range was handed out (its kernels store into it)
 std::mutex g_hw_mutex;
 std::vector<HostRange> g_hw_free, g_hw_quarantine;
+std::unordered_map<int*, int> g_hw_owner;        // live range -> device
 int* g_hw_chunk = nullptr;
 int g_hw_chunk_left = 0;
 constexpr int HW_CHUNK_WORDS = 1 << 16;          // 256 KB of pinned memory per arena chunk
+
+// free ranges are kept coalesced: adjacent ranges (same chunk by construction: chunks are separate allocations) merge
+void hw_add_free(HostRange r)
+{
+    for (size_t i = 0; i < g_hw_free.size();) {
+        HostRange& f = g_hw_free[i];
+        if (f.p + f.n == r.p) { r.p = f.p; r.n += f.n; g_hw_free[i] = g_hw_free.back(); g_hw_free.pop_back(); i = 0; continue; }
+        if (r.p + r.n == f.p) { r.n += f.n; g_hw_free[i] = g_hw_free.back(); g_hw_free.pop_back(); i = 0; continue; }
+        i++;
+    }
+    g_hw_free.push_back(r);
+}
 }
 LG_API int* lg_host_words_alloc(int n)
 {
     if (n <= 0) return nullptr;
     n = (n + 15) & ~15;                          // 64-byte granules: no two owners share a cache line
     std::lock_guard<std::mutex> lock(g_hw_mutex);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) cur = -1;
     auto take_free = [&]() -> int* {
         for (size_t i = 0; i < g_hw_free.size(); i++)
             if (g_hw_free[i].n >= n) {
@@ -154,9 +170,22 @@ LG_API int* lg_host_words_alloc(int n)
     };
     int* p = take_free();
     if (p == nullptr && !g_hw_quarantine.empty()) {
-        // nothing on the device can still be storing into a quarantined range once everything enqueued so far has completed
-        if (hipDeviceSynchronize() == hipSuccess) {
-            for (const HostRange& r : g_hw_quarantine) g_hw_free.push_back(r);
+        // nothing can still be storing into a quarantined range once everything enqueued so far ON ITS OWNER'S DEVICE has completed (the
+        // arena is process-wide and Portable: ranges of several devices may sit here; devices this process never used are not touched)
+        bool drained = true;
+        std::vector<int> devs;
+        for (const HostRange& r : g_hw_quarantine) {
+            bool seen = false;
+            for (int d : devs) seen = seen || d == r.dev;
+            if (!seen) devs.push_back(r.dev);
+        }
+        for (int d : devs) {
+            if (d >= 0 && d != cur) drained = drained && hipSetDevice(d) == hipSuccess;
+            drained = drained && hipDeviceSynchronize() == hipSuccess;
+        }
+        if (cur >= 0) (void)hipSetDevice(cur);
+        if (drained) {
+            for (const HostRange& r : g_hw_quarantine) hw_add_free(r);
             g_hw_quarantine.clear();
             p = take_free();
         }
@@ -166,11 +195,13 @@ LG_API int* lg_host_words_alloc(int n)
             const int words = n > HW_CHUNK_WORDS ? n : HW_CHUNK_WORDS;
             void* mem = nullptr;
             if (hipHostMalloc(&mem, sizeof(int) * (size_t)words, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return nullptr;
-            g_hw_chunk = (int*)mem; g_hw_chunk_left = words;          // the rest of the previous chunk is abandoned (never unmapped)
+            if (g_hw_chunk_left > 0) hw_add_free(HostRange{ g_hw_chunk, g_hw_chunk_left, -1 });      // the rest of the previous chunk stays usable
+            g_hw_chunk = (int*)mem; g_hw_chunk_left = words;
         }
         p = g_hw_chunk; g_hw_chunk += n; g_hw_chunk_left -= n;
     }
     for (int i = 0; i < n; i++) p[i] = 0;
+    g_hw_owner[p] = cur;
     return p;
 }
 LG_API void lg_host_words_free(int* words, int n)
@@ -178,7 +209,24 @@ LG_API void lg_host_words_free(int* words, int n)
     if (words == nullptr || n <= 0) return;
     n = (n + 15) & ~15;
     std::lock_guard<std::mutex> lock(g_hw_mutex);
-    g_hw_quarantine.push_back(HostRange{ words, n });
+    int dev = -1;
+    auto it = g_hw_owner.find(words);
+    if (it != g_hw_owner.end()) { dev = it->second; g_hw_owner.erase(it); }
+    g_hw_quarantine.push_back(HostRange{ words, n, dev });
+}
+
+// ---------------------------------------------------------------------------------------------
+// Always-on sanitised-word counters (lg_sanity.h): one block per translation unit that can neutralise a table word
+// ---------------------------------------------------------------------------------------------
+#include "lg_sanity.h"
+int lg_sanity_collect_binning(int* out, int reset);
+int lg_sanity_collect_tilesort(int* out, int reset);
+LG_API int lg_sanitised_counts(int* out, int reset)
+{
+    if (out == nullptr) return (int)hipErrorInvalidValue;
+    for (int i = 0; i < LG_SANITY_SITES; i++) out[i] = 0;
+    int rc = lg_sanity_collect_binning(out, reset); if (rc) return rc;
+    return lg_sanity_collect_tilesort(out, reset);
 }
 
 #define LOG2E 1.4426950408889634f
@@ -552,6 +600,9 @@ static Camera make_camera(const float* view_host, const float* proj_host, int H,
 // full.  No host decision, no synchronisation; the common case pays seven empty launches.
 // ---------------------------------------------------------------------------------------------
 static int validate_chunk_ids(const struct Exec& x, int64_t* vis_ids, const int* vis_num, int A, int chunks, int* lock, hipStream_t s);
+static int validate_zero(const struct Exec& x, const void* p, long long words, int* lock, const int* gate, int range_id, hipStream_t s);
+static int validate_order(const struct Exec& x, const int32_t* ids, const int32_t* prefix, int N, int* lock, const int* gate, hipStream_t s);
+#define LG_VALIDATE_LOCK_WORD 8            // int index inside Layout1::flags (cleared with the frame's scratch by the projection)
 
 struct Scene {            // what the projection kernel reads (raw parameters + the frame's visible chunks)
     const float *pos, *scale, *rot, *sh0, *shr, *opa;
@@ -630,11 +681,17 @@ LG_API int lg_fused_stage1(const LgFusedCtx* ctx, const float* aabb_origin, cons
         rc = validate_chunk_ids(x, vis_ids, vis_num, A, chunks, nullptr, s); if (rc) return rc;
     }
     rc = launch_projection(sc, cam, TH, TW, w, f, true, sched_cull, sched_out, nullptr, s, x.replicas ? x.hot_counter : nullptr); if (rc) return rc;
+    int* vlock = (int*)(w + f.flags) + LG_VALIDATE_LOCK_WORD;
+    if (x.validate) {      // code 8: the scratch the projection clears on the side (sort headers, look-back tables, tickets, counters) IS clear
+        rc = validate_zero(x, w + f.zeroed, (long long)(f.zero_bytes / 4), vlock, nullptr, 1, s); if (rc) return rc;
+    }
     if (use_tile_order(x, N)) {
         // no splat sort: instances are emitted in splat-id order and every tile's list is depth-sorted after the tile sort
         // (tilesort.hip).  Inclusive scan of the tile counts in id order; prefix[N-1] (the table length) also goes to the host feedback slot
-        return lg_gather_scan_gated((const int32_t*)(w + f.alloc), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
-                                    (uint32_t*)(w + f.scan_status), host_feedback_total, sched_cull ? 1 : 0, nullptr, nullptr, stream);
+        rc = lg_gather_scan_gated((const int32_t*)(w + f.alloc), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
+                                  (uint32_t*)(w + f.scan_status), host_feedback_total, sched_cull ? 1 : 0, nullptr, nullptr, stream);
+        if (rc == 0 && x.validate) rc = validate_order(x, nullptr, (const int32_t*)(w + f.prefix), (int)N, vlock, nullptr, s);
+        return rc;
     }
     float* view_z = (float*)(w + f.view_z);
     rc = lg_depth_keys_hist(view_z, N, (uint32_t*)(w + f.dk_a), (uint32_t*)(w + f.dv_a), (int*)(w + f.dsort_hdr), stream); if (rc) return rc;
@@ -645,8 +702,11 @@ LG_API int lg_fused_stage1(const LgFusedCtx* ctx, const float* aabb_origin, cons
     if (rc) return rc;
     // depth-ordered inclusive scan of the tile counts (culled splats count 0); prefix[N-1] (the table length) also goes to the host
     // feedback slot
-    return lg_gather_scan_gated((const int32_t*)(w + f.prefix), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
-                                (uint32_t*)(w + f.scan_status), host_feedback_total, sched_cull ? 1 : 0, nullptr, nullptr, stream);
+    rc = lg_gather_scan_gated((const int32_t*)(w + f.prefix), (const int32_t*)nullptr, N, (int32_t*)(w + f.prefix),
+                              (uint32_t*)(w + f.scan_status), host_feedback_total, sched_cull ? 1 : 0, nullptr, nullptr, stream);
+    if (rc == 0 && x.validate)      // codes 10 / 11: the splat sort's output is a table of ids, the prefix sums are monotone
+        rc = validate_order(x, (const int32_t*)(w + (lg_radix_sort_num_passes(0, 32) % 2 == 1 ? f.dv_b : f.dv_a)), (const int32_t*)(w + f.prefix), (int)N, vlock, nullptr, s);
+    return rc;
 }
 
 static int tile_key_bits(int ntiles)
@@ -738,7 +798,42 @@ static int validate_chunk_ids(const Exec& x, int64_t* vis_ids, const int* vis_nu
     return (int)hipGetLastError();
 }
 
-#define LG_VALIDATE_LOCK_WORD 8            // int index inside Layout1::flags (cleared with the frame's scratch by the projection)
+// code 8: a word that must be zero on entry to the kernel that follows (look-back status, ticket, counter, digit total) is not: `where` =
+// word index inside the checked range, `value` = the word, `bound` = which range (1 the projection's cleared scratch in workspace 1, checked
+// before anything counts into it; 2 the tile sort's look-back table in workspace 2; 3 the tile sort's tickets).  A status word that
+// escaped its clear and holds a negative float has both flag bits set and is taken for a finished prefix (binning.hip ST_INC | ST_AGG).
+__global__ void __launch_bounds__(256) validate_zero_kernel(const uint32_t* __restrict__ p, long long words, int* __restrict__ lock, int* __restrict__ dbg,
+                                                            const int* __restrict__ gate, int range_id)
+{
+    if (gate != nullptr && *gate == 0) return;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256)
+        if (p[i] != 0u) validate_report(lock, dbg, 8, (int)i, (int)p[i], range_id, (int)words);
+}
+static int validate_zero(const Exec& x, const void* p, long long words, int* lock, const int* gate, int range_id, hipStream_t s)
+{
+    if (words <= 0) return 0;
+    long long blocks = (words + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(validate_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)p, words, lock, x.debug_words, gate, range_id);
+    return (int)hipGetLastError();
+}
+// code 10: depth-sorted splat id `value` at slot `where` outside 0..N-1 (the splat sort left a hole of stale memory); code 11: the prefix
+// sums are not non-decreasing at `where` (value = prefix[where], bound = prefix[where - 1]) -- a slot with a negative share of the table
+__global__ void __launch_bounds__(256) validate_order_kernel(const int32_t* __restrict__ ids /*nullable*/, const int32_t* __restrict__ prefix, int N,
+                                                             int* __restrict__ lock, int* __restrict__ dbg, const int* __restrict__ gate)
+{
+    if (gate != nullptr && *gate == 0) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        if (ids != nullptr && (unsigned)ids[i] >= (unsigned)N) validate_report(lock, dbg, 10, i, ids[i], N, N);
+        const int a = i > 0 ? prefix[i - 1] : 0, b = prefix[i];
+        if (b < a) validate_report(lock, dbg, 11, i, b, a, N);
+    }
+}
+static int validate_order(const Exec& x, const int32_t* ids, const int32_t* prefix, int N, int* lock, const int* gate, hipStream_t s)
+{
+    hipLaunchKernelGGL(validate_order_kernel, dim3(1024), dim3(256), 0, s, ids, prefix, N, lock, x.debug_words, gate);
+    return (int)hipGetLastError();
+}
+
 static int validate_keys(const Exec& x, int32_t* keys, long long L, const int* n_dev, int ntiles, int* lock, const int* gate, hipStream_t s, int code = 1)
 {
     hipLaunchKernelGGL(validate_keys_kernel, dim3(2048), dim3(256), 0, s, keys, L, n_dev, ntiles, lock, x.debug_words, gate, code);
@@ -833,6 +928,9 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
         int* lock = (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD;
         rc = validate_keys(x, (int32_t*)(w + f.tk_a), Ls, total_dev, ntiles, lock, gate, s); if (rc) return rc;
         rc = validate_totals(x, tsort_hdr, lg_radix_sort_num_passes(0, bits), Ls, total_dev, lock, gate, s); if (rc) return rc;
+        // code 8: what the sort needs zero on entry -- its look-back table (cleared by the emission's zero duty) and its tickets
+        rc = validate_zero(x, w + f.tsort_table, (long long)lg_radix_table_words(Ls, lg_radix_sort_num_passes(0, bits)), lock, gate, 2, s); if (rc) return rc;
+        rc = validate_zero(x, tsort_hdr + LG_SORT_TOTALS_COPIES * LG_SORT_TOTALS_STRIDE, 4, lock, gate, 3, s); if (rc) return rc;
     }
     // instance count on the device: only that many entries are sorted and range-scanned
     CRUMB("global route: tile radix sort");

@@ -1099,6 +1099,11 @@ LG_API int lg_set_tuning(int key, int value)
     }
 }
 
+// 1 if a statistics render of this tile shape carries fragment count / weight / err_square inside the gradient record (slots 9-11, the
+// 8x16 moment-form kernel; off when that kernel was disabled through lg_set_tuning(5, 0)): the executor's caller then passes no
+// separate statistics arrays (err_square_sum == NULL); otherwise it must allocate them.
+LG_API int lg_stat_in_record_supported(int TH, int TW) { return (TH == 8 && TW == 16 && g_bwd_fast) ? 1 : 0; }
+
 LG_API int lg_raster_backward(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
                               const float* final_T, const short* last, const float* d_img, const float* d_trans,
                               int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,

@@ -22,6 +22,9 @@
 #include "litegs_hip.h"
 #include "lg_binning_internal.h"
 #include "lg_tilesort_body.h"
+#include "lg_sanity.h"
+
+LG_DEFINE_SANITY_COLLECT(tilesort)
 
 // LDS of one workgroup: four wave-private regions of { exchange buffer 4 KB, digit counters 1 KB } for regime R; the 16 KB bitonic
 // buffer of regimes M / L aliases them (the regimes are separated by workgroup barriers).
@@ -44,7 +47,10 @@ __global__ void __launch_bounds__(256) tile_depth_sort_kernel(int* __restrict__ 
     // word 12 of its 64-byte record: 4 M random reads of whole record lines (56 MB of records: L2 misses) cost more than the sort itself
     const float* __restrict__ dz = depth + (size_t)view * N;
     // (an id outside 0..N-1 cannot come out of a correct table; it must not become a gather address: clamped, the blend clamps the same way)
-    auto depth_bits = [dz, N](int id) -> uint32_t { return __float_as_uint(dz[min((unsigned)id, (unsigned)(N - 1))]); };
+    auto depth_bits = [dz, N](int id) -> uint32_t {
+        if ((unsigned)id >= (unsigned)N) lg_note_sanitised(LG_SITE_TILESORT_ID);                 // cold: counted (lg_sanity.h)
+        return __float_as_uint(dz[min((unsigned)id, (unsigned)(N - 1))]);
+    };
 
     {   // regime R: every wave its own tile
         const int tile = t0 + wave + 1;

@@ -203,17 +203,20 @@ class FusedRenderer:
         return [f.sched_cur for f in self.frames]
 
     # -- lifetime ---------------------------------------------------------------------------------------------------------------------
-    def close(self):
+    def close(self, sync: bool = True):
         """Everything enqueued so far has finished before the renderer's device words and pinned words are released.  (The pinned words
-        would survive anyway -- the arena quarantines them -- but the device tensors go back to torch's allocator.)"""
+        would survive anyway -- the arena quarantines them -- but the device tensors go back to torch's allocator.)
+        sync=False (the finaliser): no device synchronisation from a garbage collection -- the pinned words go to the arena's quarantine,
+        which re-issues them only behind a device synchronisation of its own, and the device tensors are stream-ordered in torch's allocator."""
         if self._closed:
             return
         self._closed = True
-        try:
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        except Exception:
-            pass
+        if sync:
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+            except Exception:
+                pass
         self.pending = None
         for w in (self._words, self.spec_words, self._debug_words):
             if w is not None:
@@ -222,7 +225,7 @@ class FusedRenderer:
 
     def __del__(self):
         try:
-            self.close()
+            self.close(sync=False)
         except Exception:
             pass
 
@@ -288,9 +291,20 @@ class FusedRenderer:
             self._debug_words.a[0] = 0
             what = {1: "tile key out of range in the emitted table", 2: "tile range ends beyond the valid entries", 3: "splat id out of range in the grouped table",
                     4: "visible chunk id out of range", 5: "visible chunk count out of range",
-                    6: "tile key out of range in the SORTED table", 7: "radix digit totals of the emission do not add up to the table length"}
+                    6: "tile key out of range in the SORTED table", 7: "radix digit totals of the emission do not add up to the table length",
+                    8: "a scratch word that must be zero on entry is not (bound: 1 = workspace-1 scratch after the projection, 2 = tile sort look-back table, 3 = tile sort tickets)",
+                    10: "depth-sorted splat id out of range (hole in the splat sort's output)", 11: "prefix sums decrease (value < bound)"}
             raise RuntimeError(f"litegs_amd: table validator: {what.get(rec[0], 'code %d' % rec[0])}: where={rec[1]} value={rec[2]} bound={rec[3]} "
                                f"valid_entries={rec[4]} reports_so_far={rec[7]} emission_count_mismatches={rec[5]} (last walked-counted={rec[6]})")
+
+    @staticmethod
+    def sanitised_counts(reset: bool = True) -> dict:
+        """Always-on counters of table words a kernel had to neutralise instead of indexing with them (csrc/lg_sanity.h): all zero for
+        correct tables.  Blocking -- call at a synchronisation point (FrameTrainer.flush() does).  `truncated_tables` is informational."""
+        out = (ctypes.c_int * 8)()
+        check(lib().lg_sanitised_counts(out, 1 if reset else 0), "lg_sanitised_counts")
+        names = ("emission_key", "emission_count_mismatch", "tile_range_key", "tile_scatter_key", "radix_scatter_index", "tilesort_id", "truncated_tables")
+        return {n: int(out[i]) for i, n in enumerate(names)}
 
     def note_fallback(self, k: int):
         """frame k was re-run unculled (gated repeat observed, or a speculative step replayed): widen its margin"""
@@ -485,7 +499,7 @@ class _RenderFn(torch.autograd.Function):
         fc = fw = None
         # statistic epochs, 8x16 tiles: fragment count / weight / err_square travel in slots 9-11 of the blend backward's gradient record
         # (csrc/raster.hip, STAT == 2: no per-splat atomics of their own); other tile shapes keep the forward's two counter arrays
-        stat_in_record = stat and (R.TH, R.TW) == (8, 16)
+        stat_in_record = stat and bool(L.lg_stat_in_record_supported(R.TH, R.TW))
         if stat:
             if not stat_in_record:
                 fc = _empty((1, 1, N), torch.int32, dev, zero=True)

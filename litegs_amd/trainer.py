@@ -78,6 +78,7 @@ class FrameTrainer:
         self.spec_depth = 2           # steps the host may run ahead of the device in speculative mode
         self.spec_replays = 0
         self.spec_log = []                # (step number, frame, visits of that frame so far, steps replayed) per violated bound
+        self.sanitised = {}               # site -> garbage table words neutralised by a kernel so far (csrc/lg_sanity.h); empty = none
 
     # -------------------------------------------------------------------------------------------
     def forward(self, frame: Frame, raw: bool = False):
@@ -171,6 +172,22 @@ class FrameTrainer:
         self._spec_ring = []
         self._spec_events = []
         self.renderer.check_tables()
+        self._collect_sanitised()
+
+    def _collect_sanitised(self):
+        """lg_sanity.h: a kernel neutralised a garbage table word since the last flush -> counted per site, reported once per site on stderr
+        (the run stays alive; `sanitised` is reported by bench.py and the convergence scripts)"""
+        if not self.fused:
+            return
+        counts = self.renderer.sanitised_counts(reset=True)
+        for k, v in counts.items():
+            if v:
+                first = self.sanitised.get(k, 0) == 0
+                self.sanitised[k] = self.sanitised.get(k, 0) + v
+                if first and k != "truncated_tables":
+                    import sys
+                    print(f"[litegs_amd] WARNING: {v} table word(s) neutralised at site '{k}' since the last flush -- a table held garbage "
+                          f"(DESIGN.md section 9); set LITEGS_VALIDATE_TABLES=1 to locate it", file=sys.stderr, flush=True)
 
     def _step_body(self, frame_index: int, grad_hook=None, hook_slot: int = 0, peer_frames=None):
         frame = self.frames[frame_index % len(self.frames)]
@@ -223,7 +240,7 @@ class FrameTrainer:
         try:
             if not getattr(self, "_closed", False):
                 self._closed = True
-                self.renderer.close()
+                self.renderer.close(sync=False)           # no device sync from a garbage collection: the arena quarantines the words
                 self._fb_words.close()
         except Exception:
             pass

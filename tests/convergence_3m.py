@@ -115,7 +115,8 @@ def train(student, targets, cfg, fused, epochs, eval_frames, eval_every, densify
     torch.cuda.synchronize()
     secs = time.time() - t0
     rd = tr.renderer
-    info = dict(psnr=curve, size=sizes, iterations=at, seconds=secs, ms_per_iteration=secs / (epochs * cfg["frames"]) * 1e3,
+    tr.flush()                                               # (collects the always-on sanitised-word counters, csrc/lg_sanity.h)
+    info = dict(sanitised=dict(tr.sanitised), psnr=curve, size=sizes, iterations=at, seconds=secs, ms_per_iteration=secs / (epochs * cfg["frames"]) * 1e3,
                 unculled_reruns=int(rd.fallbacks), replayed_steps=int(tr.spec_replays), truncated=int(rd.truncated_visits), finite=all(bool(torch.isfinite(p).all()) for p in tr.params),
                 epoch_ms=epoch_ms, epoch_instances=epoch_inst)
     if ctl is not None:
@@ -184,6 +185,7 @@ def to_markdown(out):
           f"| frames repeated unculled (a depth bound was violated), executor runs | {', '.join(str(r['unculled_reruns']) for r in ex)} |",
           f"| steps replayed by the speculative executor (the failed step and those enqueued behind it) | {', '.join(str(r.get('replayed_steps', 0)) for r in ex)} |",
           f"| truncated tables observed | {', '.join(str(r['truncated']) for r in ex)} |",
+          f"| garbage table words neutralised by a kernel (lg_sanity.h sites; truncations excluded) | {', '.join(str(sum(v for k, v in r.get('sanitised', {}).items() if k != 'truncated_tables')) for r in ex)} |",
           f"| parameters finite at the end | {all(r['finite'] for r in ex) and op['finite']} |"]
     if ex and ex[0].get("epoch_ms"):
         L += ["", "Cost per iteration over the run (executor run 1; plain epochs and statistics / density-control epochs alike; wall clock per epoch / frames):", "",
