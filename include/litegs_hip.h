@@ -265,7 +265,7 @@ typedef struct LgFusedCtx {
     int* poison;                /* device int32[1] */
     int* poison_host;           /* pinned int32[1] */
     int* applied_host;          /* pinned int32[1] */
-    int* debug_words;           /* pinned int32[8], zero: first violation found by the table check {code, tile, position, value, bound, ...} */
+    int* debug_words;           /* pinned int32[48], zero ([8..39]: detail records of the key emission): first violation found by the table check {code, tile, position, value, bound, ...} */
 } LgFusedCtx;
 /* Pinned host words for everything the device stores into asynchronously (sizing feedback, speculation mirrors, exchange headers).
  * They come from an arena inside the library that is never unmapped: a kernel that is still in flight when its owner dies stores into
@@ -275,7 +275,7 @@ void lg_host_words_free(int* words, int n);
 /* Always-on counters of table words that a consumer had to neutralise instead of indexing with them (csrc/lg_sanity.h; a correct table
  * never takes those branches).  out[8] receives the counts since the last reset, summed over the library's kernels: [0] emission key out
  * of range, [1] emission walk != prefix sums, [2] tile_range boundary key skipped, [3] tile count / scatter key dropped, [4] radix sort
- * scatter position outside [0, n), [5] per-tile sort id clamped, [6] truncated tables (not an error: GR/binning.cu:63), [7] unused.
+ * scatter position outside [0, n), [5] per-tile sort id clamped, [6] truncated tables (not an error: GR/binning.cu:63), [7] big-splat queue entry that names no slot of the prefix sums.
  * Blocking (device memcpy on the null stream): call at a synchronisation point.  No reference counterpart (the reference faults). */
 int lg_sanitised_counts(int* out, int reset);
 long long lg_fused_hot_offset(long long N);

@@ -317,7 +317,12 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         int pos = qbase_s + np_inc - np;
         for (int w = 0; w < wave; w++) pos += wbig[w];
         uint32_t* q = qentries + ((size_t)b * DUP_NQ + (grp % DUP_NQ)) * qcap + pos;
-        for (int p = 0; p < np; p++) q[p] = ((uint32_t)j << 8) | (uint32_t)p;
+        // (the capacity bound of dup_queue_cap makes an overflow impossible; if it ever happens the entries beyond the sub-queue are
+        // dropped and counted -- dup_big refuses the unwritten entries it then finds -- instead of landing in the next sub-queue)
+        for (int p = 0; p < np; p++) {
+            if ((long long)pos + p < qcap) q[p] = ((uint32_t)j << 8) | (uint32_t)p;
+            else lg_note_sanitised(LG_SITE_QUEUE_ENTRY);
+        }
     }
 
     // ---- small splats: exclusive block scan of their counts -> compacted LDS layout ----
@@ -402,6 +407,12 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     }
 }
 
+// first-claim of a detail record in the pinned debug words (host memory: system scope)
+__device__ __forceinline__ bool dbg_claim(int* word)
+{
+    int expected = 0;
+    return __hip_atomic_compare_exchange_strong(word, &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ float bcast_f(float v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src); }
 
@@ -465,11 +476,25 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                 if (qstart[mid] <= t) lo = mid; else hi = mid - 1;
             }
             const uint32_t ent = q[(size_t)lo * qcap + (t - qstart[lo])];
-            const int j = (int)(ent >> 8);
+            int j = (int)(ent >> 8);
             my_part = (int)(ent & 255u);
-            my_off = (j == 0) ? 0 : pf[j - 1];
-            my_cnt = pf[j] - my_off;                               // the slot's share of the table (what dup_small sized the parts by)
+            // A queue entry is an index (depth slot -> prefix sums -> splat id -> 64-byte record -> a range of the table).  An entry that
+            // dup_small did not write -- stale memory -- must never be followed: slot and part are checked against what the prefix sums say.
+            bool ok = j < N;
+            if (ok) {
+                my_off = (j == 0) ? 0 : pf[j - 1];
+                my_cnt = pf[j] - my_off;                           // the slot's share of the table (what dup_small sized the parts by)
+                ok = my_cnt > 0 && (long long)my_off + my_cnt <= table_len && my_part < dup_num_parts(my_cnt);
+            }
+            if (!ok) {
+                lg_note_sanitised(LG_SITE_QUEUE_ENTRY);
+                if (dbg != nullptr && dbg_claim(dbg + 8)) {          // first bad entry of the run: where it sat and what it held
+                    dbg[9] = lo; dbg[10] = t - qstart[lo]; dbg[11] = (int)ent; dbg[12] = qstart[lo + 1] - qstart[lo]; dbg[13] = nq; dbg[14] = (int)qcap; dbg[15] = N;
+                }
+                j = 0; my_off = 0; my_cnt = 0; my_part = 0;
+            }
             my_idx = sorted_id ? (int)sorted_id[(size_t)b * N + j] : j;
+            if ((unsigned)my_idx >= (unsigned)N) { my_idx = 0; my_cnt = 0; lg_note_sanitised(LG_SITE_QUEUE_ENTRY); }
             float nx, ny, a, bb, cc, o;
             load_splat<PACKED>(src, b, N, my_idx, nx, ny, a, bb, cc, o);
             splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
@@ -487,6 +512,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             const int sgoff = bcast_i(my_off, srcl);
             const int part = bcast_i(my_part, srcl);
             const int scnt = bcast_i(my_cnt, srcl);
+            if (scnt <= 0) continue;                                       // a neutralised queue entry (above): nothing to emit
             const WalkFrame f = walk_frame<TH, TW>(s);
             const int nsl = f.rect_max_u - f.rect_min_u;                   // <= min(grid.x, grid.y) slices
             if (nsl > DUP_MAX_SLICES) {                                    // > 4K-class images: the owner lane walks serially
@@ -590,6 +616,14 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                     const int v = w_minv[wave][sl] + (k - w_off[wave][sl]);
                     const uint32_t tk = f.isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
                     key = (int32_t)(tk + 1);
+                    if ((unsigned)key > (unsigned)(gx * gy)) {          // cannot happen for consistent slices; a key is an index downstream
+                        lg_note_sanitised(LG_SITE_EMIT_KEY);
+                        if (dbg != nullptr && dbg_claim(dbg + 16)) {
+                            dbg[17] = sidx; dbg[18] = part; dbg[19] = k; dbg[20] = r; dbg[21] = sl; dbg[22] = w_off[wave][sl]; dbg[23] = w_minv[wave][sl];
+                            dbg[24] = run; dbg[25] = scnt; dbg[26] = sgoff; dbg[27] = nsl; dbg[28] = nne; dbg[29] = key; dbg[30] = before; dbg[31] = f.isY ? 1 : 0;
+                        }
+                        key = 0;
+                    }
                     kout[sgoff + k] = key;
                     vout[sgoff + k] = sidx;
                     if (tile_counts) atomicAdd(&tile_counts[(size_t)b * (gx * gy + 2) + key], 1);
@@ -606,6 +640,31 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
     if (totals) {
         __syncthreads();
         digit_hist_flush(hist, totals, ds.passes);
+    }
+}
+
+// Validation aid (dbg != NULL: LgFusedCtx.debug_validate): the big-splat queue as dup_small left it, checked before dup_big follows it.
+// dbg[32] = 1 and dbg[33..39] = {kind, sub-queue, position, entry, sub-queue length, capacity, N}; kind 1: sub-queue longer than its
+// capacity, 2: entry names no slot / part of the prefix sums.
+__global__ void __launch_bounds__(TPB) dup_queue_check_kernel(const int32_t* __restrict__ prefix, int N, long long table_len, const int* __restrict__ qcount,
+                                                              const uint32_t* __restrict__ qentries, const int* __restrict__ gate, int* __restrict__ dbg)
+{
+    if (gate != nullptr && *gate == 0) return;
+    const long long qcap = dup_queue_cap(N, table_len);
+    const int sub = blockIdx.x;
+    const int cnt = qcount[sub];
+    if (cnt > qcap && threadIdx.x == 0 && dbg_claim(dbg + 32)) { dbg[33] = 1; dbg[34] = sub; dbg[35] = 0; dbg[36] = 0; dbg[37] = cnt; dbg[38] = (int)qcap; dbg[39] = N; }
+    const long long lim = cnt < qcap ? cnt : qcap;
+    for (long long e = threadIdx.x; e < lim; e += TPB) {
+        const uint32_t ent = qentries[(size_t)sub * qcap + e];
+        const int j = (int)(ent >> 8), part = (int)(ent & 255u);
+        bool ok = j < N;
+        if (ok) {
+            const long long off = j == 0 ? 0 : prefix[j - 1];
+            const long long c = prefix[j] - off;
+            ok = c > 0 && off + c <= table_len && part < dup_num_parts((int)c);
+        }
+        if (!ok && dbg_claim(dbg + 32)) { dbg[33] = 2; dbg[34] = sub; dbg[35] = (int)e; dbg[36] = (int)ent; dbg[37] = cnt; dbg[38] = (int)qcap; dbg[39] = N; }
     }
 }
 
@@ -651,6 +710,9 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
         else                                                                                                                               \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,   \
                                H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg); \
+        if (dbg != nullptr && V == 1)                                                                                                      \
+            hipLaunchKernelGGL(dup_queue_check_kernel, dim3(DUP_NQ), dim3(TPB), 0, s, prefix, N, table_len, (const int*)qcount,             \
+                               (const uint32_t*)qentries, gate, dbg);                                                                       \
         hipLaunchKernelGGL((dup_big_kernel<A_, B_, T_, P_>), grid_big, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id,                 \
                            N, H, W, gx, gy, table_len, keys, values, (const int*)qcount, (const uint32_t*)qentries, totals, ds, tile_counts, gate, dbg); \
     } while (0)

@@ -20,6 +20,7 @@
 #define LG_SITE_RADIX_INDEX 4     // radix sort: scatter position outside [0, n) (digit totals / look-back words inconsistent): store skipped
 #define LG_SITE_TILESORT_ID 5     // per-tile depth sort: splat id outside 0..N-1 clamped
 #define LG_SITE_TRUNCATED 6       // (not an error) tables that turned out too short for the prefix sums and were truncated (GR/binning.cu:63)
+#define LG_SITE_QUEUE_ENTRY 7     // key emission: a big-splat queue entry that names no slot / part the prefix sums know (stale memory): not followed
 
 static __device__ int lg_sanity_dev[LG_SANITY_SITES];
 

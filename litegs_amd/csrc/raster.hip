@@ -176,6 +176,23 @@ __device__ __forceinline__ void rec_id_wait(f32x16& rec, int& id) { asm volatile
 __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_fwd_fast = 1;       // launch variants (lg_set_tuning: A/B hooks of tools/ and tests/, plain ints)
+static int g_rank_prio = 0;       // 1: waves of the heaviest tiles of a heavy-first schedule raise their issue priority (wave_rank_priority)
+
+// Tail of the blend launches (profiles/r04_blend_critical_path.log): the heaviest tile of a late-phase frame walks 1127 splats; alone on
+// its SIMD it needs 142 us (forward) / 403 us (backward), but scheduled first -- as the heavy-first order does -- it SHARES its SIMD with
+// seven average waves for most of the launch and runs at an eighth of the issue rate, so it is still running when the machine has
+// drained: the launch ends with a few long tiles at the lone-wave rate and ~20-35 % of it is tail.  The hardware's answer is the wave
+// priority (s_setprio, 0..3: the SIMD's arbiter issues from the highest-priority ready wave): the first eighth of a heavy-first schedule
+// runs at priority 3, the next eighth at 2, the next quarter at 1.  The long tiles then finish early at nearly their lone rate, and the
+// light tiles, which have slack, fill the issue slots they leave.  Nothing about any wave's arithmetic changes.
+// (prio_mode travels in bits 8.. of the map_mode launch argument.)
+__device__ __forceinline__ void wave_rank_priority(int prio_mode, int slot, int nslots, bool heavy_first)
+{
+    if (prio_mode == 0 || !heavy_first) return;
+    if (slot * 8 < nslots) __builtin_amdgcn_s_setprio(3);
+    else if (slot * 4 < nslots) __builtin_amdgcn_s_setprio(2);
+    else if (slot * 2 < nslots) __builtin_amdgcn_s_setprio(1);
+}
 
 // ---------------------------------------------------------------------------------------------
 // a13 rasterize_forward (reference: GR/raster.cu:162-332)
@@ -342,9 +359,12 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
     const int nb = gridDim.x;
+    const int prio_mode = map_mode >> 8;
+    map_mode &= 0xff;
     int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
     const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
     if (slot >= nslots) return;
+    wave_rank_priority(prio_mode, slot, nslots, tiles != nullptr || order != nullptr);
     int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
     tile = rfl(tile);
     if (tile <= 0 || tile > ntiles) return;
@@ -491,7 +511,7 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_RF(A_, B_, S_) hipLaunchKernelGGL((raster_forward_kernel<A_, B_, S_>), grid, block, 0, s, sorted_points, start_index, packed, \
-                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, fail_host, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map, g_fwd_fast)
+                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, fail_host, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map | (g_rank_prio << 8), g_fwd_fast)
 #define DISPATCH_RF(A_, B_) do { if (enable_stat) LAUNCH_RF(A_, B_, true); else LAUNCH_RF(A_, B_, false); } while (0)
     if (TH == 8 && TW == 16) DISPATCH_RF(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RF(16, 16);
@@ -777,9 +797,12 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
     const int nb = gridDim.x;
+    const int prio_mode = map_mode >> 8;
+    map_mode &= 0xff;
     int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
     const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
     if (slot >= nslots) return;
+    wave_rank_priority(prio_mode, slot, nslots, tiles != nullptr || order != nullptr);
     int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
     tile = rfl(tile);
     if (tile <= 0 || tile > ntiles) return;
@@ -1000,9 +1023,12 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
     const int nb = gridDim.x;
+    const int prio_mode = map_mode >> 8;
+    map_mode &= 0xff;
     int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
     const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
     if (slot >= nslots) return;
+    wave_rank_priority(prio_mode, slot, nslots, tiles != nullptr || order != nullptr);
     int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
     tile = rfl(tile);
     if (tile <= 0 || tile > ntiles) return;
@@ -1095,6 +1121,7 @@ LG_API int lg_set_tuning(int key, int value)
     case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
     case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics
+    case 8: g_rank_prio = value ? 1 : 0; return 0;                            // 1: issue priority by rank in a heavy-first schedule (wave_rank_priority)
     default: return (int)hipErrorInvalidValue;
     }
 }
@@ -1134,7 +1161,7 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
 #define LAUNCH_RB(A_, B_, S_, T_, C_) hipLaunchKernelGGL((raster_backward_kernel<A_, B_, S_, T_, C_>), grid, block, 0, s, sorted_points, start_index, \
                                                          packed, tiles, K, final_T, last, d_img, d_trans, packed_grad, err_square_sum, tile_counters, order, \
-                                                         gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map)
+                                                         gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map | (g_rank_prio << 8))
 #define DISPATCH_RB(A_, B_)                                                   \
     do {                                                                      \
         if (enable_stat) { if (d_trans) LAUNCH_RB(A_, B_, true, true, false); else LAUNCH_RB(A_, B_, true, false, false); } \
@@ -1148,7 +1175,7 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
         return (int)hipErrorInvalidValue;          // statistics inside the gradient record exist in the 8x16 moment-form kernel only
     else if (TH == 8 && TW == 16 && g_bwd_fast && !(enable_stat && hot_of != nullptr)) {
 #define LAUNCH_RBF(T_, S_) hipLaunchKernelGGL((raster_backward_fast_kernel<T_, S_>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last, \
-                                              d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map, hot_of)
+                                              d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map | (g_rank_prio << 8), hot_of)
         if (enable_stat && err_square_sum == nullptr) { if (d_trans) LAUNCH_RBF(true, 2); else LAUNCH_RBF(false, 2); }       // executor: statistics in the record
         else if (enable_stat) { if (d_trans) LAUNCH_RBF(true, 1); else LAUNCH_RBF(false, 1); }
         else { if (d_trans) LAUNCH_RBF(true, 0); else LAUNCH_RBF(false, 0); }

@@ -30,6 +30,17 @@ _POISON_ALLOC = os.environ.get("LITEGS_GUARD_ALLOC", "0") == "poison"     # modu
 _DEPTH_ORDER = {"global": 0, "tile": 1, "auto": 2}
 
 
+def _apply_env_tuning():
+    """LITEGS_TUNING="key=value[,key=value...]" (measurement aid): lg_set_tuning launch variants for a whole process (bench.py A/B runs)"""
+    spec = os.environ.get("LITEGS_TUNING", "")
+    for kv in filter(None, spec.split(",")):
+        key, val = kv.split("=")
+        check(lib().lg_set_tuning(int(key), int(val)), f"lg_set_tuning({kv})")
+
+
+_TUNING_APPLIED = False
+
+
 class LgFusedCtx(ctypes.Structure):
     """include/litegs_hip.h: the executor's per-call context (the library keeps no process-wide executor state)"""
     _fields_ = [("struct_bytes", ctypes.c_int32), ("depth_order", ctypes.c_int32), ("bound_margin_pct", ctypes.c_int32),
@@ -107,6 +118,10 @@ class FusedRenderer:
     (LgFusedCtx) -- and the pinned words the device stores into (library arena: never unmapped, see hostwords.py)."""
 
     def __init__(self, n_frames: int, height: int, width: int, tile=(8, 16), cluster_size: int = 128):
+        global _TUNING_APPLIED
+        if not _TUNING_APPLIED:
+            _TUNING_APPLIED = True
+            _apply_env_tuning()
         self.H, self.W, self.TH, self.TW, self.S = height, width, tile[0], tile[1], cluster_size
         self.Hp = (height + tile[0] - 1) // tile[0] * tile[0]
         self.Wp = (width + tile[1] - 1) // tile[1] * tile[1]
@@ -270,7 +285,7 @@ class FusedRenderer:
             c.step_id = int(self.spec_step)
         if self.validate_tables:
             if self._debug_words is None:
-                self._debug_words = HostWords(8)
+                self._debug_words = HostWords(48)
             c.debug_validate = 1
             c.debug_words = self._debug_words.addr(0)
         return c
@@ -286,6 +301,22 @@ class FusedRenderer:
             self.emission_mismatches += n
             print(f"[litegs_amd validate] key emission: {n} slot(s) walked to a different tile count than the prefix sums hold "
                   f"(last: walked - counted = {d})", file=sys.stderr, flush=True)
+        if self._debug_words is not None and (int(self._debug_words.a[8]) != 0 or int(self._debug_words.a[16]) != 0 or int(self._debug_words.a[32]) != 0):
+            import sys
+            d = [int(x) for x in self._debug_words.a]
+            if d[32]:
+                print(f"[litegs_amd validate] big-splat queue after dup_small: {'sub-queue over capacity' if d[33] == 1 else 'entry names no slot'}: sub-queue {d[34]} position {d[35]} "
+                      f"entry 0x{d[36] & 0xffffffff:08x} sub-queue length {d[37]} capacity {d[38]} N {d[39]}", file=sys.stderr, flush=True)
+                self._debug_words.a[32] = 0
+            if d[8]:
+                print(f"[litegs_amd validate] key emission: big-splat queue entry that names no slot: sub-queue {d[9]} position {d[10]} entry 0x{d[11] & 0xffffffff:08x} "
+                      f"(sub-queue length {d[12]}, all queues {d[13]}, capacity per sub-queue {d[14]}, N {d[15]})", file=sys.stderr, flush=True)
+            if d[16]:
+                print(f"[litegs_amd validate] key emission (big splats): key {d[29]} out of range: splat {d[17]} part {d[18]} output {d[19]} owner rank {d[20]} slice {d[21]} "
+                      f"(slice offset {d[22]}, first tile {d[23]}) run {d[24]} share {d[25]} table offset {d[26]} slices {d[27]} non-empty {d[28]} before {d[30]} isY {d[31]}",
+                      file=sys.stderr, flush=True)
+            self._debug_words.a[8] = 0; self._debug_words.a[16] = 0
+            raise RuntimeError("litegs_amd: table validator: the key emission met garbage (details above)")
         if self._debug_words is not None and int(self._debug_words.a[0]) != 0:
             rec = [int(x) for x in self._debug_words.a]
             self._debug_words.a[0] = 0
@@ -303,7 +334,7 @@ class FusedRenderer:
         correct tables.  Blocking -- call at a synchronisation point (FrameTrainer.flush() does).  `truncated_tables` is informational."""
         out = (ctypes.c_int * 8)()
         check(lib().lg_sanitised_counts(out, 1 if reset else 0), "lg_sanitised_counts")
-        names = ("emission_key", "emission_count_mismatch", "tile_range_key", "tile_scatter_key", "radix_scatter_index", "tilesort_id", "truncated_tables")
+        names = ("emission_key", "emission_count_mismatch", "tile_range_key", "tile_scatter_key", "radix_scatter_index", "tilesort_id", "truncated_tables", "queue_entry")
         return {n: int(out[i]) for i, n in enumerate(names)}
 
     def note_fallback(self, k: int):

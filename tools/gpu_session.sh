@@ -79,10 +79,10 @@ for STAGE in "$@"; do
                      # densifications (the configuration that faulted), per-frame buffers poisoned (a word no kernel wrote is out of range
                      # wherever it is used), every table validator on, launch breadcrumbs on.  A validator report names the stage.
       RUNS=${STAGE#hunt:}
-      LITEGS_GUARD_ALLOC=poison LITEGS_VALIDATE_TABLES=1 LITEGS_CRUMBS=1 LITEGS_CONV_PARTIAL=gpurun_out/hunt_${TAG}_partial.json \
+      LITEGS_GUARD_ALLOC=poison LITEGS_VALIDATE_TABLES=1 LITEGS_CRUMBS=1 LITEGS_CONV_VERBOSE=1 LITEGS_CONV_PARTIAL=gpurun_out/hunt_${TAG}_partial.json \
         LITEGS_CONV_SKIP_OPERATOR=profiles/r03_convergence_3m.json timeout -s KILL 2400 python -X faulthandler tests/convergence_3m.py --runs $RUNS \
         --set keep_size_predictions=true $CONV_ARGS --out gpurun_out/hunt_$TAG.md > gpurun_out/hunt_$TAG.log 2>&1
-      echo "exit $?"; grep -a -E "executor:|fault|Error|error|crumbs|validate" gpurun_out/hunt_$TAG.log | cut -c1-400 | head -20 ;;
+      echo "exit $?"; grep -a -E "executor:|fault|Error|error|crumbs|validate" gpurun_out/hunt_$TAG.log | cut -c1-600 | head -20; grep -a "epoch .* done" gpurun_out/hunt_$TAG.log | tail -2 ;;
     conv:*)
       RUNS=${STAGE#conv:}
       rm -f /tmp/late.pt /tmp/mid.pt gpurun_out/conv_snap_$TAG.jsonl

@@ -42,6 +42,9 @@ VARIANTS = {
     "own_schedule": (dict(stat_schedule_always=False), False),             # default list building, executor's schedule + depth-bound culling
     "own_schedule_tile": (dict(stat_schedule_always=False, long_list_global=0), False),
     "no_replicas": (dict(replicas_enabled=False), False),                  # gradient replicas off (blend backward contends, nothing to fold)
+    "prio": (dict(_tuning={8: 1}), False),                                 # issue priority by rank in the heavy-first schedule (csrc/raster.hip wave_rank_priority)
+    "prio_stat_epoch": (dict(_tuning={8: 1}), True),
+    "global_prio": (dict(depth_order=0, _tuning={8: 1}), False),
     "stat_epoch": (dict(), True),
     "stat_epoch_tile": (dict(long_list_global=0), True),
 }
@@ -126,6 +129,11 @@ def configure(tr, attrs):
     rd = tr.renderer
     base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
     base.update(attrs)
+    from litegs_amd._lib import check, lib
+    tuning = {8: 0}                                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning.update(base.pop("_tuning", {}))
+    for key, val in tuning.items():
+        check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
     for k, v in base.items():
         setattr(rd, k, v)
     tr.flush()
