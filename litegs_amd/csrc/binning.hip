@@ -541,7 +541,13 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             // slice i -> (first tile w_minv[i], output offset w_off[i]); the r-th NON-EMPTY slice is c_idx[r] and sets bit w_off[i] of a
             // bitmap over the splat's output range: the owner of output k is then "number of set bits at positions <= k" - 1, i.e.
             // one uniform 64-bit LDS read and a popcount per 64 outputs instead of a binary search per output
-            int run = 0, nne = 0;
+            // A slice's tile count max_tile_v - min_tile_v can be NEGATIVE (both of its lines unselected and neither extreme point inside
+            // it -- a degenerate, measure-zero configuration of the reference's arithmetic, GR/speedy_splat.cuh:118-125, which ADDS that
+            // negative number into the count and emits nothing for the slice).  The slot's share of the table, scnt, is that signed sum
+            // (the projection's count); the layout below must be built from max(n, 0): a negative term in the offsets would put a slice
+            // start at a negative position (no owner for the first outputs -> an LDS read in front of c_idx -> a garbage key).  The share
+            // is then shorter than the tiles the slices hold and the last tiles are dropped, exactly as when the table is truncated.
+            int run = 0, nne = 0, run_signed = 0;
             for (int i0 = 0; i0 < nsl; i0 += 64) {
                 int i = i0 + lane;
                 int mn = 0, n = 0;
@@ -550,6 +556,13 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                     slice_bounds(s, f, i, K, mn, mx);
                     n = mx - mn;
                 }
+                {
+                    int sg = n;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o);
+                    run_signed += sg;
+                }
+                n = n > 0 ? n : 0;
                 int inc = n;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -587,7 +600,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             // the two are the same function of the same six floats, but every entry of [off, off + scnt) is written whatever happens
             // (tiles beyond scnt dropped, entries beyond run padded with key 0 = "no tile"), because an entry left unwritten is stale
             // memory that the sort carries to the range scan, and a word of garbage there is a wild store.
-            if (run != scnt && part == 0 && lane == 0) dup_report_mismatch(dbg, -1 - sidx, run, scnt);
+            if (run_signed != scnt && part == 0 && lane == 0) dup_report_mismatch(dbg, -1 - sidx, run_signed, scnt);
             const int nparts = dup_num_parts(scnt);
             const int k_begin = part * DUP_PART;
             const int k_end = (part == nparts - 1) ? scnt : (k_begin + DUP_PART < scnt ? k_begin + DUP_PART : scnt);

@@ -554,11 +554,16 @@ static inline f2 ellipse_intersection(float a, float b, float c, float disc, flo
     return r;
 }
 
-/* returns tiles touched; if keys!=NULL emits (tile_id+1, idx) pairs starting at off */
+/* returns tiles touched; if keys!=NULL emits (tile_id+1, idx) pairs starting at off, never at or beyond `limit`.
+ * The limit: GR/speedy_splat.cuh:118-125 adds (max_tile_v - min_tile_v) to the count even when it is NEGATIVE (a degenerate slice: both
+ * lines unselected, neither extreme point inside -- needle-like conics) but emits only the positive slices, so such a splat emits more
+ * pairs than it was counted for and the reference writes them into the next splat's share of the table (a race between CUDA threads:
+ * undefined).  The restatement fixes the outcome the only consistent way: a splat owns exactly its share [off, off + count) and its
+ * tiles beyond the share are dropped, like the tiles of a splat that does not fit a truncated table (GR/binning.cu:63). */
 static uint32_t process_tiles(int TH, int TW, float a, float b, float c, float disc, float t, f2 p,
                               f2 bbox_min, f2 bbox_max, f2 bbox_argmin, f2 bbox_argmax,
                               int rminx, int rminy, int rmaxx, int rmaxy,
-                              int grid_x, int isY, int32_t idx, int64_t off, int32_t* keys, int32_t* values)
+                              int grid_x, int isY, int32_t idx, int64_t off, int32_t* keys, int32_t* values, int64_t limit)
 {
     float BLOCK_U = isY ? (float)TH : (float)TW;
     float BLOCK_V = isY ? (float)TW : (float)TH;
@@ -591,7 +596,7 @@ static uint32_t process_tiles(int TH, int TW, float a, float b, float c, float d
         /* NB the reference adds (max-min) as unsigned even when negative; with valid ellipses max>=min. */
         tiles_count += (uint32_t)(max_tile_v - min_tile_v);
         if (keys != NULL)
-            for (int v = min_tile_v; v < max_tile_v; v++) {
+            for (int v = min_tile_v; v < max_tile_v && off < limit; v++) {
                 uint32_t key = isY ? (uint32_t)(u * grid_x + v) : (uint32_t)(v * grid_x + u);
                 keys[off] = (int32_t)(key + 1);
                 values[off] = idx;
@@ -662,7 +667,7 @@ ORC_API void orc_get_allocate_size(const float* ndc, const float* view_z, const 
             int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx, n = 0;
             if (ys * xs > 0)
                 n = (int)process_tiles(TH, TW, e.a, e.b, e.c, e.disc, e.t, e.p, e.bbox_min, e.bbox_max, e.bbox_argmin, e.bbox_argmax,
-                                       e.rminx, e.rminy, e.rmaxx, e.rmaxy, gx, ys < xs, i, 0, NULL, NULL);
+                                       e.rminx, e.rminy, e.rmaxx, e.rmaxy, gx, ys < xs, i, 0, NULL, NULL, 0);
             alloc[ao] = n;
         }
 }
@@ -689,7 +694,7 @@ ORC_API void orc_duplicate_with_keys(const float* ndc, const float* inv_cov, con
             int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
             if (ys * xs > 0)
                 process_tiles(TH, TW, e.a, e.b, e.c, e.disc, e.t, e.p, e.bbox_min, e.bbox_max, e.bbox_argmin, e.bbox_argmax,
-                              e.rminx, e.rminy, e.rmaxx, e.rmaxy, gx, ys < xs, i, off, keys + (size_t)b * table_len, values + (size_t)b * table_len);
+                              e.rminx, e.rminy, e.rmaxx, e.rmaxy, gx, ys < xs, i, off, keys + (size_t)b * table_len, values + (size_t)b * table_len, off + cnt);
         }
     }
 }

@@ -145,3 +145,70 @@ def test_giant_splats_are_emitted_in_parts(oracle):
     assert want < total and np.array_equal(ks.cpu().numpy(), ks_r)
     live = ks_r[0] > 0
     assert np.array_equal(vs.cpu().numpy()[0][live], vs_r[0][live])
+
+
+# Needle-like conics (b^2 ~ a c) and splats at the 1/255 opacity cut-off whose FIRST tile slice has both lines unselected and neither
+# extreme point inside: max_tile_v < min_tile_v, and the reference adds that NEGATIVE difference to the splat's tile count
+# (GR/speedy_splat.cuh:118-125) while emitting nothing for the slice.  Found by tests/host/walk_check.cpp's generator (1920x1080, 8x16);
+# (ndc.x, ndc.y, conic a, b, c, opacity).
+DEGENERATE_SPLATS = [
+    (-3.866354823e-01, 4.910708591e-02, 1.318661403e-02, 1.318791416e-02, 1.318921614e-02, 3.921945114e-03),   # 54 tiles counted, 63 slices, slice 0: 122..19
+    (-4.079762995e-01, -1.158427820e-01, 6.700431928e-03, 2.074851654e-02, 6.424973905e-02, 3.921761177e-03),   # 44 tiles counted, 57 slices, slice 0: 72..0
+    (8.839730918e-02, -9.655379690e-03, 1.324557648e+02, 1.950504456e+02, 2.872255554e+02, 1.000000000e+00),   # 103 tiles counted, 120 slices, slice 0: 135..0
+    (-3.678972721e-01, 8.517017215e-02, 1.051743701e-02, 1.052330341e-02, 1.052917447e-02, 3.921788651e-03),   # 38 tiles counted, 56 slices, slice 0: 108..38
+    (1.114281714e-01, 7.290778756e-01, 5.003720398e+02, 5.004038391e+02, 5.004356689e+02, 1.000000000e+00),   # 46 tiles counted, 104 slices, slice 0: 135..0
+    (-2.951445282e-01, -1.807289720e-01, 1.067461446e-02, 1.067493390e-02, 1.067525428e-02, 3.921690397e-03),   # 40 tiles counted, 62 slices, slice 0: 92..18
+    (-5.725104809e-01, 7.241415381e-01, 1.948983409e-02, 4.034486786e-02, 8.351577073e-02, 3.921918105e-03),   # 33 tiles counted, 42 slices, slice 0: 131..0
+    (-1.365235746e-01, 4.870536625e-01, 4.218530841e-03, 4.218396265e-03, 4.218262620e-03, 3.921733238e-03),   # 38 tiles counted, 72 slices, slice 0: 135..62
+    (7.500848174e-01, -4.425054789e-01, 3.454413672e-04, 3.140928748e-04, 2.855892526e-04, 3.921702038e-03),   # 55 tiles counted, 120 slices, slice 0: 135..0
+    (1.656607985e-01, -1.255498528e-01, 7.024222054e-03, 5.824854132e-03, 4.830275662e-03, 3.921741154e-03),   # 45 tiles counted, 92 slices, slice 0: 110..8
+    (-2.506476343e-01, 4.049793780e-01, 3.102688119e-03, 3.377848538e-03, 3.677412868e-03, 3.921753261e-03),   # 43 tiles counted, 65 slices, slice 0: 130..60
+    (-9.531433135e-02, -4.155531228e-01, 3.043316538e-04, 3.043696343e-04, 3.044076730e-04, 3.921619616e-03),   # 67 tiles counted, 101 slices, slice 0: 132..0
+    (2.229391038e-01, -4.387749732e-01, 3.448471427e-03, -7.875907235e-03, 1.798765734e-02, 3.921882715e-03),   # 74 tiles counted, 73 slices, slice 0: 112..35
+    (-1.885991544e-01, 4.217935205e-01, 4.597336520e-03, 7.089260500e-03, 1.093189977e-02, 3.921925556e-03),   # 66 tiles counted, 82 slices, slice 0: 135..54
+]
+
+
+def degenerate_table_inputs(copies=40, seed=3):
+    """(ndc [1,4,N], inv_cov [1,2,2,N], opacity [1,N], view depth [1,N]): `copies` of every degenerate splat, shuffled.  256 consecutive
+    slots then hold ~2x the key emission's in-workgroup budget (8192 staged keys), so its small / big threshold drops to 32 tiles and every
+    one of these splats takes the cooperative big-splat path (csrc/binning.hip dup_big_kernel), where a negative slice count used to put a
+    slice start at a negative output position."""
+    rng = np.random.default_rng(seed)
+    rows = np.array(DEGENERATE_SPLATS, dtype=np.float32)
+    idx = rng.permutation(np.repeat(np.arange(len(rows)), copies))
+    r = rows[idx]
+    N = len(r)
+    ndc = np.zeros((1, 4, N), np.float32); ndc[0, 0] = r[:, 0]; ndc[0, 1] = r[:, 1]; ndc[0, 2] = 0.5; ndc[0, 3] = 1.0
+    inv = np.zeros((1, 2, 2, N), np.float32); inv[0, 0, 0] = r[:, 2]; inv[0, 0, 1] = inv[0, 1, 0] = r[:, 3]; inv[0, 1, 1] = r[:, 4]
+    op = np.ascontiguousarray(r[:, 5][None])
+    vz = (1.0 + rng.random((1, N))).astype(np.float32)
+    return ndc, inv, op, vz
+
+
+def test_degenerate_slices_keep_the_table_inside_each_splats_share(oracle):
+    """a splat whose tile count contains a negative slice owns exactly its share of the table: the first `count` tiles in slice order, every
+    key a valid tile id, in the small-splat and in the big-splat path of the key emission; bit-exact against the oracle (whose restatement
+    bounds the emission the same way, oracle/litegs_oracle.c process_tiles)"""
+    from litegs_amd import fused as F
+    from litegs_amd.fast import FusedRenderer
+    H, W = 1080, 1920
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    FusedRenderer.sanitised_counts(reset=True)
+    for copies in (1, 40):                                   # 1: every splat alone in its group (in-workgroup path); 40: the big-splat path
+        ndc, inv, op, vz = degenerate_table_inputs(copies)
+        N = ndc.shape[-1]
+        _, _, al_r = oracle.get_allocate_size(ndc, vz, inv, op, H, W, 8, 16)
+        assert (al_r[0] > 32).all(), al_r[0].min()
+        _, _, al = F.get_allocate_size(dev(ndc), dev(vz), dev(inv), dev(op), H, W, 8, 16, None)
+        assert np.array_equal(al.cpu().numpy(), al_r)
+        dsi = np.argsort(vz, axis=-1, kind="stable").astype(np.int64)
+        prefix = np.cumsum(np.take_along_axis(al_r, dsi, axis=-1), axis=-1, dtype=np.int64).astype(np.int32)
+        ks_r, vs_r, _, _ = oracle.create_table(ndc, inv, op, prefix, dsi, H, W, 8, 16)
+        assert (ks_r > 0).all() and ks_r.max() <= 135 * 120     # the oracle fills every share with valid keys
+        ks, vs = F.create_table(dev(ndc), dev(inv), dev(op), dev(prefix), dev(dsi), None, None, H, W, 8, 16)
+        torch.cuda.synchronize()
+        assert np.array_equal(ks.cpu().numpy(), ks_r), copies
+        assert np.array_equal(vs.cpu().numpy(), vs_r), copies
+    counts = FusedRenderer.sanitised_counts(reset=True)
+    assert not any(v for k, v in counts.items() if k != "truncated_tables"), counts     # nothing had to be neutralised

@@ -117,6 +117,14 @@ def _frame(tr, k):
     return fr, [x.cpu().numpy() for x in (fr.view, fr.proj, fr.planes)]
 
 
+def _aabb(tr):
+    """chunk bounding boxes of the CURRENT parameters (the trainer's own are those of the last re-sort, as in the reference: the cloud has
+    moved since), which is what the oracle's pipeline derives from the parameters it is given"""
+    from litegs_amd import render as R
+    with torch.no_grad():
+        return R.get_cluster_AABB(tr.params[0], tr.params[1].exp(), torch.nn.functional.normalize(tr.params[2], dim=0))
+
+
 @pytest.mark.parametrize("route", range(len(ROUTES)), ids=["global", "tile_scatter", "tile_radix"])
 def test_image_and_all_gradients_on_the_trained_cloud_match_the_oracle(oracle, trained, route):
     """the whole differentiable path on the trained parameters (what test_gpu_fullsize checks on the synthetic cloud)"""
@@ -126,6 +134,7 @@ def test_image_and_all_gradients_on_the_trained_cloud_match_the_oracle(oracle, t
     depth_order, scatter = ROUTES[route]
     params_host = _host_params(tr)
     degree = int(tr.degree)
+    origin, extend = _aabb(tr)
     for k in (1, 3):
         fr, (view, proj, planes) = _frame(tr, k)
         res = oracle.render_forward(params_host, view, proj, planes, H, W, degree)
@@ -136,7 +145,7 @@ def test_image_and_all_gradients_on_the_trained_cloud_match_the_oracle(oracle, t
             p.grad = None
         rng = np.random.default_rng(11 + k)
         w_host = rng.standard_normal((1, 3, H, W)).astype(np.float32)
-        img, vis_id, vis_num = rd.render(cam, tr.cluster_origin, tr.cluster_extend, *tr.params, degree)
+        img, vis_id, vis_num = rd.render(cam, origin, extend, *tr.params, degree)
         (img * torch.from_numpy(w_host).cuda()).sum().backward()
         torch.cuda.synchronize()
         assert int(vis_num.item()) == res.nvis
@@ -183,12 +192,13 @@ def test_statistics_in_the_gradient_record_match_the_oracle_on_the_trained_cloud
     esq_o[res.visible_chunkid] = esq.reshape(res.nvis, S)
     rd = fast.FusedRenderer(1, H, W)
     cam = fast.CameraFrame(fr.view, fr.proj, fr.planes, 0)
+    origin, extend = _aabb(tr)
     STATS.reset(C, S, enabled_for_epoch=lambda e: True, device="cuda")
     STATS.tile_schedule.clear(); STATS.tile_blend_count.clear()
     STATS.current_frame = 0
     try:
         with STATS.epoch(0):
-            img, _, _ = rd.render(cam, tr.cluster_origin, tr.cluster_extend, *tr.params, degree)
+            img, _, _ = rd.render(cam, origin, extend, *tr.params, degree)
             (img * torch.from_numpy(w_host).cuda()).sum().backward()
         torch.cuda.synchronize()
         mw, me = STATS.moments["fragment_weight"], STATS.moments["fragment_err"]
