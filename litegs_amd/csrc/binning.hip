@@ -199,10 +199,13 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
                                                         uint32_t* __restrict__ zero_ptr, long long zero_words,
                                                         uint32_t* __restrict__ ones_ptr, long long ones_words,
                                                         uint32_t* __restrict__ zero2_ptr, long long zero2_words,
-                                                        const int* __restrict__ gate, int* __restrict__ trunc_flag, int* __restrict__ dbg)
+                                                        const int* __restrict__ gate, int* __restrict__ trunc_flag, int* __restrict__ dbg,
+                                                        int small_hi /*largest tile count walked in the workgroup (<= DUP_SMALL_HI)*/,
+                                                        int* __restrict__ grp_ticket /*nullable, zero on entry: groups are handed out dynamically*/)
 {
     if (gate != nullptr && *gate == 0) return;            // fallback launch of the depth-bound culling that is not needed (fused.hip)
     __shared__ LdsKeyT buf[DUP_LDS_ENTRIES];              // 16/32 KiB: compacted keys of the small splats
+    __shared__ int grp_s;
     __shared__ int t_loff[TPB + 1];                       // per-thread start in buf
     __shared__ int t_goff[TPB];                           // per-thread start in the table
     __shared__ int t_idx[TPB];                            // per-thread point id
@@ -225,21 +228,39 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     const int32_t* pf = prefix + (size_t)b * N;
     int32_t* kout = keys + (size_t)b * table_len;
     int32_t* vout = values + (size_t)b * table_len;
-    {
-        const long long gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, nthreads = (long long)gridDim.x * gridDim.y * TPB;
-        if (zero_ptr) zero_duty(zero_ptr, zero_words, gid, nthreads);
-        if (ones_ptr) for (long long i = gid; i < ones_words; i += nthreads) ones_ptr[i] = 0xffffffffu;      // tile range table: -1 = empty
-        if (zero2_ptr) {                                    // gradient accumulator of the coming blend backward (16-byte stores)
-            uint4* z4 = reinterpret_cast<uint4*>(zero2_ptr);
-            const long long n4 = zero2_words / 4;
-            for (long long i = gid; i < n4; i += nthreads) z4[i] = make_uint4(0u, 0u, 0u, 0u);
-            for (long long i = n4 * 4 + gid; i < zero2_words; i += nthreads) zero2_ptr[i] = 0u;
-        }
-    }
+    // Zero duty.  The small tables go first; the two big ones -- the tile sort's look-back table (17 MB at 23 M instances) and the gradient
+    // accumulator of the coming blend backward (64 B per compacted Gaussian: 140 MB late in a run) -- are cleared a few 16-byte stores per
+    // thread and group iteration, UNDER the walk: issued as one burst at the start of the launch they were a bandwidth-bound prologue in
+    // front of a latency-bound kernel (every workgroup stored for ~40 us before its first walk), spread over the iterations they ride on
+    // the memory pipe the walk leaves idle.  Whatever is left when a workgroup runs out of groups is finished behind the loop.
+    const long long z_gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, z_nth = (long long)gridDim.x * gridDim.y * TPB;
+    if (ones_ptr) for (long long i = z_gid; i < ones_words; i += z_nth) ones_ptr[i] = 0xffffffffu;      // tile range table: -1 = empty
+    uint4* const z4a = reinterpret_cast<uint4*>(zero_ptr);       // (both regions are 16-byte aligned; word tails below)
+    uint4* const z4b = reinterpret_cast<uint4*>(zero2_ptr);
+    const long long n4a = zero_ptr ? zero_words / 4 : 0, n4b = zero2_ptr ? zero2_words / 4 : 0;
+    long long za = z_gid, zb = z_gid;
+    if (zero_ptr) for (long long i = n4a * 4 + z_gid; i < zero_words; i += z_nth) zero_ptr[i] = 0u;
+    if (zero2_ptr) for (long long i = n4b * 4 + z_gid; i < zero2_words; i += z_nth) zero2_ptr[i] = 0u;
+    constexpr int Z_PER_ITER = 6;
     if (totals) for (int k = tid; k < ds.passes * 256; k += TPB) hist[k] = 0;
-    // persistent workgroups (the digit table is flushed once per workgroup, not once per 256 splats)
+    // persistent workgroups (the digit table is flushed once per workgroup, not once per 256 splats).  Groups are dealt round robin, or
+    // -- grp_ticket -- handed out on demand: groups differ in cost by an order of magnitude (in depth order the near groups hold the
+    // large splats), and the ticket for the NEXT group is requested at the start of the current one so that its round trip is hidden.
     const int ngroups = (N + TPB - 1) / TPB;
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    int grp = blockIdx.x;
+    if (grp_ticket != nullptr) {
+        if (tid == 0) grp_s = atomicAdd(grp_ticket, 1);
+        __syncthreads();
+        grp = grp_s;
+    }
+    while (grp < ngroups) {
+    int next_ticket = 0;
+    if (grp_ticket != nullptr && tid == 0) next_ticket = atomicAdd(grp_ticket, 1);      // consumed at the end of the iteration
+#pragma unroll
+    for (int zc = 0; zc < Z_PER_ITER; zc++) {
+        if (za < n4a) { z4a[za] = make_uint4(0u, 0u, 0u, 0u); za += z_nth; }
+        if (zb < n4b) { z4b[zb] = make_uint4(0u, 0u, 0u, 0u); zb += z_nth; }
+    }
     const int j = grp * TPB + tid;
     if (tid < DUP_LDS_ENTRIES / 64 + 4) { starts[tid] = 0ull; sstarts[tid] = 0ull; }       // (barriers below separate this from the bit sets)
 
@@ -267,17 +288,18 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     // The largest of DUP_SMALL_HI, /2, /4 ... for which the group still fits (groups of spatial neighbours -- emission in splat-id
     // order -- are all large or all small: halving step by step keeps most of such a group in the in-workgroup path instead of
     // demoting it wholesale to DUP_SMALL).
-    int thr = DUP_SMALL_HI;
+    const int hi1 = small_hi, hi2 = max(small_hi / 2, DUP_SMALL), hi4 = max(small_hi / 4, DUP_SMALL);
+    int thr = hi1;
     {
-        int c_hi = (cnt <= DUP_SMALL_HI) ? cnt : 0, c_h2 = (cnt <= DUP_SMALL_HI / 2) ? cnt : 0, c_h4 = (cnt <= DUP_SMALL_HI / 4) ? cnt : 0;
+        int c_hi = (cnt <= hi1) ? cnt : 0, c_h2 = (cnt <= hi2) ? cnt : 0, c_h4 = (cnt <= hi4) ? cnt : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { c_hi += __shfl_xor(c_hi, o); c_h2 += __shfl_xor(c_h2, o); c_h4 += __shfl_xor(c_h4, o); }
         if (lane == 0) { wbig[wave] = c_hi; wnz[wave] = c_h2; wsum[wave] = c_h4; }
         __syncthreads();
         if (wbig[0] + wbig[1] + wbig[2] + wbig[3] > DUP_LDS_ENTRIES) {
-            thr = DUP_SMALL_HI / 2;
+            thr = hi2;
             if (wnz[0] + wnz[1] + wnz[2] + wnz[3] > DUP_LDS_ENTRIES) {
-                thr = DUP_SMALL_HI / 4;
+                thr = hi4;
                 if (wsum[0] + wsum[1] + wsum[2] + wsum[3] > DUP_LDS_ENTRIES) thr = DUP_SMALL;
             }
         }
@@ -399,8 +421,13 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         }
         if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
     }
+    if (grp_ticket != nullptr) { if (tid == 0) grp_s = next_ticket; }
     __syncthreads();                                      // buf / t_* are reused by the next group
+    grp = grp_ticket != nullptr ? grp_s : grp + (int)gridDim.x;
     }
+    // what is left of the zero duty (workgroups that ran out of groups early, launches with few groups)
+    for (; za < n4a; za += z_nth) z4a[za] = make_uint4(0u, 0u, 0u, 0u);
+    for (; zb < n4b; zb += z_nth) z4b[zb] = make_uint4(0u, 0u, 0u, 0u);
     if (totals) {
         __syncthreads();
         digit_hist_flush(hist, totals, ds.passes);
@@ -562,7 +589,9 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                     for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o);
                     run_signed += sg;
                 }
-                n = n > 0 ? n : 0;
+#ifndef LG_REPRO_NEGATIVE_SLICE_BUG        // (tools/repro_negative_slice.py builds this file once WITHOUT the clamp and the key check below:
+                n = n > 0 ? n : 0;           //  the round-3 / round-4 memory access fault, profiles/r05_fault_root_cause.md)
+#endif
                 int inc = n;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -629,6 +658,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                     const int v = w_minv[wave][sl] + (k - w_off[wave][sl]);
                     const uint32_t tk = f.isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
                     key = (int32_t)(tk + 1);
+#ifndef LG_REPRO_NEGATIVE_SLICE_BUG
                     if ((unsigned)key > (unsigned)(gx * gy)) {          // cannot happen for consistent slices; a key is an index downstream
                         lg_note_sanitised(LG_SITE_EMIT_KEY);
                         if (dbg != nullptr && dbg_claim(dbg + 16)) {
@@ -637,6 +667,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                         }
                         key = 0;
                     }
+#endif
                     kout[sgoff + k] = key;
                     vout[sgoff + k] = sidx;
                     if (tile_counts) atomicAdd(&tile_counts[(size_t)b * (gx * gy + 2) + key], 1);
@@ -681,6 +712,16 @@ __global__ void __launch_bounds__(TPB) dup_queue_check_kernel(const int32_t* __r
     }
 }
 
+// launch variants of the key emission (lg_set_tuning keys 10 / 11: A/B hooks of tools/, plain ints as in raster.hip)
+static int g_dup_small_hi = DUP_SMALL_HI;      // largest tile count the owning thread walks itself; larger splats go to dup_big
+static int g_dup_dynamic = 1;                  // groups handed out on demand (needs the caller's zeroed ticket word) instead of round robin
+int lg_binning_set_tuning(int key, int value)
+{
+    if (key == 10) { if (value < DUP_SMALL || value > DUP_SMALL_HI) return (int)hipErrorInvalidValue; g_dup_small_hi = value; return 0; }
+    if (key == 11) { g_dup_dynamic = value ? 1 : 0; return 0; }
+    return (int)hipErrorInvalidValue;
+}
+
 // qcount: int32 [V][DUP_NQ], zero on entry; qentries: uint32 [V][lg_dup_queue_entries(N, table_len)].  totals (nullable): the tile sort's
 // digit counts, accumulated here.
 int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
@@ -690,7 +731,7 @@ int lg_dup_emit(const float* ndc, const float* inv_cov, const float* opacity, co
 {
     return lg_dup_emit_gated(ndc, inv_cov, opacity, packed, prefix, sorted_id, sorted_id_is_int64, V, N, H, W, TH, TW, table_len, keys, values,
                              qcount, qentries, totals, begin_bit, end_bit, nullptr, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words,
-                             nullptr, nullptr, nullptr, stream);
+                             nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opacity, const float* packed, const int32_t* prefix, const void* sorted_id,
@@ -698,7 +739,7 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
                       int* qcount, uint32_t* qentries, int* totals, int begin_bit, int end_bit, int* tile_counts,
                       uint32_t* zero_ptr, long long zero_words,
                       uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words,
-                      const int* gate, int* trunc_flag, int* dbg, void* stream)
+                      const int* gate, int* trunc_flag, int* dbg, int* grp_ticket, void* stream)
 {
     if (N <= 0) return 0;
     if (packed && sorted_id_is_int64) return (int)hipErrorInvalidValue;     // packed records: fused executor only (int32 order)
@@ -719,10 +760,10 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
     do {                                                                                                                                   \
         if (gx * gy + 1 <= 0xffff)                                                                                                         \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg, g_dup_small_hi, g_dup_dynamic ? grp_ticket : (int*)nullptr); \
         else                                                                                                                               \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,   \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg, g_dup_small_hi, g_dup_dynamic ? grp_ticket : (int*)nullptr); \
         if (dbg != nullptr && V == 1)                                                                                                      \
             hipLaunchKernelGGL(dup_queue_check_kernel, dim3(DUP_NQ), dim3(TPB), 0, s, prefix, N, table_len, (const int*)qcount,             \
                                (const uint32_t*)qentries, gate, dbg);                                                                       \

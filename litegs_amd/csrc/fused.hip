@@ -603,6 +603,7 @@ static int validate_chunk_ids(const struct Exec& x, int64_t* vis_ids, const int*
 static int validate_zero(const struct Exec& x, const void* p, long long words, int* lock, const int* gate, int range_id, hipStream_t s);
 static int validate_order(const struct Exec& x, const int32_t* ids, const int32_t* prefix, int N, int* lock, const int* gate, hipStream_t s);
 #define LG_VALIDATE_LOCK_WORD 8            // int index inside Layout1::flags (cleared with the frame's scratch by the projection)
+#define LG_DUP_TICKET_WORD 16              // ... group tickets of the key emission: [16] the frame's (culled) run, [17] its gated fallback
 
 struct Scene {            // what the projection kernel reads (raw parameters + the frame's visible chunks)
     const float *pos, *scale, *rot, *sh0, *shr, *opa;
@@ -898,7 +899,7 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
                                qcount, (uint32_t*)(w + f.dup_entries), nullptr, 0, bits, nullptr, nullptr, 0,
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
                                (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag,
-                               x.validate ? x.debug_words : nullptr, s);
+                               x.validate ? x.debug_words : nullptr, (int*)(w1 + f1.flags) + (gate != nullptr ? LG_DUP_TICKET_WORD + 1 : LG_DUP_TICKET_WORD), s);
         if (rc) return rc;
         if (x.validate) { rc = validate_keys(x, (int32_t*)(w + f.tk_a), Ls, total_dev, ntiles, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
         CRUMB("tile route: count + offsets + scatter");
@@ -922,7 +923,7 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
                                (long long)lg_radix_table_words(Ls, lg_radix_sort_num_passes(0, bits)),
                                (uint32_t*)(w + f.tile_start), (long long)ntiles + 2,
                                (uint32_t*)packed_grad_clear, packed_grad_clear ? (long long)GREC * (x.replicas ? lg_fused_grad_lines(N) : N) : 0, gate, fail_flag,
-                               x.validate ? x.debug_words : nullptr, s);
+                               x.validate ? x.debug_words : nullptr, (int*)(w1 + f1.flags) + (gate != nullptr ? LG_DUP_TICKET_WORD + 1 : LG_DUP_TICKET_WORD), s);
     if (rc) return rc;
     if (x.validate) {           // emitted keys (code 1: value -1 = never written) and the digit totals counted on the side (code 7)
         int* lock = (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD;

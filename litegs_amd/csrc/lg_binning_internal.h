@@ -43,7 +43,9 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
                       uint32_t* ones_ptr, long long ones_words, uint32_t* zero2_ptr, long long zero2_words,
                       const int* gate, int* trunc_flag,
                       int* dbg /*nullable pinned debug words: [5] += slots whose walk disagreed with the prefix sums, [6] = last difference*/,
+                      int* grp_ticket /*nullable device int, zero on entry: the persistent workgroups take their groups of 256 slots on demand*/,
                       void* stream);
+int lg_binning_set_tuning(int key, int value);       // keys 10, 11 of lg_set_tuning (binning.hip)
 
 // grouping by tile without a sort (binning.hip "Tile scatter"): per-key counts -> range table + cursors -> values dropped at their
 // tile's cursor.  Order inside a tile is arbitrary: follow with lg_tile_depth_sort_gated(any_order = 1).

@@ -42,6 +42,16 @@ for STAGE in "$@"; do
       timeout -s KILL 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; tail -1 gpurun_out/smoke_$TAG.log ;;
     bench)
       timeout -s KILL 600 python bench.py > gpurun_out/bench_$TAG.log 2>&1; tail -1 gpurun_out/bench_$TAG.log | cut -c1-900 ;;
+    benchab:*)       # the bench's fresh and noise-trained states under lg_set_tuning variants: benchab:<key=value[+key=value]>[,<variant>...] ("-" = defaults)
+      for SPEC in $(echo ${STAGE#benchab:} | tr ',' ' '); do
+        T=$(echo $SPEC | tr '+' ','); [ "$T" = "-" ] && T=""
+        LITEGS_TUNING=$T timeout -s KILL 300 python bench.py --no-cpu-baseline --no-operator-path --no-pmc --no-training-state > gpurun_out/benchab_${TAG}.log 2>&1
+        python - <<PY
+import json
+d = json.loads(open("gpurun_out/benchab_${TAG}.log").read().strip().splitlines()[-1])
+print(f"tuning '{"$T"}': fresh {d['ms_per_step']:.4f} ms (p50 {d['ms_p50']:.4f}, excl. replays {d['ms_per_step_excl_replays']:.4f})  trained {d['steady_state']['ms_per_step']:.4f} ms (p50 {d['steady_state']['ms_p50']:.4f})  sanitised {d.get('sanitised')}")
+PY
+      done ;;
     bench10m)
       timeout -s KILL 300 python bench.py --config 10m_1600x1200 --frames 4 --no-cpu-baseline --no-operator-path --no-pmc > gpurun_out/bench_10m_$TAG.log 2>&1; tail -1 gpurun_out/bench_10m_$TAG.log | cut -c1-300 ;;
     bench500k)
