@@ -175,7 +175,7 @@ class FusedRenderer:
         self.tile_order = None
         self.fallbacks = 0                 # visits that were re-run unculled (observed one visit later)
         self.truncated_visits = 0          # unculled visits whose table turned out too short (observed one visit later)
-        self.keep_size_predictions = False  # across a densification / re-sort (parameters_replaced): measured gain 1-3 %, see there
+        self.keep_size_predictions = True   # across a densification / re-sort (parameters_replaced): the reference's protocol, see there
         self.last_cull = False
         # fuse_optimizer: backward stops after the blend backward; FusedAdam.step() then runs the per-Gaussian backward fused
         # with the Adam update (csrc/fused.hip: project_backward_adam_kernel) -- parameter gradients never go to HBM.
@@ -353,17 +353,17 @@ class FusedRenderer:
 
     def parameters_replaced(self, growth: float = 1.0):
         """Density control / a Morton re-sort replaced the parameters (`growth` = new / old point count).  Depth bounds and tile schedules
-        describe the old cloud: dropped.  The SIZE predictions (visible chunks, table length) are dropped too by default: every frame's
-        next visit is an exact, blocking first visit (GR/compact.cu:543-546, GR/binning.cu:152-163).
+        describe the old cloud: dropped.
 
-        keep_size_predictions = True keeps them for the frames in use, scaled by the growth, as the reference does (it never resets its
-        feedback buffers, litegs/data.py:236-241): a densification adds a few percent of points, inside the 1.2x / 1.5x allocation
-        margins, and an under-predicted table is truncated (GR/binning.cu:63), noticed, and sized exactly on the frame's next visit;
-        frames out of use (evaluation frames) still start over.  Measured at 3 M / 150 cameras: epochs right after a densification cost
-        3.9-4.3 ms per iteration with the reset against 3.3-3.5 for the others (profiles/r04_convergence_3m_runs_11_13.md), the whole run
-        3.21 against 3.24-3.30 ms per iteration.  It is NOT the default because the three long runs that had it on lost their second
-        trainer to a memory access fault that is attributed but not root-caused (profiles/r04_fault_attribution.md); the runs without
-        it: 19 trainers, none lost."""
+        keep_size_predictions = True (default) keeps the SIZE predictions of the frames in use, scaled by the growth, as the reference does
+        (it never resets its feedback buffers, litegs/data.py:236-241): a densification adds a few percent of points, inside the 1.2x / 1.5x
+        allocation margins, and an under-predicted table is truncated (GR/binning.cu:63), noticed, and sized exactly on the frame's next
+        visit; frames out of use (evaluation frames) still start over.  Measured at 3 M / 150 cameras: epochs right after a densification
+        cost 3.9-4.3 ms per iteration with the reset against 3.3-3.5 for the others (profiles/r04_convergence_3m_runs_11_13.md), the whole
+        run 3.21 against 3.24-3.30 ms per iteration.  False: every frame's next visit is an exact, blocking first visit
+        (GR/compact.cu:543-546, GR/binning.cu:152-163).  (Round 4 shipped False: the three long runs that had it on lost their second
+        trainer to a memory access fault.  The fault had nothing to do with sizes -- profiles/r05_fault_root_cause.md: a negative tile-slice
+        count in the key emission of needle-like splats -- and is fixed.)"""
         g = max(1.0, float(growth))
         for k, f in enumerate(self.frames):
             # a densification is TWO replacements with no visit in between (density control at the end of an epoch, the Morton re-sort at
