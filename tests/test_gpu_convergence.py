@@ -36,8 +36,10 @@ def test_density_control_keeps_paths_together():
     assert a["size"][-1] > a["size"][0], a["size"]                       # a densification happened
     # After a densification the two trajectories are chaotic copies of each other (float atomics reorder the sums): the long run in
     # profiles/r02_convergence.md shows up to 0.73 dB per epoch / 0.49 dB in a 5-epoch average between the two paths while both keep
-    # climbing; the executor differs from ITSELF by 0.18 dB run to run at fixed topology.  0.75 dB on a 5-epoch mean is the sanity bound.
-    noise_log(what="executor_densify~operator_densify", final5=abs(np.mean(a["psnr"][-5:]) - np.mean(b["psnr"][-5:])), bound=0.75,
+    # climbing; the executor differs from ITSELF by 0.18 dB run to run at fixed topology.  Observed on the 5-epoch mean of this scenario:
+    # 0.12 ... 0.35 dB (profiles/r05_noise_calibration.md, and 0.34 once in round 3); a path with a defect stops climbing and falls several dB
+    # behind.  1.0 dB is the sanity bound.
+    noise_log(what="executor_densify~operator_densify", final5=abs(np.mean(a["psnr"][-5:]) - np.mean(b["psnr"][-5:])), bound=1.0,
               size_rel=abs(a["size"][-1] - b["size"][-1]) / a["size"][-1])
-    assert abs(np.mean(a["psnr"][-5:]) - np.mean(b["psnr"][-5:])) <= 0.75, (a["psnr"], b["psnr"])
+    assert abs(np.mean(a["psnr"][-5:]) - np.mean(b["psnr"][-5:])) <= 1.0, (a["psnr"], b["psnr"])
     assert abs(a["size"][-1] - b["size"][-1]) <= 0.02 * a["size"][-1], (a["size"], b["size"])
