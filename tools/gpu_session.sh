@@ -49,7 +49,7 @@ for STAGE in "$@"; do
         python - <<PY
 import json
 d = json.loads(open("gpurun_out/benchab_${TAG}.log").read().strip().splitlines()[-1])
-print(f"tuning '{"$T"}': fresh {d['ms_per_step']:.4f} ms (p50 {d['ms_p50']:.4f}, excl. replays {d['ms_per_step_excl_replays']:.4f})  trained {d['steady_state']['ms_per_step']:.4f} ms (p50 {d['steady_state']['ms_p50']:.4f})  sanitised {d.get('sanitised')}")
+print(f"tuning '$T': fresh {d['ms_per_step']:.4f} ms (p50 {d['ms_p50']:.4f}, excl. replays {d['ms_per_step_excl_replays']:.4f})  trained {d['steady_state']['ms_per_step']:.4f} ms (p50 {d['steady_state']['ms_p50']:.4f})  sanitised {d.get('sanitised')}")
 PY
       done ;;
     bench10m)
