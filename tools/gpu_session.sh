@@ -5,6 +5,8 @@
 #   tests        the whole -m gpu suite (flip counts collected)           tests:<pytest args>  a targeted run
 #   stochastic:<reps>  the noise-bounded tests repeated in one session (calibration of their bounds)
 #   smoke        __graft_entry__.smoke()
+#   benchdriver  bench.py --gpus 1 --steps 20 --warmup 5 (the driver's command)
+#   benchab:<specs>  fresh / trained step time under lg_set_tuning variants
 #   bench        the default bench line                                     bench10m / bench500k  the other BASELINE sizes
 #   benchdp2     bench.py --gpus 2 with both ranks on this GPU over gloo (control-flow check of the N>1 path)
 #   trace        rocprofv3 --kernel-trace --stats of the default bench -> step timeline + kernel stats
@@ -52,6 +54,8 @@ d = json.loads(open("gpurun_out/benchab_${TAG}.log").read().strip().splitlines()
 print(f"tuning '$T': fresh {d['ms_per_step']:.4f} ms (p50 {d['ms_p50']:.4f}, excl. replays {d['ms_per_step_excl_replays']:.4f})  trained {d['steady_state']['ms_per_step']:.4f} ms (p50 {d['steady_state']['ms_p50']:.4f})  sanitised {d.get('sanitised')}")
 PY
       done ;;
+    benchdriver)     # the command line the driver records (BENCH_rNN.json)
+      timeout -s KILL 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver_$TAG.log 2>&1; tail -1 gpurun_out/bench_driver_$TAG.log | cut -c1-700 ;;
     bench10m)
       timeout -s KILL 300 python bench.py --config 10m_1600x1200 --frames 4 --no-cpu-baseline --no-operator-path --no-pmc > gpurun_out/bench_10m_$TAG.log 2>&1; tail -1 gpurun_out/bench_10m_$TAG.log | cut -c1-300 ;;
     bench500k)
