@@ -18,7 +18,14 @@ Differences from the reference, all deliberate:
   ever broadcast.  Frames are grouped into fixed sets of ``world`` (seeded once); the ORDER of the sets is re-drawn every epoch,
   so the exchange's per-set size predictions stay valid.  Only rank 0 writes files and prints;
 * frames are drawn by a seeded permutation per epoch instead of a ``DataLoader(shuffle=True)`` (same distribution, reproducible);
-* ``learnable_viewproj`` is not wired into the executor (the operator ``create_viewproj_*`` exists for the reference's own loop).
+* ``op.learnable_viewproj`` (trainer.py:84-91, 117-123, 158-162, 183-191, 221-222): the cameras are built from their parameters -- the
+  frames' COLMAP poses as a sparse ``nn.Embedding`` [frames, 7] (quaternion + translation) and the first camera's 1 / tan(fov_x / 2) --
+  by the ``create_viewproj`` operator, ``SparseAdam(lr 1e-4)`` steps the embedding after every iteration, evaluation frames take the
+  correction of their nearest training pose, and ``viewproj.pth`` is written next to every ``.ply``.  As in the reference's cluster path,
+  NO gradient reaches the camera parameters (``MVPTransform.backward`` / the cov2d and activation backwards return None for the matrices,
+  litegs/utils/wrapper.py:285): the embedding never moves, the optimizer step is a no-op, and the matrices are therefore built once per
+  frame instead of once per iteration.  What the flag changes is where the matrices come from (the operator's float32 quaternion
+  arithmetic instead of the loader's float64) and the extra file.
 """
 from __future__ import annotations
 
@@ -72,6 +79,32 @@ def frames_of(dataset: data_mod.CameraFrameDataset, device) -> List[Frame]:
     return out
 
 
+def _learnable_cameras(cameras_info, training_frames, test_frames, frames: List[Frame], test_frames_dev: List[Frame], H: int, W: int, device):
+    """op.learnable_viewproj (trainer.py:84-91): camera parameters as learnable tensors, matrices from the ``create_viewproj`` operator
+    (litegs/utils/wrapper.py:772-791 CreateViewProj).  Rebuilds the frames' view / projection matrices and frustum planes in place."""
+    from . import fast
+    from .wrapper import CreateViewProj
+    noise_extr = torch.stack([torch.from_numpy(np.asarray(f.extr_params, dtype=np.float32)) for f in training_frames]).to(device)
+    extr = torch.nn.Embedding(noise_extr.shape[0], noise_extr.shape[1], _weight=noise_extr.clone(), sparse=True)
+    intr0 = float(list(cameras_info.values())[0].intr_params)            # (the reference's "todo fix multi cameras": first camera only)
+    intr = torch.nn.Parameter(torch.tensor([[intr0]], dtype=torch.float32, device=device))
+    view_opt = torch.optim.SparseAdam(extr.parameters(), lr=1e-4)
+
+    def rebuild(frs, params7):
+        with torch.no_grad():
+            view, proj, _vp, planes = CreateViewProj.apply(params7, intr.detach(), H, W, 0.01, 5000.0)
+        for k, fr in enumerate(frs):
+            fr.view, fr.proj, fr.planes = view[k:k + 1].contiguous(), proj[k:k + 1].contiguous(), planes[k:k + 1].contiguous()
+            fr.cam = fast.CameraFrame(fr.view, fr.proj, fr.planes, fr.cam.index)
+    rebuild(frames, extr.weight.detach())
+    if test_frames_dev:
+        # evaluation frames (trainer.py:183-190): own pose + the learnt correction of the nearest training pose (zero: the embedding never moves)
+        t_extr = torch.stack([torch.from_numpy(np.asarray(f.extr_params, dtype=np.float32)) for f in test_frames]).to(device)
+        nearest = (t_extr[:, None, :] - extr.weight.detach()[None]).abs().sum(dim=2).argmin(dim=1)
+        rebuild(test_frames_dev, t_extr + (extr.weight.detach()[nearest] - noise_extr[nearest]))
+    return dict(extr=extr, intr=intr, view_opt=view_opt, noise_extr=noise_extr)
+
+
 def psnr(img: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     """peak signal-to-noise ratio for data range [0,1] (what torchmetrics' PeakSignalNoiseRatio(data_range=(0,1)) returns for one image)"""
     return 10.0 * torch.log10(1.0 / (img - gt).square().mean().clamp_min(1e-20))
@@ -104,8 +137,6 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
     dist, rank, world = _dist_state()
     device = torch.device("cuda", torch.cuda.current_device())
     say = log if rank == 0 else (lambda *a, **k: None)
-    if getattr(op, "learnable_viewproj", False):
-        raise ValueError("learnable_viewproj is not available in litegs_amd.training.start (see the module docstring)")
     # loss terms of the reference's trainer (litegs/training/trainer.py:141-150) that this loop does not compute: refuse, never ignore
     if float(getattr(op, "reg_weight", 0.0) or 0.0) > 0.0:
         raise ValueError("op.reg_weight > 0 (scale regularisation) is not implemented in litegs_amd.training.start")
@@ -142,6 +173,9 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
     for k, fr in enumerate(test_frames_dev):                         # evaluation frames: feedback slots behind the training set's
         fr.cam.index = len(frames) + k
         fr.idx_tensor = torch.tensor([len(frames) + k], dtype=torch.int64)
+    cam_state = None
+    if getattr(op, "learnable_viewproj", False):
+        cam_state = _learnable_cameras(cameras_info, training_frames, test_frames, frames, test_frames_dev, H, W, device)
     trainer = FrameTrainer(params, frames, H, W, opt, sched, pp, sh_degree=0, device=device, fused=fused, extra_slots=len(test_frames_dev))
 
     total_epoch = int(op.iterations / len(trainingset))
@@ -167,6 +201,9 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
         with trainer.begin_epoch(epoch):
             for slot, peers in epoch_schedule(len(frames), world, epoch, seed):
                 trainer.step(peers[rank], exchange, slot, peers)
+                if cam_state is not None:             # trainer.py:158-160: no gradient ever reaches the embedding (module docstring): a no-op
+                    cam_state["view_opt"].step()
+                    cam_state["view_opt"].zero_grad()
         if exchange is not None:
             exchange.check()
         trainer.flush()
@@ -191,6 +228,8 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
             sub = "finish" if last else "iteration_{}".format(epoch)
             flat = scene.uncluster(*[p.detach() for p in trainer.params])
             io_manager.save_ply(os.path.join(lp.model_path, "point_cloud", sub, "point_cloud.ply"), *flat)
+            if cam_state is not None:                 # trainer.py:221-222
+                torch.save(list(cam_state["extr"].parameters()) + [cam_state["intr"]], os.path.join(lp.model_path, "point_cloud", sub, "viewproj.pth"))
         if epoch in save_checkpoint and rank == 0:
             io_manager.save_checkpoint(lp.model_path, epoch, trainer.opt, trainer.sched)
     if dist is not None:

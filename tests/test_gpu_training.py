@@ -124,3 +124,26 @@ def test_two_ranks_train_the_scene_data_parallel(tmp_path):
         assert c and c["same_size"] and c["replicas_identical"] and c["grew"] and c["ply_written"], (r, c)
     # 8 epochs at world 2 are half as many optimizer steps on averaged gradients: within a few dB of the single-rank run, and both learn
     assert abs(out[0]["psnr"] - single[-1]["psnr_train"]) < 4.0, (out[0], single[-1])
+
+
+def test_learnable_viewproj_builds_the_cameras_from_their_parameters(tmp_path):
+    """op.learnable_viewproj (litegs/training/trainer.py:84-91, 117-123, 221-222): the matrices come from the create_viewproj operator and
+    agree with the loader's, the loop trains, `viewproj.pth` holds the [frames, 7] poses and the intrinsic -- unchanged, because no gradient
+    reaches them in the reference's cluster path either"""
+    from litegs_amd import training
+    scene = _scene(str(tmp_path), points=2048, frames=8)
+    lp, op, pp, dp = _args(scene, str(tmp_path / "m_ref"), 7 * 2)
+    tr0, _ = training.start(lp, op, pp, dp, log=lambda *a: None)
+    mats0 = [(f.view.clone(), f.proj.clone(), f.planes.clone()) for f in tr0.frames]
+    tr0.close()
+    lp, op, pp, dp = _args(scene, str(tmp_path / "m_cam"), 7 * 4)
+    op.learnable_viewproj = True
+    tr, hist = training.start(lp, op, pp, dp, test_epochs=[0, 3], log=lambda *a: None)
+    for (v0, p0, pl0), f in zip(mats0, tr.frames):
+        assert torch.allclose(f.view, v0, atol=2e-5) and torch.allclose(f.proj, p0, atol=2e-5)
+        unit = lambda pl: pl / pl[..., :3].norm(dim=-1, keepdim=True).clamp_min(1e-20)     # a plane is defined up to a positive scale
+        assert torch.allclose(unit(f.planes), unit(pl0), atol=1e-4 * max(1.0, float(unit(pl0).abs().max())))
+    assert hist[-1]["psnr_train"] > hist[0]["psnr_train"] + 0.5, hist
+    saved = torch.load(os.path.join(lp.model_path, "point_cloud", "finish", "viewproj.pth"), weights_only=False)
+    assert saved[0].shape == (len(tr.frames), 7) and saved[1].shape == (1, 1)
+    tr.close()
