@@ -94,6 +94,7 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 // per group: returning atomics on a single address serialise at ~8 ns each in L2, and one counter for the whole launch
 // (10 k wave-level appends at 3 M Gaussians) cost 85 us -- more than the rest of the kernel.
 #define DUP_NQ 64
+#define DUP_GRP_BATCH 2        // groups of 256 slots a workgroup of dup_small takes per ticket (see the kernel)
 // A queue entry is (depth slot << 8 | part): a splat with more than DUP_PART tiles is emitted in parts of DUP_PART outputs by different
 // waves (every part recomputes the slices, which is cheap next to 1024 outputs) -- otherwise the launch waits for the one wave that
 // owns the largest splat (11 033 tiles at 500 k Gaussians: 172 store instructions in a row).  Sub-queue capacity: one entry per slot
@@ -228,39 +229,38 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     const int32_t* pf = prefix + (size_t)b * N;
     int32_t* kout = keys + (size_t)b * table_len;
     int32_t* vout = values + (size_t)b * table_len;
-    // Zero duty.  The small tables go first; the two big ones -- the tile sort's look-back table (17 MB at 23 M instances) and the gradient
-    // accumulator of the coming blend backward (64 B per compacted Gaussian: 140 MB late in a run) -- are cleared a few 16-byte stores per
-    // thread and group iteration, UNDER the walk: issued as one burst at the start of the launch they were a bandwidth-bound prologue in
-    // front of a latency-bound kernel (every workgroup stored for ~40 us before its first walk), spread over the iterations they ride on
-    // the memory pipe the walk leaves idle.  Whatever is left when a workgroup runs out of groups is finished behind the loop.
-    const long long z_gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, z_nth = (long long)gridDim.x * gridDim.y * TPB;
-    if (ones_ptr) for (long long i = z_gid; i < ones_words; i += z_nth) ones_ptr[i] = 0xffffffffu;      // tile range table: -1 = empty
-    uint4* const z4a = reinterpret_cast<uint4*>(zero_ptr);       // (both regions are 16-byte aligned; word tails below)
-    uint4* const z4b = reinterpret_cast<uint4*>(zero2_ptr);
-    const long long n4a = zero_ptr ? zero_words / 4 : 0, n4b = zero2_ptr ? zero2_words / 4 : 0;
-    long long za = z_gid, zb = z_gid;
-    if (zero_ptr) for (long long i = n4a * 4 + z_gid; i < zero_words; i += z_nth) zero_ptr[i] = 0u;
-    if (zero2_ptr) for (long long i = n4b * 4 + z_gid; i < zero2_words; i += z_nth) zero2_ptr[i] = 0u;
-    constexpr int Z_PER_ITER = 6;
+    // Zero duty, one burst of 16-byte stores at the start of the launch: the tile range table (-1), the tile sort's look-back table
+    // (17 MB at 23 M instances) and the gradient accumulator of the coming blend backward (64 B per compacted Gaussian: 140 MB late in a
+    // run).  (Round 5 tried to issue the two big ones a few stores per group iteration, "under the walk": +26 us on this kernel at 23 M
+    // instances -- on gfx9-family parts stores count on vmcnt like loads, so every wait for the walk's loads also waited for the zero
+    // stores issued in front of them.  profiles/r05_emission_ab_training_state.log, r05_step_timeline.md.)
+    {
+        const long long z_gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, z_nth = (long long)gridDim.x * gridDim.y * TPB;
+        if (ones_ptr) for (long long i = z_gid; i < ones_words; i += z_nth) ones_ptr[i] = 0xffffffffu;      // tile range table: -1 = empty
+        if (zero_ptr) {
+            uint4* z4 = reinterpret_cast<uint4*>(zero_ptr);
+            const long long n4 = zero_words / 4;
+            for (long long i = z_gid; i < n4; i += z_nth) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (long long i = n4 * 4 + z_gid; i < zero_words; i += z_nth) zero_ptr[i] = 0u;
+        }
+        if (zero2_ptr) {
+            uint4* z4 = reinterpret_cast<uint4*>(zero2_ptr);
+            const long long n4 = zero2_words / 4;
+            for (long long i = z_gid; i < n4; i += z_nth) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (long long i = n4 * 4 + z_gid; i < zero2_words; i += z_nth) zero2_ptr[i] = 0u;
+        }
+    }
     if (totals) for (int k = tid; k < ds.passes * 256; k += TPB) hist[k] = 0;
     // persistent workgroups (the digit table is flushed once per workgroup, not once per 256 splats).  Groups are dealt round robin, or
-    // -- grp_ticket -- handed out on demand: groups differ in cost by an order of magnitude (in depth order the near groups hold the
-    // large splats), and the ticket for the NEXT group is requested at the start of the current one so that its round trip is hidden.
+    // -- grp_ticket -- in batches of DUP_GRP_BATCH on demand: groups differ in cost by an order of magnitude (in depth order the near
+    // groups hold the large splats).  A returning atomic on one address costs ~8 ns serialised in L2, so (a) every workgroup's FIRST batch
+    // is static (batch blockIdx.x: no ticket storm at the start of the launch -- one ticket per group cost the fresh bench frame 36 us),
+    // (b) a ticket hands out DUP_GRP_BATCH consecutive groups, (c) it is requested at the start of the batch it follows.
     const int ngroups = (N + TPB - 1) / TPB;
-    int grp = blockIdx.x;
-    if (grp_ticket != nullptr) {
-        if (tid == 0) grp_s = atomicAdd(grp_ticket, 1);
-        __syncthreads();
-        grp = grp_s;
-    }
+    int batch = blockIdx.x, in_batch = 0, next_ticket = 0;
+    int grp = grp_ticket != nullptr ? batch * DUP_GRP_BATCH : (int)blockIdx.x;
     while (grp < ngroups) {
-    int next_ticket = 0;
-    if (grp_ticket != nullptr && tid == 0) next_ticket = atomicAdd(grp_ticket, 1);      // consumed at the end of the iteration
-#pragma unroll
-    for (int zc = 0; zc < Z_PER_ITER; zc++) {
-        if (za < n4a) { z4a[za] = make_uint4(0u, 0u, 0u, 0u); za += z_nth; }
-        if (zb < n4b) { z4b[zb] = make_uint4(0u, 0u, 0u, 0u); zb += z_nth; }
-    }
+    if (grp_ticket != nullptr && in_batch == 0 && tid == 0) next_ticket = atomicAdd(grp_ticket, 1) + (int)gridDim.x;   // consumed at the end of the batch
     const int j = grp * TPB + tid;
     if (tid < DUP_LDS_ENTRIES / 64 + 4) { starts[tid] = 0ull; sstarts[tid] = 0ull; }       // (barriers below separate this from the bit sets)
 
@@ -421,13 +421,12 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         }
         if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
     }
-    if (grp_ticket != nullptr) { if (tid == 0) grp_s = next_ticket; }
+    if (grp_ticket != nullptr && in_batch == DUP_GRP_BATCH - 1 && tid == 0) grp_s = next_ticket;
     __syncthreads();                                      // buf / t_* are reused by the next group
-    grp = grp_ticket != nullptr ? grp_s : grp + (int)gridDim.x;
+    if (grp_ticket == nullptr) grp += (int)gridDim.x;
+    else if (++in_batch < DUP_GRP_BATCH) grp++;
+    else { in_batch = 0; batch = grp_s; grp = batch * DUP_GRP_BATCH; }
     }
-    // what is left of the zero duty (workgroups that ran out of groups early, launches with few groups)
-    for (; za < n4a; za += z_nth) z4a[za] = make_uint4(0u, 0u, 0u, 0u);
-    for (; zb < n4b; zb += z_nth) z4b[zb] = make_uint4(0u, 0u, 0u, 0u);
     if (totals) {
         __syncthreads();
         digit_hist_flush(hist, totals, ds.passes);
@@ -583,14 +582,15 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                     slice_bounds(s, f, i, K, mn, mx);
                     n = mx - mn;
                 }
-                {
-                    int sg = n;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o);
-                    run_signed += sg;
-                }
 #ifndef LG_REPRO_NEGATIVE_SLICE_BUG        // (tools/repro_negative_slice.py builds this file once WITHOUT the clamp and the key check below:
-                n = n > 0 ? n : 0;           //  the round-3 / round-4 memory access fault, profiles/r05_fault_root_cause.md)
+                                            //  the round-3 / round-4 memory access fault, profiles/r05_fault_root_cause.md)
+                if (__ballot(n < 0) != 0ull) {                 // never in a healthy cloud: one ballot per 64 slices
+                    int ng = n < 0 ? n : 0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) ng += __shfl_xor(ng, o);
+                    run_signed += ng;                          // the negative counts; the positive ones are added below (run)
+                }
+                n = n > 0 ? n : 0;
 #endif
                 int inc = n;
 #pragma unroll
@@ -629,6 +629,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             // the two are the same function of the same six floats, but every entry of [off, off + scnt) is written whatever happens
             // (tiles beyond scnt dropped, entries beyond run padded with key 0 = "no tile"), because an entry left unwritten is stale
             // memory that the sort carries to the range scan, and a word of garbage there is a wild store.
+            run_signed += run;                                 // signed sum of the slice counts = what the projection counted
             if (run_signed != scnt && part == 0 && lane == 0) dup_report_mismatch(dbg, -1 - sidx, run_signed, scnt);
             const int nparts = dup_num_parts(scnt);
             const int k_begin = part * DUP_PART;
