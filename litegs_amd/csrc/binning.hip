@@ -94,8 +94,8 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 // per group: returning atomics on a single address serialise at ~8 ns each in L2, and one counter for the whole launch
 // (10 k wave-level appends at 3 M Gaussians) cost 85 us -- more than the rest of the kernel.
 #define DUP_NQ 64
-#define DUP_GRP_BATCH 2        // groups of 256 slots a workgroup of dup_small takes per ticket (see the kernel)
-#define DUP_STATIC_ROUNDS 2    // batches per workgroup dealt statically before the tickets start
+#define DUP_GRP_BATCH 1        // groups of 256 slots a workgroup of dup_small takes per ticket (see the kernel; 2 measured slower: fewer, longer rounds)
+#define DUP_STATIC_ROUNDS 3    // batches per workgroup dealt statically (round robin, as without tickets) before the tickets start
 // A queue entry is (depth slot << 8 | part): a splat with more than DUP_PART tiles is emitted in parts of DUP_PART outputs by different
 // waves (every part recomputes the slices, which is cheap next to 1024 outputs) -- otherwise the launch waits for the one wave that
 // owns the largest splat (11 033 tiles at 500 k Gaussians: 172 store instructions in a row).  Sub-queue capacity: one entry per slot
