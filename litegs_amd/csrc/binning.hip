@@ -725,7 +725,9 @@ __global__ void __launch_bounds__(TPB) dup_queue_check_kernel(const int32_t* __r
 
 // launch variants of the key emission (lg_set_tuning keys 10 / 11: A/B hooks of tools/, plain ints as in raster.hip)
 static int g_dup_small_hi = DUP_SMALL_HI;      // largest tile count the owning thread walks itself; larger splats go to dup_big
-static int g_dup_dynamic = 1;                  // groups handed out on demand (needs the caller's zeroed ticket word) instead of round robin
+static int g_dup_dynamic = 0;                  // 1: the tail of the launch is handed out on demand (needs the caller's zeroed ticket word).  Off: measured
+                                               // between -38 and +12 us per 23 M-instance frame over three ticket schemes, +1.6 .. +36 us on the bench's
+                                               // fresh frame (profiles/r05_emission_ab.log): inside the session-to-session spread, not adopted
 int lg_binning_set_tuning(int key, int value)
 {
     if (key == 10) { if (value < DUP_SMALL || value > DUP_SMALL_HI) return (int)hipErrorInvalidValue; g_dup_small_hi = value; return 0; }
