@@ -95,7 +95,6 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 // (10 k wave-level appends at 3 M Gaussians) cost 85 us -- more than the rest of the kernel.
 #define DUP_NQ 64
 #define DUP_GRP_BATCH 1        // groups of 256 slots a workgroup of dup_small takes per ticket (see the kernel; 2 measured slower: fewer, longer rounds)
-#define DUP_STATIC_ROUNDS 3    // batches per workgroup dealt statically (round robin, as without tickets) before the tickets start
 // A queue entry is (depth slot << 8 | part): a splat with more than DUP_PART tiles is emitted in parts of DUP_PART outputs by different
 // waves (every part recomputes the slices, which is cheap next to 1024 outputs) -- otherwise the launch waits for the one wave that
 // owns the largest splat (11 033 tiles at 500 k Gaussians: 172 store instructions in a row).  Sub-queue capacity: one entry per slot
@@ -203,7 +202,8 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
                                                         uint32_t* __restrict__ zero2_ptr, long long zero2_words,
                                                         const int* __restrict__ gate, int* __restrict__ trunc_flag, int* __restrict__ dbg,
                                                         int small_hi /*largest tile count walked in the workgroup (<= DUP_SMALL_HI)*/,
-                                                        int* __restrict__ grp_ticket /*nullable, zero on entry: groups are handed out dynamically*/)
+                                                        int* __restrict__ grp_ticket /*nullable, zero on entry: groups are handed out dynamically*/,
+                                                        int static_rounds /*>= 1: rounds dealt round robin before the tickets start*/)
 {
     if (gate != nullptr && *gate == 0) return;            // fallback launch of the depth-bound culling that is not needed (fused.hip)
     __shared__ LdsKeyT buf[DUP_LDS_ENTRIES];              // 16/32 KiB: compacted keys of the small splats
@@ -258,14 +258,16 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     // density-control run 38 us (profiles/r05_emission_ab.log).  A returning atomic on one address is serialised in L2 (~8 ns each) and --
     // vector memory operations return in order -- its round trip sits in front of the requesting wave's next load: a ticket per group
     // cost the bench's fresh frame (3 groups per workgroup) 36 us, a ticket per batch from the first batch on still 27 us.  So every
-    // workgroup's first DUP_STATIC_ROUNDS batches are static (batch blockIdx.x + r * gridDim.x: short launches never take a ticket), and
-    // the first ticket is requested when the workgroups have long left lockstep.
+    // workgroup's first `static_rounds` batches are static (batch blockIdx.x + r * gridDim.x), and the HOST turns tickets on only for
+    // long launches (>= 5 groups per workgroup: lg_dup_emit_gated), where one static round is followed by tickets; short launches stay
+    // round robin.  Measured over four schemes (profiles/r05_emission_ab.log): tickets early in a long launch -23 .. -38 us, tickets only
+    // for the tail of a long launch +12 us, tickets in a short launch +1.6 .. +36 us.
     const int ngroups = (N + TPB - 1) / TPB;
     int batch = blockIdx.x, in_batch = 0, next_ticket = 0, round = 0;
     int grp = grp_ticket != nullptr ? batch * DUP_GRP_BATCH : (int)blockIdx.x;
     while (grp < ngroups) {
-    if (grp_ticket != nullptr && in_batch == 0 && round >= DUP_STATIC_ROUNDS - 1 && tid == 0)
-        next_ticket = atomicAdd(grp_ticket, 1) + DUP_STATIC_ROUNDS * (int)gridDim.x;   // the batch after this one; consumed at the end of this one
+    if (grp_ticket != nullptr && in_batch == 0 && round >= static_rounds - 1 && tid == 0)
+        next_ticket = atomicAdd(grp_ticket, 1) + static_rounds * (int)gridDim.x;   // the batch after this one; consumed at the end of this one
     const int j = grp * TPB + tid;
     if (tid < DUP_LDS_ENTRIES / 64 + 4) { starts[tid] = 0ull; sstarts[tid] = 0ull; }       // (barriers below separate this from the bit sets)
 
@@ -426,13 +428,13 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         }
         if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
     }
-    if (grp_ticket != nullptr && in_batch == DUP_GRP_BATCH - 1 && round >= DUP_STATIC_ROUNDS - 1 && tid == 0) grp_s = next_ticket;
+    if (grp_ticket != nullptr && in_batch == DUP_GRP_BATCH - 1 && round >= static_rounds - 1 && tid == 0) grp_s = next_ticket;
     __syncthreads();                                      // buf / t_* are reused by the next group
     if (grp_ticket == nullptr) grp += (int)gridDim.x;
     else if (++in_batch < DUP_GRP_BATCH) grp++;
     else {
         in_batch = 0;
-        batch = (round < DUP_STATIC_ROUNDS - 1) ? batch + (int)gridDim.x : grp_s;
+        batch = (round < static_rounds - 1) ? batch + (int)gridDim.x : grp_s;
         round++;
         grp = batch * DUP_GRP_BATCH;
     }
@@ -725,13 +727,12 @@ __global__ void __launch_bounds__(TPB) dup_queue_check_kernel(const int32_t* __r
 
 // launch variants of the key emission (lg_set_tuning keys 10 / 11: A/B hooks of tools/, plain ints as in raster.hip)
 static int g_dup_small_hi = DUP_SMALL_HI;      // largest tile count the owning thread walks itself; larger splats go to dup_big
-static int g_dup_dynamic = 0;                  // 1: the tail of the launch is handed out on demand (needs the caller's zeroed ticket word).  Off: measured
-                                               // between -38 and +12 us per 23 M-instance frame over three ticket schemes, +1.6 .. +36 us on the bench's
-                                               // fresh frame (profiles/r05_emission_ab.log): inside the session-to-session spread, not adopted
+static int g_dup_dynamic = 1;                  // 1: long launches (>= 5 groups per workgroup) hand their groups out on demand after one static round
+                                               // (needs the caller's zeroed ticket word); 0: never; 2: always.  profiles/r05_emission_ab.log
 int lg_binning_set_tuning(int key, int value)
 {
     if (key == 10) { if (value < DUP_SMALL || value > DUP_SMALL_HI) return (int)hipErrorInvalidValue; g_dup_small_hi = value; return 0; }
-    if (key == 11) { g_dup_dynamic = value ? 1 : 0; return 0; }
+    if (key == 11) { if (value < 0 || value > 2) return (int)hipErrorInvalidValue; g_dup_dynamic = value; return 0; }
     return (int)hipErrorInvalidValue;
 }
 
@@ -760,6 +761,8 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
     int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ngroups = lg_cdiv(N, TPB);
     dim3 grid(ngroups < 1280 ? ngroups : 1280, V);        // persistent workgroups (5 per CU), 256 depth slots at a time
+    // groups on demand (after one static round): long launches only (auto), never, or always -- lg_set_tuning(11, 1 / 0 / 2)
+    const bool use_ticket = grp_ticket != nullptr && (g_dup_dynamic == 2 || (g_dup_dynamic == 1 && ngroups >= 5 * (int)grid.x));
     dim3 grid_big(1024, V);                               // persistent: 4096 waves drain the queue
     hipStream_t s = (hipStream_t)stream;
     DigitSpec ds = { begin_bit, 0, 0u };
@@ -773,10 +776,10 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
     do {                                                                                                                                   \
         if (gx * gy + 1 <= 0xffff)                                                                                                         \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg, g_dup_small_hi, g_dup_dynamic ? grp_ticket : (int*)nullptr); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg, g_dup_small_hi, use_ticket ? grp_ticket : (int*)nullptr, 1); \
         else                                                                                                                               \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,   \
-                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg, g_dup_small_hi, g_dup_dynamic ? grp_ticket : (int*)nullptr); \
+                               H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg, g_dup_small_hi, use_ticket ? grp_ticket : (int*)nullptr, 1); \
         if (dbg != nullptr && V == 1)                                                                                                      \
             hipLaunchKernelGGL(dup_queue_check_kernel, dim3(DUP_NQ), dim3(TPB), 0, s, prefix, N, table_len, (const int*)qcount,             \
                                (const uint32_t*)qentries, gate, dbg);                                                                       \
