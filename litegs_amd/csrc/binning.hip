@@ -260,8 +260,9 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     // cost the bench's fresh frame (3 groups per workgroup) 36 us, a ticket per batch from the first batch on still 27 us.  So every
     // workgroup's first `static_rounds` batches are static (batch blockIdx.x + r * gridDim.x), and the HOST turns tickets on only for
     // long launches (>= 5 groups per workgroup: lg_dup_emit_gated), where one static round is followed by tickets; short launches stay
-    // round robin.  Measured over four schemes (profiles/r05_emission_ab.log): tickets early in a long launch -23 .. -38 us, tickets only
-    // for the tail of a long launch +12 us, tickets in a short launch +1.6 .. +36 us.
+    // round robin.  Measured over five schemes (profiles/r05_emission_ab.log): tickets early in a long GLOBAL-route launch -38 .. 0 us,
+    // tickets only for the tail +12 us, tickets in a short launch +1.6 .. +36 us, in the long TILE-route launch of the 10 M frame +80 us.
+    // Default: off (lg_set_tuning(11, 0)); the mechanism stays for the next look at this kernel.
     const int ngroups = (N + TPB - 1) / TPB;
     int batch = blockIdx.x, in_batch = 0, next_ticket = 0, round = 0;
     int grp = grp_ticket != nullptr ? batch * DUP_GRP_BATCH : (int)blockIdx.x;
@@ -727,8 +728,10 @@ __global__ void __launch_bounds__(TPB) dup_queue_check_kernel(const int32_t* __r
 
 // launch variants of the key emission (lg_set_tuning keys 10 / 11: A/B hooks of tools/, plain ints as in raster.hip)
 static int g_dup_small_hi = DUP_SMALL_HI;      // largest tile count the owning thread walks itself; larger splats go to dup_big
-static int g_dup_dynamic = 1;                  // 1: long launches (>= 5 groups per workgroup) hand their groups out on demand after one static round
-                                               // (needs the caller's zeroed ticket word); 0: never; 2: always.  profiles/r05_emission_ab.log
+static int g_dup_dynamic = 0;                  // 0 (default): groups dealt round robin; 1: long launches (>= 5 groups per workgroup) hand their groups out
+                                               // on demand after one static round (needs the caller's zeroed ticket word); 2: always.  Five schemes measured,
+                                               // none adopted: -38 .. +12 us on a 23 M-instance frame, +2 .. +36 us on the bench's fresh frame, +80 us on the
+                                               // 10 M @1600x1200 frame (profiles/r05_emission_ab.log)
 int lg_binning_set_tuning(int key, int value)
 {
     if (key == 10) { if (value < DUP_SMALL || value > DUP_SMALL_HI) return (int)hipErrorInvalidValue; g_dup_small_hi = value; return 0; }

@@ -45,7 +45,7 @@ VARIANTS = {
     "prio": (dict(_tuning={8: 1}), False),                                 # issue priority by rank in the heavy-first schedule (csrc/raster.hip wave_rank_priority)
     "prio_stat_epoch": (dict(_tuning={8: 1}), True),
     "global_prio": (dict(depth_order=0, _tuning={8: 1}), False),
-    "emit_static": (dict(_tuning={11: 0}), False),                         # key emission: groups dealt round robin whatever the launch's length
+    "emit_dynamic": (dict(_tuning={11: 2}), False),                        # key emission: groups handed out on demand after one static round (default: round robin)
     "emit_hi128": (dict(_tuning={10: 128}), False),                        # ... in-workgroup walk up to 128 tiles (default 256), larger splats cooperative
     "emit_hi64": (dict(_tuning={10: 64}), False),
     "stat_epoch": (dict(), True),
@@ -133,7 +133,7 @@ def configure(tr, attrs):
     base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
     base.update(attrs)
     from litegs_amd._lib import check, lib
-    tuning = {8: 0, 10: 256, 11: 1}                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning = {8: 0, 10: 256, 11: 0}                          # lg_set_tuning keys a variant may change, at their defaults
     tuning.update(base.pop("_tuning", {}))
     for key, val in tuning.items():
         check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
