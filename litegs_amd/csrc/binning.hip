@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     // (17 MB at 23 M instances) and the gradient accumulator of the coming blend backward (64 B per compacted Gaussian: 140 MB late in a
     // run).  (Round 5 tried to issue the two big ones a few stores per group iteration, "under the walk": +26 us on this kernel at 23 M
     // instances -- on gfx9-family parts stores count on vmcnt like loads, so every wait for the walk's loads also waited for the zero
-    // stores issued in front of them.  profiles/r05_emission_ab_training_state.log, r05_step_timeline.md.)
+    // stores issued in front of them.  profiles/r05_emission_ab.log.)
     {
         const long long z_gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, z_nth = (long long)gridDim.x * gridDim.y * TPB;
         if (ones_ptr) for (long long i = z_gid; i < ones_words; i += z_nth) ones_ptr[i] = 0xffffffffu;      // tile range table: -1 = empty
