@@ -273,14 +273,9 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     if (tid < DUP_LDS_ENTRIES / 64 + 4) { starts[tid] = 0ull; sstarts[tid] = 0ull; }       // (barriers below separate this from the bit sets)
 
     // 1. size of the slot (tile count > 0 <=> non-empty tile rectangle, so no geometry is needed to classify it)
-    // The slot's loads form a chain -- prefix sums -> (is it small?) -> splat id -> 64-byte record -- and this kernel is bound by exactly
-    // such round trips (56-61 % of its wave cycles parked, profiles/r05_sq_*): the id does not depend on the prefix sums, so it is loaded
-    // with them, and the record is requested as soon as the slot is known to emit anything (cnt > 0: small or big), BEFORE the block-wide
-    // threshold reduction and its barriers; a big splat's record is then loaded for nothing here (a few percent of the slots).
     long long off = 0;
     int cnt = 0, idx = 0;
     if (j < N) {
-        idx = sorted_id ? (int)sorted_id[(size_t)b * N + j] : j;         // no order given: slots are the splats themselves
         off = (j == 0) ? 0 : pf[j - 1];
         const long long c = pf[j] - off;
         if (c > 0 && off + c <= table_len) cnt = (int)c;
@@ -301,11 +296,6 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     // The largest of DUP_SMALL_HI, /2, /4 ... for which the group still fits (groups of spatial neighbours -- emission in splat-id
     // order -- are all large or all small: halving step by step keeps most of such a group in the in-workgroup path instead of
     // demoting it wholesale to DUP_SMALL).
-    float s_nx = 0.f, s_ny = 0.f, s_a = 0.f, s_bb = 0.f, s_cc = 0.f, s_o = 0.f;
-    if (cnt > 0) {
-        if ((unsigned)idx >= (unsigned)N) { idx = 0; lg_note_sanitised(LG_SITE_QUEUE_ENTRY); }     // (an id is an index: cannot happen for a sorted table of ids)
-        load_splat<PACKED>(src, b, N, idx, s_nx, s_ny, s_a, s_bb, s_cc, s_o);
-    }
     const int hi1 = small_hi, hi2 = max(small_hi / 2, DUP_SMALL), hi4 = max(small_hi / 4, DUP_SMALL);
     int thr = hi1;
     {
@@ -345,7 +335,12 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
 
     // 3. geometry of the small splats
     SplatExtent e;
-    if (small) splat_extent<TH, TW>(s_nx, s_ny, s_a, s_bb, s_cc, s_o, H, W, gx, gy, e);
+    if (small) {
+        idx = sorted_id ? (int)sorted_id[(size_t)b * N + j] : j;          // no order given: slots are the splats themselves
+        float nx, ny, a, bb, cc, o;
+        load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
+        splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
+    }
     if (tid == 0) qbase_s = qb;
     __syncthreads();
     if (big) {
