@@ -397,6 +397,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
     __syncthreads();
     int sbase = 0;                                        // set bits below position p0
     int scarry = 0;                                       // position of the last slice start below p0
+    int bad_keys = 0;
     for (int p0 = 0; p0 < total_small; p0 += TPB) {
         const int p = p0 + tid;
         const bool act = p < total_small;
@@ -421,7 +422,11 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             const unsigned long long sm = sword & ((2ull << lane) - 1ull);
             const int ps = sm ? p0 + wave * 64 + 63 - __clzll(sm) : sprev;
             key = (int32_t)buf[ps] + (p - ps) * t_stride[t];
-            if ((unsigned)key > (unsigned)(gx * gy)) { key = 0; lg_note_sanitised(LG_SITE_EMIT_KEY); }   // cannot happen while walk and count agree; a key is an index downstream
+            // cannot happen while walk and count agree; a key is an index downstream.  A select here, the count behind the loop: a branch
+            // with an atomic in this loop cost the kernel 15 us per frame (profiles/r05_emission_ab.log)
+            const bool oob = (unsigned)key > (unsigned)(gx * gy);
+            key = oob ? 0 : key;
+            bad_keys += oob ? 1 : 0;
             const int g = t_goff[t] + (p - t_loff[t]);
             kout[g] = key;
             vout[g] = t_idx[t];
@@ -429,6 +434,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         }
         if (totals) digit_hist_add(hist, (uint32_t)key, act, ds);
     }
+    if (bad_keys) lg_note_sanitised(LG_SITE_EMIT_KEY, bad_keys);
     if (grp_ticket != nullptr && in_batch == DUP_GRP_BATCH - 1 && round >= static_rounds - 1 && tid == 0) grp_s = next_ticket;
     __syncthreads();                                      // buf / t_* are reused by the next group
     if (grp_ticket == nullptr) grp += (int)gridDim.x;
@@ -499,6 +505,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
     __syncthreads();
     const int nq = qstart[DUP_NQ];
     const int nwaves = gridDim.x * (TPB / 64);
+    int bad_keys = 0;
     // entries are dealt round-robin (entry = slot * nwaves + wave): the queues are roughly in depth order and the giant
     // near-camera splats sit together -- contiguous batches would hand all of them to a few waves
     const int gw = blockIdx.x * (TPB / 64) + wave;
@@ -673,14 +680,15 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
                     const uint32_t tk = f.isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
                     key = (int32_t)(tk + 1);
 #ifndef LG_REPRO_NEGATIVE_SLICE_BUG
-                    if ((unsigned)key > (unsigned)(gx * gy)) {          // cannot happen for consistent slices; a key is an index downstream
-                        lg_note_sanitised(LG_SITE_EMIT_KEY);
-                        if (dbg != nullptr && dbg_claim(dbg + 16)) {
+                    const bool oob = (unsigned)key > (unsigned)(gx * gy);       // cannot happen for consistent slices; a key is an index downstream
+                    bad_keys += oob ? 1 : 0;
+                    if (dbg != nullptr && oob) {
+                        if (dbg_claim(dbg + 16)) {
                             dbg[17] = sidx; dbg[18] = part; dbg[19] = k; dbg[20] = r; dbg[21] = sl; dbg[22] = w_off[wave][sl]; dbg[23] = w_minv[wave][sl];
                             dbg[24] = run; dbg[25] = scnt; dbg[26] = sgoff; dbg[27] = nsl; dbg[28] = nne; dbg[29] = key; dbg[30] = before; dbg[31] = f.isY ? 1 : 0;
                         }
-                        key = 0;
                     }
+                    key = oob ? 0 : key;
 #endif
                     kout[sgoff + k] = key;
                     vout[sgoff + k] = sidx;
@@ -695,6 +703,7 @@ __global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_
             __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order: no fence (a fence would also wait for the global stores)
         }
     }
+    if (bad_keys) lg_note_sanitised(LG_SITE_EMIT_KEY, bad_keys);
     if (totals) {
         __syncthreads();
         digit_hist_flush(hist, totals, ds.passes);
@@ -1010,7 +1019,7 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
             const uint32_t k = lds_k[p];
             const uint32_t d = (k >> shift) & mask;
             const int g = global_base[d] + (p - digit_run[d]);
-            if ((unsigned long long)(long long)g >= (unsigned long long)n) { lg_note_sanitised(LG_SITE_RADIX_INDEX); continue; }
+            if ((unsigned long long)(long long)g >= (unsigned long long)n) { lg_note_sanitised(LG_SITE_RADIX_INDEX); continue; }     // (few-tile sorts: not a hot loop)
             keys_out[g] = k;
             vals_out[g] = lds_v[p];
         }
@@ -1178,6 +1187,7 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
     }
     global_base[tid] = gbase;
     __syncthreads();
+    int bad_pos = 0;
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
         const int p = j * TPB + tid;
@@ -1189,12 +1199,17 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
             // g is built from the producer's digit totals and the predecessors' look-back words: if either is inconsistent with the keys
             // (a total that over-counts, a status word that was not zero on entry) g leaves [0, n) -- or lands on another key's slot,
             // which leaves a hole of stale memory elsewhere.  The first is caught here and counted; never a wild store.
-            if ((unsigned long long)(long long)g >= (unsigned long long)n) { lg_note_sanitised(LG_SITE_RADIX_INDEX); continue; }
-            keys_out[g] = k;
-            vals_out[g] = v;
-            if (aux_in) aux_out[g] = aux_in[v];          // last pass of the depth sort: tile counts gathered into depth order on the way out
+            // (a predicated store and a count behind the loop: no branch with an atomic in the streaming loop)
+            const bool in_range = (unsigned long long)(long long)g < (unsigned long long)n;
+            bad_pos += in_range ? 0 : 1;
+            if (in_range) {
+                keys_out[g] = k;
+                vals_out[g] = v;
+                if (aux_in) aux_out[g] = aux_in[v];      // last pass of the depth sort: tile counts gathered into depth order on the way out
+            }
         }
     }
+    if (bad_pos) lg_note_sanitised(LG_SITE_RADIX_INDEX, bad_pos);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1752,7 +1767,8 @@ __global__ void __launch_bounds__(TPB) tile_range_kernel(const int32_t* __restri
     }
     // A key outside 0..max_tile cannot come out of a correct table; if one does (an entry the emission left unwritten, DESIGN.md section 9
     // "memory access fault"), it must not become a store address: such boundaries are skipped, the tile keeps "empty".
-    if (i0 == 0) { if ((unsigned)key[0] <= (unsigned)max_tile) o[key[0]] = 0; else lg_note_sanitised(LG_SITE_RANGE_KEY); }
+    int skipped = 0;
+    if (i0 == 0) { if ((unsigned)key[0] <= (unsigned)max_tile) o[key[0]] = 0; else skipped++; }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const long long i = i0 + j;
@@ -1762,9 +1778,10 @@ __global__ void __launch_bounds__(TPB) tile_range_kernel(const int32_t* __restri
             if (cur != nxt && (unsigned)nxt <= (unsigned)max_tile) {
                 if (cur + 1 < nxt && cur >= -1) o[cur + 1] = (int32_t)(i + 1);
                 o[nxt] = (int32_t)(i + 1);
-            } else if (cur != nxt) lg_note_sanitised(LG_SITE_RANGE_KEY);
+            } else if (cur != nxt) skipped++;
         }
     }
+    if (skipped) lg_note_sanitised(LG_SITE_RANGE_KEY, skipped);
 }
 
 // `out` already filled with -1 (by a producer kernel's fill duty)
@@ -1893,10 +1910,12 @@ __global__ void __launch_bounds__(TPB) tile_count_lds_kernel(const int32_t* __re
     __syncthreads();
     int k[TG_PER_THREAD];
     tg_load(keys, i0, n, k, -1);
+    int dropped = 0;
 #pragma unroll
     for (int j = 0; j < TG_PER_THREAD; j++)
         if ((unsigned)k[j] <= (unsigned)max_tile) atomicAdd(&hist[k[j] >> 1], 1u << ((k[j] & 1) * 16));      // (a key is an index: range-checked)
-        else if (i0 + (long long)(j >> 2) * (TPB * 4) + (long long)threadIdx.x * 4 + (j & 3) < n) lg_note_sanitised(LG_SITE_SCATTER_KEY);
+        else dropped += (i0 + (long long)(j >> 2) * (TPB * 4) + (long long)threadIdx.x * 4 + (j & 3) < n) ? 1 : 0;
+    if (dropped) lg_note_sanitised(LG_SITE_SCATTER_KEY, dropped);
     __syncthreads();
     for (int w = threadIdx.x; w < TG_BINS / 2; w += TPB) {
         const unsigned int c = hist[w];

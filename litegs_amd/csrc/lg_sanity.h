@@ -24,9 +24,9 @@
 
 static __device__ int lg_sanity_dev[LG_SANITY_SITES];
 
-__device__ __forceinline__ void lg_note_sanitised(int site)
+__device__ __forceinline__ void lg_note_sanitised(int site, int n = 1)
 {
-    __hip_atomic_fetch_add(&lg_sanity_dev[site], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&lg_sanity_dev[site], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out[site] += this unit's counts; reset != 0 clears them.  Blocking (a memcpy on the null stream): call at a synchronisation point.
