@@ -11,7 +11,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblitegs_hip.so")
+LIB_PATH = os.environ.get("LITEGS_HIP_LIB") or os.path.join(_HERE, "liblitegs_hip.so")      # (override: A/B builds of the SAME library, tools/)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "litegs_hip.h")
 
 _SCALARS = {

@@ -353,6 +353,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
             if ((long long)pos + p < qcap) q[p] = ((uint32_t)j << 8) | (uint32_t)p;
             else lg_note_sanitised(LG_SITE_QUEUE_ENTRY);
         }
+
     }
 
     // ---- small splats: exclusive block scan of their counts -> compacted LDS layout ----
@@ -446,6 +447,7 @@ __global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int3
         grp = batch * DUP_GRP_BATCH;
     }
     }
+
     if (totals) {
         __syncthreads();
         digit_hist_flush(hist, totals, ds.passes);
