@@ -10,6 +10,7 @@
 #   bench        the default bench line                                     bench10m / bench500k  the other BASELINE sizes
 #   benchdp2     bench.py --gpus 2 with both ranks on this GPU over gloo (control-flow check of the N>1 path)
 #   trace        rocprofv3 --kernel-trace --stats of the default bench -> step timeline + kernel stats
+#   hbm          per-kernel HBM traffic (PMC FETCH_SIZE / WRITE_SIZE + durations) -> GB/s and fraction of 8 TB/s, fresh and training state
 #   sq           SQ counters (VALU / SALU / LDS bank conflicts) of the bench workload, fresh and trained state
 #   poison       short scenarios plain vs with poisoned per-frame buffers + validators (tools/poison_probe.py): must be indistinguishable
 #   hunt:<runs>  the same loop in the configuration that faulted, with poisoned buffers + validators + breadcrumbs (see the stage)
@@ -79,6 +80,17 @@ PY
           python tools/sq_summary.py $C "$STATE cloud, $NAME set" > gpurun_out/sq_${STATE}_${NAME}_$TAG.md 2>> gpurun_out/sq_$TAG.err; sed -n 5,16p gpurun_out/sq_${STATE}_${NAME}_$TAG.md
           rm -rf gpurun_out/pmc_${STATE}_${NAME}_$TAG
         done
+      done ;;
+    hbm)             # per-kernel HBM traffic (FETCH_SIZE / WRITE_SIZE passes with the kernel trace) in the fresh and the training state
+      for STATE in fresh training; do
+        if [ $STATE = fresh ]; then CMD="python $R/bench.py --pmc-child --steps 8 --warmup 0"; else CMD="python $R/tools/late_phase.py trace recipe default"; fi
+        for C in FETCH_SIZE WRITE_SIZE; do
+          (cd /tmp && LATE_TRACE_STEPS=8 timeout -s KILL 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/hbm_${STATE}_${C}_$TAG -o pmc -- $CMD > $R/gpurun_out/hbm_${STATE}_${C}_$TAG.log 2>&1)
+        done
+        FC=$(find gpurun_out/hbm_${STATE}_FETCH_SIZE_$TAG -name "*counter_collection.csv" | head -1); FT=$(find gpurun_out/hbm_${STATE}_FETCH_SIZE_$TAG -name "*kernel_trace.csv" | head -1)
+        WC=$(find gpurun_out/hbm_${STATE}_WRITE_SIZE_$TAG -name "*counter_collection.csv" | head -1)
+        python tools/hbm_summary.py $FC $FT $WC "$STATE state (3 M Gaussians @1080p)" > gpurun_out/hbm_${STATE}_$TAG.md 2>> gpurun_out/hbm_$TAG.err; head -30 gpurun_out/hbm_${STATE}_$TAG.md | cut -c1-200
+        rm -rf gpurun_out/hbm_${STATE}_FETCH_SIZE_$TAG gpurun_out/hbm_${STATE}_WRITE_SIZE_$TAG
       done ;;
     convown:*)       # whole-run A/B: the executor keeps its own schedule + depth-bound culling after the first statistics epoch
       RUNS=${STAGE#convown:}
