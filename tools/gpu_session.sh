@@ -89,7 +89,8 @@ PY
         done
         FC=$(find gpurun_out/hbm_${STATE}_FETCH_SIZE_$TAG -name "*counter_collection.csv" | head -1); FT=$(find gpurun_out/hbm_${STATE}_FETCH_SIZE_$TAG -name "*kernel_trace.csv" | head -1)
         WC=$(find gpurun_out/hbm_${STATE}_WRITE_SIZE_$TAG -name "*counter_collection.csv" | head -1)
-        python tools/hbm_summary.py $FC $FT $WC "$STATE state (3 M Gaussians @1080p)" > gpurun_out/hbm_${STATE}_$TAG.md 2>> gpurun_out/hbm_$TAG.err; head -30 gpurun_out/hbm_${STATE}_$TAG.md | cut -c1-200
+        LASTK=0; [ $STATE = training ] && LASTK=8
+        python tools/hbm_summary.py $FC "$FT" $WC "$STATE state (3 M Gaussians @1080p)" $LASTK > gpurun_out/hbm_${STATE}_$TAG.md 2>> gpurun_out/hbm_$TAG.err; head -30 gpurun_out/hbm_${STATE}_$TAG.md | cut -c1-200
         rm -rf gpurun_out/hbm_${STATE}_FETCH_SIZE_$TAG gpurun_out/hbm_${STATE}_WRITE_SIZE_$TAG
       done ;;
     convown:*)       # whole-run A/B: the executor keeps its own schedule + depth-bound culling after the first statistics epoch

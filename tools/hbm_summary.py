@@ -2,7 +2,7 @@
 """Developer tool: per-kernel HBM-side traffic against the chip's roofline from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do
 not fit one pass) that were collected WITH --kernel-trace, so every dispatch carries its own duration.
 
-    python tools/hbm_summary.py <fetch counter_collection.csv> <fetch kernel_trace.csv> <write counter_collection.csv> <label>
+    python tools/hbm_summary.py <fetch counter_collection.csv> <unused> <write counter_collection.csv> <label> [last K dispatches per kernel]
 
 Per kernel, averages over the working launches (launches below 10 % of the kernel's largest fetch are gated no-ops): duration, FETCH / WRITE
 in MB, the guide's gfx950 correction 2F + W (MI355X_MICROARCH.md: FETCH_SIZE reports half of a wide coalesced read; an upper bound for
@@ -12,6 +12,7 @@ import collections, csv, re, sys
 
 fetch_csv, trace_csv, write_csv = sys.argv[1:4]
 label = sys.argv[4] if len(sys.argv) > 4 else ""
+LAST = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # > 0: only the last LAST dispatches of every kernel (the steady tail of a run that first has to reach its state)
 short = lambda n: re.sub(r"^void ", "", n).split("(")[0]
 PEAK = 8.0e12
 
@@ -50,6 +51,8 @@ for k in byk_f:
         continue
     f, t = byk_f[k], byk_t[k]
     w = byk_w.get(k, [0.0])
+    if LAST > 0:
+        f, t, w = f[-LAST:], t[-LAST:], w[-LAST:]
     big = max(max(f), 1e-9)
     keep = [i for i, v in enumerate(f) if v >= 0.1 * big]
     bigw = max(max(w), 1e-9)
