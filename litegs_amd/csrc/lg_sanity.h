@@ -36,8 +36,9 @@ __device__ __forceinline__ void lg_note_sanitised(int site, int n = 1)
         int h[LG_SANITY_SITES];                                                                                             \
         hipError_t e = hipMemcpyFromSymbol(h, HIP_SYMBOL(lg_sanity_dev), sizeof(h));                                        \
         if (e != hipSuccess) return (int)e;                                                                                 \
-        for (int i = 0; i < LG_SANITY_SITES; i++) out[i] += h[i];                                                           \
-        if (reset) {                                                                                                        \
+        int any = 0;                                                                                                        \
+        for (int i = 0; i < LG_SANITY_SITES; i++) { out[i] += h[i]; any |= h[i]; }                                          \
+        if (reset && any) {                          /* (all zero -- the normal case -- needs no second copy) */             \
             for (int i = 0; i < LG_SANITY_SITES; i++) h[i] = 0;                                                             \
             e = hipMemcpyToSymbol(HIP_SYMBOL(lg_sanity_dev), h, sizeof(h));                                                 \
         }                                                                                                                   \
