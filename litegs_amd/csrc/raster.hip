@@ -1113,6 +1113,132 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
 #undef HOT_TARGET
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// a14, SPLAT-PARALLEL formulation ("measure both"; the shape of the reference's backward, GR/raster.cu:696-849, where
+// threads own Gaussians).  A/B variant, lg_set_tuning(5, 2); not the default -- the numbers are in DESIGN.md section 9 (round 5).
+//
+// One wave per 8x16 tile.  The tile's list is walked from its deep end in batches of 64 positions; lane l of a batch owns position
+// hi - 1 - l (lane 0 = the deepest splat of the batch) and keeps that splat's record and its nine moment sums in registers.  The tile's
+// 128 pixels are LOOPED: a pixel's constants (position, dL/dC, last_contributor) and its running state -- T behind the batch and Bd, the
+// colour blended behind it dotted with dL/dC -- sit in LDS and are read by broadcast.  What the pixel-parallel kernel gets for free from
+// its sequential walk has to be rebuilt across the lanes: the transmittance in front of splat l is T_state / prod_{i <= l} (1 - alpha_i)
+// and the behind-colour recursion Bd <- (1 - alpha) Bd + alpha (c . g) is an affine map per splat, so one inclusive scan of affine maps
+// over the 64 lanes (six DPP steps: row_shr 1, 2, 4, 8, row_bcast 15, 31; a multiply and a multiply-add each) yields both, its exclusive
+// form (wave_shr 1) gives every lane the Bd it sees, and lane 63 holds the pixel's new state.  No nine-value reduction per (tile, splat),
+// nine plain atomics per lane and batch instead of one nine-lane atomic per (tile, splat) -- against two 64-lane scans per (pixel, batch).
+// ---------------------------------------------------------------------------------------------
+#define DPP_MOV_F(old_, v_, ctrl_, rm_) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old_), __float_as_int(v_), ctrl_, rm_, 0xF, false))
+// One step of the inclusive scan of affine maps: (A, B) <- (A, B) o (A_low, B_low) -- first the lower lanes' map, then this lane's.  With the
+// DPP operand on the instruction itself a lane WITHOUT a source is disabled and keeps (A, B), which is the composition with the identity:
+//   B += B_low * A   (v_fmac_f32 with the DPP-shifted B as first operand; A is still this lane's own factor)
+//   A *= A_low
+// (the compiler does not fold update_dpp into these two: as v_mov_dpp + op + a re-initialised `old` every step the scan was 40 instructions
+// instead of 12; s_nop 0: a VGPR written by a VALU instruction needs two wait states before a DPP read)
+#define AFFINE_STEP(A_, B_, CTRL_)                                                       \
+    asm volatile("s_nop 0\n\t"                                                          \
+                 "v_fmac_f32_dpp %1, %1, %0 " CTRL_ " bank_mask:0xf\n\t"                \
+                 "v_mul_f32_dpp %0, %0, %0 " CTRL_ " bank_mask:0xf" : "+v"(A_), "+v"(B_))
+
+__global__ void __launch_bounds__(256) raster_backward_sp_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
+                                                                 const float* __restrict__ packed, const int* __restrict__ tiles, int K,
+                                                                 const float* __restrict__ final_T, const short* __restrict__ last,
+                                                                 const float* __restrict__ d_img, float* __restrict__ packed_grad,
+                                                                 const int* __restrict__ order,
+                                                                 int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode)
+{
+    constexpr int TH = 8, TW = 16, NPX = TH * TW;
+    __shared__ float4 px_a[4][NPX];       // per pixel: T behind the current batch, Bd, dL/dR, dL/dG
+    __shared__ float4 px_b[4][NPX];       // dL/dB, last_contributor (int bits), x, y
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int view = blockIdx.y;
+    const int nb = gridDim.x;
+    const int prio_mode = map_mode >> 8;
+    map_mode &= 0xff;
+    int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
+    const int slot = rfl(blk * 4 + wave);
+    if (slot >= nslots) return;
+    wave_rank_priority(prio_mode, slot, nslots, tiles != nullptr || order != nullptr);
+    int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
+    tile = rfl(tile);
+    if (tile <= 0 || tile > ntiles) return;
+    const int* __restrict__ si = start_index + (size_t)view * (ntiles + 2);
+    const int start = rfl(si[tile]);
+    const int end = rfl(si[tile + 1]);
+    if (start < 0 || start >= end) return;
+    const int* __restrict__ sp = sorted_points + (size_t)view * L + start;
+    const float4* __restrict__ pk4 = reinterpret_cast<const float4*>(packed + (size_t)view * N * REC);
+    float* __restrict__ pg = packed_grad + (size_t)view * N * GREC;
+    const int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
+    const size_t plane = (size_t)Hp * Wp;
+    int maxlast = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {                                  // pixel p = lane + 64 k: row p / 16, column p % 16 (coalesced image rows)
+        const int p = lane + 64 * k;
+        const int x = tx * TW + (p % TW), y = ty * TH + (p / TW);
+        const size_t o = (size_t)y * Wp + x;
+        const int lc = last[(size_t)view * plane + o];
+        px_a[wave][p] = make_float4(final_T[(size_t)view * plane + o], 0.0f, d_img[((size_t)view * 3) * plane + o], d_img[((size_t)view * 3 + 1) * plane + o]);
+        px_b[wave][p] = make_float4(d_img[((size_t)view * 3 + 2) * plane + o], __int_as_float(lc), (float)x, (float)y);
+        maxlast = max(maxlast, lc);
+    }
+    maxlast = rfl(wave_max_i(maxlast));
+    const int n = min(maxlast, end - start);                        // list positions n-1 .. 0 are walked
+    if (n <= 0) return;
+    __builtin_amdgcn_wave_barrier();                                // (LDS operations of one wave execute in order)
+    const float amax = 255.0f / 256;
+    for (int hi = n; hi > 0; hi -= 64) {
+        const int lo = hi > 64 ? hi - 64 : 0;
+        const int j = hi - 1 - lane;                                // this lane's list position (lane 0: the deepest of the batch)
+        const bool act = j >= lo;
+        const int id = sp[act ? j : lo];
+        const unsigned rid = min((unsigned)id, (unsigned)(N - 1));
+        const float4 r0 = pk4[(size_t)rid * 4], r1 = pk4[(size_t)rid * 4 + 1], r2 = pk4[(size_t)rid * 4 + 2], r3 = pk4[(size_t)rid * 4 + 3];
+        const float spx = r0.x, spy = r0.y, A2 = r0.z, B2 = r0.w, C2 = r1.x, cr = r1.z, cg = r1.w, cb = r2.x, LO = r3.w;
+        float Mx = 0.f, My = 0.f, Mxx = 0.f, Mxy = 0.f, Myy = 0.f, dR = 0.f, dG = 0.f, dB = 0.f, M0 = 0.f;
+        for (int p = 0; p < NPX; p++) {
+            const float4 sa = px_a[wave][p], sb = px_b[wave][p];      // broadcast reads
+            const int lc = rfl(__float_as_int(sb.y));
+            if (lc <= lo) continue;                                  // the pixel stopped in front of this batch: nothing changes for it
+            const float dx = spx - sb.z, dy = spy - sb.w;
+            const float q = __builtin_fmaf(__builtin_fmaf(C2, dy, B2 * dx), dy, __builtin_fmaf(A2 * dx, dx, LO));
+            const float E = __builtin_amdgcn_exp2f(q);
+            const bool val = act && (E >= 1.0f / 256) && (j < lc);
+            const float Ev = val ? E : 0.0f;
+            const float am = vmin(Ev, amax);
+            const float cdot = __builtin_fmaf(cr, sa.z, __builtin_fmaf(cg, sa.w, cb * sb.x));
+            float A = 1.0f - am, B = am * cdot;                      // this splat's map on Bd: Bd <- A Bd + B; A is also its factor on T
+            asm volatile("s_nop 0" : "+v"(A), "+v"(B));              // (second wait state in front of the first DPP read)
+            AFFINE_STEP(A, B, "row_shr:1 row_mask:0xf");
+            AFFINE_STEP(A, B, "row_shr:2 row_mask:0xf");
+            AFFINE_STEP(A, B, "row_shr:4 row_mask:0xf");
+            AFFINE_STEP(A, B, "row_shr:8 row_mask:0xf");
+            AFFINE_STEP(A, B, "row_bcast:15 row_mask:0xa");
+            AFFINE_STEP(A, B, "row_bcast:31 row_mask:0xc");
+            // exclusive form: what the deeper lanes of the batch did to Bd before this splat (lane 0: nothing)
+            const float Ae = DPP_MOV_F(1.0f, A, 0x138, 0xF), Be = DPP_MOV_F(0.0f, B, 0x138, 0xF);      // wave_shr:1
+            const float Tb = vmin(sa.x * __builtin_amdgcn_rcpf(A), 1.0f);                               // T in front of this splat
+            const float Bd = __builtin_fmaf(Ae, sa.y, Be);
+            const float w = am * Tb;
+            dR = __builtin_fmaf(w, sa.z, dR); dG = __builtin_fmaf(w, sa.w, dG); dB = __builtin_fmaf(w, sb.x, dB);
+            const float m = (cdot - Bd) * Tb * Ev;
+            const float mx = m * dx, my = m * dy;
+            M0 += m; Mx += mx; My += my;
+            Mxx = __builtin_fmaf(mx, dx, Mxx); Mxy = __builtin_fmaf(mx, dy, Mxy); Myy = __builtin_fmaf(my, dy, Myy);
+            if (lane == 63) {                                        // the pixel's state behind the NEXT (shallower) batch
+                float2 st2 = make_float2(Tb, __builtin_fmaf(A, sa.y, B));
+                *reinterpret_cast<float2*>(&px_a[wave][p]) = st2;
+            }
+        }
+        if (act) {
+            float* g = pg + (size_t)rid * GREC;
+            unsafeAtomicAdd(g + 0, Mx); unsafeAtomicAdd(g + 1, My); unsafeAtomicAdd(g + 2, Mxx); unsafeAtomicAdd(g + 3, Mxy); unsafeAtomicAdd(g + 4, Myy);
+            unsafeAtomicAdd(g + 5, dR); unsafeAtomicAdd(g + 6, dG); unsafeAtomicAdd(g + 7, dB); unsafeAtomicAdd(g + 8, M0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 LG_API int lg_set_tuning(int key, int value)
 {
     switch (key) {
@@ -1120,7 +1246,7 @@ LG_API int lg_set_tuning(int key, int value)
     case 2: g_fwd_map = value; return 0;                                      // ... of the blend forward
     case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
     case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
-    case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics
+    case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics; 2: the splat-parallel variant (A/B)
     case 8: g_rank_prio = value ? 1 : 0; return 0;                            // 1: issue priority by rank in a heavy-first schedule (wave_rank_priority)
     case 10: case 11: return lg_binning_set_tuning(key, value);                // key emission (binning.hip): in-workgroup ceiling, dynamic groups
     default: return (int)hipErrorInvalidValue;
@@ -1174,6 +1300,11 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
     }
     else if (enable_stat && err_square_sum == nullptr && !(TH == 8 && TW == 16 && g_bwd_fast && hot_of == nullptr))
         return (int)hipErrorInvalidValue;          // statistics inside the gradient record exist in the 8x16 moment-form kernel only
+    else if (TH == 8 && TW == 16 && g_bwd_fast == 2 && !enable_stat && d_trans == nullptr) {
+        // splat-parallel A/B variant (adds into the splats' main records; a frame's gradient replicas, if any, stay zero and fold to nothing)
+        hipLaunchKernelGGL(raster_backward_sp_kernel, grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last, d_img, packed_grad, order,
+                           gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map | (g_rank_prio << 8));
+    }
     else if (TH == 8 && TW == 16 && g_bwd_fast && !(enable_stat && hot_of != nullptr)) {
 #define LAUNCH_RBF(T_, S_) hipLaunchKernelGGL((raster_backward_fast_kernel<T_, S_>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last, \
                                               d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map | (g_rank_prio << 8), hot_of)

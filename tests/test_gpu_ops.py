@@ -310,6 +310,35 @@ def test_raster_backward(F, oracle, name, trans):
     assert np.abs(ref[0]).max() > 0
 
 
+@pytest.mark.parametrize("name", ["small", "pad"])
+def test_raster_backward_splat_parallel_variant(F, oracle, name):
+    """the splat-parallel formulation of the blend backward (csrc/raster.hip raster_backward_sp_kernel, lg_set_tuning(5, 2): an A/B variant,
+    not the default) against the oracle and against the default kernel"""
+    from litegs_amd._lib import check, lib
+    c = case(name)
+    res = oracle_forward(name)
+    H, W = c["H"], c["W"]
+    col, op = res.act[3], res.act[4]
+    d_img = d_img_for(res)
+    ref = oracle.raster_backward(res.sorted_point, res.tile_start, res.packed, res.trans, res.last, d_img, H, W, 8, 16, inv_scaler=0.5)
+    fwd = F.rasterize_forward(dev(res.sorted_point), dev(res.tile_start), dev(res.ndc), dev(res.inv_cov), dev(col), dev(op), None,
+                              H, W, 8, 16, False, False, False)
+    packed = fwd[4]
+    out = {}
+    try:
+        for variant in (2, 1):
+            check(lib().lg_set_tuning(5, variant), "lg_set_tuning")
+            out[variant] = F.rasterize_backward(dev(res.sorted_point), dev(res.tile_start), packed, None, dev(res.trans), dev(res.last), dev(d_img),
+                                                None, None, torch.tensor(0.5).cuda(), H, W, 8, 16, False)
+            torch.cuda.synchronize()
+    finally:
+        check(lib().lg_set_tuning(5, 1), "lg_set_tuning")
+    for g, g1, r, n in zip(out[2][:4], out[1][:4], ref[:4], ["d_ndc", "d_cov2d_inv", "d_color", "d_opacity"]):
+        assert_close(host(g), r, atol=1e-4, normalize=True, **GRAD_FLIP, name=n + " (splat-parallel)")
+        scale = max(float(np.abs(r).max()), 1e-30)
+        assert np.abs(host(g) - host(g1)).max() / scale < 2e-4, n           # the two kernels: rounding and the rare threshold flip only
+
+
 def test_raster_specific_tiles(F, oracle):
     """specific_tiles = heavy-first schedule (statistic_helper.py:77): same image, any order; 0 entries are skipped."""
     c = case("small")

@@ -40,9 +40,10 @@ def ab(state):
     for g in tr.opt.param_groups:
         g["lr"] = 0.0
     tr.sched.step = lambda: None
-    for v, name in ((0, "generic"), (1, "fast"), (0, "generic"), (1, "fast")):
+    for v, name in ((0, "generic"), (1, "fast"), (2, "splat-parallel"), (1, "fast"), (2, "splat-parallel")):
         L.lg_set_tuning(5, v)
         measure(f"{state}: {name} kernel")
+    L.lg_set_tuning(5, 1)
     for v, name in ((0, "generic"), (1, "packed"), (0, "generic"), (1, "packed")):      # blend forward: generic loop vs the packed 8x16 loop
         L.lg_set_tuning(7, v)
         for i in range(8):

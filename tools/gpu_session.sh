@@ -16,6 +16,7 @@
 #   hunt:<runs>  the same loop in the configuration that faulted, with poisoned buffers + validators + breadcrumbs (see the stage)
 #   conv:<runs>  tests/convergence_3m.py with <runs> executor trainers in ONE process (operator curve taken from profiles/), allocator
 #                snapshots on, late-phase state saved to /tmp/late.pt at epoch 120 by the first trainer
+#   bwdab        tools/bwd_ab.py: blend backward variants (lg_set_tuning key 5: generic / fast / splat-parallel) on the bench workload
 #   late         tools/late_phase.py ab + parity on /tmp/late.pt            latetrace  kernel trace + LDS counters of late-phase steps
 #   dpglue       tools/dp_glue_bench.py on the trained-state cloud
 TAG=$1; shift
@@ -124,6 +125,8 @@ PY
       timeout -s KILL 600 python tools/late_phase.py parity /tmp/late.pt > gpurun_out/late_parity_$TAG.log 2>&1; grep -E "parity|PARITY" gpurun_out/late_parity_$TAG.log | tail -12 ;;
     critical)        # blend kernels: whole frame against the heaviest tiles alone (is the launch a critical path?)
       timeout -s KILL 300 python tools/late_phase.py critical recipe > gpurun_out/critical_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/critical_$TAG.log | tail -12 ;;
+    bwdab)           # blend backward in situ on the bench workload: generic / fast / splat-parallel kernels, fresh and after 1000 steps
+      timeout -s KILL 400 python tools/bwd_ab.py 3m_1080p 1000 > gpurun_out/bwd_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/bwd_ab_$TAG.log | tail -24 ;;
     recipeab:*)      # step / forward time of chosen variants on the training_state recipe
       timeout -s KILL 600 python tools/late_phase.py ab recipe ${STAGE#recipeab:} > gpurun_out/recipe_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/recipe_ab_$TAG.log | tail -12 ;;
     recipetrace:*)   # kernel trace of one named variant on the recipe state
