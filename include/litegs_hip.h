@@ -204,7 +204,10 @@ int lg_unpack_gradient(const float* packed_grad, const float* packed /*[V,N,16] 
                        float* d_color /*[V,3,N]*/, float* d_opacity /*[1,N]*/, void* stream);                        /* raster.cu:855-886 */
 /* developer hook (no reference counterpart): selects launch variants of the blend kernels for A/B measurements.
  * key 0: tiles per workgroup of the blend backward (1, 2, 4); key 1 / 2: workgroup -> tile map of the backward / forward
- * (0 = one band per XCD, 1 = identity, C >= 2 = runs of C workgroups interleaved over the XCDs). */
+ * (0 = one band per XCD, 1 = identity, C >= 2 = runs of C workgroups interleaved over the XCDs); key 4: heaviest-first tile schedule
+ * on / off; key 5: blend backward of 8x16 tiles without statistics (0 generic, 1 the packed two-pixel kernel = default, 2 the
+ * splat-parallel formulation); key 7: packed blend forward on / off; key 8: issue priority by schedule rank; keys 10 / 11: key emission
+ * (in-workgroup tile ceiling, groups on demand).  Defaults are the measured best; see DESIGN.md section 9. */
 int lg_set_tuning(int key, int value);
 int lg_stat_in_record_supported(int TH, int TW);   /* 1: statistic renders of this tile shape carry their three statistics in gradient-record slots 9-11 (raster.hip) */
 

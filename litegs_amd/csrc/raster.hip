@@ -1125,8 +1125,9 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
 // its sequential walk has to be rebuilt across the lanes: the transmittance in front of splat l is T_state / prod_{i <= l} (1 - alpha_i)
 // and the behind-colour recursion Bd <- (1 - alpha) Bd + alpha (c . g) is an affine map per splat, so one inclusive scan of affine maps
 // over the 64 lanes (six DPP steps: row_shr 1, 2, 4, 8, row_bcast 15, 31; a multiply and a multiply-add each) yields both, its exclusive
-// form (wave_shr 1) gives every lane the Bd it sees, and lane 63 holds the pixel's new state.  No nine-value reduction per (tile, splat),
-// nine plain atomics per lane and batch instead of one nine-lane atomic per (tile, splat) -- against two 64-lane scans per (pixel, batch).
+// form (wave_shr 1) gives every lane the Bd it sees, and lane 63 holds the pixel's new state.  No nine-value reduction per (tile, splat);
+// the 64 x 9 sums of a batch are transposed through LDS into nine atomic instructions of consecutive words -- against two 64-lane scans
+// per (pixel, batch).
 // ---------------------------------------------------------------------------------------------
 #define DPP_MOV_F(old_, v_, ctrl_, rm_) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old_), __float_as_int(v_), ctrl_, rm_, 0xF, false))
 // One step of the inclusive scan of affine maps: (A, B) <- (A, B) o (A_low, B_low) -- first the lower lanes' map, then this lane's.  With the
@@ -1150,6 +1151,8 @@ __global__ void __launch_bounds__(256) raster_backward_sp_kernel(const int* __re
     constexpr int TH = 8, TW = 16, NPX = TH * TW;
     __shared__ float4 px_a[4][NPX];       // per pixel: T behind the current batch, Bd, dL/dR, dL/dG
     __shared__ float4 px_b[4][NPX];       // dL/dB, last_contributor (int bits), x, y
+    __shared__ float tr9[4][64 * 9];      // a batch's 64 x 9 sums, transposed for the atomics
+    __shared__ int trid[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int view = blockIdx.y;
     const int nb = gridDim.x;
@@ -1230,10 +1233,22 @@ __global__ void __launch_bounds__(256) raster_backward_sp_kernel(const int* __re
                 *reinterpret_cast<float2*>(&px_a[wave][p]) = st2;
             }
         }
-        if (act) {
-            float* g = pg + (size_t)rid * GREC;
-            unsafeAtomicAdd(g + 0, Mx); unsafeAtomicAdd(g + 1, My); unsafeAtomicAdd(g + 2, Mxx); unsafeAtomicAdd(g + 3, Mxy); unsafeAtomicAdd(g + 4, Myy);
-            unsafeAtomicAdd(g + 5, dR); unsafeAtomicAdd(g + 6, dG); unsafeAtomicAdd(g + 7, dB); unsafeAtomicAdd(g + 8, M0);
+        // The 64 x 9 sums leave through an LDS transpose: as nine atomics per lane every instruction touched 64 records (576 line requests
+        // per batch, measured 4x the whole kernel's issue time); transposed, consecutive lanes hold consecutive words of a record and an
+        // instruction touches 7-8 of them -- the request count of the pixel-parallel kernel's one nine-lane atomic per (tile, splat).
+        float* t9 = tr9[wave];
+        t9[lane * 9 + 0] = Mx; t9[lane * 9 + 1] = My; t9[lane * 9 + 2] = Mxx; t9[lane * 9 + 3] = Mxy; t9[lane * 9 + 4] = Myy;
+        t9[lane * 9 + 5] = dR; t9[lane * 9 + 6] = dG; t9[lane * 9 + 7] = dB; t9[lane * 9 + 8] = M0;
+        trid[wave][lane] = (int)rid;
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = hi - lo;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int f = k * 64 + lane;
+            const int sidx = (f * 7282) >> 16;                       // f / 9 for f < 576
+            const int c = f - 9 * sidx;
+            const float v = t9[f];
+            if (sidx < cnt && v != 0.0f) unsafeAtomicAdd(pg + (size_t)trid[wave][sidx] * GREC + c, v);
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -1,4 +1,4 @@
-"""Developer A/B tool: in-situ blend-backward time of the bench workload, generic kernel vs the 8x16 fast kernel (lg_set_tuning key 5),
+"""Developer A/B tool: in-situ blend-backward time of the bench workload, generic kernel vs the 8x16 fast kernel vs the splat-parallel variant (lg_set_tuning key 5: 0 / 1 / 2),
 on the fresh cloud and after a soak of training steps (the trained-state cloud).  Learning rates are zeroed while measuring so that both
 variants see the same cloud.  usage: python tools/bwd_ab.py [config] [soak_steps]"""
 import os, sys, time
