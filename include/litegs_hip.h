@@ -359,6 +359,24 @@ int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count, int ch
                         float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
                         const float* lr6 /*host: xyz, sh_0, sh_rest, opacity, scale, rot*/, float b1, float b2, float eps,
                         unsigned char* touched /*nullable uint8[chunks*S], as in lg_fused_backward_adam*/, void* stream);
+/* The same three steps under SPECULATIVE depth-bound culling across ranks (no gated repeat of a culled frame; litegs_amd/dp.py
+ * "rank-consistent speculation").  poison: the renderer's sticky device word (LgFusedCtx.poison): a rank whose culled forward failed
+ * sends header word 1 = 1 with its records; the slot map of EVERY rank derives the step's verdict from the same gathered headers --
+ * some rank failed, or some block overflowed (then a failed step, not an error) -- raises its own poison word and writes
+ * status_host[0] = step_id, status_host[1] = bit r: rank r's flag | bit 8: overflow (a function of the headers only); the backward +
+ * Adam launch of a poisoned replica changes nothing, any other records step_id in applied_host.  All pointers nullable = the plain forms. */
+int lg_dp_compact_moments_spec(const float* packed_grad, const int64_t* vis_ids, const int* vis_num, int A, int S, int cap, float* block,
+                               const int* hot_of, int* hot_counter, const int* poison, void* stream);
+int lg_dp_build_slotmap_spec(const float* gathered, int W, int cap, long long total, int* slot, int* host_max_k, int* overflow,
+                             int* poison, int* status_host /*pinned int[2]*/, int step_id, void* stream);
+int lg_dp_backward_adam_spec(const int64_t* union_ids, const int* union_count, int chunks, int S, int H, int W_img,
+                             const float* views_host, const float* projs_host, int world, int degree, int R,
+                             const float* gathered, int cap, int* slot,
+                             float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
+                             float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
+                             float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
+                             const float* lr6, float b1, float b2, float eps, unsigned char* touched,
+                             const int* poison, int* applied_host /*pinned int*/, int step_id, void* stream);
 
 /* ---- knn.hip : simple_knn._C.distCUDA2 (litegs/submodules/simple-knn/simple_knn.cu:186-222; caller litegs/scene/point.py:8) --------
  * mean squared distance of every point to its 3 nearest neighbours (exact).  points [P,3] fp32, mean_dist2 [P]. */

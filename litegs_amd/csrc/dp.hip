@@ -34,7 +34,8 @@
 __global__ void __launch_bounds__(256) dp_compact_kernel(const float4* __restrict__ packed_grad, const int64_t* __restrict__ vis_ids,
                                                          const int* __restrict__ vis_num, int A, int S, int cap, float* __restrict__ block,
                                                          const int* __restrict__ hot_of /*nullable: gradient replicas to fold (raster.hip)*/,
-                                                         int* __restrict__ hot_counter /*nullable: reset for the next frame's projection*/)
+                                                         int* __restrict__ hot_counter /*nullable: reset for the next frame's projection*/,
+                                                         const int* __restrict__ poison /*nullable: speculative culling, see dp_slotmap_kernel*/)
 {
     __shared__ int cnt[4][4];          // [j][wave]: touched records of round j in that wave
     __shared__ int base_s;
@@ -43,6 +44,9 @@ __global__ void __launch_bounds__(256) dp_compact_kernel(const float4* __restric
     const long long i0 = (long long)blockIdx.x * DP_BATCH;
     const int nvis = vis_num[0];
     if (hot_counter != nullptr && blockIdx.x == 0 && tid == 0) *hot_counter = 0;
+    // header word 1: "this rank's culled forward failed (or an earlier step did)" travels with the records, so that every rank learns it
+    // from the same gathered headers
+    if (poison != nullptr && blockIdx.x == 0 && tid == 0) reinterpret_cast<int*>(block)[1] = (*poison != 0) ? 1 : 0;
     // thread t takes records i0 + j * 256 + t, j = 0..3: every wave instruction reads 64 consecutive 64-byte lines
     float mom[4][9];
     int gid[4], rank[4];
@@ -95,18 +99,32 @@ LG_API int lg_dp_record_floats(void) { return DP_REC; }
 LG_API int lg_dp_compact_moments(const float* packed_grad, const int64_t* vis_ids, const int* vis_num, int A, int S, int cap,
                                  float* block /*[(1 + cap) * 10]*/, const int* hot_of, int* hot_counter, void* stream)
 {
+    return lg_dp_compact_moments_spec(packed_grad, vis_ids, vis_num, A, S, cap, block, hot_of, hot_counter, nullptr, stream);
+}
+
+LG_API int lg_dp_compact_moments_spec(const float* packed_grad, const int64_t* vis_ids, const int* vis_num, int A, int S, int cap,
+                                      float* block, const int* hot_of, int* hot_counter, const int* poison /*nullable device int*/, void* stream)
+{
     if (A <= 0 || cap <= 0 || (hot_of != nullptr && hot_counter == nullptr)) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(block, 0, sizeof(float) * DP_REC, s);          // the header row
     if (e != hipSuccess) return (int)e;
     const long long N = (long long)A * S;
-    hipLaunchKernelGGL(dp_compact_kernel, dim3(lg_cdiv(N, DP_BATCH)), dim3(256), 0, s, (const float4*)packed_grad, vis_ids, vis_num, A, S, cap, block, hot_of, hot_counter);
+    hipLaunchKernelGGL(dp_compact_kernel, dim3(lg_cdiv(N, DP_BATCH)), dim3(256), 0, s, (const float4*)packed_grad, vis_ids, vis_num, A, S, cap, block, hot_of, hot_counter, poison);
     LG_RETURN_LAST();
 }
 
 // ---------------------------------------------------------------------------------------------
+// Speculative culling across ranks (no reference counterpart; litegs_amd/dp.py "rank-consistent speculation").  With `poison` given, a step
+// FAILS when some rank's header carries the failure flag (its culled forward violated a depth bound, or an earlier step failed: the flag is
+// sticky) or when some rank's record count outgrew the block capacity.  Every rank derives that verdict from the SAME gathered headers, so
+// all replicas raise their sticky poison word at the same step -- from which on no backward + Adam launch changes anything on any rank
+// -- and report it in the same per-step status words: status[0] = step number, status[1] = bit r: rank r's flag (its forward failed in this step or it was
+// poisoned before), bit 8: a block overflowed -- nothing a rank knows on its own enters the status.  The hosts read a step's status behind that step's event, at a fixed lag, and so
+// all start the replay at the same step of their enqueue sequence: the collectives stay matched.
 __global__ void __launch_bounds__(256) dp_slotmap_kernel(const float* __restrict__ gathered, int W, int cap, long long total,
-                                                         int* __restrict__ slot, int* __restrict__ host_max_k, int* __restrict__ overflow)
+                                                         int* __restrict__ slot, int* __restrict__ host_max_k, int* __restrict__ overflow,
+                                                         int* __restrict__ poison, int* __restrict__ status_host, int step_id)
 {
     const int r = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -120,6 +138,21 @@ __global__ void __launch_bounds__(256) dp_slotmap_kernel(const float* __restrict
     if (r == 0 && k == 0) {
         int mx = 0;
         for (int q = 0; q < W; q++) mx = max(mx, __float_as_int(gathered[(size_t)q * (1 + cap) * DP_REC]));
+        if (poison != nullptr) {  // speculative step: an overflow is a failed step (replayed with an exact capacity), not an error
+            int flags = 0;
+            for (int q = 0; q < W; q++) flags |= (__float_as_int(gathered[(size_t)q * (1 + cap) * DP_REC + 1]) != 0) ? (1 << q) : 0;
+            if (mx > cap) flags |= 1 << 8;
+            if (flags != 0) __hip_atomic_store(poison, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (host_max_k) {
+                __hip_atomic_store(host_max_k, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(host_max_k + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (status_host) {
+                __hip_atomic_store(status_host + 1, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(status_host, step_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
         if (host_max_k) {         // word 0: the job's largest count (sizes the slot's next visit); word 1: that count when it outgrew THIS step's capacity
             __hip_atomic_store(host_max_k, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(host_max_k + 1, mx > cap ? mx : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -132,9 +165,16 @@ LG_API int lg_dp_build_slotmap(const float* gathered /*[W][(1 + cap) * 10]*/, in
                                int* slot /*[W][total], all zero between steps*/, int* host_max_k /*nullable pinned int[2]: {largest count, overflow marker}*/,
                                int* overflow /*nullable device flag, sticky*/, void* stream)
 {
+    return lg_dp_build_slotmap_spec(gathered, W, cap, total, slot, host_max_k, overflow, nullptr, nullptr, 0, stream);
+}
+
+// poison (nullable device int, sticky), status_host (nullable pinned int[2]), step_id: see dp_slotmap_kernel
+LG_API int lg_dp_build_slotmap_spec(const float* gathered, int W, int cap, long long total, int* slot, int* host_max_k, int* overflow,
+                                    int* poison, int* status_host, int step_id, void* stream)
+{
     if (W <= 0 || W > DP_MAX_WORLD || cap <= 0) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(dp_slotmap_kernel, dim3(lg_cdiv(cap, 256), W), dim3(256), 0, (hipStream_t)stream, gathered, W, cap, total, slot,
-                       host_max_k, overflow);
+                       host_max_k, overflow, poison, status_host, step_id);
     LG_RETURN_LAST();
 }
 
@@ -151,9 +191,14 @@ __global__ void dp_backward_adam_kernel(const int64_t* __restrict__ union_ids, c
                                         float* __restrict__ m_sh0, float* __restrict__ m_shr, float* __restrict__ m_opa,
                                         float* __restrict__ v_pos, float* __restrict__ v_scale, float* __restrict__ v_rot,
                                         float* __restrict__ v_sh0, float* __restrict__ v_shr, float* __restrict__ v_opa,
-                                        unsigned char* __restrict__ touched)
+                                        unsigned char* __restrict__ touched,
+                                        const int* __restrict__ poison, int* __restrict__ applied_host, int step_id)
 {
     const int a = blockIdx.x, t = threadIdx.x;
+    if (poison != nullptr) {                 // speculative culling: a failed step (this one or an earlier one) -> nothing is updated, on any rank
+        if (*poison != 0) return;
+        if (a == 0 && t == 0) __hip_atomic_store(applied_host, step_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (a >= union_count[0]) return;
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const size_t CS = (size_t)C * S;
@@ -239,6 +284,22 @@ LG_API int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count,
                                const float* lr6 /*xyz, sh_0, sh_rest, opacity, scale, rot*/, float b1, float b2, float eps,
                                unsigned char* touched /*nullable, as in lg_fused_backward_adam*/, void* stream)
 {
+    return lg_dp_backward_adam_spec(union_ids, union_count, chunks, S, H, W_img, views_host, projs_host, world, degree, R, gathered, cap, slot,
+                                    pos, scale, rot, sh0, shr, opa, m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa, v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa,
+                                    lr6, b1, b2, eps, touched, nullptr, nullptr, 0, stream);
+}
+
+// poison (nullable device int) raised -> the launch changes nothing; otherwise it records step_id in the pinned word applied_host
+LG_API int lg_dp_backward_adam_spec(const int64_t* union_ids, const int* union_count, int chunks, int S, int H, int W_img,
+                                    const float* views_host, const float* projs_host, int world, int degree, int R,
+                                    const float* gathered, int cap, int* slot,
+                                    float* pos, float* scale, float* rot, float* sh0, float* shr, float* opa,
+                                    float* m_pos, float* m_scale, float* m_rot, float* m_sh0, float* m_shr, float* m_opa,
+                                    float* v_pos, float* v_scale, float* v_rot, float* v_sh0, float* v_shr, float* v_opa,
+                                    const float* lr6, float b1, float b2, float eps, unsigned char* touched,
+                                    const int* poison, int* applied_host, int step_id, void* stream)
+{
+    if (poison != nullptr && applied_host == nullptr) return (int)hipErrorInvalidValue;
     if (world <= 0 || world > DP_MAX_WORLD || chunks <= 0 || S <= 0 || S > 1024) return (int)hipErrorInvalidValue;
     CameraSet cams;
     for (int r = 0; r < DP_MAX_WORLD; r++) {
@@ -250,7 +311,7 @@ LG_API int lg_dp_backward_adam(const int64_t* union_ids, const int* union_count,
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_DP(D) hipLaunchKernelGGL(dp_backward_adam_kernel<D>, dim3(chunks), dim3(S), 0, s, union_ids, union_count, cams, world, ar, chunks, S, R, \
                                         gathered, cap, slot, pos, scale, rot, sh0, shr, opa, m_pos, m_scale, m_rot, m_sh0, m_shr, m_opa,               \
-                                        v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched)
+                                        v_pos, v_scale, v_rot, v_sh0, v_shr, v_opa, touched, poison, applied_host, step_id)
     switch (degree) {
     case 0: LAUNCH_DP(0); break;
     case 1: LAUNCH_DP(1); break;

@@ -240,31 +240,142 @@ def frame_for(step: int, rank: int, world: int, n_frames: int, perm=None) -> int
 class HipMomentOps:
     """Device primitives of the moment exchange on the HIP kernels (no CPU path)."""
 
+    # `spec` (optional, all three): a Speculation record of the exchange -- the step runs under rank-consistent speculative culling
     @staticmethod
-    def compact_moments(pg, vis_ids, vis_num, A, S, cap, block, hot_of=None, hot_counter=None):
+    def compact_moments(pg, vis_ids, vis_num, A, S, cap, block, hot_of=None, hot_counter=None, spec=None):
         """hot_of / hot_counter (device addresses, optional): the frame's gradient replicas (csrc/raster.hip) are folded into the records"""
         from ._lib import check, lib
-        check(lib().lg_dp_compact_moments(pg.data_ptr(), vis_ids.data_ptr(), vis_num.data_ptr(), A, S, cap, block.data_ptr(), hot_of, hot_counter,
-                                          torch.cuda.current_stream().cuda_stream), "dp_compact_moments")
+        check(lib().lg_dp_compact_moments_spec(pg.data_ptr(), vis_ids.data_ptr(), vis_num.data_ptr(), A, S, cap, block.data_ptr(), hot_of, hot_counter,
+                                               spec.poison.data_ptr() if spec is not None else None,
+                                               torch.cuda.current_stream().cuda_stream), "dp_compact_moments")
 
     @staticmethod
-    def build_slotmap(gathered, W, cap, total, slot, host_max_k_ptr, overflow):
+    def build_slotmap(gathered, W, cap, total, slot, host_max_k_ptr, overflow, spec=None):
         from ._lib import check, lib
-        check(lib().lg_dp_build_slotmap(gathered.data_ptr(), W, cap, total, slot.data_ptr(), host_max_k_ptr, overflow.data_ptr(),
-                                        torch.cuda.current_stream().cuda_stream), "dp_build_slotmap")
+        check(lib().lg_dp_build_slotmap_spec(gathered.data_ptr(), W, cap, total, slot.data_ptr(), host_max_k_ptr, overflow.data_ptr(),
+                                             spec.poison.data_ptr() if spec is not None else None,
+                                             spec.status_addr(spec.step_id) if spec is not None else None, spec.step_id if spec is not None else 0,
+                                             torch.cuda.current_stream().cuda_stream), "dp_build_slotmap")
 
     @staticmethod
-    def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps, touched=None):
+    def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps, touched=None,
+                      spec=None):
         import ctypes
         from ._lib import check, lib
         va = (ctypes.c_float * (16 * W))(*[float(x) for v in views for x in v])
         pa = (ctypes.c_float * (16 * W))(*[float(x) for v in projs for x in v])
         la = (ctypes.c_float * 6)(*lr6)
-        check(lib().lg_dp_backward_adam(union_ids.data_ptr(), union_count.data_ptr(), chunks, S, H, Wimg, va, pa, W, degree, R,
-                                        gathered.data_ptr(), cap, slot.data_ptr(), *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms],
-                                        *[v.data_ptr() for v in vs], la, 0.9, 0.999, eps, touched.data_ptr() if touched is not None else None,
-                                        torch.cuda.current_stream().cuda_stream),
+        check(lib().lg_dp_backward_adam_spec(union_ids.data_ptr(), union_count.data_ptr(), chunks, S, H, Wimg, va, pa, W, degree, R,
+                                             gathered.data_ptr(), cap, slot.data_ptr(), *[p.data_ptr() for p in ps], *[m.data_ptr() for m in ms],
+                                             *[v.data_ptr() for v in vs], la, 0.9, 0.999, eps, touched.data_ptr() if touched is not None else None,
+                                             spec.poison.data_ptr() if spec is not None else None,
+                                             spec.applied_addr if spec is not None else None, spec.step_id if spec is not None else 0,
+                                             torch.cuda.current_stream().cuda_stream),
               "dp_backward_adam")
+
+
+class Speculation:
+    """What a step under rank-consistent speculative culling hands to the device primitives: the renderer's sticky poison word, the pinned
+    word that receives the number of the last step whose Adam ran, and a ring of per-step status words {step number, flags} (flags: bit r =
+    rank r's culled forward failed, bit 8 = a record block overflowed: functions of the gathered headers, the same on every rank)."""
+    RING = 64
+    OVERFLOW = 1 << 8
+
+    def __init__(self, poison: torch.Tensor, applied_addr, words=None):
+        self.poison, self.applied_addr = poison, applied_addr
+        self.step_id = 0
+        if words is None:                      # device stores land here: pinned words of the library's arena (hostwords.py)
+            from .hostwords import HostWords
+            self._owner = HostWords(2 * self.RING)
+            self.words = self._owner.a
+            self._addr = self._owner.addr
+        else:                                  # CPU tests: a plain integer array, "addresses" are indices
+            self.words = words
+            self._addr = lambda i: i
+        self.words[:] = 0
+
+    def status_addr(self, step_id: int):
+        return self._addr(2 * (step_id % self.RING))
+
+    def status(self, step_id: int) -> int:
+        """flags of step `step_id` -- call only after the step's event completed"""
+        i = 2 * (step_id % self.RING)
+        if int(self.words[i]) != step_id:
+            raise RuntimeError(f"litegs_amd.dp: status word of step {step_id} holds step {int(self.words[i])} (ring overrun, or the step never ran)")
+        return int(self.words[i + 1])
+
+    def close(self):
+        owner = getattr(self, "_owner", None)
+        if owner is not None:
+            owner.close()
+            self._owner = None
+
+
+class LockstepSpeculation:
+    """Host side of rank-consistent speculative culling (see MomentExchange): which steps may still have to be replayed, when a step's
+    verdict is read, and the replay itself.  Device agnostic -- the owner supplies
+
+      run(record, force)        enqueue the step `record` = (step number, ...) again; force: unculled on this rank
+      on_failed(record, flags)  bookkeeping before the forced replay of a failed step (clear the poison word, widen the frame's margin ...)
+      event()                   -> an object with synchronize(), recorded behind the step just enqueued
+      sync()                    everything enqueued so far has run
+
+    Every rank calls before_step / after_step / flush at the same points of its step sequence; since the verdicts are the same on every
+    rank (they are functions of the gathered headers), so are all decisions taken here, and the collectives inside `run` stay matched."""
+
+    def __init__(self, exchange, depth: int, run, on_failed, event, sync):
+        self.ex, self.depth = exchange, max(int(depth), 1)
+        self.run, self.on_failed, self.event, self.sync = run, on_failed, event, sync
+        self.ring = []                 # records of the steps whose verdict has not been read (or that follow a failed one)
+        self.events = []               # (step number, event) in step order
+        self.replays = 0
+
+    def before_step(self, record) -> None:
+        """record[0] = the step number.  Reads the verdicts that are due, replays if one of them is a failure, then registers the step."""
+        while len(self.events) >= self.depth:
+            self._verify(*self.events.pop(0))
+        self.ring.append(record)
+
+    def after_step(self, record) -> None:
+        self.events.append((record[0], self.event()))
+
+    def flush(self) -> None:
+        while self.events:
+            self._verify(*self.events.pop(0))
+        self.ring = []
+
+    def _verify(self, no: int, ev) -> None:
+        ev.synchronize()
+        flags = self.ex.status(no)
+        if flags == 0:
+            self.ring = [r for r in self.ring if r[0] > no]
+            return
+        self._recover(no, flags)
+
+    def _recover(self, first_failed: int, flags: int) -> None:
+        """From `first_failed` on no replica changed anything.  Replay in order, each step checked before the next: the failed one
+        unculled on every rank and -- after an overflow -- with an exact block capacity (MomentExchange.after_failed_step)."""
+        self.sync()                    # the steps enqueued behind the failed one have run (as no-ops), their collectives included
+        todo = [r for r in self.ring if r[0] >= first_failed]
+        self.ring, self.events = [], []
+        i, force = 0, True
+        while i < len(todo):
+            rec = todo[i]
+            if force:
+                self.on_failed(rec, flags)
+            self.ring = [rec]
+            self.run(rec, force)
+            self.replays += 1
+            self.sync()
+            again = self.ex.status(rec[0])
+            if again != 0:
+                if force:
+                    raise RuntimeError(f"litegs_amd.dp: step {rec[0]} failed again when replayed unculled with an exact block capacity (flags {again:#x})")
+                force, flags = True, again            # a culled step behind the failed one failed as well: same treatment, from here
+                continue
+            force = False
+            i += 1
+        self.ring = []
 
 
 class MomentExchange:
@@ -284,14 +395,60 @@ class MomentExchange:
 
     ``profile = True`` brackets the phases of every step with events (``timing()``): wait for the union-of-visibility collective,
     record compaction, all_gather, slot map, backward + Adam over the union.
+
+    **Rank-consistent speculation** (``enable_speculation``; driven by ``FrameTrainer`` with ``speculative = True``).  On one GPU a culled
+    step enqueues no gated repeat: a violated depth bound poisons the Adam launches from that step on and the trainer replays them
+    (csrc/fused.hip).  Across ranks the same works only if every replica stops updating at the SAME step and every host starts the replay
+    at the SAME point of its enqueue sequence -- otherwise the collectives of a replaying rank pair up with those of a rank that is
+    still enqueuing new steps.  Both follow from one rule: *the verdict on a step is a function of the gathered headers*.  A rank
+    whose culled forward failed sends a flag in its header; every rank's slot-map kernel reads all W headers, raises its own sticky
+    poison word when any flag is set -- or when any record count outgrew the block capacity, which turns the overflow from an error
+    into a failed step -- and writes the verdict into that step's status words (``Speculation``).  The hosts never look at the sticky
+    word (its value at a given wall-clock moment differs between ranks); they read the status of step n - depth behind that step's event
+    while enqueuing step n, so all of them find the first failed step s at the same n, with the same steps s+1 .. n-1 enqueued behind it
+    (no-ops on every replica, collectives matched).  The replay runs step s unculled on every rank, with an exact (blocking) block
+    capacity if the failure was an overflow, then the steps behind it as they were -- checking each before the next.  Because an
+    overflow is now survivable the capacity shrinks from 1.5 x to ``spec_cap_factor`` = 1.125 x the slot's previous count: the
+    all_gather moves a quarter less (the padding was a third of the exchanged bytes).
     """
 
     def __init__(self, params, world: int, ops=HipMomentOps, union_ops=HipOps, group=None, n_slots: int = 64):
         self.world, self.ops, self.union_ops, self.group = world, ops, union_ops, group
         self.n_slots = max(int(n_slots), 1)
         self.cap_factor, self.cap_margin = 1.5, 64       # block capacity = factor x (largest count of the slot's last visit) + margin
+        self.spec_cap_factor = 1.125                     # ... under speculation, where an overflow is a replayed step instead of an error
         self.profile = False
+        self.spec = None                                 # Speculation record while rank-consistent speculative culling is on
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.overflow_replays = 0
         self.rebind(params)
+
+    supports_speculation = True
+
+    def enable_speculation(self, poison: torch.Tensor, applied_addr, words=None) -> "Speculation":
+        """poison: the renderer's sticky device word; applied_addr: address of its pinned 'last applied step' word (fast.FusedRenderer)"""
+        if self.spec is None or self.spec.poison is not poison:
+            if self.spec is not None:
+                self.spec.close()
+            self.spec = Speculation(poison, applied_addr, words)
+        return self.spec
+
+    def disable_speculation(self) -> None:
+        if self.spec is not None:
+            self.spec.step_id = 0
+
+    def status(self, step_id: int) -> int:
+        return self.spec.status(step_id)
+
+    def after_failed_step(self, slot: int, flags: int) -> None:
+        """host side of a replay (every rank, same point): the slot map may hold entries of the steps that ran as no-ops; an overflowed
+        slot is sized exactly (blocking) on its next visit -- which is the replay of the failed step"""
+        self.slot.zero_()
+        self.in_flight = []
+        if flags & Speculation.OVERFLOW:
+            self._wait_slot(slot)
+            self.fb_k[slot, 0] = 0
+            self.overflow_replays += 1
 
     def rebind(self, params) -> None:
         p0 = params[0]
@@ -400,17 +557,24 @@ class MomentExchange:
         return {"steps": n, **{k: round(v / max(n, 1), 4) for k, v in acc.items()}}
 
     @torch.no_grad()
-    def step(self, pending: dict, cams, ps, ms, vs, lr6, eps: float, H: int, Wimg: int, slot: int = 0, touched=None):
+    def step(self, pending: dict, cams, ps, ms, vs, lr6, eps: float, H: int, Wimg: int, slot: int = 0, touched=None, step_id: int = 0):
         """pending: what the blend backward left (litegs_amd/fast.py: pg, A, S, vis_ids, vis_num, degree, chunks, Rr); cams: the W
         ranks' (view_host16, proj_host16) of this step in rank order; ps / ms / vs: parameters and Adam moments in the order
         xyz, scale, rot, sh_0, sh_rest, opacity; touched (nullable uint8[chunks*S]): the optimizer's "has Adam history" flags -- Gaussians
-        without history that no rank sent a record for are skipped (an exact no-op).  -> (union_ids, union_count)"""
+        without history that no rank sent a record for are skipped (an exact no-op); step_id > 0 (with enable_speculation): the step runs
+        under rank-consistent speculative culling and reports into the status words of that number.  -> (union_ids, union_count)"""
         W, S, chunks = self.world, self.S, self.chunks
+        spec = self.spec if (self.spec is not None and step_id > 0) else None
+        sk = {}
+        if spec is not None:
+            spec.step_id = int(step_id)
+            sk = dict(spec=spec)
         A, vis_ids, vis_num, pg = pending["A"], pending["vis_ids"], pending["vis_num"], pending["pg"]
         if not 0 <= slot < self.n_slots:
             raise ValueError(f"MomentExchange: slot {slot} outside [0, {self.n_slots}) -- construct it with n_slots = steps per epoch")
         self.steps += 1
-        self._raise_if_dropped(self.steps - 2)           # steps older than the previous one: their words have landed
+        if spec is None:
+            self._raise_if_dropped(self.steps - 2)       # steps older than the previous one: their words have landed
         dev = pg.device
         hot = {}                                         # gradient replicas of this frame (litegs_amd/fast.py): folded by the compaction
         if pending.get("replicas"):
@@ -429,33 +593,39 @@ class MomentExchange:
         self._mark("union_wait_ms")
         union_ids, union_count, _ = self.union_ops.compact(self.mask)
         # capacity of the record blocks: the count every rank's device derived from the gathered headers of the slot's last visit
-        self._raise_if_dropped(0, only_slot=slot)
+        if spec is None:
+            self._raise_if_dropped(0, only_slot=slot)
         self._wait_slot(slot)
         pred = int(self.fb_k[slot, 0])
-        if pred <= 0:                                    # first visit of the slot: blocking count
+        exact = pred <= 0
+        if exact:                                        # first visit of the slot (or the replay of an overflowed step): blocking count
             probe = torch.empty(((1 + A * S) * nrec,), dtype=torch.int32, device=dev)
             self.ops.compact_moments(pg, vis_ids, vis_num, A, S, A * S, probe, **hot)
             k = probe[:1].clone()
             dist.all_reduce(k, op=dist.ReduceOp.MAX, group=self.group)
             pred = max(int(k.item()), 1)
-        cap = int(self.cap_factor * pred) + self.cap_margin
+        if exact:
+            cap = pred + self.cap_margin                 # the count IS this step's: no slack needed
+        else:
+            cap = int((self.spec_cap_factor if spec is not None else self.cap_factor) * pred) + self.cap_margin
         self.last_cap = cap
         # wire container: int32 words (record = index word + nine float bit patterns) -- an integer collective can only copy
         block = torch.empty(((1 + cap) * nrec,), dtype=torch.int32, device=dev)
-        self.ops.compact_moments(pg, vis_ids, vis_num, A, S, cap, block, **hot)
+        self.ops.compact_moments(pg, vis_ids, vis_num, A, S, cap, block, **hot, **sk)
         self._mark("compact_ms")
         gathered = torch.empty((W * (1 + cap) * nrec,), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(gathered, block, group=self.group)
         self._mark("all_gather_ms")
         self.bytes_last = (W - 1) * block.numel() * 4
-        self.ops.build_slotmap(gathered, W, cap, chunks * S, self.slot, self.fb_k.data_ptr() + 8 * slot, self.overflow)
+        self.ops.build_slotmap(gathered, W, cap, chunks * S, self.slot, self.fb_k.data_ptr() + 8 * slot, self.overflow, **sk)
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record()
             self.fb_event[slot] = ev
-        self.in_flight.append((self.steps, slot))
+        if spec is None:
+            self.in_flight.append((self.steps, slot))
         self._mark("slotmap_ms")
         self.ops.backward_adam(union_ids, union_count, chunks, S, H, Wimg, [c[0] for c in cams], [c[1] for c in cams], W, pending["degree"],
-                               pending["Rr"], gathered, cap, self.slot, ps, ms, vs, lr6, eps, touched)
+                               pending["Rr"], gathered, cap, self.slot, ps, ms, vs, lr6, eps, touched, **sk)
         self._mark("backward_adam_ms")
         return union_ids, union_count

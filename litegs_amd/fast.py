@@ -739,8 +739,11 @@ class FusedAdam:
         vs = [self.opt.state[p]["exp_avg_sq"] for p in ps]
         lr6 = [float(self._by_name[n]["lr"]) for n in ["xyz", "sh_0", "sh_rest", "opacity", "scale", "rot"]]
         R = self.renderer
+        step_id = 0
+        if R.speculating and getattr(exchange, "spec", None) is not None:       # rank-consistent speculative culling (litegs_amd/dp.py)
+            step_id = int(R.spec_step)
         return exchange.step(pend, cams, ps, ms, vs, lr6, float(self.groups[0]["eps"]), R.H, R.W, slot,
-                             self._touched_flags() if self.skip_untouched else None)
+                             self._touched_flags() if self.skip_untouched else None, step_id=step_id)
 
     @torch.no_grad()
     def step(self, visible_chunk: torch.Tensor, visible_chunks_num: Optional[torch.Tensor]):

@@ -75,6 +75,8 @@ class FrameTrainer:
         self._spec_ring = []          # (step number, frame index, learning rates) of the steps that may still have to be replayed
         self._spec_next = 1
         self._spec_events = []        # one event behind every speculative step still in flight
+        self._spec_exchange = None    # the dp.MomentExchange the speculative steps in flight went through (None: single GPU)
+        self._spec_dp = None          # ... and their bookkeeping (dp.LockstepSpeculation)
         self.spec_depth = 2           # steps the host may run ahead of the device in speculative mode
         self.spec_replays = 0
         self.spec_log = []                # (step number, frame, visits of that frame so far, steps replayed) per violated bound
@@ -101,32 +103,99 @@ class FrameTrainer:
         """grad_hook: None, a gradient hook (dp.GradientExchange.hook: parameter gradients are materialised and exchanged) or a
         dp.MomentExchange (native executor only: the blend backward's moment records are exchanged, backward + Adam stay fused;
         peer_frames = the frame indices of ranks 0..W-1 of this step)."""
-        spec = self.speculative and grad_hook is None and self.fused and self.fuse_adam and self.raw_loss and not STATS.active
-        if self._spec_ring and not spec:
-            self.flush()                                  # leaving the speculative regime: everything enqueued so far must have landed
+        moments = grad_hook is not None and hasattr(grad_hook, "step") and not callable(grad_hook)
+        dp_spec = moments and getattr(grad_hook, "supports_speculation", False)
+        spec = (self.speculative and (grad_hook is None or dp_spec) and self.fused and self.fuse_adam and self.raw_loss and not STATS.active)
+        if self._spec_pending and (not spec or (self._spec_exchange is not (grad_hook if dp_spec else None))):
+            self.flush()                                  # leaving the speculative regime (or changing its kind): everything enqueued must have landed
         if spec:
-            # The host must not run far ahead of the device: everything enqueued behind a failed step is wasted and replayed.  Two steps
-            # in flight keep the device busy (enqueueing a step takes a third of its run time); the wait is on the step before those.
-            if len(self._spec_events) >= self.spec_depth:
-                self._spec_events.pop(0).synchronize()
-            self._spec_poll()
             self.renderer.enable_speculation(self.device)
+            if dp_spec:
+                # across ranks: the verdict on step n - depth is read behind that step's event, at the same point of every rank's enqueue
+                # sequence (litegs_amd/dp.py "rank-consistent speculation"); never the sticky word, whose value at a wall-clock moment differs
+                if self._spec_exchange is not grad_hook:
+                    self._spec_dp_start(grad_hook)
+                rec = (self._spec_next, frame_index, [float(g["lr"]) for g in self.opt.param_groups], hook_slot, peer_frames)
+                self._spec_dp.before_step(rec)
+                self._spec_dp_restore_lrs()
+            else:
+                # The host must not run far ahead of the device: everything enqueued behind a failed step is wasted and replayed.  Two steps
+                # in flight keep the device busy (enqueueing a step takes a third of its run time); the wait is on the step before those.
+                if len(self._spec_events) >= self.spec_depth:
+                    self._spec_events.pop(0).synchronize()
+                self._spec_poll()
             self.renderer.spec_step = self._spec_next
-            self._spec_ring.append((self._spec_next, frame_index, [float(g["lr"]) for g in self.opt.param_groups]))
+            if not dp_spec:
+                self._spec_ring.append((self._spec_next, frame_index, [float(g["lr"]) for g in self.opt.param_groups], hook_slot, peer_frames))
             self._spec_next += 1
-            if len(self._spec_ring) > 64:                 # steps whose Adam launch has reported in need no replay any more
+            if len(self._spec_ring) > 64 and not dp_spec:  # steps whose Adam launch has reported in need no replay any more
                 done = self.renderer.applied_step()
                 self._spec_ring = [r for r in self._spec_ring if r[0] > done]
         else:
             self.renderer.disable_speculation()
+            if moments and hasattr(grad_hook, "disable_speculation"):
+                grad_hook.disable_speculation()
         loss = self._step_body(frame_index, grad_hook, hook_slot, peer_frames)
-        if spec:
+        if spec and dp_spec:
+            self._spec_dp.after_step(rec)
+        elif spec:
             ev = torch.cuda.Event()
             ev.record()
             self._spec_events.append(ev)
         for _ in range(self.sched_ticks):
             self.sched.step()
         return loss
+
+    @property
+    def _spec_pending(self) -> bool:
+        """speculative steps are in flight whose verdict has not been read: the parameters are final only after flush()"""
+        return bool(self._spec_ring) or self._spec_exchange is not None
+
+    # -- speculative culling across ranks (dp.MomentExchange): verdicts at a fixed lag, replay in lock-step (dp.LockstepSpeculation) ---
+    def _spec_dp_start(self, exchange):
+        from . import dp
+        R = self.renderer
+        exchange.enable_speculation(R.spec_poison, R.spec_words.addr(1))
+        state = {}
+
+        def on_failed(rec, flags):
+            no, frame_index, _lrs, slot, _peers = rec
+            R.clear_poison()
+            exchange.after_failed_step(slot, flags)
+            if (flags >> exchange.rank) & 1:              # this rank's bounds were violated: what the gated repeat's bookkeeping does
+                k = self.frames[frame_index % len(self.frames)].cam.index
+                if len(self.spec_log) < 64:
+                    self.spec_log.append((int(no), int(k), int(R.frames[k].visits), 1))
+                R.note_fallback(k)
+
+        def run(rec, force):
+            no, frame_index, lrs, slot, peers = rec
+            if "lrs" not in state:                        # the learning rates of the step being enqueued come back after the replay
+                state["lrs"] = [float(g["lr"]) for g in self.opt.param_groups]
+            for g, lr in zip(self.opt.param_groups, lrs):
+                g["lr"] = lr
+            R.spec_step = no
+            R.force_full = force
+            self._step_body(frame_index, exchange, slot, peers)
+            self.spec_replays += 1
+
+        def event():
+            ev = torch.cuda.Event()
+            ev.record()
+            return ev
+
+        def sync():
+            torch.cuda.current_stream().synchronize()
+
+        self._spec_dp = dp.LockstepSpeculation(exchange, self.spec_depth, run, on_failed, event, sync)
+        self._spec_dp_state = state
+        self._spec_exchange = exchange
+
+    def _spec_dp_restore_lrs(self):
+        lrs = self._spec_dp_state.pop("lrs", None)
+        if lrs is not None:
+            for g, lr in zip(self.opt.param_groups, lrs):
+                g["lr"] = lr
 
     # -- speculative culling: notice, replay ------------------------------------------------------------------------------------
     def _spec_poll(self):
@@ -148,7 +217,7 @@ class FrameTrainer:
             R.clear_poison()
             torch.cuda.current_stream().synchronize()
             current = [float(g["lr"]) for g in self.opt.param_groups]
-            for i, (no, frame_index, lrs) in enumerate(todo):
+            for i, (no, frame_index, lrs, _slot, _peers) in enumerate(todo):
                 for g, lr in zip(self.opt.param_groups, lrs):
                     g["lr"] = lr
                 R.spec_step = no
@@ -158,7 +227,7 @@ class FrameTrainer:
                     if len(self.spec_log) < 64:
                         self.spec_log.append((int(no), int(k), int(R.frames[k].visits), len(todo)))
                     R.note_fallback(k)
-                self._spec_ring.append((no, frame_index, lrs))
+                self._spec_ring.append((no, frame_index, lrs, 0, None))
                 self._step_body(frame_index, None, 0, None)
                 self.spec_replays += 1
             for g, lr in zip(self.opt.param_groups, current):
@@ -167,7 +236,11 @@ class FrameTrainer:
     def flush(self):
         """the parameters reflect every step enqueued so far (speculative mode: failed steps are replayed first); synchronises"""
         torch.cuda.current_stream().synchronize()
-        if self.renderer.spec_words is not None:
+        if self._spec_exchange is not None:               # across ranks: the verdicts not read yet, in step order (every rank flushes at the same step)
+            self._spec_dp.flush()
+            self._spec_dp_restore_lrs()
+            self._spec_exchange = None
+        elif self.renderer.spec_words is not None:
             self._spec_recover()
         self._spec_ring = []
         self._spec_events = []
@@ -247,7 +320,7 @@ class FrameTrainer:
 
     @torch.no_grad()
     def forward_only(self, frame_index: int):
-        if self._spec_ring:
+        if self._spec_pending:
             self.flush()
         frame = self.frames[frame_index % len(self.frames)]
         return self.forward(frame)[0]
@@ -256,7 +329,7 @@ class FrameTrainer:
     def _rebind(self):
         """parameters were replaced / re-sorted: refresh everything derived from them (chunk AABBs, cached pointers, depth bounds and tile
         schedules).  The per-frame SIZE predictions of the GPU-driven protocol are kept, as in the reference."""
-        if self._spec_ring:
+        if self._spec_pending:
             self.flush()
         by_name = {g["name"]: g["params"][0] for g in self.opt.param_groups}
         self.params = [by_name[n] for n in ("xyz", "scale", "rot", "sh_0", "sh_rest", "opacity")]
@@ -285,7 +358,7 @@ class FrameTrainer:
 
     def begin_epoch(self, epoch: int):
         """Morton re-sort one epoch after every densification (trainer.py:113-116); returns the statistics guard for the epoch."""
-        if self._spec_ring:
+        if self._spec_pending:
             self.flush()
         ctl = getattr(self, "controller", None)
         if ctl is not None and (epoch - 1) % ctl.p.densification_interval == 0:
@@ -295,7 +368,7 @@ class FrameTrainer:
         return STATS.epoch(epoch)
 
     def end_epoch(self, epoch: int):
-        if self._spec_ring:
+        if self._spec_pending:
             self.flush()
         ctl = getattr(self, "controller", None)
         if ctl is not None:
@@ -304,7 +377,7 @@ class FrameTrainer:
     def workload_stats(self, frame_index: int = 0):
         """N_vis (Gaussians after chunk culling), I (tile instances) for one frame -- host sync, call outside timed regions."""
         frame = self.frames[frame_index % len(self.frames)]
-        if self._spec_ring:
+        if self._spec_pending:
             self.flush()
         torch.cuda.synchronize()
         k = int(frame.idx_tensor[0])

@@ -376,3 +376,157 @@ def test_moment_exchange_world2():
     out = mgr.dict()
     mp.spawn(_moment_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Rank-consistent speculative culling (litegs_amd/dp.py: Speculation, LockstepSpeculation, MomentExchange.enable_speculation): the
+# verdict on a step is a function of the gathered headers, the hosts read it at a fixed lag and replay in lock-step.  The device
+# is played by plain-torch primitives that honour a poison word exactly as csrc/dp.hip does.
+# ------------------------------------------------------------------------------------------------------------------------------
+class TorchSpecMomentOps(TorchMomentOps):
+    @staticmethod
+    def compact_moments(pg, vis_ids, vis_num, A, S, cap, block, spec=None):
+        TorchMomentOps.compact_moments(pg, vis_ids, vis_num, A, S, cap, block)
+        if spec is not None:
+            block.view(-1, TorchMomentOps.NREC)[0, 1] = 1 if int(spec.poison[0]) != 0 else 0
+
+    @staticmethod
+    def build_slotmap(gathered, W, cap, total, slot, host_max_k_ptr, overflow, spec=None):
+        if spec is None:
+            return TorchMomentOps.build_slotmap(gathered, W, cap, total, slot, host_max_k_ptr, overflow)
+        g = gathered.view(W, 1 + cap, TorchMomentOps.NREC)
+        ks = [int(g[r, 0, 0]) for r in range(W)]
+        for r in range(W):
+            k = min(ks[r], cap)
+            slot[r, g[r, 1:1 + k, 0].long()] = torch.arange(1, k + 1, dtype=torch.int32)
+        flags = 0
+        for r in range(W):
+            flags |= (1 << r) if int(g[r, 0, 1]) != 0 else 0
+        if max(ks) > cap:
+            flags |= 1 << 8
+        if flags:
+            spec.poison[0] = 1
+        TorchMomentOps.fb_target[0] = max(ks)
+        TorchMomentOps.fb_target[1] = 0
+        i = spec.status_addr(spec.step_id)
+        spec.words[i + 1] = flags
+        spec.words[i] = spec.step_id
+
+    @staticmethod
+    def backward_adam(union_ids, union_count, chunks, S, H, Wimg, views, projs, W, degree, R, gathered, cap, slot, ps, ms, vs, lr6, eps, touched=None,
+                      spec=None):
+        if spec is not None and int(spec.poison[0]) != 0:
+            return                                         # a failed step: nothing changes (the slot map stays dirty, as on the device)
+        g = gathered.view(torch.float32).view(W, 1 + cap, TorchMomentOps.NREC)
+        acc = torch.zeros((9, chunks * S))
+        for r in range(W):                                 # rank order
+            for gid in slot[r].nonzero()[:, 0].tolist():
+                acc[:, gid] += g[r, int(slot[r, gid]), 1:] * float(views[r][0])
+        slot.zero_()
+        ps[0].view(9, chunks * S).add_(acc / W * lr6[0])   # "Adam": the learning rate of the step scales the update
+        if spec is not None:
+            TorchSpecMomentOps.applied.append(spec.step_id)
+
+
+def _spec_worker(rank, world, port, out):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from litegs_amd import dp
+    chunks, S, T = 10, 4, 14
+    vis = [torch.tensor([1, 4, 5, 9, 0, 0]), torch.tensor([4, 5, 6, 8, 2, 0])][rank]
+    cnt = torch.tensor([4 if rank == 0 else 5], dtype=torch.int32)
+    A = len(vis)
+    cams = [([2.0] + [0.0] * 15, [0.0] * 16), ([3.0] + [0.0] * 15, [0.0] * 16)]
+    fail_plan = {(5, 1), (6, 0), (11, 0), (11, 1)}          # (step, rank): that rank's culled forward violates a bound (unless unculled)
+    dense_step = 9                                          # ... and here rank 1 produces far more records than the slot's last visit
+
+    def records(no, r):
+        g = torch.Generator().manual_seed(100 * no + r)
+        pg = torch.zeros((A * S, 16))
+        touched = torch.rand((A * S,), generator=g) < (0.95 if (no == dense_step and r == 1) else 0.5)
+        pg[touched, :9] = torch.randn((int(touched.sum()), 9), generator=g)
+        pg[int([4, 5][r]) * S:] = 7.0                       # slots beyond vis_num are dirty by design
+        return pg
+
+    def lr_of(no):
+        return 1.0 / no                                     # a schedule: a replayed step must run with ITS learning rate
+
+    # what T steps must add up to, each applied exactly once (both ranks' records, rank order, mean)
+    expect = torch.zeros((9, chunks * S))
+    for no in range(1, T + 1):
+        for r in range(world):
+            v, n = [torch.tensor([1, 4, 5, 9, 0, 0]), torch.tensor([4, 5, 6, 8, 2, 0])][r], [4, 5][r] * S
+            gid = v[torch.arange(n) // S] * S + torch.arange(n) % S
+            expect[:, gid] += records(no, r)[:n, :9].t() * cams[r][0][0] / world * lr_of(no)
+
+    params = [torch.zeros((9, chunks, S))]
+    ex = dp.MomentExchange(params, world, ops=TorchSpecMomentOps, union_ops=TorchOps, n_slots=4)
+    ex.cap_margin = 1
+    poison = torch.zeros((1,), dtype=torch.int32)
+    ex.enable_speculation(poison, None, words=np.zeros((2 * dp.Speculation.RING,), dtype=np.int32))
+    TorchSpecMomentOps.applied = []
+    log = []
+
+    def body(rec, force):
+        no, slot = rec
+        log.append((no, bool(force)))
+        if (no, rank) in fail_plan and not force:
+            poison[0] = 1                                   # the culled forward's bound check
+        TorchMomentOps.fb_target = ex.fb_k[slot]
+        pend = dict(pg=records(no, rank), A=A, S=S, vis_ids=vis, vis_num=cnt, degree=3, Rr=15)
+        ex.step(pend, cams, params, [None], [None], [lr_of(no)] + [0.0] * 5, 1e-15, 8, 8, slot=slot, step_id=no)
+
+    class Done:
+        def synchronize(self):
+            pass
+
+    failed = []
+
+    def on_failed(rec, flags):
+        failed.append((rec[0], flags))
+        poison[0] = 0
+        ex.after_failed_step(rec[1], flags)
+
+    ls = dp.LockstepSpeculation(ex, 2, body, on_failed, Done, lambda: None)
+    for no in range(1, T + 1):
+        rec = (no, no % 3)
+        ls.before_step(rec)
+        body(rec, False)
+        ls.after_step(rec)
+    ls.flush()
+    got = params[0].view(9, chunks * S)
+    other = [None] * world
+    dist.all_gather_object(other, (log, failed, TorchSpecMomentOps.applied))
+    why = []
+    if not torch.allclose(got, expect, atol=1e-5):
+        why.append(("values", float((got - expect).abs().max())))
+    if other[0] != other[1]:
+        why.append(("ranks took different decisions", other))
+    if sorted(TorchSpecMomentOps.applied) != list(range(1, T + 1)):
+        why.append(("every step's update exactly once", TorchSpecMomentOps.applied))
+    kinds = {no: fl for no, fl in failed}
+    # step 5: rank 1 alone; step 6 fails in the replay behind it (rank 0); step 9: overflow; step 11: both ranks
+    if not (kinds.get(5, 0) & 0xff == 0b10 and kinds.get(6, 0) & 0xff == 0b01 and kinds.get(9, 0) & (1 << 8) and kinds.get(11, 0) & 0xff == 0b11):
+        why.append(("failures", failed))
+    if ex.overflow_replays != 1 or int(poison[0]) != 0 or int(ex.slot.abs().sum()) != 0 or int(ex.overflow[0]) != 0:
+        why.append(("end state", ex.overflow_replays, int(poison[0]), int(ex.slot.abs().sum())))
+    if ls.replays < 6:
+        why.append(("replays", ls.replays, log))
+    ex.check()                                              # an overflow under speculation is a replayed step, never an error
+    out[rank] = not why
+    if why:
+        out[f"why{rank}"] = str(why)
+    dist.destroy_process_group()
+
+
+def test_speculative_culling_stays_rank_consistent_world2():
+    """failed culled forwards on either rank, a failure inside a replay and a record-block overflow: both ranks take the same decisions at
+    the same steps (the collectives would deadlock or pair up wrongly otherwise), every step's update lands exactly once, with its own
+    learning rate, and the result equals the plain sum"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_spec_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)

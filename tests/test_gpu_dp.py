@@ -82,12 +82,23 @@ def test_single_rank_moment_exchange_equals_the_fused_step():
         ta = SyntheticTrainer(6000, 320, 200, 300.0, n_frames=2, scene=scene)
         tb = SyntheticTrainer(6000, 320, 200, 300.0, n_frames=2, scene=scene)
         ex = dp.MomentExchange(tb.params, 1)
+        tc = SyntheticTrainer(6000, 320, 200, 300.0, n_frames=2, scene=scene)       # the same over RCCL under rank-consistent speculation
+        tc.speculative = True
+        exc = dp.MomentExchange(tc.params, 1)
         for i in range(6):
             la = ta.step(i)
             lb = tb.step(i, ex, i % 2, [i])
-            assert abs(la.item() - lb.item()) < 1e-6
+            lc = tc.step(i, exc, i % 2, [i])
+            assert abs(la.item() - lb.item()) < 1e-6 and abs(la.item() - lc.item()) < 1e-6
         ex.check()
+        tc.flush()
+        exc.check()
+        assert exc.spec is not None and tc.renderer.applied_step() == 6 and int(tc.renderer.spec_poison.item()) == 0
         assert ex.last_cap > 0 and int(ex.slot.abs().sum().item()) == 0, "the slot map must be left clean"
+        assert int(exc.slot.abs().sum().item()) == 0
+        for pb, pc in zip(tb.params, tc.params):
+            d = (pb - pc).abs()
+            assert (d > 2e-5).float().mean().item() < 1e-3 and d.max().item() < 0.1
         for pa, pb in zip(ta.params, tb.params):
             # two independent runs: the blend backward's float atomics reorder the sums, and Adam without bias correction turns a
             # near-zero gradient of either sign into a step of ~3 lr -- a handful of elements may differ by that much (and their
@@ -269,3 +280,94 @@ def test_two_ranks_epochs_with_density_control_stay_identical(mode):
     for r in range(world):
         c = dict(out.get(r) or {})
         assert c and all(c.values()), (r, c)
+
+
+def _two_rank_speculation_worker(rank, world, port, out):
+    """two ranks on cuda:0 over gloo: data-parallel steps under rank-consistent speculative culling against the gated repeat"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from litegs_amd import dp, synthetic as S
+        from litegs_amd.trainer import SyntheticTrainer
+        scene = S.make_scene(150_000, seed=5)
+        nf, steps = 2 * world, 14
+
+        def run(speculative, drop_step=-1, tight=False):
+            tr = SyntheticTrainer(150_000, 640, 360, 380.0, n_frames=nf, scene=scene)
+            tr.speculative = speculative
+            ex = dp.MomentExchange(tr.params, world, n_slots=2)
+            if tight:
+                ex.spec_cap_factor, ex.cap_margin = 1.0, 0      # any growth of a slot's record count is an overflow: replayed, exactly
+            rd = tr.renderer
+            losses = []
+            for i in range(steps):
+                peers = [dp.frame_for(i, r, world, nf) for r in range(world)]
+                if i in (6, 9) and rank == 0:                  # RANK 0's frame of this step was visited before: sabotage its bounds; rank 1 is fine
+                    torch.cuda.synchronize()
+                    k = peers[0]
+                    gx, gy = -(-640 // 16), -(-360 // 8)
+                    upper = sum((-(-gx // (1 << q))) * (-(-gy // (1 << q))) for q in range(1, 4))
+                    rd.sched[k, rd.sched_cur[k]][:upper + gx * gy].view(torch.float32).mul_(0.2)
+                if i == drop_step:
+                    continue
+                tr.step(peers[rank], ex, i % 2, peers)
+                losses.append(tr.last["loss"])
+            tr.flush()
+            ex.check()
+            torch.cuda.synchronize()
+            return tr, ex, [float(l) for l in losses]
+
+        ta, _, la = run(False)
+        t_lost, _, _ = run(False, drop_step=12)
+        tb, exb, lb = run(True)
+        tc, exc, _ = run(True, tight=True)
+        c = {}
+        c["gated_run_fell_back"] = ta.renderer.fallbacks >= 1 if rank == 0 else True
+        c["replays"] = tb.spec_replays
+        c["replayed"] = tb.spec_replays >= 2
+        c["poison_clear"] = int(tb.renderer.spec_poison.item()) == 0 and int(tc.renderer.spec_poison.item()) == 0
+        c["applied_all"] = tb.renderer.applied_step() == steps and tc.renderer.applied_step() >= steps
+        c["slot_clean"] = int(exb.slot.abs().sum().item()) == 0 and int(exc.slot.abs().sum().item()) == 0
+        c["overflow_replayed"] = exc.overflow_replays >= 1
+        c["overflow_replays"] = exc.overflow_replays
+        ratios = []
+        for pa, pl, pb, pc in zip(ta.params, t_lost.params, tb.params, tc.params):
+            d_lost = (pa.detach() - pl.detach()).abs().mean().item()
+            ratios.append(max((pa.detach() - pb.detach()).abs().mean().item(), (pa.detach() - pc.detach()).abs().mean().item()) / max(d_lost, 1e-30))
+        c["ratio"] = max(ratios)
+        c["matches_gated"] = max(ratios) <= 0.06             # the bound of tests/test_gpu_cull.py: geometric middle of noise and a lost step
+        c["losses"] = bool(np.allclose(la, lb, rtol=2e-4))
+        for name, t in (("spec", tb), ("tight", tc)):
+            flat = torch.cat([p.detach().reshape(-1) for p in t.params]).cpu()
+            both = [torch.zeros_like(flat) for _ in range(world)]
+            dist.all_gather(both, flat)
+            c["replicas_identical_" + name] = torch.equal(both[0], both[1])
+        counts = [None] * world
+        dist.all_gather_object(counts, (tb.spec_replays, tc.spec_replays, exc.overflow_replays))
+        c["same_replays_on_every_rank"] = counts[0] == counts[1]
+        out[rank] = c
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.stochastic
+def test_two_ranks_speculative_culling_replays_in_lock_step():
+    """Rank-consistent speculative culling (litegs_amd/dp.py): rank 0's bounds are sabotaged before two of its visits, rank 1's never.  Both
+    ranks must notice at the same step, replay the same steps (replay counts equal), end with bit-identical replicas and agree with the
+    gated-repeat run up to the atomics-order noise (same yardstick as tests/test_gpu_cull.py).  A second speculative run with a block
+    capacity of exactly the previous count turns record-count growth into overflows: replayed with an exact capacity, never an error."""
+    import torch.multiprocessing as mp
+    from util import noise_log
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_rank_speculation_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        c = dict(out.get(r) or {})
+        noise_log(what=f"dp spec vs gated / lost step, rank {r}", ratio=c.get("ratio"), bound=0.06, replays=c.get("replays"),
+                  overflow_replays=c.get("overflow_replays"))
+        assert c and all(v for k, v in c.items() if k not in ("ratio", "replays", "overflow_replays")), (r, c)
