@@ -354,7 +354,7 @@ class LockstepSpeculation:
 
     def _recover(self, first_failed: int, flags: int) -> None:
         """From `first_failed` on no replica changed anything.  Replay in order, each step checked before the next: the failed one
-        unculled on every rank and -- after an overflow -- with an exact block capacity (MomentExchange.after_failed_step)."""
+        unculled on every rank and with an exact block capacity (MomentExchange.after_failed_step)."""
         self.sync()                    # the steps enqueued behind the failed one have run (as no-ops), their collectives included
         todo = [r for r in self.ring if r[0] >= first_failed]
         self.ring, self.events = [], []
@@ -406,8 +406,8 @@ class MomentExchange:
     into a failed step -- and writes the verdict into that step's status words (``Speculation``).  The hosts never look at the sticky
     word (its value at a given wall-clock moment differs between ranks); they read the status of step n - depth behind that step's event
     while enqueuing step n, so all of them find the first failed step s at the same n, with the same steps s+1 .. n-1 enqueued behind it
-    (no-ops on every replica, collectives matched).  The replay runs step s unculled on every rank, with an exact (blocking) block
-    capacity if the failure was an overflow, then the steps behind it as they were -- checking each before the next.  Because an
+    (no-ops on every replica, collectives matched).  The replay runs step s unculled on every rank with an exact (blocking) block
+    capacity, then the steps behind it as they were -- checking each before the next.  Because an
     overflow is now survivable the capacity shrinks from 1.5 x to ``spec_cap_factor`` = 1.125 x the slot's previous count: the
     all_gather moves a quarter less (the padding was a third of the exchanged bytes).
     """
@@ -441,13 +441,14 @@ class MomentExchange:
         return self.spec.status(step_id)
 
     def after_failed_step(self, slot: int, flags: int) -> None:
-        """host side of a replay (every rank, same point): the slot map may hold entries of the steps that ran as no-ops; an overflowed
-        slot is sized exactly (blocking) on its next visit -- which is the replay of the failed step"""
+        """host side of a replay (every rank, same point): the slot map may hold entries of the steps that ran as no-ops; the slot's next
+        visit -- the forced replay of the failed step -- sizes its blocks exactly (blocking count): an unculled frame yields another
+        record count than the prediction was made for, and the forced replay must not fail"""
         self.slot.zero_()
         self.in_flight = []
+        self._wait_slot(slot)
+        self.fb_k[slot, 0] = 0
         if flags & Speculation.OVERFLOW:
-            self._wait_slot(slot)
-            self.fb_k[slot, 0] = 0
             self.overflow_replays += 1
 
     def rebind(self, params) -> None:
