@@ -340,7 +340,7 @@ def _two_rank_speculation_worker(rank, world, port, out):
             ratios.append(max((pa.detach() - pb.detach()).abs().mean().item(), (pa.detach() - pc.detach()).abs().mean().item()) / max(d_lost, 1e-30))
         c["ratio"] = max(ratios)
         c["matches_gated"] = max(ratios) <= 0.06             # the bound of tests/test_gpu_cull.py: geometric middle of noise and a lost step
-        c["losses"] = bool(np.allclose(la, lb, rtol=2e-4))
+        c["losses"] = bool(np.allclose(la[:6], lb[:6], rtol=1e-4))       # before the first sabotage the two runs are the same computation
         for name, t in (("spec", tb), ("tight", tc)):
             flat = torch.cat([p.detach().reshape(-1) for p in t.params]).cpu()
             both = [torch.zeros_like(flat) for _ in range(world)]
