@@ -439,9 +439,10 @@ def main():
     if args.operator_path and world > 1:
         raise SystemExit("--operator-path is a single-GPU measurement")
     tr = SyntheticTrainer(n, W, H, focal, n_frames=args.frames * world, scene=scene, fused=not args.operator_path)
-    # single-GPU executor: culled steps run speculatively (no gated repeat launches; a failed step is replayed by the trainer, exactly) --
-    # tr.flush() inside every timed region makes the replays part of what is timed
-    tr.speculative = (world == 1 and not args.operator_path and os.environ.get("LITEGS_SPECULATIVE", "1") != "0")
+    # native executor: culled steps run speculatively (no gated repeat launches; a failed step is replayed by the trainer, exactly) --
+    # tr.flush() inside every timed region makes the replays part of what is timed.  Across ranks (moment exchange only) the ranks agree
+    # on the failed step through the gathered record headers and replay in lock-step (litegs_amd/dp.py "rank-consistent speculation")
+    tr.speculative = (not args.operator_path and os.environ.get("LITEGS_SPECULATIVE", "1") != "0")
     hook = None
     if world > 1:
         from litegs_amd import dp
@@ -536,6 +537,7 @@ def main():
             for i in range(args.steps):
                 tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
                 step_no += 1
+            tr.flush()                                # speculative steps: replays are part of what is timed
             torch.cuda.synchronize()
             dist.barrier()
             tt = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
@@ -607,7 +609,9 @@ def main():
             result["roofline"] = roofline_probe(tr, list(range(len(tr.frames))))    # in situ, after the timed region
         if world > 1 and hasattr(hook, "bytes_last"):
             result["dp_exchange"] = {"mode": "moments", "bytes_received_per_rank_per_step": int(hook.bytes_last), "record_capacity": int(hook.last_cap),
-                                     **dp_diag}
+                                     "speculative_culling": bool(tr.speculative and hook.spec is not None),
+                                     "capacity_factor": hook.spec_cap_factor if (tr.speculative and hook.spec is not None) else hook.cap_factor,
+                                     "overflow_replays": int(hook.overflow_replays), "replayed_steps": int(tr.spec_replays), **dp_diag}
         if world == 1 and not args.operator_path and not args.no_operator_path:
             result["operator_path_ms"] = operator_path_ms(n, W, H, focal, scene, args.frames)
         if world == 1 and not args.operator_path and args.soak_steps > 0:

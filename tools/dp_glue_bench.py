@@ -27,22 +27,32 @@ for g in tr.opt.param_groups:
     g["lr"] = 0.0
 tr.sched.step = lambda: None
 out = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "dp_glue.log"), "a")
-modes = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()] or ["none", "moments", "sparse"]
+modes = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()] or ["none", "moments", "moments_spec", "sparse"]
 label = ("outside " if outside else "") + (f"trained {trained} steps " if trained else "")
 for mode in modes:
-    ex = None if mode == "none" else (dp.MomentExchange(tr.params, 1) if mode == "moments" else dp.GradientExchange(tr.params, 1, mode=mode))
-    hook = None if ex is None else (ex if mode == "moments" else ex.hook)
+    moments = mode in ("moments", "moments_spec")
+    ex = None if mode == "none" else (dp.MomentExchange(tr.params, 1) if moments else dp.GradientExchange(tr.params, 1, mode=mode))
+    hook = None if ex is None else (ex if moments else ex.hook)
+    # moments_spec: rank-consistent speculative culling (no gated repeat launches; record blocks at 1.125x instead of 1.5x the last count)
+    tr.speculative = mode == "moments_spec"
+    r0 = tr.spec_replays
     for i in range(8):
         tr.step(i, hook, i % 4, [i % 4])
+    tr.flush()
     torch.cuda.synchronize(); t = time.perf_counter()
     K = 24
     for i in range(K):
         tr.step(i, hook, i % 4, [i % 4])
+    tr.flush()
     torch.cuda.synchronize()
     extra = ""
-    if mode == "moments":
+    if moments:
         ex.check()
         extra = f", record capacity {ex.last_cap}, block bytes {(1 + ex.last_cap) * 40}"
+        if mode == "moments_spec":
+            extra += f", replayed steps {tr.spec_replays - r0} (overflows {ex.overflow_replays})"
+        tr.speculative = False
+        tr.flush()
     elif ex is not None:
         extra = f", last K = {ex.last_k}"
     line = f"{label}{mode}: {(time.perf_counter() - t) / K * 1e3:.3f} ms/step (world 1){extra}"
