@@ -409,6 +409,9 @@ def relaunch(args):
 
 def main():
     args = parse_args()
+    if os.environ.get("LITEGS_HANG_DUMP"):            # debugging aid: every thread's Python stack after N seconds, then exit (a stuck collective)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["LITEGS_HANG_DUMP"]), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -63,7 +63,7 @@ PY
     bench500k)
       timeout -s KILL 200 python bench.py --config 500k_1080p --no-cpu-baseline --no-operator-path --no-pmc --soak-steps 0 > gpurun_out/bench_500k_$TAG.log 2>&1; tail -1 gpurun_out/bench_500k_$TAG.log | cut -c1-300 ;;
     benchdp2)
-      LITEGS_BENCH_ONE_GPU=1 timeout -s KILL 400 python bench.py --gpus 2 --steps 10 --warmup 4 --no-cpu-baseline --no-operator-path --no-pmc > gpurun_out/bench_dp2_$TAG.log 2>&1; grep '^{' gpurun_out/bench_dp2_$TAG.log | cut -c1-600; tail -3 gpurun_out/bench_dp2_$TAG.log | cut -c1-300 ;;
+      LITEGS_BENCH_ONE_GPU=1 LITEGS_HANG_DUMP=${LITEGS_HANG_DUMP:-150} timeout -s KILL 200 python bench.py --gpus 2 --steps 10 --warmup 4 --no-cpu-baseline --no-operator-path --no-pmc > gpurun_out/bench_dp2_$TAG.log 2>&1; grep '^{' gpurun_out/bench_dp2_$TAG.log | cut -c1-600; tail -3 gpurun_out/bench_dp2_$TAG.log | cut -c1-300 ;;
     trace)
       (cd /tmp && timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o trace -- python $R/bench.py --no-cpu-baseline --no-operator-path --no-pmc --no-training-state > $R/gpurun_out/rocprof_$TAG.log 2>&1)
       T=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
