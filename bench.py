@@ -409,11 +409,11 @@ def relaunch(args):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch(args))
     if os.environ.get("LITEGS_HANG_DUMP"):            # debugging aid: every thread's Python stack after N seconds, then exit (a stuck collective)
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["LITEGS_HANG_DUMP"]), exit=True)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(relaunch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and not args.pmc_child:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a number for the wrong job size")

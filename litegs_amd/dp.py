@@ -408,15 +408,17 @@ class MomentExchange:
     while enqueuing step n, so all of them find the first failed step s at the same n, with the same steps s+1 .. n-1 enqueued behind it
     (no-ops on every replica, collectives matched).  The replay runs step s unculled on every rank with an exact (blocking) block
     capacity, then the steps behind it as they were -- checking each before the next.  Because an
-    overflow is now survivable the capacity shrinks from 1.5 x to ``spec_cap_factor`` = 1.125 x the slot's previous count: the
-    all_gather moves a quarter less (the padding was a third of the exchanged bytes).
+    overflow is now survivable the capacity shrinks from 1.5 x to ``spec_cap_factor`` = 1.125 x the slot's previous count once that count
+    has settled (growth <= 5 % between its last two visits; early in training it doubles between visits and replays would cost more than
+    padding): the all_gather moves a quarter less (the padding was a third of the exchanged bytes).
     """
 
     def __init__(self, params, world: int, ops=HipMomentOps, union_ops=HipOps, group=None, n_slots: int = 64):
         self.world, self.ops, self.union_ops, self.group = world, ops, union_ops, group
         self.n_slots = max(int(n_slots), 1)
         self.cap_factor, self.cap_margin = 1.5, 64       # block capacity = factor x (largest count of the slot's last visit) + margin
-        self.spec_cap_factor = 1.125                     # ... under speculation, where an overflow is a replayed step instead of an error
+        self.spec_cap_factor = 1.125                     # ... under speculation, where an overflow is a replayed step instead of an error,
+        self.spec_settled_growth = 1.05                  #     once the slot's count grew by no more than this factor between its last two visits
         self.profile = False
         self.spec = None                                 # Speculation record while rank-consistent speculative culling is on
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -473,6 +475,7 @@ class MomentExchange:
             from .hostwords import pinned_int32
             self.fb_k, self._fb_k_owner = pinned_int32((self.n_slots, 2))
         self.fb_event = [None] * self.n_slots            # recorded behind the kernel that writes fb_k[slot]
+        self.prev_k = [0] * self.n_slots                 # the count each slot's last visit was sized from
         self.in_flight = []                              # (step number, slot) of steps whose overflow word has not been read yet
         self.steps = 0
         self.last_cap = 0
@@ -493,6 +496,7 @@ class MomentExchange:
             grown[: self.n_slots] = self.fb_k
             self.fb_k, self._fb_k_owner = grown, owner
             self.fb_event += [None] * (n_slots - self.n_slots)
+            self.prev_k += [0] * (n_slots - self.n_slots)
             self.n_slots = n_slots
 
     def begin(self, vis_ids, vis_num) -> None:
@@ -605,10 +609,16 @@ class MomentExchange:
             k = probe[:1].clone()
             dist.all_reduce(k, op=dist.ReduceOp.MAX, group=self.group)
             pred = max(int(k.item()), 1)
+        # how fast the slot's count has been moving (host-side memory of the values read here: the same on every rank)
+        last = self.prev_k[slot]
+        settled = last > 0 and pred <= self.spec_settled_growth * last
+        self.prev_k[slot] = pred
         if exact:
             cap = pred + self.cap_margin                 # the count IS this step's: no slack needed
         else:
-            cap = int((self.spec_cap_factor if spec is not None else self.cap_factor) * pred) + self.cap_margin
+            # under speculation an overflow costs a replay, not the run: the slack shrinks once the slot's count has stopped moving
+            # (early in training it doubles between visits: there the replays would cost more than the padding)
+            cap = int((self.spec_cap_factor if (spec is not None and settled) else self.cap_factor) * pred) + self.cap_margin
         self.last_cap = cap
         # wire container: int32 words (record = index word + nine float bit patterns) -- an integer collective can only copy
         block = torch.empty(((1 + cap) * nrec,), dtype=torch.int32, device=dev)

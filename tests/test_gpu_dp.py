@@ -301,7 +301,8 @@ def _two_rank_speculation_worker(rank, world, port, out):
             tr.speculative = speculative
             ex = dp.MomentExchange(tr.params, world, n_slots=2)
             if tight:
-                ex.spec_cap_factor, ex.cap_margin = 1.0, 0      # any growth of a slot's record count is an overflow: replayed, exactly
+                ex.spec_cap_factor = ex.cap_factor = 1.0       # any growth of a slot's record count is an overflow: replayed, exactly
+                ex.cap_margin = 0
             rd = tr.renderer
             losses = []
             for i in range(steps):
