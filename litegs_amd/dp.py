@@ -423,6 +423,7 @@ class MomentExchange:
         self.spec = None                                 # Speculation record while rank-consistent speculative culling is on
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.overflow_replays = 0
+        self._overflow_at = []
         self.rebind(params)
 
     supports_speculation = True
@@ -452,6 +453,11 @@ class MomentExchange:
         self.fb_k[slot, 0] = 0
         if flags & Speculation.OVERFLOW:
             self.overflow_replays += 1
+            # a run of overflows (counts that keep jumping although they looked settled): give the slack back rather than live on replays.
+            # Decided from events every rank sees at the same step, so the ranks keep sizing their blocks alike
+            self._overflow_at = [t for t in self._overflow_at if self.steps - t < 64] + [self.steps]
+            if len(self._overflow_at) >= 8:
+                self.spec_cap_factor = self.cap_factor
 
     def rebind(self, params) -> None:
         p0 = params[0]
