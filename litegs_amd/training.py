@@ -190,7 +190,8 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
         exchange = dp_mod.MomentExchange(trainer.params, world, n_slots=(len(frames) + world - 1) // world)
     trainer.exchange = exchange
     trainer.sched_ticks = world                           # the lr schedule counts frames, not optimizer steps (FrameTrainer.sched_ticks)
-    trainer.speculative = (world == 1 and fused)          # single GPU: speculative depth-bound culling (csrc/fused.hip); flushed at every epoch boundary
+    # speculative depth-bound culling (csrc/fused.hip; across ranks: litegs_amd/dp.py "rank-consistent speculation"); flushed at every epoch boundary
+    trainer.speculative = bool(fused)
     say(f"[litegs_amd] {len(frames)} training frames {W}x{H}, {len(test_frames_dev)} test frames, {init_points_num} initial points, "
         f"{total_epoch} epochs, world {world}, scene radius {norm_radius:.3f}")
 
