@@ -470,6 +470,7 @@ def main():
     for i in range(args.warmup):
         tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
         step_no += 1
+    tr.flush()                                        # the warm-up is complete: a speculative warm-up step that failed is replayed HERE, not on the clock
     torch.cuda.synchronize()
     if args.pmc_child:                                # wrapped by rocprofv3 --pmc (pmc_traffic): a few more training steps, nothing else
         for i in range(args.steps):
