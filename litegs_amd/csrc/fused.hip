@@ -237,7 +237,13 @@ LG_API int lg_sanitised_counts(int* out, int reset)
 // outputs are SoA over N = A*S:  ndc[4,N] (rows 0,1,2 written), view_z[N], inv_cov[4,N], opacity[N],
 // alloc[N] is produced by a second tiny kernel (tile walk lives in binning.hip), packed[N,16]
 // ---------------------------------------------------------------------------------------------
-template <int DEG, int TH, int TW>
+// EARLY (A/B variant, lg_set_tuning(12, 1); DEG 3, 8x16 tiles): the SH coefficients are requested as soon as the cheap part of the fine test
+// has passed, BEFORE the tile walk, so that their round trip overlaps the walk instead of following it -- at the price of 48 live
+// registers across the walk.  Numbers: DESIGN.md section 9 (round 5).
+int g_proj_early = 0;
+int lg_fused_set_tuning(int key, int value) { if (key == 12) { g_proj_early = value ? 1 : 0; return 0; } return (int)hipErrorInvalidValue; }
+
+template <int DEG, int TH, int TW, bool EARLY = false>
 __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_id, const int* __restrict__ visible_chunks_num,
                                      Camera cam,
                                      const float* __restrict__ pos, const float* __restrict__ scale, const float* __restrict__ rot,
@@ -280,6 +286,21 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
     J6[0] = j4[0]; J6[1] = 0.0f; J6[2] = 0.0f; J6[3] = j4[1]; J6[4] = j4[2]; J6[5] = j4[3];
     lg_cov2d(T9, cam.V, J6, c4);
     lg_inv2x2(c4[0], c4[1], c4[2], c4[3], i4);
+    constexpr int NBE = (DEG + 1) * (DEG + 1);
+    float shv[EARLY ? NBE * 3 : 1];
+    if (EARLY) {                                          // the tests lg_tile_count starts with: everything it can count passes them
+        const bool pre = !((n[0] < -1.3f) || (n[0] > 1.3f) || (n[1] < -1.3f) || (n[1] > 1.3f) || (v[2] <= 0.2f) || (o < 1.0f / 255)) &&
+                         (i4[0] > 0) && (i4[3] > 0) && (i4[1] * i4[1] - i4[0] * i4[3] < 0);
+        if (pre) {
+            shv[0] = sh0[sd]; shv[1] = sh0[CS + sd]; shv[2] = sh0[2 * CS + sd];
+#pragma unroll
+            for (int k = 1; k < NBE; k++) {
+                const float* s = shr + ((size_t)(k - 1) * 3) * CS + sd;
+                shv[3 * k] = s[0]; shv[3 * k + 1] = s[CS]; shv[3 * k + 2] = s[2 * CS];
+            }
+        }
+        asm volatile("" ::: "memory");                   // (keeps the compiler from sinking the loads into the branch that uses them)
+    }
     int rect[4];
     int tiles = lg_tile_count<TH, TW>(n[0], n[1], v[2], i4[0], i4[1], i4[3], o, cam.H, cam.W, gx, gy, rect);     // a8, fused
     // ---- depth-bound culling (see "depth-bound culling" below): deeper than the saturation bound of every tile of its rectangle ->
@@ -308,11 +329,17 @@ __global__ void project_fused_kernel(const int64_t* __restrict__ visible_chunk_i
         float b[16];
         lg_sh_basis<DEG>(dx, dy, dz, b);
         constexpr int NB = (DEG + 1) * (DEG + 1);
-        r0 = b[0] * sh0[sd]; r1 = b[0] * sh0[CS + sd]; r2 = b[0] * sh0[2 * CS + sd];
+        if (EARLY) {
+            r0 = b[0] * shv[0]; r1 = b[0] * shv[1]; r2 = b[0] * shv[2];
 #pragma unroll
-        for (int k = 1; k < NB; k++) {
-            const float* s = shr + ((size_t)(k - 1) * 3) * CS + sd;
-            r0 += b[k] * s[0]; r1 += b[k] * s[CS]; r2 += b[k] * s[2 * CS];
+            for (int k = 1; k < NB; k++) { r0 += b[k] * shv[3 * k]; r1 += b[k] * shv[3 * k + 1]; r2 += b[k] * shv[3 * k + 2]; }
+        } else {
+            r0 = b[0] * sh0[sd]; r1 = b[0] * sh0[CS + sd]; r2 = b[0] * sh0[2 * CS + sd];
+#pragma unroll
+            for (int k = 1; k < NB; k++) {
+                const float* s = shr + ((size_t)(k - 1) * 3) * CS + sd;
+                r0 += b[k] * s[0]; r1 += b[k] * s[CS]; r2 += b[k] * s[2 * CS];
+            }
         }
         r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
     }
@@ -634,7 +661,14 @@ static int launch_projection(const Scene& sc, const Camera& cam, int TH, int TW,
     case 3: LAUNCH_PF(3, A_, B_); break;                                     \
     default: return (int)hipErrorInvalidValue;                               \
     }
-    if (TH == 8 && TW == 16) { DISPATCH_PF(8, 16) }
+    if (TH == 8 && TW == 16 && sc.degree == 3 && g_proj_early) {
+        hipLaunchKernelGGL((project_fused_kernel<3, 8, 16, true>), dim3(sc.A), dim3(sc.S), 0, s, sc.vis_ids, sc.vis_num, cam,
+                           sc.pos, sc.scale, sc.rot, sc.sh0, sc.shr, sc.opa, sc.chunks, sc.S, sc.A, view_z, alloc, packed,
+                           gx, gy, (uint32_t*)(w + f.zeroed), zero_duty ? (long long)(f.zero_bytes / 4) : 0LL,
+                           (uint32_t*)sched_out, sched_out ? lg_sched_clear_words(gx, gy) : 0LL, bound_pyr, gate,
+                           hot ? (int*)(w + f.hot_of) : (int*)nullptr, hot_counter, (int)hot_capacity((long long)sc.A * sc.S));
+    }
+    else if (TH == 8 && TW == 16) { DISPATCH_PF(8, 16) }
     else if (TH == 16 && TW == 16) { DISPATCH_PF(16, 16) }
     else if (TH == 12 && TW == 16) { DISPATCH_PF(12, 16) }
     else if (TH == 8 && TW == 8) { DISPATCH_PF(8, 8) }

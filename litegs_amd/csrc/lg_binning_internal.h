@@ -46,6 +46,7 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
                       int* grp_ticket /*nullable device int, zero on entry: the persistent workgroups take their groups of 256 slots on demand*/,
                       void* stream);
 int lg_binning_set_tuning(int key, int value);       // keys 10, 11 of lg_set_tuning (binning.hip)
+int lg_fused_set_tuning(int key, int value);         // key 12 (fused.hip)
 
 // grouping by tile without a sort (binning.hip "Tile scatter"): per-key counts -> range table + cursors -> values dropped at their
 // tile's cursor.  Order inside a tile is arbitrary: follow with lg_tile_depth_sort_gated(any_order = 1).

@@ -1264,6 +1264,7 @@ LG_API int lg_set_tuning(int key, int value)
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics; 2: the splat-parallel variant (A/B)
     case 8: g_rank_prio = value ? 1 : 0; return 0;                            // 1: issue priority by rank in a heavy-first schedule (wave_rank_priority)
     case 10: case 11: return lg_binning_set_tuning(key, value);                // key emission (binning.hip): in-workgroup ceiling, dynamic groups
+    case 12: return lg_fused_set_tuning(key, value);                           // fused projection (fused.hip): SH loads in front of the tile walk
     default: return (int)hipErrorInvalidValue;
     }
 }

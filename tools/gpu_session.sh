@@ -125,6 +125,8 @@ PY
       timeout -s KILL 600 python tools/late_phase.py parity /tmp/late.pt > gpurun_out/late_parity_$TAG.log 2>&1; grep -E "parity|PARITY" gpurun_out/late_parity_$TAG.log | tail -12 ;;
     critical)        # blend kernels: whole frame against the heaviest tiles alone (is the launch a critical path?)
       timeout -s KILL 300 python tools/late_phase.py critical recipe > gpurun_out/critical_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/critical_$TAG.log | tail -12 ;;
+    projab)          # fused projection: SH loads behind / in front of the tile walk (lg_set_tuning key 12), fresh and after 1000 steps
+      timeout -s KILL 300 python tools/proj_ab.py 3m_1080p 1000 > gpurun_out/proj_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/proj_ab_$TAG.log | tail -14 ;;
     bwdab)           # blend backward in situ on the bench workload: generic / fast / splat-parallel kernels, fresh and after 1000 steps
       timeout -s KILL 400 python tools/bwd_ab.py 3m_1080p 1000 > gpurun_out/bwd_ab_$TAG.log 2>&1; grep -v "amdgpu.ids" gpurun_out/bwd_ab_$TAG.log | tail -24 ;;
     recipeab:*)      # step / forward time of chosen variants on the training_state recipe

@@ -48,6 +48,7 @@ VARIANTS = {
     "emit_dynamic": (dict(_tuning={11: 2}), False),                        # key emission: groups handed out on demand after one static round (default: round robin)
     "emit_hi128": (dict(_tuning={10: 128}), False),                        # ... in-workgroup walk up to 128 tiles (default 256), larger splats cooperative
     "emit_hi64": (dict(_tuning={10: 64}), False),
+    "proj_early": (dict(_tuning={12: 1}), False),                          # fused projection: SH loads in front of the tile walk (csrc/fused.hip)
     "bwd_sp": (dict(_tuning={5: 2}), False),                               # blend backward: the splat-parallel formulation (csrc/raster.hip raster_backward_sp_kernel)
     "stat_epoch": (dict(), True),
     "stat_epoch_tile": (dict(long_list_global=0), True),
@@ -134,7 +135,7 @@ def configure(tr, attrs):
     base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
     base.update(attrs)
     from litegs_amd._lib import check, lib
-    tuning = {5: 1, 8: 0, 10: 256, 11: 0}                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0}                          # lg_set_tuning keys a variant may change, at their defaults
     tuning.update(base.pop("_tuning", {}))
     for key, val in tuning.items():
         check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
