@@ -207,7 +207,8 @@ int lg_unpack_gradient(const float* packed_grad, const float* packed /*[V,N,16] 
  * (0 = one band per XCD, 1 = identity, C >= 2 = runs of C workgroups interleaved over the XCDs); key 4: heaviest-first tile schedule
  * on / off; key 5: blend backward of 8x16 tiles without statistics (0 generic, 1 the packed two-pixel kernel = default, 2 the
  * splat-parallel formulation); key 7: packed blend forward on / off; key 8: issue priority by schedule rank; keys 10 / 11: key emission
- * (in-workgroup tile ceiling, groups on demand).  Defaults are the measured best; see DESIGN.md section 9. */
+ * (in-workgroup tile ceiling, groups on demand); key 12: fused projection with the SH loads in front of the tile walk.  Defaults are the
+ * measured best; see DESIGN.md section 9. */
 int lg_set_tuning(int key, int value);
 int lg_stat_in_record_supported(int TH, int TW);   /* 1: statistic renders of this tile shape carry their three statistics in gradient-record slots 9-11 (raster.hip) */
 
