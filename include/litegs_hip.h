@@ -125,7 +125,8 @@ int lg_get_allocate_size(const float* ndc, const float* view_z, const float* inv
                          const int* valid_length, int V, int N, int H, int W, int TH, int TW,
                          int32_t* left_up /*[V,2,N] or NULL*/, int32_t* right_down, int32_t* allocate_size /*[V,N]*/,
                          void* stream);                                                                             /* binning.cu:290-440 */
-/* create_table, first half (binning.cu:34-110): keys must be zero-filled; sorted_id int64 (torch.sort) or int32.
+/* create_table, first half (binning.cu:34-110): keys must be zero-filled; sorted_id int64 (torch.sort) or int32, or NULL = ascending id
+ * (prefix_sum then runs over the splats in id order: the grouped form of the table, lg_tile_group + lg_tile_depth_sort_unordered).
  * temp (lg_duplicate_with_keys_temp_bytes): queue of the splats that touch many tiles, emitted by a second launch (giants in
  * parts of 1024 tiles).  N < 2^24. */
 long long lg_duplicate_with_keys_temp_bytes(int V, int N, long long table_len);

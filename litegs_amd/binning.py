@@ -7,6 +7,8 @@ makes its output order for equal depths implementation defined) and the indices 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .binding import ops as fused
@@ -45,6 +47,54 @@ def depth_order_and_prefix(view_depth: torch.Tensor, allocate_size: torch.Tensor
     return (vb if odd else va), prefix
 
 
+def grouped_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_binning_allocate_size, idx_tensor, H, W, th, tw, tiles_num):
+    """The same table WITHOUT the two full-length sorts (single view): instances are emitted in ascending splat-id order (no depth sort of
+    the splats: prefix sums in id order), grouped by tile with per-tile counts and cursors (lg_tile_group: no sort over the instances
+    either) and every tile's list is then ordered by (view depth, id) in LDS (lg_tile_depth_sort_unordered) -- which is the order a STABLE
+    depth sort followed by a STABLE tile sort leaves (csrc/tilesort.hip), so tile_start_index and sorted_pointId are bit for bit what
+    depth_order_and_prefix + create_table + tileRange return.  Table sizing: the reference's protocol (GR/binning.cu:139-163: 1.5 x the
+    frame's previous total from the pinned feedback buffer, blocking on the first visit).  One difference, in the failure mode only: a
+    table that turns out too short drops the entries of the highest splat ids, not those of the deepest splats (the reference drops by
+    emission position, binning.cu:63, silently in both cases).  -> (tile_start_index i32[1,T+2], sorted_pointId i32[1,L])"""
+    L = lib()
+    s = _s()
+    dev = ndc.device
+    N = view_depth.shape[1]
+    ndc, inv_cov2d, opacity, view_depth = ndc.contiguous(), inv_cov2d.contiguous(), opacity.contiguous(), view_depth.contiguous()
+    allocate_size = allocate_size.contiguous()
+    tb = L.lg_scan_temp_bytes(N)
+    temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
+    prefix = torch.empty((1, N), dtype=torch.int32, device=dev)
+    check(L.lg_gather_inclusive_scan(allocate_size.data_ptr(), None, 0, N, prefix.data_ptr(), temp.data_ptr(), tb, s), "inclusive_scan")
+    pred = 0
+    if feedback_binning_allocate_size is not None and idx_tensor is not None:
+        k = int(idx_tensor[0])
+        pred = int(feedback_binning_allocate_size[k])
+        check(L.lg_feedback_d2h(feedback_binning_allocate_size.data_ptr() + 4 * k, prefix.data_ptr() + 4 * (N - 1), s), "feedback copy")
+    pred = int(1.5 * pred)
+    if pred <= 0 and N > 0:                  # blocking path (binning.cu:152-163)
+        pred = int(prefix[0, -1].item())
+    if pred <= 0:
+        raise RuntimeError("error pred_allocate_size")
+    keys = torch.zeros((1, pred), dtype=torch.int32, device=dev)
+    vals = torch.empty((1, pred), dtype=torch.int32, device=dev)
+    db = L.lg_duplicate_with_keys_temp_bytes(1, N, pred)
+    dtemp = torch.empty((db,), dtype=torch.uint8, device=dev)
+    check(L.lg_duplicate_with_keys(ndc.data_ptr(), inv_cov2d.data_ptr(), opacity.data_ptr(), prefix.data_ptr(), None, 0, 1, N, H, W, th, tw, pred,
+                                   keys.data_ptr(), vals.data_ptr(), dtemp.data_ptr(), db, s), "duplicate_with_keys")
+    tile_start = torch.empty((1, tiles_num + 2), dtype=torch.int32, device=dev)
+    grouped = torch.empty((1, pred), dtype=torch.int32, device=dev)
+    gtemp = torch.empty((2 * (tiles_num + 2),), dtype=torch.int32, device=dev)
+    check(L.lg_tile_group(keys.data_ptr(), vals.data_ptr(), pred, tiles_num, tile_start.data_ptr(), grouped.data_ptr(), gtemp.data_ptr(), s), "tile_group")
+    check(L.lg_tile_depth_sort_unordered(grouped.data_ptr(), tile_start.data_ptr(), view_depth.data_ptr(), 1, pred, N, tiles_num,
+                                         vals.data_ptr(), s), "tile_depth_sort")      # (vals is free again: scratch of the long lists)
+    return tile_start, grouped
+
+
+# LITEGS_OPERATOR_BINNING=sorted keeps the reference's structure (depth sort of the splats, stable tile radix sort) in this mirror too
+_GROUPED = os.environ.get("LITEGS_OPERATOR_BINNING", "grouped") != "sorted"
+
+
 @torch.no_grad()
 def binning(ndc, view_depth, inv_cov2d, opacity, valid_length, feedback_binning_allocate_size, idx_tensor,
             img_pixel_shape, tile_size, on_visible=None):
@@ -59,6 +109,10 @@ def binning(ndc, view_depth, inv_cov2d, opacity, valid_length, feedback_binning_
     b_visible = allocate_size != 0
     if on_visible is not None:
         on_visible(b_visible)
+    if _GROUPED and view_depth.shape[0] == 1 and view_depth.shape[1] < (1 << 24):
+        tile_start_index, sorted_point = grouped_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_binning_allocate_size,
+                                                       idx_tensor, H, W, th, tw, tiles_num)
+        return tile_start_index, sorted_point, b_visible.sum(0)
     depth_sorted_index, prefix_sum = depth_order_and_prefix(view_depth, allocate_size)
     sorted_tile, sorted_point = fused.create_table(ndc, inv_cov2d, opacity, prefix_sum, depth_sorted_index,
                                                    feedback_binning_allocate_size, idx_tensor, H, W, th, tw)

@@ -829,7 +829,7 @@ LG_API int lg_duplicate_with_keys(const float* ndc, const float* inv_cov, const 
                                   long long table_len, int32_t* keys, int32_t* values, void* temp, long long temp_bytes, void* stream)
 {
     if (N <= 0) return 0;
-    LG_REQUIRE(ndc, inv_cov, opacity, prefix, sorted_id, keys, values);
+    LG_REQUIRE(ndc, inv_cov, opacity, prefix, keys, values);            // sorted_id == NULL: the slots are the splats themselves (ascending id)
     if (temp == nullptr || temp_bytes < lg_duplicate_with_keys_temp_bytes(V, N, table_len)) return (int)hipErrorInvalidValue;
     int* qcount = (int*)temp;                                                                        // [V][DUP_NQ]
     uint32_t* qentries = (uint32_t*)(qcount + (size_t)V * DUP_NQ);

@@ -195,6 +195,44 @@ def test_binning_bit_exact(F, oracle, name):
     assert np.array_equal(host(tr), res.tile_start)
 
 
+@pytest.mark.parametrize("name", ["small", "pad"])
+def test_grouped_binning_returns_the_sorted_pipelines_table(oracle, name):
+    """litegs_amd.binning.binning (the host mirror of Binning.call_fused, wrapper.py:717-763) builds its table without the two full-length
+    sorts (emission in id order, grouping by tile, per-tile depth sort): tile ranges and point ids must be bit for bit what the reference's
+    structure (stable depth sort, create_table, tileRange) yields -- exact first visit and 1.5x over-allocated revisit"""
+    from litegs_amd import binning as B
+    c = case(name)
+    res = oracle_forward(name)
+    H, W = c["H"], c["W"]
+    op = res.act[4]
+    vd = np.ascontiguousarray(res.view_pos[:, 2, :])
+    total = int(res.prefix[0, -1])
+    ntiles = ((H + 7) // 8) * ((W + 15) // 16)
+    fb = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    idx = torch.tensor([0])
+    for visit in range(2):                       # first visit: blocking exact size; second: 1.5 x the total the first one fed back
+        want = total if visit == 0 else int(1.5 * total)
+        ks_r, vs_r, _, _ = oracle.create_table(res.ndc, res.inv_cov, op, res.prefix, res.depth_sorted_index, H, W, 8, 16, table_len=want)
+        assert B._GROUPED
+        ts, sp, nvis = B.binning(dev(res.ndc), dev(vd), dev(res.inv_cov), dev(op), None, fb, idx, (H, W), (8, 16))
+        torch.cuda.synchronize()
+        assert sp.shape[1] == want and int(fb[0]) == total
+        live = ks_r[0] > 0                        # payload of the zero padding is undefined
+        assert np.array_equal(host(sp)[0][live], vs_r[0][live])
+        B._GROUPED = False
+        try:
+            fb2 = fb.clone().pin_memory()
+            if visit == 0:
+                fb2.zero_()
+            ts2, sp2, nvis2 = B.binning(dev(res.ndc), dev(vd), dev(res.inv_cov), dev(op), None, fb2, idx, (H, W), (8, 16))
+        finally:
+            B._GROUPED = True
+        assert np.array_equal(host(ts), host(ts2)) and np.array_equal(host(nvis), host(nvis2))
+        assert np.array_equal(host(sp2)[0][live], vs_r[0][live])
+        if visit == 0:
+            assert np.array_equal(host(ts), res.tile_start)
+
+
 def test_create_table_overallocated_and_truncated(F, oracle):
     """GPU-driven sizing: a 1.5x over-allocated table sorts its zero padding to the front (tile 0); an under-sized
     table silently drops whole splats (GR/binning.cu:63)."""
