@@ -195,6 +195,8 @@ class FusedRenderer:
         self.spec_poison = None       # device int32[1], sticky
         self.spec_words = None        # HostWords(2): [0] mirror of the poison word, [1] step number of the last fused Adam launch that ran
         self.spec_step = 0            # number of the training step being enqueued
+        self.spec_forward = True      # False: culled forwards keep the gated repeat even while the steps are speculative (trainer.py: data-parallel
+                                      # runs whose bounds fail too often -- there a failure costs every rank a replay, the repeat only 40 us)
         self.force_full = False       # the next render runs unculled (the first replayed step)
         self._debug_words = None      # HostWords(8), validate_tables only
         self.emission_mismatches = 0  # validate_tables: slots whose emission walk disagreed with the projection's tile count
@@ -504,7 +506,7 @@ class _RenderFn(torch.autograd.Function):
         order_out = order_ptr if (use_sched and (refresh or not F.order_valid)) else None
         F.visits += 1
         # a culled render that a fused Adam step follows may run speculatively (no gated repeat); anything else keeps the repeat
-        cx = R.context(depth_order, replicas, F.margin, cull and R.fuse_optimizer and needs_grad)
+        cx = R.context(depth_order, replicas, F.margin, cull and R.fuse_optimizer and needs_grad and R.spec_forward)
         check(L.lg_fused_stage1(ctypes.byref(cx), *common, do_cull, visibility.data_ptr(), vis_num.data_ptr(), vis_ids.data_ptr(), A,
                                 ws1.data_ptr(), ws1_bytes, fb_vis_ptr if do_cull else None, fb_tot_ptr,
                                 *(R.cull_scratch(chunks, dev) if do_cull else (None, 0)), in_ptr if cull else None, out_ptr, s), "fused stage1")

@@ -77,6 +77,13 @@ class FrameTrainer:
         self._spec_events = []        # one event behind every speculative step still in flight
         self._spec_exchange = None    # the dp.MomentExchange the speculative steps in flight went through (None: single GPU)
         self._spec_dp = None          # ... and their bookkeeping (dp.LockstepSpeculation)
+        # Across ranks a failed forward costs EVERY rank a synchronisation and the replay of up to three steps, the gated repeat 40 us per
+        # step: with more than one failure per 64 steps the forwards go back to the gated repeat for a while (the exchange stays
+        # speculative: an overflowing record block is still a replayed step).  Decided from the job-wide verdicts: the same on every rank.
+        self.dp_fail_window, self.dp_fail_limit, self.dp_gated_steps = 64, 2, 256
+        self._dp_fail_steps = []
+        self._dp_gated_until = 0
+        self.dp_gated_periods = 0
         self.spec_depth = 2           # steps the host may run ahead of the device in speculative mode
         self.spec_replays = 0
         self.spec_log = []                # (step number, frame, visits of that frame so far, steps replayed) per violated bound
@@ -115,10 +122,21 @@ class FrameTrainer:
                 # sequence (litegs_amd/dp.py "rank-consistent speculation"); never the sticky word, whose value at a wall-clock moment differs
                 if self._spec_exchange is not grad_hook:
                     self._spec_dp_start(grad_hook)
+                R = self.renderer
+                if R.spec_forward:
+                    recent = [t for t in self._dp_fail_steps if self._spec_next - t < self.dp_fail_window]
+                    if len(recent) >= self.dp_fail_limit:
+                        R.spec_forward = False
+                        self._dp_gated_until = self._spec_next + self.dp_gated_steps
+                        self.dp_gated_periods += 1
+                elif self._spec_next >= self._dp_gated_until:
+                    R.spec_forward = True
+                    self._dp_fail_steps = []
                 rec = (self._spec_next, frame_index, [float(g["lr"]) for g in self.opt.param_groups], hook_slot, peer_frames)
                 self._spec_dp.before_step(rec)
                 self._spec_dp_restore_lrs()
             else:
+                self.renderer.spec_forward = True
                 # The host must not run far ahead of the device: everything enqueued behind a failed step is wasted and replayed.  Two steps
                 # in flight keep the device busy (enqueueing a step takes a third of its run time); the wait is on the step before those.
                 if len(self._spec_events) >= self.spec_depth:
@@ -133,6 +151,7 @@ class FrameTrainer:
                 self._spec_ring = [r for r in self._spec_ring if r[0] > done]
         else:
             self.renderer.disable_speculation()
+            self.renderer.spec_forward = True
             if moments and hasattr(grad_hook, "disable_speculation"):
                 grad_hook.disable_speculation()
         loss = self._step_body(frame_index, grad_hook, hook_slot, peer_frames)
@@ -162,6 +181,8 @@ class FrameTrainer:
             no, frame_index, _lrs, slot, _peers = rec
             R.clear_poison()
             exchange.after_failed_step(slot, flags)
+            if flags & 0xff:                              # a culled forward failed on some rank (not a mere block overflow)
+                self._dp_fail_steps.append(int(no))
             if (flags >> exchange.rank) & 1:              # this rank's bounds were violated: what the gated repeat's bookkeeping does
                 k = self.frames[frame_index % len(self.frames)].cam.index
                 if len(self.spec_log) < 64:
