@@ -614,7 +614,7 @@ def main():
         if world > 1 and hasattr(hook, "bytes_last"):
             result["dp_exchange"] = {"mode": "moments", "bytes_received_per_rank_per_step": int(hook.bytes_last), "record_capacity": int(hook.last_cap),
                                      "speculative_culling": bool(tr.speculative and hook.spec is not None),
-                                     "capacity_factor": hook.spec_cap_factor if (tr.speculative and hook.spec is not None) else hook.cap_factor,
+                                     "capacity_factor": hook.last_factor,
                                      "overflow_replays": int(hook.overflow_replays), "replayed_steps": int(tr.spec_replays),
                                      "periods_with_gated_forwards": int(tr.dp_gated_periods), **dp_diag}
         if world == 1 and not args.operator_path and not args.no_operator_path:

@@ -424,6 +424,7 @@ class MomentExchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.overflow_replays = 0
         self._overflow_at = []
+        self._loose_until = 0
         self.rebind(params)
 
     supports_speculation = True
@@ -453,11 +454,13 @@ class MomentExchange:
         self.fb_k[slot, 0] = 0
         if flags & Speculation.OVERFLOW:
             self.overflow_replays += 1
-            # a run of overflows (counts that keep jumping although they looked settled): give the slack back rather than live on replays.
+            # a run of overflows (counts that keep jumping although they looked settled): give the slack back for 256 steps rather than live on
+            # replays.
             # Decided from events every rank sees at the same step, so the ranks keep sizing their blocks alike
             self._overflow_at = [t for t in self._overflow_at if self.steps - t < 64] + [self.steps]
             if len(self._overflow_at) >= 8:
-                self.spec_cap_factor = self.cap_factor
+                self._loose_until = self.steps + 256
+                self._overflow_at = []
 
     def rebind(self, params) -> None:
         p0 = params[0]
@@ -485,6 +488,8 @@ class MomentExchange:
         self.in_flight = []                              # (step number, slot) of steps whose overflow word has not been read yet
         self.steps = 0
         self.last_cap = 0
+        self.last_factor = self.cap_factor
+        self._overflow_at, self._loose_until = [], 0      # (step numbers start over)
         self.bytes_last = 0
         self._mask_work = None
         self._marks = []
@@ -624,7 +629,9 @@ class MomentExchange:
         else:
             # under speculation an overflow costs a replay, not the run: the slack shrinks once the slot's count has stopped moving
             # (early in training it doubles between visits: there the replays would cost more than the padding)
-            cap = int((self.spec_cap_factor if (spec is not None and settled) else self.cap_factor) * pred) + self.cap_margin
+            tight = spec is not None and settled and self.steps >= self._loose_until
+            cap = int((self.spec_cap_factor if tight else self.cap_factor) * pred) + self.cap_margin
+            self.last_factor = self.spec_cap_factor if tight else self.cap_factor
         self.last_cap = cap
         # wire container: int32 words (record = index word + nine float bit patterns) -- an integer collective can only copy
         block = torch.empty(((1 + cap) * nrec,), dtype=torch.int32, device=dev)
