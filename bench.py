@@ -471,6 +471,7 @@ def main():
         tr.step(frame_of(step_no), hook, step_no % n_slots, peers_of(step_no))
         step_no += 1
     tr.flush()                                        # the warm-up is complete: a speculative warm-up step that failed is replayed HERE, not on the clock
+    replays_before_timing = int(tr.spec_replays)      # (reported: `replayed_steps_before_timed_region`)
     torch.cuda.synchronize()
     if args.pmc_child:                                # wrapped by rocprofv3 --pmc (pmc_traffic): a few more training steps, nothing else
         for i in range(args.steps):
@@ -577,7 +578,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), **{k: v for k, v in percentiles(step_ms).items() if k != "samples"},
             # mean over the steps whose event interval holds no speculative replay (`value` and ms_per_step include every replay)
             "ms_per_step_excl_replays": round(float(np.mean([m for i, m in enumerate(step_ms) if i not in set(with_replay)] or [0.0])), 4),
-            "steps_with_replay": with_replay, "steps_replayed_in_final_flush": int(replays_in_flush), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "steps_with_replay": with_replay, "steps_replayed_in_final_flush": int(replays_in_flush),
+            "replayed_steps_before_timed_region": replays_before_timing, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} Gaussians SH3, {W}x{H}, 1 camera frame per GPU per step, full training iteration "
                                    "(render_preprocess+render+L1/SSIM loss+backward+sparse Adam), seed 0 (SURVEY 8d)",
