@@ -65,6 +65,39 @@ def test_oracle_binning_invariants(oracle):
         assert keys[ts[t]] == t and (ts[t] == 0 or keys[ts[t] - 1] != t)
 
 
+def test_oracle_bounds_a_degenerate_splats_entries_to_its_share(oracle):
+    """The first tile slice of a needle-like splat can count NEGATIVE tiles (GR/speedy_splat.cuh:118-125 adds the difference to the splat's
+    count all the same): the count is then smaller than the tiles its slices hold.  Pinned here on the CPU: the signed counts of the fourteen
+    fixture splats (found by tests/host/walk_check.cpp's generator, the numbers in their comments), and the oracle's rule that a splat owns
+    exactly [offset, offset + count) of the table -- every word of it a valid tile id, the surplus tiles of the last slices dropped
+    (oracle/litegs_oracle.c process_tiles; csrc/binning.hip follows it bit for bit: tests/test_gpu_edge.py, profiles/r05_fault_root_cause.md)."""
+    from test_gpu_edge import DEGENERATE_SPLATS, degenerate_table_inputs
+    H, W = 1080, 1920
+    rows = np.array(DEGENERATE_SPLATS, dtype=np.float32)
+    N = len(rows)
+    ndc = np.zeros((1, 4, N), np.float32); ndc[0, 0] = rows[:, 0]; ndc[0, 1] = rows[:, 1]; ndc[0, 2] = 0.5; ndc[0, 3] = 1.0
+    inv = np.zeros((1, 2, 2, N), np.float32); inv[0, 0, 0] = rows[:, 2]; inv[0, 0, 1] = inv[0, 1, 0] = rows[:, 3]; inv[0, 1, 1] = rows[:, 4]
+    op = np.ascontiguousarray(rows[:, 5][None])
+    vz = np.linspace(1.0, 2.0, N, dtype=np.float32)[None]
+    lu, rd, al = oracle.get_allocate_size(ndc, vz, inv, op, H, W, 8, 16)
+    assert al[0].tolist() == [54, 44, 103, 38, 46, 40, 33, 38, 55, 45, 43, 67, 74, 66]
+    area = (rd[0, 0] - lu[0, 0]) * (rd[0, 1] - lu[0, 1])
+    assert (al[0] <= area).all()                                          # (a count never exceeds the tile rectangle)
+    for copies in (1, 7):
+        ndc, inv, op, vz = degenerate_table_inputs(copies)
+        _, _, al = oracle.get_allocate_size(ndc, vz, inv, op, H, W, 8, 16)
+        dsi = np.argsort(vz, axis=-1, kind="stable").astype(np.int64)
+        prefix = np.cumsum(np.take_along_axis(al, dsi, axis=-1), axis=-1, dtype=np.int64).astype(np.int32)
+        ks, vs, ks_u, vs_u = oracle.create_table(ndc, inv, op, prefix, dsi, H, W, 8, 16)
+        assert ks.shape[1] == int(prefix[0, -1]) and (ks > 0).all() and ks.max() <= (H // 8) * (W // 16)
+        assert (np.diff(ks[0]) >= 0).all()
+        assert np.array_equal(np.bincount(vs[0], minlength=al.shape[1]), al[0])      # every splat: exactly its count, no more, no less
+        if ks_u is not None:                                                         # unsorted emission: splat j's entries sit in its own share
+            off = np.concatenate([[0], prefix[0]])
+            for slot in range(al.shape[1]):
+                assert (vs_u[0, off[slot]:off[slot + 1]] == dsi[0, slot]).all()
+
+
 def test_train_loop_schedule_with_a_fake_trainer():
     """litegs_amd.trainer.train(): the reference's epoch shape (trainer.py:108-195) -- begin_epoch guard, ceil(frames / world) steps of
     disjoint frames per rank, end_epoch hook, the exchange attached to the trainer (re-bound by the trainer only when the parameters
