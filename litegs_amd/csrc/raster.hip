@@ -1257,13 +1257,14 @@ __global__ void __launch_bounds__(256) raster_backward_sp_kernel(const int* __re
 LG_API int lg_set_tuning(int key, int value)
 {
     switch (key) {
-    case 1: g_bwd_map = value; return 0;                                      // workgroup -> tile map of the blend backward (block_remap)
-    case 2: g_fwd_map = value; return 0;                                      // ... of the blend forward
+    // (maps travel in the low byte of the kernels' map_mode argument, the priority switch above it: a map beyond 255 would turn priorities on)
+    case 1: if (value < 0 || value > 255) return (int)hipErrorInvalidValue; g_bwd_map = value; return 0;      // workgroup -> tile map of the blend backward (block_remap)
+    case 2: if (value < 0 || value > 255) return (int)hipErrorInvalidValue; g_fwd_map = value; return 0;      // ... of the blend forward
     case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
     case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics; 2: the splat-parallel variant (A/B)
     case 8: g_rank_prio = value ? 1 : 0; return 0;                            // 1: issue priority by rank in a heavy-first schedule (wave_rank_priority)
-    case 10: case 11: return lg_binning_set_tuning(key, value);                // key emission (binning.hip): in-workgroup ceiling, dynamic groups
+    case 10: case 11: case 13: case 14: case 15: return lg_binning_set_tuning(key, value);   // binning.hip: key emission variants (10, 11, 13, 14), look-back width of small sorts (15)
     case 12: return lg_fused_set_tuning(key, value);                           // fused projection (fused.hip): SH loads in front of the tile walk
     default: return (int)hipErrorInvalidValue;
     }

@@ -33,9 +33,12 @@ _DEPTH_ORDER = {"global": 0, "tile": 1, "auto": 2}
 def _apply_env_tuning():
     """LITEGS_TUNING="key=value[,key=value...]" (measurement aid): lg_set_tuning launch variants for a whole process (bench.py A/B runs)"""
     spec = os.environ.get("LITEGS_TUNING", "")
-    for kv in filter(None, spec.split(",")):
-        key, val = kv.split("=")
-        check(lib().lg_set_tuning(int(key), int(val)), f"lg_set_tuning({kv})")
+    for kv in filter(None, (t.strip() for t in spec.split(","))):
+        try:
+            key, val = (int(t) for t in kv.split("="))
+        except ValueError:
+            raise ValueError(f"LITEGS_TUNING: malformed entry {kv!r} (expected key=value with integer key and value)") from None
+        check(lib().lg_set_tuning(key, val), f"lg_set_tuning({kv})")
 
 
 _TUNING_APPLIED = False

@@ -212,3 +212,56 @@ def test_degenerate_slices_keep_the_table_inside_each_splats_share(oracle):
         assert np.array_equal(vs.cpu().numpy(), vs_r), copies
     counts = FusedRenderer.sanitised_counts(reset=True)
     assert not any(v for k, v in counts.items() if k != "truncated_tables"), counts     # nothing had to be neutralised
+
+
+EMISSION_VARIANTS = {                       # lg_set_tuning(13, mode), (14, in-wave ceiling): csrc/binning.hip emit_wave_kernel
+    "workgroup_form": (0, 1024),            # round 2-5's dup_small + dup_big
+    "wave_form": (1, 1024),                 # the default
+    "wave_form_all_queued": (1, 32),        # every splat beyond the staged class goes to dup_big
+    "wave_form_nothing_queued": (1, 1 << 20),   # ... is emitted by the wave that owns its slot (2-D lane map), whatever its size
+}
+
+
+@pytest.mark.parametrize("variant", list(EMISSION_VARIANTS))
+def test_emission_variants_build_one_table(oracle, variant):
+    """the three size classes of the key emission (staged in LDS by the owning lane / one lane per slice with the 2-D lane map / queued for
+    the cooperative kernel) are the same walk: whatever the ceilings, create_table returns the oracle's table bit for bit -- on the
+    degenerate splats (negative first slice), on near-camera giants (1 000..16 000 tiles, runs longer than 64 tiles) and on an exact and a
+    truncated table"""
+    from litegs_amd import fused as F
+    from litegs_amd._lib import lib, check
+    from litegs_amd.fast import FusedRenderer
+    mode, big = EMISSION_VARIANTS[variant]
+    H, W = 1080, 1920
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    FusedRenderer.sanitised_counts(reset=True)
+    check(lib().lg_set_tuning(13, mode), "tuning"); check(lib().lg_set_tuning(14, big), "tuning")
+    try:
+        for copies in (1, 40):
+            ndc, inv, op, vz = degenerate_table_inputs(copies)
+            _, _, al_r = oracle.get_allocate_size(ndc, vz, inv, op, H, W, 8, 16)
+            dsi = np.argsort(vz, axis=-1, kind="stable").astype(np.int64)
+            prefix = np.cumsum(np.take_along_axis(al_r, dsi, axis=-1), axis=-1, dtype=np.int64).astype(np.int32)
+            ks_r, vs_r, _, _ = oracle.create_table(ndc, inv, op, prefix, dsi, H, W, 8, 16)
+            ks, vs = F.create_table(dev(ndc), dev(inv), dev(op), dev(prefix), dev(dsi), None, None, H, W, 8, 16)
+            torch.cuda.synchronize()
+            assert np.array_equal(ks.cpu().numpy(), ks_r) and np.array_equal(vs.cpu().numpy(), vs_r), copies
+        scene = list(S.make_scene(2048, seed=21, scale_mult=1.5))
+        view, proj, planes = S.make_camera(W, H, 1200.0, 1200.0, (0.4, -0.1, 0.3))
+        ref = oracle.render_forward(scene, view, proj, planes, H, W, 3)
+        assert (ref.alloc[0] > 4096).sum() >= 3
+        op = ref.act[4]
+        ks, vs = F.create_table(dev(ref.ndc), dev(ref.inv_cov), dev(op), dev(ref.prefix), dev(ref.depth_sorted_index), None, None, H, W, 8, 16)
+        assert np.array_equal(ks.cpu().numpy(), ref.sorted_tile) and np.array_equal(vs.cpu().numpy(), ref.sorted_point)
+        total = int(ref.prefix[0, -1])
+        want = int(1.5 * int(0.45 * total))
+        ks_r, vs_r, _, _ = oracle.create_table(ref.ndc, ref.inv_cov, op, ref.prefix, ref.depth_sorted_index, H, W, 8, 16, table_len=want)
+        fb = torch.tensor([int(0.45 * total)], dtype=torch.int32).pin_memory()
+        ks, vs = F.create_table(dev(ref.ndc), dev(ref.inv_cov), dev(op), dev(ref.prefix), dev(ref.depth_sorted_index), fb, torch.tensor([0]), H, W, 8, 16)
+        torch.cuda.synchronize()
+        live = ks_r[0] > 0
+        assert want < total and np.array_equal(ks.cpu().numpy(), ks_r) and np.array_equal(vs.cpu().numpy()[0][live], vs_r[0][live])
+    finally:
+        check(lib().lg_set_tuning(13, 1), "tuning"); check(lib().lg_set_tuning(14, 1024), "tuning")
+    counts = FusedRenderer.sanitised_counts(reset=True)
+    assert not any(v for k, v in counts.items() if k != "truncated_tables"), counts

@@ -48,6 +48,11 @@ VARIANTS = {
     "emit_dynamic": (dict(_tuning={11: 2}), False),                        # key emission: groups handed out on demand after one static round (default: round robin)
     "emit_hi128": (dict(_tuning={10: 128}), False),                        # ... in-workgroup walk up to 128 tiles (default 256), larger splats cooperative
     "emit_hi64": (dict(_tuning={10: 64}), False),
+    "emit_wg": (dict(_tuning={13: 0, 15: 8}), False),                      # round 5's binning: workgroup-form emission (dup_small), look-back 8 wide in the splat sort
+    "emit_wave_only": (dict(_tuning={13: 1, 15: 8}), False),               # wave-form emission alone
+    "sort_lb32_only": (dict(_tuning={13: 0, 15: 32}), False),              # 32-wide look-back in the splat sort alone
+    "emit_big512": (dict(_tuning={14: 512}), False),                       # wave-form emission: in-wave ceiling 512 / 4096 tiles (default 1024)
+    "emit_big4096": (dict(_tuning={14: 4096}), False),
     "proj_early": (dict(_tuning={12: 1}), False),                          # fused projection: SH loads in front of the tile walk (csrc/fused.hip)
     "bwd_sp": (dict(_tuning={5: 2}), False),                               # blend backward: the splat-parallel formulation (csrc/raster.hip raster_backward_sp_kernel)
     "stat_epoch": (dict(), True),
@@ -135,7 +140,7 @@ def configure(tr, attrs):
     base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
     base.update(attrs)
     from litegs_amd._lib import check, lib
-    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0}                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 13: 1, 14: 1024, 15: 32}                          # lg_set_tuning keys a variant may change, at their defaults
     tuning.update(base.pop("_tuning", {}))
     for key, val in tuning.items():
         check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
