@@ -60,6 +60,8 @@ def grouped_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_b
     s = _s()
     dev = ndc.device
     N = view_depth.shape[1]
+    if N <= 0:                               # nothing to size a table from (and prefix[N - 1] below would lie in front of the buffer)
+        raise RuntimeError("error pred_allocate_size")
     ndc, inv_cov2d, opacity, view_depth = ndc.contiguous(), inv_cov2d.contiguous(), opacity.contiguous(), view_depth.contiguous()
     allocate_size = allocate_size.contiguous()
     tb = L.lg_scan_temp_bytes(N)

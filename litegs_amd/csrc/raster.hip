@@ -175,7 +175,25 @@ __device__ __forceinline__ void rec_id_wait(f32x16& rec, int& id) { asm volatile
 // v_min_f32 without the canonicalising v_max the compiler puts in front of fminf when it cannot prove its operand quiet
 __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_fwd_fast = 1;       // launch variants (lg_set_tuning: A/B hooks of tools/ and tests/, plain ints)
+// L2 warm-up of the scalar path (round 6).  A scalar load can only be waited for with lgkmcnt(0) (scalar loads return out of order), so
+// the record of splat p + 1 is requested while splat p is blended and waited for at the end of that splat: ONE splat of latency cover,
+// whatever the register budget.  That is enough while the records sit in L2 (the fresh cloud: ~80 splats per tile) and not when they
+// do not: in the training state (1 400 instances per tile, 138 MB of records in per-tile depth order) SQ counters show the blend
+// forward parked at s_waitcnt for 45 % of its wave cycles with the vector pipes active in 41 % of the launch, the backward 24 % / 57 %
+// (profiles/r06_sq_training_state_before_prefetch.md).  The vector memory path has in-order counters and nothing else to do in these
+// kernels: every `pfb` list positions, `pfb` lanes load the splat ids two blocks ahead (one coalesced line of the list) and touch
+// one dword of each record one block ahead (a gather of `pfb` lines), with the ids that arrived a block earlier.  Nothing is done
+// with the data; the lines are in L2 when the scalar loads ask for them.  Lists shorter than 2 * pfb + 64 positions skip it.
+struct PfState { int ids; unsigned g; };
+__device__ __forceinline__ unsigned pf_touch(const float* __restrict__ pk, int id, int N)
+{
+    return reinterpret_cast<const unsigned*>(pk)[(size_t)(min((unsigned)id, (unsigned)(N - 1))) << 4];
+}
+// consume the previous block's gather (it was issued a block ago: no stall) so that its register is free again
+__device__ __forceinline__ void pf_retire(unsigned g) { asm volatile("" : : "v"(g)); }
+
+static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_fwd_fast = 1;
+static int g_pf_block = 16;       // list positions per L2 warm-up block of the fast blend kernels (0: off; lg_set_tuning(16, 0 | 8 | 16 | 32 | 64))       // launch variants (lg_set_tuning: A/B hooks of tools/ and tests/, plain ints)
 static int g_rank_prio = 0;       // 1: waves of the heaviest tiles of a heavy-first schedule raise their issue priority (wave_rank_priority)
 
 // Tail of the blend launches (profiles/r04_blend_critical_path.log): the heaviest tile of a late-phase frame walks 1127 splats; alone on
@@ -388,7 +406,7 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     const int n = (start >= 0 && end > start) ? end - start : 0;
     const int* __restrict__ sp = sorted_points + (size_t)view * L + (start >= 0 ? start : 0);
     if constexpr (PPL == 2) {
-        if (n > 0 && fast) {
+        if (n > 0 && (fast & 0xff)) {
             FwdFast f;
             f.X = st.X; f.Y = v2f{ st.Y[0], st.Y[1] }; f.T = v2f{ 1.0f, 1.0f };
             f.Cr = f.Cg = f.Cb = v2f{ 0.0f, 0.0f };
@@ -402,7 +420,21 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id_a), "+s"(id_b));
             rec_request(ra, pk, rec_off(id_a, N));
             rec_wait(ra);
+            const int pfb = fast >> 8;                                         // L2 warm-up block (PfState above); 0: off
+            const bool pf_on = pfb > 0 && n >= 2 * pfb + 64;
+            PfState pf = { 0, 0u };
+            if (pf_on && lane < pfb) {
+                pf.g = pf_touch(pk, sp[min(pfb + lane, n - 1)], N);          // block 1 (one dependent round trip before the walk)
+                pf.ids = sp[min(2 * pfb + lane, n - 1)];                       // ids of block 2, left in flight
+            }
             for (int pos = 0; pos < n; pos += 2) {                            // `ra` holds position pos
+                if (pf_on && pos > 0 && (pos & (pfb - 1)) == 0) {             // uniform: start of a block
+                    pf_retire(pf.g);
+                    if (lane < pfb) {
+                        pf.g = pf_touch(pk, pf.ids, N);                        // records of the next block
+                        pf.ids = sp[min(pos + 2 * pfb + lane, n - 1)];         // ids of the block after it
+                    }
+                }
                 const unsigned cur_a = rec_off(id_a, N) >> 6, cur_b = rec_off(id_b, N) >> 6;  // splat ids of `ra` / `rb` (statistics)
                 rec_request(rb, pk, rec_off(id_b, N));
                 id_request(id_a, sp, (unsigned)min(pos + 2, n - 1) << 2);
@@ -418,6 +450,7 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
                 if (!live) break;
                 visited = pos + 2;
             }
+            pf_retire(pf.g);
             st.T[0] = f.T.x; st.T[1] = f.T.y;
             st.Cr[0] = f.Cr.x; st.Cr[1] = f.Cr.y; st.Cg[0] = f.Cg.x; st.Cg[1] = f.Cg.y; st.Cb[0] = f.Cb.x; st.Cb[1] = f.Cb.y;
             st.lc[0] = f.lc0; st.lc[1] = f.lc1;
@@ -511,7 +544,7 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_RF(A_, B_, S_) hipLaunchKernelGGL((raster_forward_kernel<A_, B_, S_>), grid, block, 0, s, sorted_points, start_index, packed, \
-                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, fail_host, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map | (g_rank_prio << 8), g_fwd_fast)
+                                                 tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, fail_host, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map | (g_rank_prio << 8), (g_fwd_fast ? 1 : 0) | (g_pf_block << 8))
 #define DISPATCH_RF(A_, B_) do { if (enable_stat) LAUNCH_RF(A_, B_, true); else LAUNCH_RF(A_, B_, false); } while (0)
     if (TH == 8 && TW == 16) DISPATCH_RF(8, 16);
     else if (TH == 16 && TW == 16) DISPATCH_RF(16, 16);
@@ -1023,7 +1056,8 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
     const int nb = gridDim.x;
-    const int prio_mode = map_mode >> 8;
+    const int map_mode_in = map_mode;                 // bits 0-7 map, 8-15 priority switch, 16-23 L2 warm-up block
+    const int prio_mode = (map_mode >> 8) & 0xff;
     map_mode &= 0xff;
     int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
     const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
@@ -1089,10 +1123,27 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     rec_request(ra, pk, off_a);
     id_request(hot_a, hot, hot_on ? off_a >> 4 : 0u);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(hot_a));
+    // L2 warm-up one block down the list (PfState above); the walk descends, blocks end at positions = pfb - 1 (mod pfb)
+    const int pfb = (map_mode_in >> 16) & 0xff;
+    const bool pf_on = pfb > 0 && n >= 2 * pfb + 64;
+    PfState pf = { 0, 0u };
+    if (pf_on && lane < pfb) {
+        pf.g = pf_touch(pk, sp[max(pos - pfb - lane, 0)], N);
+        pf.ids = sp[max(pos - 2 * pfb - lane, 0)];
+    }
+#define PF_STEP()                                                                                             \
+    if (pf_on && (pos & (pfb - 1)) == pfb - 1) {                                                              \
+        pf_retire(pf.g);                                                                                      \
+        if (lane < pfb) {                                                                                     \
+            pf.g = pf_touch(pk, pf.ids, N);                                                                   \
+            pf.ids = sp[max(pos - 2 * pfb - lane, 0)];                                                        \
+        }                                                                                                     \
+    }
     // phase 1: positions that some pixel of the tile had already stopped before (pos >= minlast): per-pixel last_contributor test
 #define HOT_TARGET(h, off) ((hot_on && (h) >= 0) ? (((unsigned)N + ((unsigned)(h) >> 6) + ((unsigned)tile & ((1u << ((h) & 63)) - 1u))) << 6) : (off))
 #define BWD_PAIR(CHK)                                                                                         \
     {                                                                                                         \
+        PF_STEP()                                                                                             \
         rec_request(rb, pk, off_b);                                                                           \
         id_request(hot_b, hot, hot_on ? off_b >> 4 : 0u);                                                     \
         id_request(id_a, sp, (unsigned)max(pos - 2, 0) << 2);                                                 \
@@ -1109,7 +1160,9 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     }
     for (; pos >= 1 && pos >= minlast; ) BWD_PAIR(true)
     for (; pos >= 1; ) BWD_PAIR(false)
+    pf_retire(pf.g);
 #undef BWD_PAIR
+#undef PF_STEP
 #undef HOT_TARGET
 }
 
@@ -1263,6 +1316,7 @@ LG_API int lg_set_tuning(int key, int value)
     case 4: g_use_order = value; return 0;                                    // 0: ignore the heaviest-first tile schedule
     case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics; 2: the splat-parallel variant (A/B)
+    case 16: if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return (int)hipErrorInvalidValue; g_pf_block = value; return 0;   // L2 warm-up block of the fast blend kernels
     case 8: g_rank_prio = value ? 1 : 0; return 0;                            // 1: issue priority by rank in a heavy-first schedule (wave_rank_priority)
     case 10: case 11: case 13: case 14: case 15: return lg_binning_set_tuning(key, value);   // binning.hip: key emission variants (10, 11, 13, 14), look-back width of small sorts (15)
     case 12: return lg_fused_set_tuning(key, value);                           // fused projection (fused.hip): SH loads in front of the tile walk
@@ -1324,7 +1378,7 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
     }
     else if (TH == 8 && TW == 16 && g_bwd_fast && !(enable_stat && hot_of != nullptr)) {
 #define LAUNCH_RBF(T_, S_) hipLaunchKernelGGL((raster_backward_fast_kernel<T_, S_>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last, \
-                                              d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map | (g_rank_prio << 8), hot_of)
+                                              d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map | (g_rank_prio << 8) | (g_pf_block << 16), hot_of)
         if (enable_stat && err_square_sum == nullptr) { if (d_trans) LAUNCH_RBF(true, 2); else LAUNCH_RBF(false, 2); }       // executor: statistics in the record
         else if (enable_stat) { if (d_trans) LAUNCH_RBF(true, 1); else LAUNCH_RBF(false, 1); }
         else { if (d_trans) LAUNCH_RBF(true, 0); else LAUNCH_RBF(false, 0); }

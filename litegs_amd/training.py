@@ -87,7 +87,9 @@ def _learnable_cameras(cameras_info, training_frames, test_frames, frames: List[
     noise_extr = torch.stack([torch.from_numpy(np.asarray(f.extr_params, dtype=np.float32)) for f in training_frames]).to(device)
     extr = torch.nn.Embedding(noise_extr.shape[0], noise_extr.shape[1], _weight=noise_extr.clone(), sparse=True)
     intr0 = float(list(cameras_info.values())[0].intr_params)            # (the reference's "todo fix multi cameras": first camera only)
-    intr = torch.nn.Parameter(torch.tensor([[intr0]], dtype=torch.float32, device=device))
+    # shape [1], as the reference builds it (torch.tensor(scalar).unsqueeze(0), trainer.py:87-88) and as its consumers of viewproj.pth
+    # expect (CreateViewProj takes a 1-D accessor: GR/compact.cu:19, example_metrics.py:90)
+    intr = torch.nn.Parameter(torch.tensor([intr0], dtype=torch.float32, device=device))
     view_opt = torch.optim.SparseAdam(extr.parameters(), lr=1e-4)
 
     def rebuild(frs, params7):

@@ -851,6 +851,74 @@ ORC_API void orc_raster_forward(const int32_t* sorted_points /*[V,L]*/, const in
 }
 
 /* ------------------------------------------------------------------------- */
+/* Decision masks of the blend (test infrastructure of tests/util.py's parity  */
+/* rule; no reference counterpart).  The forward of GR/raster.cu:226-329 takes */
+/* two kinds of threshold decisions per (pixel, splat) pair: "active" (T >     */
+/* 1/8192, tested before the splat) and "valid" (alpha >= 1/256).  An          */
+/* implementation whose exp() differs by an ulp can decide a pair the other    */
+/* way when the tested quantity sits within a relative `delta` of its          */
+/* threshold; that moves the pixel by up to colour/256 and changes every       */
+/* gradient term of that pixel from this splat on (T and the behind-colour of  */
+/* all later splats).  This walk marks                                         */
+/*   near_px[V,1,Hp,Wp]  pixels with at least one such pair,                   */
+/*   near_splat[V,N]     splats that stand at or behind such a pair in some    */
+/*                       pixel (their gradient sums contain affected terms).   */
+/* Everything NOT marked can only differ by rounding.                          */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_raster_decisions(const int32_t* sorted_points, const int32_t* start_index, const float* packed,
+                                  int V, int64_t L, int N, int H, int W, int TH, int TW, float delta,
+                                  uint8_t* near_px /*[V,1,Hp,Wp] zeroed*/, uint8_t* near_splat /*[V,N] zeroed*/)
+{
+    int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
+    int Wp = gx * TW, Hp = gy * TH, ntiles = gx * gy;
+    int P = TH * TW;
+    const float a_lo = (1.0f / 256) * (1.0f - delta), a_hi = (1.0f / 256) * (1.0f + delta);
+    const float t_lo = (1.0f / 8192) * (1.0f - delta), t_hi = (1.0f / 8192) * (1.0f + delta);
+    for (int b = 0; b < V; b++) {
+        const int32_t* sp = sorted_points + (size_t)b * L;
+        const int32_t* si = start_index + (size_t)b * (ntiles + 2);
+        const float* pk = packed + (size_t)b * N * ORC_REC;
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int tile = 1; tile <= ntiles; tile++) {
+            int start = si[tile], end = si[tile + 1];
+            if (start == -1) continue;
+            int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
+            float T[256];
+            uint8_t near[256];
+            for (int q = 0; q < P; q++) { T[q] = 1.0f; near[q] = 0; }
+            for (int idx = start; idx < end; idx++) {
+                int any_active = 0;
+                /* a pixel that is only just inactive may be active in another implementation: it keeps the walk alive here too */
+                for (int q = 0; q < P; q++) any_active |= (T[q] > t_lo);
+                if (!any_active) break;
+                int pid = sp[idx];
+                const float* r = pk + (size_t)pid * ORC_REC;
+                int touched = 0;
+                for (int q = 0; q < P; q++) {
+                    int active = T[q] > 1.0f / 8192;
+                    if (T[q] > t_lo && T[q] <= t_hi) near[q] = 1;
+                    float dx, dy;
+                    float power = splat_power(r, (float)(tx * TW + q % TW), (float)(ty * TH + q / TW), &dx, &dy);
+                    float alpha = r[8] * expf(power);
+                    if ((active || near[q]) && alpha >= a_lo && alpha < a_hi) near[q] = 1;
+                    int valid = active && (alpha >= 1.0f / 256);
+                    alpha = fminf_(255.0f / 256, alpha);
+                    if (!valid) alpha = 0.0f;
+                    /* the splat's sums contain a term of this pixel if it is (or, decided the other way, would be) taken here */
+                    if (near[q] && (alpha > 0.0f || (r[8] * expf(power)) >= a_lo)) touched = 1;
+                    T[q] = T[q] * (1.0f - alpha);
+                }
+                if (touched) near_splat[(size_t)b * N + pid] = 1;      /* (racing stores of the same value) */
+            }
+            for (int q = 0; q < P; q++) {
+                int x = tx * TW + q % TW, y = ty * TH + q / TW;
+                near_px[(size_t)b * Hp * Wp + (size_t)y * Wp + x] = near[q];
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* a14 rasterize_backward       GR/raster.cu:651-849 (+ unpack :866-884)       */
 /* Reverse order from max(last)-1; pixel valid iff alpha>=1/256 && idx<last;    */
 /* T_i = min(1, T_{i+1}/(1-alpha)); dC/dc = alpha*T; dalpha = sum_ch (c-Cbehind)*T*dL/dC */

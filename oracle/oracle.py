@@ -318,6 +318,21 @@ def raster_backward(sorted_points, start_index, packed, final_T, last, d_img, H,
     return d_ndc, d_ic, d_color, d_opa, esq
 
 
+def raster_decisions(sorted_points, start_index, packed, H, W, TH, TW, delta=1e-3):
+    """-> (near_px bool[V,1,Hp,Wp], near_splat bool[V,N]): where a blend threshold decision (alpha >= 1/256, T > 1/8192) sits within a
+    relative `delta` of its threshold, and which splats' gradient sums contain terms behind such a decision (orc_raster_decisions)."""
+    sorted_points = np.ascontiguousarray(sorted_points, np.int32)
+    start_index = np.ascontiguousarray(start_index, np.int32)
+    V, L = sorted_points.shape
+    N = packed.shape[1]
+    Hp, Wp = padded_hw(H, W, TH, TW)
+    near_px = np.zeros((V, 1, Hp, Wp), np.uint8)
+    near_splat = np.zeros((V, N), np.uint8)
+    lib().orc_raster_decisions(_p(sorted_points), _p(start_index), _p(_f32(packed)), _i(V), _l(L), _i(N), _i(H), _i(W), _i(TH), _i(TW),
+                               _f(delta), _p(near_px), _p(near_splat))
+    return near_px.astype(bool), near_splat.astype(bool)
+
+
 # ---- the reference BINARY's blend arithmetic (half2, x128 transmittance scale), emulated: litegs_oracle_fp16.c -------------------
 def pack_params_fp16(packed):
     """colour and opacity rounded to binary16 as GR/raster.cu:353-354 packs them (oracle record slots 5..8)"""

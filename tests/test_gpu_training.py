@@ -149,5 +149,5 @@ def test_learnable_viewproj_builds_the_cameras_from_their_parameters(tmp_path):
         assert float((a[..., 5, :3] * b[..., 5, :3]).sum(-1).min()) > 0.999 and float((a[..., 5, 3] / b[..., 5, 3] - 1).abs().max()) < 0.1
     assert hist[-1]["psnr_train"] > hist[0]["psnr_train"] + 0.5, hist
     saved = torch.load(os.path.join(lp.model_path, "point_cloud", "finish", "viewproj.pth"), weights_only=False)
-    assert saved[0].shape == (len(tr.frames), 7) and saved[1].shape == (1, 1)
+    assert saved[0].shape == (len(tr.frames), 7) and saved[1].shape == (1,)
     tr.close()

@@ -137,6 +137,16 @@ PY
       T=$(find gpurun_out/prof_rec_${V}_$TAG -name "*kernel_trace.csv" | head -1)
       python tools/late_timeline.py $T 8 > gpurun_out/recipe_timeline_${V}_$TAG.md 2>> gpurun_out/recipe_timeline_$TAG.err; grep -v "rocprim\|at::native" gpurun_out/recipe_timeline_${V}_$TAG.md | head -32
       rm -rf gpurun_out/prof_rec_${V}_$TAG ;;
+    recipesq:*)      # SQ counter passes (issue shares, VALU / SALU / LDS instruction counts) of one variant on the training_state recipe
+      V=${STAGE#recipesq:}
+      I=0
+      for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAVES SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT"; do
+        I=$((I+1))
+        (cd /tmp && LATE_TRACE_STEPS=4 timeout -s KILL 400 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $R/gpurun_out/pmc_rec_$TAG -o pmc -- python $R/tools/late_phase.py trace recipe $V > $R/gpurun_out/pmc_rec_${I}_$TAG.log 2>&1)
+        C=$(find gpurun_out/pmc_rec_$TAG -name "*counter_collection.csv" | head -1)
+        python tools/sq_summary.py $C "training_state recipe, variant $V, set $I" > gpurun_out/sq_recipe_${V}_${I}_$TAG.md 2>> gpurun_out/recipe_timeline_$TAG.err; sed -n 5,24p gpurun_out/sq_recipe_${V}_${I}_$TAG.md | cut -c1-330
+        rm -rf gpurun_out/pmc_rec_$TAG
+      done ;;
     recipetrace)     # the same traces on the bench's training_state recipe (no stored cloud needed: 1.6 s to reach the state)
       for V in default stat_epoch; do
         (cd /tmp && timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_rec_${V}_$TAG -o trace -- python $R/tools/late_phase.py trace recipe $V > $R/gpurun_out/recipe_trace_${V}_$TAG.log 2>&1)

@@ -53,6 +53,10 @@ VARIANTS = {
     "sort_lb32_only": (dict(_tuning={13: 0, 15: 32}), False),              # 32-wide look-back in the splat sort alone
     "emit_big512": (dict(_tuning={14: 512}), False),                       # wave-form emission: in-wave ceiling 512 / 4096 tiles (default 1024)
     "emit_big4096": (dict(_tuning={14: 4096}), False),
+    "pf_off": (dict(_tuning={16: 0}), False),                              # blend kernels: L2 warm-up of the scalar record path off / block of 8, 32, 64 list positions (default 16)
+    "pf8": (dict(_tuning={16: 8}), False),
+    "pf32": (dict(_tuning={16: 32}), False),
+    "pf64": (dict(_tuning={16: 64}), False),
     "proj_early": (dict(_tuning={12: 1}), False),                          # fused projection: SH loads in front of the tile walk (csrc/fused.hip)
     "bwd_sp": (dict(_tuning={5: 2}), False),                               # blend backward: the splat-parallel formulation (csrc/raster.hip raster_backward_sp_kernel)
     "stat_epoch": (dict(), True),
@@ -140,7 +144,7 @@ def configure(tr, attrs):
     base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
     base.update(attrs)
     from litegs_amd._lib import check, lib
-    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 13: 1, 14: 1024, 15: 32}                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 13: 1, 14: 1024, 15: 32, 16: 16}                          # lg_set_tuning keys a variant may change, at their defaults
     tuning.update(base.pop("_tuning", {}))
     for key, val in tuning.items():
         check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
