@@ -208,9 +208,17 @@ int lg_unpack_gradient(const float* packed_grad, const float* packed /*[V,N,16] 
  * (0 = one band per XCD, 1 = identity, C >= 2 = runs of C workgroups interleaved over the XCDs); key 4: heaviest-first tile schedule
  * on / off; key 5: blend backward of 8x16 tiles without statistics (0 generic, 1 the packed two-pixel kernel = default, 2 the
  * splat-parallel formulation); key 7: packed blend forward on / off; key 8: issue priority by schedule rank; keys 10 / 11: key emission
- * (in-workgroup tile ceiling, groups on demand); key 12: fused projection with the SH loads in front of the tile walk.  Defaults are the
+ * (in-workgroup tile ceiling, groups on demand); key 12: fused projection with the SH loads in front of the tile walk; key 13 / 14: key
+ * emission in wave-autonomous form on / off, its in-wave tile ceiling; key 15: look-back width of small radix sorts (8 | 32); key 16: L2
+ * warm-up block of the blend kernels' scalar record path (0 | 8 | 16 | 32 | 64 list positions); key 17: lean blend forward on / off;
+ * key 18: measurement hooks (wrong results: bit 0 blend backward without its atomics, bits 1 / 2 forward / backward read 1024 always-cached
+ * records); keys 19 / 20: KB of unused dynamic LDS per workgroup of the lean forward / fast backward (caps their occupancy).  Out-of-range
+ * values are refused.  Defaults are the
  * measured best; see DESIGN.md section 9. */
 int lg_set_tuning(int key, int value);
+/* developer hook: per-wave {start, end (100 MHz), list length << 32 | tile, XCC_ID << 32 | HW_ID} of the lean blend forward / the fast
+ * blend backward into device int64[slots][4] buffers (NULL, NULL = off; tools/wave_clock.py: SIMD occupancy over a launch) */
+int lg_debug_wave_clock(void* fwd_buf, void* bwd_buf);
 int lg_stat_in_record_supported(int TH, int TW);   /* 1: statistic renders of this tile shape carry their three statistics in gradient-record slots 9-11 (raster.hip) */
 
 /* ---- loss.hip : fused_ssim.fused_l1_ssim_loss (litegs/training/trainer.py:145; un-vendored submodule, formula in

@@ -1009,7 +1009,8 @@ __global__ void __launch_bounds__(TPB) emit_wave_kernel(SplatSrc src, const int3
 }
 
 // launch variants of the key emission (lg_set_tuning keys 10 / 11: A/B hooks of tools/, plain ints as in raster.hip)
-static int g_small_sort_lb = 32;               // look-back width of radix sorts with < 1024 key tiles (lg_set_tuning(15, 8 | 32); radix_onesweep_kernel)
+static int g_small_sort_lb = 8;                // look-back width of radix sorts with < 1024 key tiles (lg_set_tuning(15, 8 | 32); radix_onesweep_kernel).  32 measured SLOWER
+                                               // (36-37 against 30 us per pass of the 2.2 M-key splat sort, profiles/r06_binning_ab.log): the passes are not bound by the look-back chain
 static int g_emit_mode = 1;                    // 1 (default): emit_wave_kernel + dup_big; 0: dup_small + dup_big (lg_set_tuning(13, .))
 static int g_emit_big = 1024;                  // emit_wave_kernel: splats with more tiles are queued for dup_big (lg_set_tuning(14, .))
 static int g_dup_small_hi = DUP_SMALL_HI;      // largest tile count the owning thread walks itself; larger splats go to dup_big
@@ -1444,9 +1445,8 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
     }
     if (act && bid != 0) {
         // look-back, LB predecessors per step: the loads of one step are independent, so the walk costs one L2 round trip per
-        // LB workgroups instead of one per workgroup (matters when ~1000 resident workgroups start together).  A sort whose tiles are ALL
-        // resident at once (the splat depth sort: ~540 tiles) publishes every aggregate at about the same time and then advances LB tiles
-        // per round trip -- 67 dependent round trips per pass at LB = 8 (30 us per pass for 2.2 M keys, pure latency): such sorts walk 32 wide.
+        // LB workgroups instead of one per workgroup (matters when ~1000 resident workgroups start together).  (LB = 32 for the splat
+        // depth sort, whose ~540 tiles are all resident at once, was tried in round 6: slower, lg_set_tuning(15, 32).)
         uint32_t excl = 0;
         int b = bid - 1;
         bool done = false;

@@ -193,6 +193,23 @@ __device__ __forceinline__ unsigned pf_touch(const float* __restrict__ pk, int i
 __device__ __forceinline__ void pf_retire(unsigned g) { asm volatile("" : : "v"(g)); }
 
 static int g_bwd_map = 0, g_fwd_map = 0, g_use_order = 1, g_bwd_fast = 1, g_fwd_fast = 1;
+// Measurement aid (tools/wave_clock.py): when set, every wave of the lean blend forward / the fast blend backward leaves
+// {start, end (s_memrealtime: 100 MHz), list length << 32 | tile, XCC_ID << 32 | HW_ID} in its slot's four words -- the occupancy of every
+// SIMD over the launch, i.e. how much of it is tail.  NULL (default): one scalar compare per wave.
+static long long* g_wclk_fwd = nullptr;
+static long long* g_wclk_bwd = nullptr;
+LG_API int lg_debug_wave_clock(void* fwd_buf /*nullable device int64[slots][4]*/, void* bwd_buf) { g_wclk_fwd = (long long*)fwd_buf; g_wclk_bwd = (long long*)bwd_buf; return 0; }
+__device__ __forceinline__ void wclk_store(long long* __restrict__ w, int slot, long long t0, int n, int tile, int lane)
+{
+    if (w == nullptr || lane != 0) return;
+    const long long t1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    w[(size_t)slot * 4 + 0] = t0; w[(size_t)slot * 4 + 1] = t1;
+    w[(size_t)slot * 4 + 2] = ((long long)n << 32) | (unsigned)tile; w[(size_t)slot * 4 + 3] = ((long long)xcc << 32) | hw;
+}
+static int g_blend_lds_fwd = 0, g_blend_lds_bwd = 0;    // KB of (unused) dynamic LDS per workgroup: caps the resident workgroups per CU (160 KB / value); lg_set_tuning(19 / 20, KB)
+static int g_fwd_lean = 1;        // 1: renders without statistics / depth bounds / gates take the lean blend forward (lg_set_tuning(17, 0 | 1))
+static int g_bwd_probe = 0;       // measurement hook (wrong gradients!): 1 = the blend backward's atomics are issued with an empty lane mask (lg_set_tuning(18, .))
 static int g_pf_block = 16;       // list positions per L2 warm-up block of the fast blend kernels (0: off; lg_set_tuning(16, 0 | 8 | 16 | 32 | 64))       // launch variants (lg_set_tuning: A/B hooks of tools/ and tests/, plain ints)
 static int g_rank_prio = 0;       // 1: waves of the heaviest tiles of a heavy-first schedule raise their issue priority (wave_rank_priority)
 
@@ -515,6 +532,157 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// a13, lean form (round 6): the 8x16 blend forward without statistics, depth bounds or gates, with the SCALAR instruction count cut.
+//
+// What bounds the packed loop of raster_forward_kernel in the training state is not the vector pipe: per (tile, splat) it issues ~21
+// vector and ~35 scalar-type instructions (scalar ALU, scalar memory, branches: profiles/r06_forward_isa_mix.md), a SIMD takes one
+// instruction of each type per 4-cycle issue slot, so the scalar side needs ~140 cycles per splat against ~95 for the vector side --
+// and the launch runs at 157 cycles per splat and SIMD whether 4 or 8 waves share it (profiles/r05_blend_tail_priority_ab.log), with the
+// vector pipes busy in 44 % of it (SQ_INSTS_VALU x 4.4 clocks, profiles/r06_sq_training_state_before_prefetch.md).  Batching the
+// scalar loads two or three records per wait made it slower (more scalar work: profiles/r06_forward_lean_ab.log).  This kernel:
+//   * list ids four at a time (one s_load_dwordx4 per four splats instead of one s_load_dword per splat, no per-splat index clamp);
+//   * groups of four splats per loop trip: one loop test, one warm-up test, one saturation test per group instead of per splat -- a
+//     splat blended after every pixel of the tile has stopped changes nothing (its validity masks are empty), and the tile's work
+//     count is the largest last_contributor, taken once at the end;
+//   * no "nobody takes this splat" branch: 97.5 % of the walked entries of a trained cloud contribute; alpha = 0 blends to the same bits.
+// ~9 scalar-type instructions per splat.  Same arithmetic in the same order as fwd_splat_fast: identical images, T and last_contributor.
+// ---------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ids4_request(i32x4& q, const int* __restrict__ sp, unsigned byte_off)
+{
+    asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(q) : "s"(sp), "s"(byte_off));
+}
+
+__device__ __forceinline__ void fwd_splat_lean(FwdFast& st, const f32x16& rec, unsigned long long& act0, unsigned long long& act1)
+{
+    act0 = __builtin_amdgcn_ballot_w64(st.T.x > 1.0f / 8192); act1 = __builtin_amdgcn_ballot_w64(st.T.y > 1.0f / 8192);
+    const float dx = rec[R_PX] - st.X;
+    const float t1 = rec[R_B2] * dx;
+    const float t0 = __builtin_fmaf(rec[R_A2] * dx, dx, rec[R_LO]);
+    const v2f dyv = rec[R_PY] - st.Y;
+    const v2f qv = dyv * (rec[R_C2] * dyv + t1) + t0;
+    const float E0 = __builtin_amdgcn_exp2f(qv.x);
+    const float E1 = __builtin_amdgcn_exp2f(qv.y);
+    add_mask_bit(st.lc0, act0);
+    add_mask_bit(st.lc1, act1);
+    const unsigned long long val0 = act0 & __builtin_amdgcn_ballot_w64(E0 >= 1.0f / 256), val1 = act1 & __builtin_amdgcn_ballot_w64(E1 >= 1.0f / 256);
+    const float amax = 255.0f / 256;
+    const v2f alpha = { min_where(E0, amax, val0), min_where(E1, amax, val1) };
+    const v2f w = st.T * alpha;
+    st.Cr = rec[R_CR] * w + st.Cr;
+    st.Cg = rec[R_CG] * w + st.Cg;
+    st.Cb = rec[R_CB] * w + st.Cb;
+    st.T = st.T - w;
+}
+
+__global__ void __launch_bounds__(256) raster_forward_lean_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
+                                                                  const float* __restrict__ packed, const int* __restrict__ tiles, int K,
+                                                                  float* __restrict__ img, float* __restrict__ trans, short* __restrict__ last,
+                                                                  const int* __restrict__ order, int* __restrict__ tile_work,
+                                                                  int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int pfb,
+                                                                  long long* __restrict__ wclk)
+{
+    const int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, gridDim.x, map_mode & 0xff) : (int)blockIdx.x;
+    const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
+    if (slot >= nslots) return;
+    constexpr int TH = 8, TW = 16;
+    const long long wclk_t0 = wclk != nullptr ? __builtin_amdgcn_s_memrealtime() : 0;
+    const int lane = threadIdx.x & 63;
+    const int view = blockIdx.y;
+    int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
+    tile = rfl(tile);
+    if (tile <= 0 || tile > ntiles) return;
+    const int* __restrict__ si = start_index + (size_t)view * (ntiles + 2);
+    const int start = rfl(si[tile]);
+    const int end = rfl(si[tile + 1]);
+    const float* __restrict__ pk = packed + (size_t)view * N * REC;
+    const int tx = (tile - 1) % gx, ty = (tile - 1) / gx;
+    const int x = tx * TW + lane % TW;
+    const int q = lane / TW;
+    const int y0 = ty * TH + (q >> 1) * 4 + (q & 1);
+    FwdFast f;
+    f.X = (float)x; f.Y = v2f{ (float)y0, (float)(y0 + 2) }; f.T = v2f{ 1.0f, 1.0f };
+    f.Cr = f.Cg = f.Cb = v2f{ 0.0f, 0.0f };
+    f.lc0 = f.lc1 = 0;
+    const int n = (start >= 0 && end > start) ? end - start : 0;
+    const int* __restrict__ sp = sorted_points + (size_t)view * L + (start >= 0 ? start : 0);
+    unsigned long long act0 = ~0ull, act1 = ~0ull;
+    const int ng = n >> 2;                               // full groups of four list positions
+    const unsigned idmask = (pfb & 0x100) ? 0x3ffu : 0xffffffffu;      // measurement hook (wrong image): every tile reads the same 1024 records (always cached)
+    pfb &= 0xff;
+#define rec_off(id_, N_) rec_off((int)((unsigned)(id_) & idmask), N_)
+    if (ng > 0) {
+        i32x4 qa, qb;                                    // ids of the current group / of the next one
+        f32x16 ra, rb;
+        ids4_request(qa, sp, 0u);
+        ids4_request(qb, sp, (unsigned)min(1, ng - 1) << 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qa), "+s"(qb));
+        rec_request(ra, pk, rec_off(qa[0], N));
+        rec_wait(ra);
+        const bool pf_on = pfb > 0 && n >= 2 * pfb + 64;
+        PfState pf = { 0, 0u };
+        int pf_next = pfb;                               // first position of the next block to warm
+        if (pf_on && lane < pfb) {
+            pf.g = pf_touch(pk, sp[min(pfb + lane, n - 1)], N);
+            pf.ids = sp[min(2 * pfb + lane, n - 1)];
+        }
+        // one group: `ra` holds the record of its first position, qcur its ids, qnxt the ids of the next group (requested a group ago);
+        // on exit `ra` holds the first record of the next group and qcur the ids of the group after it (in flight until the last wait)
+#define LEAN_GROUP(qcur, qnxt, g_)                                                                                           \
+        {                                                                                                                   \
+            if (pf_on && (g_) * 4 >= pf_next) {                                                                             \
+                pf_retire(pf.g);                                                                                            \
+                if (lane < pfb) {                                                                                           \
+                    pf.g = pf_touch(pk, pf.ids, N);                                                                         \
+                    pf.ids = sp[min(pf_next + 2 * pfb + lane, n - 1)];                                                      \
+                }                                                                                                           \
+                pf_next += pfb;                                                                                             \
+            }                                                                                                               \
+            rec_request(rb, pk, rec_off(qcur[1], N)); fwd_splat_lean(f, ra, act0, act1); rec_wait(rb);                      \
+            rec_request(ra, pk, rec_off(qcur[2], N)); fwd_splat_lean(f, rb, act0, act1); rec_wait(ra);                      \
+            rec_request(rb, pk, rec_off(qcur[3], N)); fwd_splat_lean(f, ra, act0, act1); rec_wait(rb);                      \
+            rec_request(ra, pk, rec_off(qnxt[0], N));                                                                       \
+            ids4_request(qcur, sp, (unsigned)min((g_) + 2, ng - 1) << 4);                                                   \
+            fwd_splat_lean(f, rb, act0, act1);                                                                              \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(qcur));                                                    \
+        }
+        for (int g = 0; g < ng; g += 2) {
+            LEAN_GROUP(qa, qb, g)
+            if ((act0 | act1) == 0ull || g + 1 >= ng) break;     // (masks of the group's last splat; activity is monotone)
+            LEAN_GROUP(qb, qa, g + 1)
+            if ((act0 | act1) == 0ull) break;
+        }
+#undef LEAN_GROUP
+        pf_retire(pf.g);
+    }
+    if ((act0 | act1) != 0ull) {
+        for (int p = ng << 2; p < n; p++) {              // the last n % 4 positions, one at a time
+            int id;
+            f32x16 r;
+            id_request(id, sp, (unsigned)p << 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id));
+            rec_request(r, pk, rec_off(id, N));
+            rec_wait(r);
+            fwd_splat_lean(f, r, act0, act1);
+        }
+    }
+#undef rec_off
+    // work done for this tile = splats walked while some pixel was active = the largest last_contributor
+    if (tile_work != nullptr) {
+        const int visited = wave_max_i(max(f.lc0, f.lc1));
+        if (lane == 0) tile_work[(size_t)view * (ntiles + 1) + tile] = visited;
+    }
+    const size_t plane = (size_t)Hp * Wp;
+    const size_t o0 = (size_t)y0 * Wp + x, o1 = (size_t)(y0 + 2) * Wp + x;
+    img[((size_t)view * 3) * plane + o0] = fminf(f.Cr.x, 1.0f); img[((size_t)view * 3) * plane + o1] = fminf(f.Cr.y, 1.0f);
+    img[((size_t)view * 3 + 1) * plane + o0] = fminf(f.Cg.x, 1.0f); img[((size_t)view * 3 + 1) * plane + o1] = fminf(f.Cg.y, 1.0f);
+    img[((size_t)view * 3 + 2) * plane + o0] = fminf(f.Cb.x, 1.0f); img[((size_t)view * 3 + 2) * plane + o1] = fminf(f.Cb.y, 1.0f);
+    trans[(size_t)view * plane + o0] = f.T.x; trans[(size_t)view * plane + o1] = f.T.y;
+    last[(size_t)view * plane + o0] = (short)f.lc0; last[(size_t)view * plane + o1] = (short)f.lc1;
+    wclk_store(wclk, slot, wclk_t0, n, tile, lane);
+}
+
 LG_API int lg_raster_forward(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
                              int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
                              float* img, float* trans, short* last, int* frag_count, float* frag_weight,
@@ -543,6 +711,12 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
     if (!g_use_order) order = nullptr;
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (g_fwd_lean && g_fwd_fast && TH == 8 && TW == 16 && !enable_stat && sched_in == nullptr && sched_out == nullptr && fail_flag == nullptr &&
+        fail_host == nullptr && gate == nullptr) {
+        hipLaunchKernelGGL(raster_forward_lean_kernel, grid, block, (size_t)g_blend_lds_fwd << 10, s, sorted_points, start_index, packed, tiles, K, img, trans, last, order,
+                           tile_work, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map, g_pf_block | ((g_bwd_probe & 2) << 7), g_wclk_fwd);
+        LG_RETURN_LAST();
+    }
 #define LAUNCH_RF(A_, B_, S_) hipLaunchKernelGGL((raster_forward_kernel<A_, B_, S_>), grid, block, 0, s, sorted_points, start_index, packed, \
                                                  tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, fail_flag, fail_host, gate, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map | (g_rank_prio << 8), (g_fwd_fast ? 1 : 0) | (g_pf_block << 8))
 #define DISPATCH_RF(A_, B_) do { if (enable_stat) LAUNCH_RF(A_, B_, true); else LAUNCH_RF(A_, B_, false); } while (0)
@@ -1042,6 +1216,7 @@ __device__ __forceinline__ int stat_lane_slot(int lane)
     return lane == 15 ? STAT_SLOT_COUNT : (lane == 31 ? STAT_SLOT_WEIGHT : (lane == 63 ? STAT_SLOT_ERRSQ : -1));
 }
 
+// map_mode: bits 0-7 workgroup -> tile map, 8-15 priority switch, 16-23 L2 warm-up block, 24 / 25 measurement hooks
 template <bool TRANS, int STAT>
 __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
                                                                    const float* __restrict__ packed, const int* __restrict__ tiles, int K,
@@ -1049,20 +1224,17 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
                                                                    const float* __restrict__ d_img, const float* __restrict__ d_trans,
                                                                    float* __restrict__ packed_grad, float* __restrict__ err_square_sum /*STAT*/,
                                                                    const int* __restrict__ order,
-                                                                   int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode,
-                                                                   const int* __restrict__ hot_of)
+                                                                   int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode_in,
+                                                                   const int* __restrict__ hot_of, long long* __restrict__ wclk)
 {
-    constexpr int TH = 8, TW = 16;
-    const int lane = threadIdx.x & 63;
-    const int view = blockIdx.y;
-    const int nb = gridDim.x;
-    const int map_mode_in = map_mode;                 // bits 0-7 map, 8-15 priority switch, 16-23 L2 warm-up block
-    const int prio_mode = (map_mode >> 8) & 0xff;
-    map_mode &= 0xff;
-    int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, nb, map_mode) : (int)blockIdx.x;
+    const int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, gridDim.x, map_mode_in & 0xff) : (int)blockIdx.x;
     const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
     if (slot >= nslots) return;
-    wave_rank_priority(prio_mode, slot, nslots, tiles != nullptr || order != nullptr);
+    wave_rank_priority((map_mode_in >> 8) & 0xff, slot, nslots, tiles != nullptr || order != nullptr);
+    constexpr int TH = 8, TW = 16;
+    const long long wclk_t0 = wclk != nullptr ? __builtin_amdgcn_s_memrealtime() : 0;
+    const int lane = threadIdx.x & 63;
+    const int view = blockIdx.y;
     int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
     tile = rfl(tile);
     if (tile <= 0 || tile > ntiles) return;
@@ -1102,7 +1274,9 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     int myslot = wave_slot(lane);
     myslot = myslot == 6 ? 7 : (myslot == 7 ? 6 : myslot);       // reduce9_pk is fed (.., dr, db, dg, ..)
     if (STAT == 2 && stat_lane_slot(lane) >= 0) myslot = stat_lane_slot(lane);
-    const unsigned long long writers = __ballot(myslot >= 0);
+    const unsigned long long writers = ((map_mode_in >> 24) & 1) ? 0ull : __ballot(myslot >= 0);      // (bit 24: measurement hook, no atomics)
+    const unsigned idmask = ((map_mode_in >> 25) & 1) ? 0x3ffu : 0xffffffffu;                          // (bit 25: measurement hook, every tile reads the same 1024 records)
+#define rec_off(id_, N_) rec_off((int)((unsigned)(id_) & idmask), N_)
     const unsigned slot_off = (unsigned)max(myslot, 0) * 4u;
     // An even number of iterations (two per trip over a ping-pong pair of record registers): if n is odd the walk starts one
     // position early, at `n`, with the record of position n-1 -- no pixel has last_contributor > n, so that splat adds nothing.
@@ -1161,6 +1335,8 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     for (; pos >= 1 && pos >= minlast; ) BWD_PAIR(true)
     for (; pos >= 1; ) BWD_PAIR(false)
     pf_retire(pf.g);
+    wclk_store(wclk, slot, wclk_t0, n, tile, lane);
+#undef rec_off
 #undef BWD_PAIR
 #undef PF_STEP
 #undef HOT_TARGET
@@ -1317,6 +1493,10 @@ LG_API int lg_set_tuning(int key, int value)
     case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics; 2: the splat-parallel variant (A/B)
     case 16: if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return (int)hipErrorInvalidValue; g_pf_block = value; return 0;   // L2 warm-up block of the fast blend kernels
+    case 17: if (value < 0 || value > 1) return (int)hipErrorInvalidValue; g_fwd_lean = value; return 0;      // lean blend forward on / off
+    case 19: if (value < 0 || value > 64) return (int)hipErrorInvalidValue; g_blend_lds_fwd = value; return 0;   // occupancy cap of the lean blend forward (KB of dynamic LDS per workgroup)
+    case 20: if (value < 0 || value > 64) return (int)hipErrorInvalidValue; g_blend_lds_bwd = value; return 0;   // ... of the fast blend backward
+    case 18: g_bwd_probe = value; return 0;                                      // measurement hook: blend backward without its atomics
     case 8: g_rank_prio = value ? 1 : 0; return 0;                            // 1: issue priority by rank in a heavy-first schedule (wave_rank_priority)
     case 10: case 11: case 13: case 14: case 15: return lg_binning_set_tuning(key, value);   // binning.hip: key emission variants (10, 11, 13, 14), look-back width of small sorts (15)
     case 12: return lg_fused_set_tuning(key, value);                           // fused projection (fused.hip): SH loads in front of the tile walk
@@ -1377,8 +1557,9 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
                            gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map | (g_rank_prio << 8));
     }
     else if (TH == 8 && TW == 16 && g_bwd_fast && !(enable_stat && hot_of != nullptr)) {
-#define LAUNCH_RBF(T_, S_) hipLaunchKernelGGL((raster_backward_fast_kernel<T_, S_>), grid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last, \
-                                              d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots, g_bwd_map | (g_rank_prio << 8) | (g_pf_block << 16), hot_of)
+#define LAUNCH_RBF(T_, S_) hipLaunchKernelGGL((raster_backward_fast_kernel<T_, S_>), grid, block, (size_t)g_blend_lds_bwd << 10, s, sorted_points, start_index, packed, tiles, K, final_T, last, \
+                                              d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots,                                                             \
+                                              g_bwd_map | (g_rank_prio << 8) | (g_pf_block << 16) | ((g_bwd_probe & 1) << 24) | (((g_bwd_probe >> 2) & 1) << 25), hot_of, g_wclk_bwd)
         if (enable_stat && err_square_sum == nullptr) { if (d_trans) LAUNCH_RBF(true, 2); else LAUNCH_RBF(false, 2); }       // executor: statistics in the record
         else if (enable_stat) { if (d_trans) LAUNCH_RBF(true, 1); else LAUNCH_RBF(false, 1); }
         else { if (d_trans) LAUNCH_RBF(true, 0); else LAUNCH_RBF(false, 0); }

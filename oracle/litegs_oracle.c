@@ -764,6 +764,13 @@ ORC_API void orc_pack_params(const float* ndc /*[V,4,N]*/, const float* inv_cov,
         }
 }
 
+/* The blend's two decision thresholds (GR/raster.cu:256, 264: alpha >= 1/256, T > 1/8192).  Test infrastructure may scale them
+ * (tests/util.py's bracket rule: an implementation whose exp() differs in the last bit decides a pair that sits ON a threshold
+ * the other way; its result must then lie between this oracle's results with both thresholds lowered and raised by a relative delta).
+ * Defaults are the reference's constants; nothing but orc_set_blend_thresholds changes them. */
+static float g_alpha_thr = 1.0f / 256, g_T_thr = 1.0f / 8192;
+ORC_API void orc_set_blend_thresholds(float alpha_thr, float t_thr) { g_alpha_thr = alpha_thr; g_T_thr = t_thr; }
+
 static inline float splat_power(const float* r, float pixel_x, float pixel_y, float* dx, float* dy)
 {
     /* GR/raster.cu:237-240 */
@@ -809,17 +816,17 @@ ORC_API void orc_raster_forward(const int32_t* sorted_points /*[V,L]*/, const in
             if (start != -1) {
                 for (int idx = start; idx < end; idx++) {
                     int any_active = 0;
-                    for (int q = 0; q < P; q++) any_active |= (T[q] > 1.0f / 8192);
+                    for (int q = 0; q < P; q++) any_active |= (T[q] > g_T_thr);
                     if (!any_active) break;
                     int pid = sp[idx];
                     const float* r = pk + (size_t)pid * ORC_REC;
                     int fc = 0; double ws = 0.0;
                     for (int q = 0; q < P; q++) {
-                        int active = T[q] > 1.0f / 8192;
+                        int active = T[q] > g_T_thr;
                         float dx, dy;
                         float power = splat_power(r, (float)(tx * TW + q % TW), (float)(ty * TH + q / TW), &dx, &dy);
                         float alpha = r[8] * expf(power);
-                        int valid = active && (alpha >= 1.0f / 256);
+                        int valid = active && (alpha >= g_alpha_thr);
                         alpha = fminf_(255.0f / 256, alpha);
                         lc[q] += active;
                         if (!valid) alpha = 0.0f;
@@ -987,7 +994,7 @@ ORC_API void orc_raster_backward(const int32_t* sorted_points, const int32_t* st
                     float power = splat_power(r, (float)(tx * TW + q % TW), (float)(ty * TH + q / TW), &dx, &dy);
                     float G = expf(power);
                     float alpha = fminf_(255.0f / 256, r[8] * G);
-                    int valid = (alpha >= 1.0f / 256) && (idx < lc[q]);
+                    int valid = (alpha >= g_alpha_thr) && (idx < lc[q]);
                     valid_pix[q] = valid; ga_pix[q] = 0.0f;
                     if (!valid) continue;
                     anyvalid = 1;

@@ -16,7 +16,9 @@ Array conventions follow the reference: SoA with the Gaussian index innermost, f
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import dataclasses
 import os
 import subprocess
 from dataclasses import dataclass
@@ -316,6 +318,24 @@ def raster_backward(sorted_points, start_index, packed, final_T, last, d_img, H,
                               _i(V), _l(L), _i(N), _i(H), _i(W), _i(TH), _i(TW), _i(int(enable_stat)),
                               _p(d_ndc), _p(d_ic), _p(d_color), _p(d_opa), _p(esq))
     return d_ndc, d_ic, d_color, d_opa, esq
+
+
+@contextlib.contextmanager
+def blend_thresholds(alpha_scale=1.0, t_scale=1.0):
+    """the blend's two decision thresholds (alpha >= 1/256, T > 1/8192) scaled for the duration of the block -- tests/util.py's bracket
+    rule; every oracle blend outside such a block uses the reference's constants"""
+    lib().orc_set_blend_thresholds(_f(np.float32(1.0 / 256) * np.float32(alpha_scale)), _f(np.float32(1.0 / 8192) * np.float32(t_scale)))
+    try:
+        yield
+    finally:
+        lib().orc_set_blend_thresholds(_f(1.0 / 256), _f(1.0 / 8192))
+
+
+def reblend(res, H, W, tile=(8, 16)):
+    """a copy of a PipelineResult whose blend outputs (img, trans, last) are recomputed from its table and records -- under whatever
+    blend_thresholds block is active"""
+    img, trans, last, fc, fw = raster_forward(res.sorted_point, res.tile_start, res.packed, H, W, tile[0], tile[1])
+    return dataclasses.replace(res, img=img, trans=trans, last=last, frag_count=fc, frag_weight=fw)
 
 
 def raster_decisions(sorted_points, start_index, packed, H, W, TH, TW, delta=1e-3):

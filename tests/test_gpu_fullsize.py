@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, case, oracle_forward, GRAD_FLIP, IMG_FLIP
+from tests.util import assert_close, case, oracle_forward
 
 pytestmark = pytest.mark.gpu
 
@@ -43,17 +43,13 @@ def test_fullsize_render_forward_backward_matches_oracle(oracle, name):
     # apart), so a splat whose ellipse grazes a tile boundary may gain or lose one tile.  Given identical inputs the count is bit exact
     # (test_fullsize_binning_bit_exact_3m below); end to end it is allowed to move by 2e-6 of the instances.
     assert abs(int(rd.fb_total[0]) - res.n_instances) <= max(2, int(2e-6 * res.n_instances)), (int(rd.fb_total[0]), res.n_instances)
-    # image, 1e-4 (north_star), with the bounded allowance for threshold flips documented in tests/util.py
-    ref_img = np.clip(res.img[..., :H, :W], 0, 1)
-    assert_close(img.detach().cpu().numpy(), ref_img, **IMG_FLIP, name="img")
-    d_img = np.zeros_like(res.img)
-    inside = (res.img[..., :H, :W] >= 0) & (res.img[..., :H, :W] <= 1)
-    d_img[..., :H, :W] = w_host * inside
-    (grads, _) = oracle.render_backward(res, c["params"], c["view"], c["proj"], d_img, H, W, c["degree"])
-    for p, g_ref, nm in zip(params, grads, ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]):
-        got = p.grad.compacted_values.cpu().numpy()
-        got = got.reshape(g_ref.shape[:-2] + (-1, g_ref.shape[-1]))[..., :res.nvis, :]
-        assert_close(got.reshape(g_ref.shape), g_ref, atol=1e-4, normalize=True, **GRAD_FLIP, name=f"grad.{nm}")
+    # image and the six parameter gradients, 1e-4 (north_star; gradients normalised by their tensor's max-abs), under the two-part rule of
+    # tests/util.py: rounding error <= 1e-4 with no allowance; elements fed by a blend decision within 1e-3 of its threshold must lie
+    # between the oracle's results with the thresholds lowered and raised
+    from tests.util import compacted_grads, parity_image_and_gradients
+    like = oracle.render_backward(res, c["params"], c["view"], c["proj"], np.zeros_like(res.img), H, W, c["degree"])[0]
+    parity_image_and_gradients(oracle, res, img.detach().cpu().numpy(), compacted_grads(params, res.nvis, like), c["params"], c["view"], c["proj"],
+                               w_host, H, W, c["degree"])
 
 
 @pytest.mark.parametrize("name", ["10k_400", "500k_1080p"])
@@ -69,7 +65,8 @@ def test_fullsize_operator_path(oracle, name):
                                                    c["degree"], (H, W), pp)
     assert int(vis_num.item()) == res.nvis
     assert int((prim_vis > 0).sum().item()) == int((res.alloc > 0).sum())
-    assert_close(img.detach().cpu().numpy(), np.clip(res.img[..., :H, :W], 0, 1), **IMG_FLIP, name="img")
+    from tests.util import parity_image
+    parity_image(oracle, res, img.detach().cpu().numpy(), H, W)
     img.sum().backward()
     assert all(torch.isfinite(p.grad.compacted_values).all() for p in params)
 

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, case, oracle_forward, GRAD_FLIP, IMG_FLIP
+from tests.util import assert_close, case, oracle_forward
 
 pytestmark = pytest.mark.gpu
 
@@ -41,17 +41,12 @@ def test_fused_render_matches_oracle_and_operator_path(oracle, name):
     assert outs[1][3] == min(int(1.2 * res.nvis), params[0].shape[-2])
     assert int(rd.fb_total[0]) == res.n_instances and int(rd.fb_vis[0]) == res.nvis
 
-    # 1. vs oracle
-    ref_img = np.clip(res.img[..., :H, :W], 0, 1)
-    d_img = np.zeros_like(res.img)
-    inside = (res.img[..., :H, :W] >= 0) & (res.img[..., :H, :W] <= 1)
-    d_img[..., :H, :W] = w.cpu().numpy() * inside
-    (grads, _) = oracle.render_backward(res, c["params"], c["view"], c["proj"], d_img, H, W, c["degree"])
+    # 1. vs oracle (tests/util.py: rounding <= 1e-4 without allowance; threshold-sensitive elements inside the oracle's bracket)
+    from tests.util import parity_image_and_gradients
+    like = oracle.render_backward(res, c["params"], c["view"], c["proj"], np.zeros_like(res.img), H, W, c["degree"])[0]
     for it in range(2):
-        assert_close(outs[it][0], ref_img, **IMG_FLIP, name=f"img[{it}]")
-        for g, g_ref, nm in zip(outs[it][1], grads, ["xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"]):
-            got = g.reshape(g_ref.shape[:-2] + (-1, g_ref.shape[-1]))[..., :res.nvis, :]
-            assert_close(got.reshape(g_ref.shape), g_ref, atol=1e-4, normalize=True, **GRAD_FLIP, name=f"grad.{nm}[{it}]")
+        got = [g.reshape(gr.shape[:-2] + (-1, gr.shape[-1]))[..., :res.nvis, :].reshape(gr.shape) for g, gr in zip(outs[it][1], like)]
+        parity_image_and_gradients(oracle, res, outs[it][0], got, c["params"], c["view"], c["proj"], w.cpu().numpy(), H, W, c["degree"], tag=f"[{it}]")
 
     # 2. vs the operator path: same arithmetic -> identical image, gradients equal up to atomic summation order
     for p in params:
@@ -162,18 +157,18 @@ def test_fused_render_with_underpredicted_table(oracle):
     ks, vs, _, _ = oracle.create_table(res.ndc, res.inv_cov, op, res.prefix, res.depth_sorted_index, H, W, 8, 16, table_len=want)
     ntiles = ((H + 7) // 8) * ((W + 15) // 16)
     ts = oracle.tile_range(ks, ntiles)
-    ref_img, *_ = oracle.raster_forward(vs, ts, res.packed, H, W, 8, 16)
-    ref_img = np.clip(ref_img[..., :H, :W], 0, 1)
+    from tests.util import assert_bracket, bracket_of, parity_image
+    ref_img, ref_var = bracket_of(oracle, lambda: np.clip(oracle.raster_forward(vs, ts, res.packed, H, W, 8, 16)[0][..., :H, :W], 0, 1))
     full_img = np.clip(res.img[..., :H, :W], 0, 1)
     assert np.abs(ref_img - full_img).max() > 0.05, "the truncation must be visible in this case"
-    assert_close(img.cpu().numpy(), ref_img, **IMG_FLIP, name="truncated img")
+    assert_bracket(img.cpu().numpy(), ref_img, ref_var, name="truncated img", decided_max=250)
     # the truncation is silent in the reference; here the next visit notices (the true total came back through the feedback slot),
     # counts it and sizes its table exactly again
     with torch.no_grad():
         img3, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
         torch.cuda.synchronize()
     assert rd.truncated_visits == 1 and rd.last_sizes[1] == total
-    assert_close(img3.cpu().numpy(), full_img, **IMG_FLIP, name="healed img")
+    parity_image(oracle, res, img3.cpu().numpy(), H, W, name="healed img")
 
 
 def test_underpredicted_table_in_per_tile_depth_mode(oracle):
@@ -217,16 +212,16 @@ def test_underpredicted_table_in_per_tile_depth_mode(oracle):
             vs[0, a:b] = ids[np.lexsort((ids, dkey[ids]))]
     ntiles = ((H + 7) // 8) * ((W + 15) // 16)
     ts = oracle.tile_range(ks, ntiles)
-    ref_img, *_ = oracle.raster_forward(vs, ts, res.packed, H, W, 8, 16)
-    ref_img = np.clip(ref_img[..., :H, :W], 0, 1)
+    from tests.util import assert_bracket, bracket_of, parity_image
+    ref_img, ref_var = bracket_of(oracle, lambda: np.clip(oracle.raster_forward(vs, ts, res.packed, H, W, 8, 16)[0][..., :H, :W], 0, 1))
     full_img = np.clip(res.img[..., :H, :W], 0, 1)
     assert np.abs(ref_img - full_img).max() > 0.05
-    assert_close(img.cpu().numpy(), ref_img, **IMG_FLIP, name="truncated img (tile mode)")
+    assert_bracket(img.cpu().numpy(), ref_img, ref_var, name="truncated img (tile mode)", decided_max=250)
     with torch.no_grad():
         img3, _, _ = rd.render(cam, origin, extend, *params, c["degree"])
         torch.cuda.synchronize()
     assert rd.truncated_visits == 1 and rd.last_sizes[1] == total
-    assert_close(img3.cpu().numpy(), full_img, **IMG_FLIP, name="healed img (tile mode)")
+    parity_image(oracle, res, img3.cpu().numpy(), H, W, name="healed img (tile mode)")
 
 
 def test_gradient_replicas_do_not_change_the_update():

@@ -48,11 +48,22 @@ VARIANTS = {
     "emit_dynamic": (dict(_tuning={11: 2}), False),                        # key emission: groups handed out on demand after one static round (default: round robin)
     "emit_hi128": (dict(_tuning={10: 128}), False),                        # ... in-workgroup walk up to 128 tiles (default 256), larger splats cooperative
     "emit_hi64": (dict(_tuning={10: 64}), False),
-    "emit_wg": (dict(_tuning={13: 0, 15: 8}), False),                      # round 5's binning: workgroup-form emission (dup_small), look-back 8 wide in the splat sort
-    "emit_wave_only": (dict(_tuning={13: 1, 15: 8}), False),               # wave-form emission alone
-    "sort_lb32_only": (dict(_tuning={13: 0, 15: 32}), False),              # 32-wide look-back in the splat sort alone
+    "emit_wg": (dict(_tuning={13: 0}), False),                             # round 5's workgroup-form emission (dup_small)
+    "sort_lb32": (dict(_tuning={15: 32}), False),                          # 32-wide look-back in the splat sort
     "emit_big512": (dict(_tuning={14: 512}), False),                       # wave-form emission: in-wave ceiling 512 / 4096 tiles (default 1024)
     "emit_big4096": (dict(_tuning={14: 4096}), False),
+    "occ6": (dict(_tuning={19: 26, 20: 26}), False),                      # blend kernels capped at 6 / 5 / 4 / 3 waves per SIMD (unused dynamic LDS)
+    "occ5": (dict(_tuning={19: 32, 20: 32}), False),
+    "occ4": (dict(_tuning={19: 40, 20: 40}), False),
+    "occ3": (dict(_tuning={19: 53, 20: 53}), False),
+    "occ4_bwd": (dict(_tuning={20: 40}), False),
+    "occ4_fwd": (dict(_tuning={19: 40}), False),
+    "probe_fwd_cached": (dict(_tuning={18: 2}), False),                   # measurement hooks (wrong results): forward reads 1024 always-cached records
+    "probe_bwd_cached": (dict(_tuning={18: 5}), False),                   # backward: the same, and no atomics
+    "probe_both_cached": (dict(_tuning={18: 7}), False),
+                            # blend launches: one wave per tile, heaviest first (round 5) instead of the snake schedule
+    "lean0": (dict(_tuning={17: 0}), False),                               # blend forward: the full kernel instead of the lean one
+    "bwd_no_atomics": (dict(_tuning={18: 1}), False),                      # measurement hook: blend backward without its atomics (wrong gradients)
     "pf_off": (dict(_tuning={16: 0}), False),                              # blend kernels: L2 warm-up of the scalar record path off / block of 8, 32, 64 list positions (default 16)
     "pf8": (dict(_tuning={16: 8}), False),
     "pf32": (dict(_tuning={16: 32}), False),
@@ -144,7 +155,7 @@ def configure(tr, attrs):
     base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
     base.update(attrs)
     from litegs_amd._lib import check, lib
-    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 13: 1, 14: 1024, 15: 32, 16: 16}                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 13: 1, 14: 1024, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0}                          # lg_set_tuning keys a variant may change, at their defaults
     tuning.update(base.pop("_tuning", {}))
     for key, val in tuning.items():
         check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
