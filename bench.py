@@ -296,19 +296,49 @@ def training_state(args, n, W, H, focal, scene, n_frames):
            "unculled_reruns": int(rd.fallbacks), "replayed_steps": int(tr.spec_replays), "truncated_tables": int(rd.truncated_visits)}
     out["roofline"] = roofline_probe(tr, list(range(n_frames)))
     out["finite"] = all(bool(torch.isfinite(p).all()) for p in tr.params)
+    state_scene = [p.detach().cpu().numpy() for p in tr.params]
+    state_targets = [tr.frames[k].gt.clone() for k in range(n_frames)]
+    state_degree, state_n = int(tr.degree), int(tr.n_chunks * tr.S)
     tr.close()
+    if not args.no_operator_path:
+        # the same cloud, targets and SH degree driven through the litegs_fused operator surface (litegs_amd's mirror of wrapper.py / render)
+        torch.cuda.empty_cache()
+        out["operator_path_ms"] = operator_path_ms(state_n, W, H, focal, state_scene, n_frames, targets=state_targets, degree=state_degree)
+        torch.cuda.empty_cache()
+        out["reference_call_pattern_ms"] = operator_path_ms(state_n, W, H, focal, state_scene, n_frames, targets=state_targets, degree=state_degree,
+                                                            pattern="reference")
     out["keep_size_predictions"] = bool(rd.keep_size_predictions)
     out["sanitised"] = dict(tr.sanitised)                  # csrc/lg_sanity.h: garbage table words neutralised during this leg ({} = none)
     return out
 
 
-def operator_path_ms(n, W, H, focal, scene, frames, steps=16):
+def operator_path_ms(n, W, H, focal, scene, frames, steps=16, targets=None, degree=None, pattern=None):
     """ms per training iteration when the SAME iteration is driven operator by operator through the drop-in `litegs_fused` surface
     (what the reference's unmodified trainer calls; the compiled binding when it is built) instead of the native executor --
-    reported next to the headline, never as the headline."""
+    reported next to the headline, never as the headline.  targets / degree: the training-state leg hands over its cloud (`scene`), its
+    teacher images and its SH degree."""
     from litegs_amd.trainer import SyntheticTrainer
     from litegs_amd.binding import ops
-    tr = SyntheticTrainer(n, W, H, focal, n_frames=frames, scene=scene, fused=False)
+    from litegs_amd import binning as B
+    # pattern="reference": the mirror drives the boundary with the reference's own sequence (torch.sort + int64 ids + cumsum + create_table +
+    # tileRange, grad-image normalisation, six adamUpdate calls) -- call for call what tests/golden/reference_call_trace.json records of the
+    # unmodified reference, held to it by tests/test_gpu_reference_call_pattern.py.  The Python reference itself is not on this box.
+    mode, grouped = B._MODE, B._GROUPED
+    if pattern == "reference":
+        B._MODE, B._GROUPED = "reference", False
+    try:
+        return _operator_path_ms(SyntheticTrainer, ops, n, W, H, focal, scene, frames, steps, targets, degree, pattern)
+    finally:
+        B._MODE, B._GROUPED = mode, grouped
+
+
+def _operator_path_ms(SyntheticTrainer, ops, n, W, H, focal, scene, frames, steps, targets, degree, pattern):
+    tr = SyntheticTrainer(n, W, H, focal, n_frames=frames, scene=scene, fused=False, noise_targets=targets is None)
+    if targets is not None:
+        for k in range(frames):
+            tr.frames[k].gt = targets[k]
+    if degree is not None:
+        tr.degree = degree
     for i in range(frames + 8):
         tr.step(i % frames)
     torch.cuda.synchronize()
@@ -316,7 +346,10 @@ def operator_path_ms(n, W, H, focal, scene, frames, steps=16):
     for i in range(steps):
         tr.step(i % frames)
     torch.cuda.synchronize()
-    return {"ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 4), "binding": ops.binding, "steps": steps}
+    out = {"ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 4), "binding": ops.binding, "steps": steps,
+           "binning": "reference sequence (torch.sort, cumsum, create_table, tileRange)" if pattern == "reference" else "grouped (no full-length sorts)"}
+    tr.close() if hasattr(tr, "close") else None
+    return out
 
 
 def cpu_baseline(scene, cam, H, W, degree, tile_stride):
@@ -376,6 +409,8 @@ def cpu_baseline(scene, cam, H, W, degree, tile_stride):
     n_total = xyz.shape[-2] * xyz.shape[-1]
     return {
         "value": round(1.0 / t_iter, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+        # `cores` = the OpenMP threads the oracle ran on (the contract's meaning: threads used); the machine underneath:
+        "physical_cores": _physical_cores()[0], "sockets": _physical_cores()[1], "logical_cpus": os.cpu_count(),
         "fwd_msplats_per_s": round(n_total / t_fwd / 1e6, 4),
         "sample": ("one whole frame of the same workload: per-Gaussian chain + binning + sort + blend fwd+bwd + Adam"
                    if tile_stride == 1 else
@@ -383,6 +418,25 @@ def cpu_baseline(scene, cam, H, W, degree, tile_stride):
                   + f"; measured {t_chain + t_bchain + t_rf + t_rb:.1f}s of CPU work, OpenMP {cores} threads",
         "cpu_model": _cpu_model(), "n_vis": int(N), "instances": int(prefix[0, -1]),
     }
+
+
+def _physical_cores():
+    """(physical cores, sockets) of the host from /proc/cpuinfo; os.cpu_count() counts SMT threads"""
+    cores, sockets = set(), set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core)); sockets.add(phys)
+                phys = core = None
+    except OSError:
+        pass
+    return (len(cores) or None), (len(sockets) or None)
 
 
 def _cpu_model():
@@ -621,10 +675,27 @@ def main():
                                      "periods_with_gated_forwards": int(tr.dp_gated_periods), **dp_diag}
         if world == 1 and not args.operator_path and not args.no_operator_path:
             result["operator_path_ms"] = operator_path_ms(n, W, H, focal, scene, args.frames)
+            result["reference_call_pattern_ms"] = operator_path_ms(n, W, H, focal, scene, args.frames, pattern="reference")
         if world == 1 and not args.operator_path and args.soak_steps > 0:
             result["steady_state"] = steady_state(tr, args, len(tr.frames))
         if world == 1 and not args.operator_path and not args.no_training_state:
             result["training_state"] = training_state(args, n, W, H, focal, scene, args.frames)
+        # The three states at top level.  `value` / `ms_per_step` are the contract's line: the configuration BASELINE.json
+        # names, a FRESH cloud -- where two exact elisions are active (Adam skips the Gaussians without history, depth-bound culling drops
+        # instances behind saturated tiles).  What a density-control run costs per iteration is `training_state_*`; hold THAT against the target.
+        result["fresh_state_note"] = ("value / ms_per_step: fresh 3 M cloud of SURVEY 8d; exact elisions active there: adam_noop_skip (see gaussians_with_history) and "
+                                      "depth_bound_culling (instances vs depth_bound_culling.full_instances); both idle in training_state")
+        if "steady_state" in result:
+            result["steady_state_ms_per_step"] = result["steady_state"]["ms_per_step"]
+            result["steady_state_frames_per_s"] = result["steady_state"]["frames_per_s"]
+        if "training_state" in result:
+            ts = result["training_state"]
+            result["training_state_ms_per_step"] = ts["ms_per_step"]
+            result["training_state_frames_per_s"] = ts["frames_per_s"]
+            result["training_state_statistics_epoch_ms_per_step"] = ts["statistics_epoch_ms_per_step"]
+            if "operator_path_ms" in ts:
+                result["training_state_operator_path_ms_per_step"] = ts["operator_path_ms"]["ms_per_step"]
+                result["training_state_reference_call_pattern_ms_per_step"] = ts["reference_call_pattern_ms"]["ms_per_step"]
         if world == 1 and not args.operator_path:
             if args.no_pmc:
                 result["roofline"]["traffic_note"] = "PMC passes skipped (--no-pmc)"

@@ -93,8 +93,25 @@ def grouped_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_b
     return tile_start, grouped
 
 
-# LITEGS_OPERATOR_BINNING=sorted keeps the reference's structure (depth sort of the splats, stable tile radix sort) in this mirror too
-_GROUPED = os.environ.get("LITEGS_OPERATOR_BINNING", "grouped") != "sorted"
+def reference_pattern_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_binning_allocate_size, idx_tensor, H, W, th, tw, tiles_num):
+    """Binning.__binning_fused's own sequence, operation for operation (litegs/utils/wrapper.py:738-761): torch.sort of the view depths
+    (int64 indices, not stable), the per-view gather of the tile counts into depth order, an int32 cumsum, then create_table and tileRange
+    through the boundary with exactly those tensors.  What tests/golden/reference_call_trace.json records the unmodified reference doing;
+    tests/test_gpu_reference_call_pattern.py holds this function to that trace and bench.py times it (`reference_call_pattern_ms`)."""
+    _, depth_sorted_index = view_depth.sort(dim=-1, descending=False)
+    for i in range(ndc.shape[0]):
+        allocate_size[i] = allocate_size[i, depth_sorted_index[i]]
+    prefix_sum = allocate_size.cumsum(1, dtype=torch.int32)
+    sorted_tile, sorted_point = fused.create_table(ndc, inv_cov2d, opacity, prefix_sum, depth_sorted_index, feedback_binning_allocate_size, idx_tensor,
+                                                   H, W, th, tw)
+    return fused.tileRange(sorted_tile, int(tiles_num)), sorted_point
+
+
+# LITEGS_OPERATOR_BINNING: "grouped" (default: no full-length sorts, grouped_table), "sorted" (the reference's structure on this
+# repository's stable radix sort / scan: depth_order_and_prefix + create_table + tileRange) or "reference" (the reference's own sequence
+# of torch operations and boundary calls, reference_pattern_table)
+_MODE = os.environ.get("LITEGS_OPERATOR_BINNING", "grouped")
+_GROUPED = _MODE not in ("sorted", "reference")
 
 
 @torch.no_grad()
@@ -111,6 +128,10 @@ def binning(ndc, view_depth, inv_cov2d, opacity, valid_length, feedback_binning_
     b_visible = allocate_size != 0
     if on_visible is not None:
         on_visible(b_visible)
+    if _MODE == "reference":
+        tile_start_index, sorted_point = reference_pattern_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_binning_allocate_size,
+                                                                 idx_tensor, H, W, th, tw, tiles_num)
+        return tile_start_index, sorted_point, b_visible.sum(0)
     if _GROUPED and view_depth.shape[0] == 1 and view_depth.shape[1] < (1 << 24):
         tile_start_index, sorted_point = grouped_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_binning_allocate_size,
                                                        idx_tensor, H, W, th, tw, tiles_num)

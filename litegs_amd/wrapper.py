@@ -197,10 +197,18 @@ class GaussiansRasterFunc(torch.autograd.Function):
         sorted_pointId, tile_start_index, trans, last, packed, tiles, frag_count, frag_weight = ctx.saved_tensors
         img_h, img_w, tile_h, tile_w = ctx.geom
         # fp32 blend: the reference's max-normalisation of grad_img (wrapper.py:490-491) is an fp16 range hack and
-        # an exact identity here, so it is skipped (saves a full-image reduction and a host-visible dependency).
+        # an exact identity here, so it is skipped (saves a full-image reduction and a host-visible dependency) -- except in the
+        # reference-pattern mode (binning.py: the reference's own sequence at the boundary), which normalises and hands the scale over
+        from . import binning as _binning
+        scaler = None
+        if _binning._MODE == "reference":
+            scaler = grad_img.abs().max()
+            grad_img = grad_img / scaler
         d_ndc, d_cov2d_inv, d_color, d_opacity, _, err_sq = fused.rasterize_backward(
-            sorted_pointId, tile_start_index, packed, tiles, trans, last, grad_img.contiguous(), grad_trans, grad_depth, None,
+            sorted_pointId, tile_start_index, packed, tiles, trans, last, grad_img.contiguous(), grad_trans, grad_depth, scaler,
             img_h, img_w, tile_h, tile_w, ctx.stat)
+        if scaler is not None and ctx.stat:
+            err_sq = err_sq * scaler * scaler
         if ctx.stat:
             STATS.add_moments("fragment_weight", frag_weight, frag_weight * frag_weight, frag_count)
             STATS.add_moments("fragment_err", d_opacity.unsqueeze(0), err_sq, frag_count)
