@@ -208,8 +208,8 @@ int lg_unpack_gradient(const float* packed_grad, const float* packed /*[V,N,16] 
  * (0 = one band per XCD, 1 = identity, C >= 2 = runs of C workgroups interleaved over the XCDs); key 4: heaviest-first tile schedule
  * on / off; key 5: blend backward of 8x16 tiles without statistics (0 generic, 1 the packed two-pixel kernel = default, 2 the
  * splat-parallel formulation); key 7: packed blend forward on / off; key 8: issue priority by schedule rank; keys 10 / 11: key emission
- * (in-workgroup tile ceiling, groups on demand); key 12: fused projection with the SH loads in front of the tile walk; key 13 / 14: key
- * emission in wave-autonomous form on / off, its in-wave tile ceiling; key 15: look-back width of small radix sorts (8 | 32); key 16: L2
+ * (in-workgroup tile ceiling, groups on demand); key 12: fused projection with the SH loads in front of the tile walk; key 15: look-back
+ * width of small radix sorts (8 | 32); key 16: L2
  * warm-up block of the blend kernels' scalar record path (0 | 8 | 16 | 32 | 64 list positions); key 17: lean blend forward on / off;
  * key 18: measurement hooks (wrong results: bit 0 blend backward without its atomics, bits 1 / 2 forward / backward read 1024 always-cached
  * records); keys 19 / 20: KB of unused dynamic LDS per workgroup of the lean forward / fast backward (caps their occupancy).  Out-of-range

@@ -110,6 +110,7 @@ def reference_pattern_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, 
 # LITEGS_OPERATOR_BINNING: "grouped" (default: no full-length sorts, grouped_table), "sorted" (the reference's structure on this
 # repository's stable radix sort / scan: depth_order_and_prefix + create_table + tileRange) or "reference" (the reference's own sequence
 # of torch operations and boundary calls, reference_pattern_table)
+LONG_LIST_PER_TILE = 640
 _MODE = os.environ.get("LITEGS_OPERATOR_BINNING", "grouped")
 _GROUPED = _MODE not in ("sorted", "reference")
 
@@ -132,7 +133,13 @@ def binning(ndc, view_depth, inv_cov2d, opacity, valid_length, feedback_binning_
         tile_start_index, sorted_point = reference_pattern_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_binning_allocate_size,
                                                                  idx_tensor, H, W, th, tw, tiles_num)
         return tile_start_index, sorted_point, b_visible.sum(0)
-    if _GROUPED and view_depth.shape[0] == 1 and view_depth.shape[1] < (1 << 24):
+    # Long lists (the executor's rule, fast.py long_list_global: more than 640 instances per tile in the frame's previous visit): the per-tile
+    # depth sort of grouped_table loses to the reference's structure there (training state, 3 M Gaussians: 5.66 against 4.48 ms per
+    # iteration, gpurun r6o), so such frames take depth_order_and_prefix + create_table + tileRange.
+    long_lists = False
+    if _GROUPED and feedback_binning_allocate_size is not None and idx_tensor is not None:
+        long_lists = int(feedback_binning_allocate_size[int(idx_tensor[0])]) > LONG_LIST_PER_TILE * tiles_num
+    if _GROUPED and not long_lists and view_depth.shape[0] == 1 and view_depth.shape[1] < (1 << 24):
         tile_start_index, sorted_point = grouped_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_binning_allocate_size,
                                                        idx_tensor, H, W, th, tw, tiles_num)
         return tile_start_index, sorted_point, b_visible.sum(0)

@@ -737,282 +737,16 @@ __global__ void __launch_bounds__(TPB) dup_queue_check_kernel(const int32_t* __r
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Key emission, wave-autonomous form (round 6; replaces dup_small_kernel in front of dup_big_kernel).
-//
-// What the 256-slot workgroup form above costs is not its instruction count but its shape: six workgroup barriers per group of 256 slots
-// around a divergent serial walk, five resident workgroups per CU -- at 23.7 M instances it ran at 0.07 of the HBM rate
-// (profiles/r05_hbm_training_state.md).  Here a WAVE owns 64 consecutive depth slots and never waits for another wave:
-//   * slot -> (offset, share) from the prefix sums, splat id, 64-byte record, extent: one lane per slot, every load independent;
-//   * SMALL splats (<= EW_SMALL tiles in <= EW_SMALL_SLICES slices): the owning lane walks its slices and stages key + owner lane in the
-//     wave's private LDS buffer (walk_tiles_stage); the wave then streams the buffer out -- position p belongs to lane ob[p], its table
-//     position is p + (table offset - LDS offset of that lane) and its value that lane's splat id, both fetched by ds_bpermute from the
-//     owner's registers -- so global stores are coalesced and there is no owner search;
-//   * MEDIUM splats (up to `big_thr` tiles): one at a time, the extent broadcast through v_readlane (scalar registers), one lane per
-//     slice (slice_bounds: the serial walk's carried intersections are pure functions of the slice index), a wave scan for the run
-//     offsets, then a 2-D lane map (64 / Wp slices x Wp tiles per instruction, Wp = the chunk's longest run rounded up to a power of
-//     two) writes the runs -- no LDS, no per-key search;
-//   * BIG splats go to dup_big_kernel's queue as before (near-camera Gaussians with thousands of tiles: split into parts over the chip).
-// The tile sort's digit counts are plain LDS adds (lanes of one instruction hold keys of different splats: no wave-uniform shortcut).
-// Same table, bit for bit, as walk_tiles<> / dup_small / dup_big: the slot's share bounds what is written, a short walk is padded with
-// key 0, both counted (LG_SITE_EMIT_COUNT) -- tests/test_gpu_edge.py's degenerate splats run through all three size classes.
-// ---------------------------------------------------------------------------------------------
-#define EW_SMALL 32
-#define EW_SMALL_SLICES 8
-#define EW_CAP (64 * EW_SMALL)
-
-__device__ __forceinline__ float rl_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
-__device__ __forceinline__ int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-
-__device__ __forceinline__ void emit_hist_add(int* __restrict__ h, uint32_t key, bool active, const DigitSpec& ds)
-{
-    if (!active) return;
-    for (int p = 0; p < ds.passes; p++) {
-        const uint32_t d = (key >> (ds.begin_bit + p * 8)) & ((p == ds.passes - 1) ? ds.last_mask : 255u);
-        atomicAdd(&h[p * 256 + HPERM(d)], 1);
-    }
-}
-
-template <int TH, int TW, typename IdxT, bool PACKED, typename LdsKeyT>
-__global__ void __launch_bounds__(TPB) emit_wave_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
-                                                        const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
-                                                        long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
-                                                        int* __restrict__ qcount, uint32_t* __restrict__ qentries,
-                                                        int* __restrict__ totals, DigitSpec ds,
-                                                        uint32_t* __restrict__ zero_ptr, long long zero_words,
-                                                        uint32_t* __restrict__ ones_ptr, long long ones_words,
-                                                        uint32_t* __restrict__ zero2_ptr, long long zero2_words,
-                                                        const int* __restrict__ gate, int* __restrict__ trunc_flag, int* __restrict__ dbg, int big_thr)
-{
-    if (gate != nullptr && *gate == 0) return;
-    __shared__ LdsKeyT kbuf[TPB / 64][EW_CAP];
-    __shared__ uint8_t obuf[TPB / 64][EW_CAP];
-    __shared__ int hist[SORT_MAX_PASSES_DUP * 256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const long long qcap = dup_queue_cap(N, table_len);
-    const int32_t* pf = prefix + (size_t)b * N;
-    int32_t* kout = keys + (size_t)b * table_len;
-    int32_t* vout = values + (size_t)b * table_len;
-    const int nkeys = gx * gy;
-    {   // zero duty, one burst of 16-byte stores at the start of the launch (see dup_small_kernel)
-        const long long z_gid = ((long long)b * gridDim.x + blockIdx.x) * TPB + tid, z_nth = (long long)gridDim.x * gridDim.y * TPB;
-        if (ones_ptr) for (long long i = z_gid; i < ones_words; i += z_nth) ones_ptr[i] = 0xffffffffu;
-        if (zero_ptr) {
-            uint4* z4 = reinterpret_cast<uint4*>(zero_ptr);
-            const long long n4 = zero_words / 4;
-            for (long long i = z_gid; i < n4; i += z_nth) z4[i] = make_uint4(0u, 0u, 0u, 0u);
-            for (long long i = n4 * 4 + z_gid; i < zero_words; i += z_nth) zero_ptr[i] = 0u;
-        }
-        if (zero2_ptr) {
-            uint4* z4 = reinterpret_cast<uint4*>(zero2_ptr);
-            const long long n4 = zero2_words / 4;
-            for (long long i = z_gid; i < n4; i += z_nth) z4[i] = make_uint4(0u, 0u, 0u, 0u);
-            for (long long i = n4 * 4 + z_gid; i < zero2_words; i += z_nth) zero2_ptr[i] = 0u;
-        }
-    }
-    if (totals) {
-        for (int k = tid; k < ds.passes * 256; k += TPB) hist[k] = 0;
-        __syncthreads();                                  // the only barrier in front of the loop: the digit table is shared by the four waves
-    }
-    LdsKeyT* kb = kbuf[wave];
-    uint8_t* ob = obuf[wave];
-    const int ngroups = (N + 63) / 64;
-    const int nwaves = (int)gridDim.x * (TPB / 64);
-    int bad_keys = 0;
-    for (int wg = (int)blockIdx.x * (TPB / 64) + wave; wg < ngroups; wg += nwaves) {
-        const int j = wg * 64 + lane;
-        // 1. the slot's share of the table (tile count > 0 <=> non-empty tile rectangle)
-        long long off = 0;
-        int cnt = 0;
-        if (j < N) {
-            off = (j == 0) ? 0 : pf[j - 1];
-            const long long c = pf[j] - off;
-            if (c > 0 && off + c <= table_len) cnt = (int)c;
-            else if (c > 0 && off <= table_len) {
-                // first splat that does not fit (GR/binning.cu:63 drops it and every later one): the rest of the table becomes key 0
-                for (long long q = off; q < table_len; q++) { kout[q] = 0; vout[q] = 0; }
-                if (trunc_flag) atomicOr(trunc_flag, 1);
-                lg_note_sanitised(LG_SITE_TRUNCATED);
-                if (totals)
-                    for (int p = 0; p < ds.passes; p++) atomicAdd(&totals[p * 256], (int)(table_len - off));
-            }
-        }
-        // 2. geometry of every slot that emits
-        int idx = 0;
-        SplatExtent e = {};
-        int nsl = 0;
-        if (cnt > 0) {
-            idx = sorted_id ? (int)sorted_id[(size_t)b * N + j] : j;
-            if ((unsigned)idx >= (unsigned)N) { idx = 0; cnt = 0; lg_note_sanitised(LG_SITE_QUEUE_ENTRY); }
-        }
-        if (cnt > 0) {
-            float nx, ny, a, bb, cc, o;
-            load_splat<PACKED>(src, b, N, idx, nx, ny, a, bb, cc, o);
-            splat_extent<TH, TW>(nx, ny, a, bb, cc, o, H, W, gx, gy, e);
-            const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
-            nsl = ys < xs ? ys : xs;
-        }
-        const bool small = cnt > 0 && cnt <= EW_SMALL && nsl <= EW_SMALL_SLICES;
-        const bool big = cnt > big_thr;
-        const bool medium = cnt > 0 && !small && !big;
-
-        // 3. big splats: queue entries for dup_big_kernel (one returning atomic per wave group that has any)
-        if (__ballot(big) != 0ull) {
-            const int np = big ? dup_num_parts(cnt) : 0;
-            int np_inc = np;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int nb = __shfl_up(np_inc, o);
-                if (lane >= o) np_inc += nb;
-            }
-            const int nent = rl_i(np_inc, 63);
-            const int sub = (wg >> 2) % DUP_NQ;
-            int qb = 0;
-            if (lane == 0) qb = atomicAdd(qcount + (size_t)b * DUP_NQ + sub, nent);
-            qb = rl_i(qb, 0);
-            if (big) {
-                const int pos = qb + np_inc - np;
-                uint32_t* q = qentries + ((size_t)b * DUP_NQ + sub) * qcap + pos;
-                for (int p = 0; p < np; p++) {
-                    if ((long long)pos + p < qcap) q[p] = ((uint32_t)j << 8) | (uint32_t)p;
-                    else lg_note_sanitised(LG_SITE_QUEUE_ENTRY);
-                }
-            }
-        }
-
-        // 4. small splats: serial walk into the wave's LDS buffer, coalesced stream-out
-        {
-            const int scnt = small ? cnt : 0;
-            int incl = scnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int nb = __shfl_up(incl, o);
-                if (lane >= o) incl += nb;
-            }
-            const int total_small = rl_i(incl, 63);
-            const int loff = incl - scnt;
-            if (small) {
-                int staged = 0;
-                const int walked = walk_tiles_stage<TH, TW, LdsKeyT>(e, gx, kb, ob, loff, cnt, lane, staged);
-                for (int c = staged; c < cnt; c++) { kb[loff + c] = (LdsKeyT)0; ob[loff + c] = (uint8_t)lane; }       // short walk: padding (key 0 = "no tile")
-                if (walked != cnt) dup_report_mismatch(dbg, j, walked, cnt);
-            }
-            __builtin_amdgcn_wave_barrier();              // LDS operations of one wave execute in order
-            const int delta = (int)off - loff;            // table position - LDS position of this lane's entries
-            for (int p0 = 0; p0 < total_small; p0 += 64) {
-                const int p = p0 + lane;
-                const bool act = p < total_small;
-                const int owner = act ? (int)ob[p] : lane;
-                int32_t key = act ? (int32_t)kb[p] : 0;
-                const int g = p + __shfl(delta, owner);
-                const int id = __shfl(idx, owner);
-                const bool oob = (unsigned)key > (unsigned)nkeys;       // cannot happen while walk and count agree; a key is an index downstream
-                key = oob ? 0 : key;
-                bad_keys += oob ? 1 : 0;
-                if (act) { kout[g] = key; vout[g] = id; }
-                if (totals) emit_hist_add(hist, (uint32_t)key, act, ds);
-            }
-            __builtin_amdgcn_wave_barrier();              // the buffer is reused by the next group
-        }
-
-        // 5. medium splats, one at a time across the wave
-        unsigned long long mm = __ballot(medium);
-        while (mm != 0ull) {
-            const int srcl = __ffsll((long long)mm) - 1;
-            mm &= mm - 1ull;
-            SplatExtent s;
-            s.a = rl_f(e.a, srcl); s.b = rl_f(e.b, srcl); s.c = rl_f(e.c, srcl); s.disc = rl_f(e.disc, srcl); s.t = rl_f(e.t, srcl);
-            s.px = rl_f(e.px, srcl); s.py = rl_f(e.py, srcl);
-            s.bbox_min_x = rl_f(e.bbox_min_x, srcl); s.bbox_min_y = rl_f(e.bbox_min_y, srcl);
-            s.bbox_max_x = rl_f(e.bbox_max_x, srcl); s.bbox_max_y = rl_f(e.bbox_max_y, srcl);
-            s.argmin_x = rl_f(e.argmin_x, srcl); s.argmin_y = rl_f(e.argmin_y, srcl);
-            s.argmax_x = rl_f(e.argmax_x, srcl); s.argmax_y = rl_f(e.argmax_y, srcl);
-            s.rminx = rl_i(e.rminx, srcl); s.rminy = rl_i(e.rminy, srcl); s.rmaxx = rl_i(e.rmaxx, srcl); s.rmaxy = rl_i(e.rmaxy, srcl);
-            const int sidx = rl_i(idx, srcl);
-            const int sgoff = rl_i((int)off, srcl);
-            const int scnt = rl_i(cnt, srcl);
-            const WalkFrame f = walk_frame<TH, TW>(s);
-            const int nslices = f.rect_max_u - f.rect_min_u;
-            int K = 0;                                    // number of leading slices whose upper line is <= bmax_u
-            for (int i0 = 0; i0 < nslices; i0 += 64) {
-                const int i = i0 + lane;
-                const bool c = (i < nslices) && ((float)(f.rect_min_u + i) * f.BLOCK_U + f.BLOCK_U <= f.bmax_u);
-                K += __popcll(__ballot(c));
-            }
-            int run = 0, run_signed = 0;
-            for (int i0 = 0; i0 < nslices; i0 += 64) {
-                const int i = i0 + lane;
-                int mn = 0, n = 0;
-                if (i < nslices) {
-                    int mx;
-                    slice_bounds(s, f, i, K, mn, mx);
-                    n = mx - mn;
-                }
-                if (__ballot(n < 0) != 0ull) {             // a degenerate slice (see dup_big_kernel): the layout is built from max(n, 0)
-                    int ng = n < 0 ? n : 0;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) ng += __shfl_xor(ng, o);
-                    run_signed += ng;
-                }
-                n = n > 0 ? n : 0;
-                int inc = n, wmax = n;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    int nbv = __shfl_up(inc, o);
-                    if (lane >= o) inc += nbv;
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
-                wmax = rl_i(wmax, 0);
-                const int soff_mine = run + inc - n;
-                if (wmax > 0) {
-                    // 2-D lane map: 64 / Wp slices x Wp tiles per instruction
-                    int lg = 0;
-                    while ((1 << lg) < wmax && lg < 6) lg++;
-                    const int wp = 1 << lg, per = 64 >> lg;
-                    const int chunk = nslices - i0 < 64 ? nslices - i0 : 64;
-                    const int sl_in = lane >> lg, vv0 = lane & (wp - 1);
-                    for (int s0 = 0; s0 < chunk; s0 += per) {
-                        const int sl = s0 + sl_in;                       // < 64
-                        const int smn = __shfl(mn, sl), sn = __shfl(n, sl), soff = __shfl(soff_mine, sl);
-                        const int u = f.rect_min_u + i0 + sl;
-                        for (int vv = vv0; vv < wmax; vv += wp) {        // one trip unless a run is longer than 64 tiles
-                            const int k = soff + vv;
-                            const bool act = sl < chunk && vv < sn && k < scnt;
-                            const int v = smn + vv;
-                            const uint32_t tk = f.isY ? (uint32_t)(u * gx + v) : (uint32_t)(v * gx + u);
-                            int32_t key = act ? (int32_t)(tk + 1) : 0;
-                            const bool oob = (unsigned)key > (unsigned)nkeys;
-                            key = oob ? 0 : key;
-                            bad_keys += oob ? 1 : 0;
-                            if (act) { kout[sgoff + k] = key; vout[sgoff + k] = sidx; }
-                            if (totals) emit_hist_add(hist, (uint32_t)key, act, ds);
-                        }
-                    }
-                }
-                run += rl_i(inc, 63);
-            }
-            run_signed += run;                            // signed sum of the slice counts = what the projection counted
-            if (run_signed != scnt && lane == 0) dup_report_mismatch(dbg, -1 - sidx, run_signed, scnt);
-            for (int k = run + lane; k < scnt; k += 64) {  // padding (only if the counts disagree)
-                kout[sgoff + k] = 0; vout[sgoff + k] = 0;
-                if (totals) emit_hist_add(hist, 0u, true, ds);
-            }
-        }
-    }
-    if (bad_keys) lg_note_sanitised(LG_SITE_EMIT_KEY, bad_keys);
-    if (totals) {
-        __syncthreads();
-        digit_hist_flush(hist, totals, ds.passes);
-    }
-}
-
+// (Round 6 built a wave-autonomous form of this emission -- a wave owns 64 depth slots and never waits for another wave; small splats staged
+// in LDS by the owning lane, medium ones one at a time with one lane per slice and a 2-D lane map for the runs, giants queued for
+// dup_big_kernel -- and measured it in situ: 330 + 22 us against 207 + 143 us for dup_small + dup_big at 23.7 M instances (no gain), 245 us
+// against 54 us on the bench's fresh frame in splat-id order, where whole wave groups are made of large splats.  SQ counters: 3.0 vector
+// instructions per key against a budget of ~1 for the 100 us the round-5 verdict asked for; what binds either form is the instruction
+// count per key -- extent 250 and slice bounds ~100 per slice of ~3.5 keys -- not the barriers.  Removed; profiles/r06_binning_ab.log,
+// profiles/r06_emission_fresh_state_ab.log, git history of this file.)
 // launch variants of the key emission (lg_set_tuning keys 10 / 11: A/B hooks of tools/, plain ints as in raster.hip)
 static int g_small_sort_lb = 8;                // look-back width of radix sorts with < 1024 key tiles (lg_set_tuning(15, 8 | 32); radix_onesweep_kernel).  32 measured SLOWER
                                                // (36-37 against 30 us per pass of the 2.2 M-key splat sort, profiles/r06_binning_ab.log): the passes are not bound by the look-back chain
-static int g_emit_mode = 1;                    // 1 (default): emit_wave_kernel + dup_big; 0: dup_small + dup_big (lg_set_tuning(13, .))
-static int g_emit_big = 1024;                  // emit_wave_kernel: splats with more tiles are queued for dup_big (lg_set_tuning(14, .))
 static int g_dup_small_hi = DUP_SMALL_HI;      // largest tile count the owning thread walks itself; larger splats go to dup_big
 static int g_dup_dynamic = 0;                  // 0 (default): groups dealt round robin; 1: long launches (>= 5 groups per workgroup) hand their groups out
                                                // on demand after one static round (needs the caller's zeroed ticket word); 2: always.  Five schemes measured,
@@ -1023,8 +757,6 @@ int lg_binning_set_tuning(int key, int value)
     if (key == 10) { if (value < DUP_SMALL || value > DUP_SMALL_HI) return (int)hipErrorInvalidValue; g_dup_small_hi = value; return 0; }
     if (key == 11) { if (value < 0 || value > 2) return (int)hipErrorInvalidValue; g_dup_dynamic = value; return 0; }
     if (key == 15) { if (value != 8 && value != 32) return (int)hipErrorInvalidValue; g_small_sort_lb = value; return 0; }
-    if (key == 13) { if (value < 0 || value > 1) return (int)hipErrorInvalidValue; g_emit_mode = value; return 0; }
-    if (key == 14) { if (value < EW_SMALL || value > (1 << 20)) return (int)hipErrorInvalidValue; g_emit_big = value; return 0; }
     return (int)hipErrorInvalidValue;
 }
 
@@ -1066,14 +798,6 @@ int lg_dup_emit_gated(const float* ndc, const float* inv_cov, const float* opaci
     SplatSrc src = { ndc, inv_cov, opacity, (const float4*)packed };
 #define LAUNCH_DUP(A_, B_, T_, P_)                                                                                                          \
     do {                                                                                                                                   \
-        if (g_emit_mode == 1 && tile_counts == nullptr) {                                                                                  \
-            if (gx * gy + 1 <= 0xffff)                                                                                                     \
-                hipLaunchKernelGGL((emit_wave_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N, \
-                                   H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg, g_emit_big); \
-            else                                                                                                                           \
-                hipLaunchKernelGGL((emit_wave_kernel<A_, B_, T_, P_, int32_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
-                                   H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg, g_emit_big); \
-        } else                                                                                                                             \
         if (gx * gy + 1 <= 0xffff)                                                                                                         \
             hipLaunchKernelGGL((dup_small_kernel<A_, B_, T_, P_, uint16_t>), grid, dim3(TPB), 0, s, src, prefix, (const T_*)sorted_id, N,  \
                                H, W, gx, gy, table_len, keys, values, qcount, qentries, totals, ds, tile_counts, zero_ptr, zero_words, ones_ptr, ones_words, zero2_ptr, zero2_words, gate, trunc_flag, dbg, g_dup_small_hi, use_ticket ? grp_ticket : (int*)nullptr, 1); \

@@ -114,56 +114,6 @@ __device__ __forceinline__ uint32_t walk_tiles(const SplatExtent& e, int gx, int
     return count;
 }
 
-// The same serial walk, staging ONE splat's keys for a wave-private buffer (binning.hip emit_wave_kernel): entry c of the splat goes to
-// kb[base + c] with its owner lane in ob[base + c], at most `share` entries (the splat's share of the table, i.e. the count the projection
-// made with the same arithmetic).  Returns the SIGNED sum of the slice counts (== share for a consistent walk; a degenerate first slice
-// can contribute a negative count, GR/speedy_splat.cuh:118-125) and the number of entries written through `staged`.
-template <int TH, int TW, typename LdsKeyT>
-__device__ __forceinline__ int walk_tiles_stage(const SplatExtent& e, int gx, LdsKeyT* kb, uint8_t* ob, int base, int share, int owner, int& staged)
-{
-    const int ys = e.rmaxy - e.rminy, xs = e.rmaxx - e.rminx;
-    const bool isY = ys < xs;
-    const float BLOCK_U = isY ? (float)TH : (float)TW;
-    const float BLOCK_V = isY ? (float)TW : (float)TH;
-    const int rect_min_u = isY ? e.rminy : e.rminx, rect_max_u = isY ? e.rmaxy : e.rmaxx;
-    const int rect_min_v = isY ? e.rminx : e.rminy, rect_max_v = isY ? e.rmaxx : e.rmaxy;
-    const float bmin_u = isY ? e.bbox_min_y : e.bbox_min_x, bmin_v = isY ? e.bbox_min_x : e.bbox_min_y;
-    const float bmax_u = isY ? e.bbox_max_y : e.bbox_max_x, bmax_v = isY ? e.bbox_max_x : e.bbox_max_y;
-    const float argmin_v = isY ? e.argmin_x : e.argmin_y;
-    const float argmax_v = isY ? e.argmax_x : e.argmax_y;
-    const int stride = isY ? 1 : gx;
-
-    int count = 0, c = 0;
-    float imax_lo = bmax_v, imax_hi = bmin_v;
-    float imin_lo, imin_hi;
-    float min_line = rect_min_u * BLOCK_U;
-    if (bmin_u <= min_line) ellipse_cut(e, isY, rect_min_u * BLOCK_U, imin_lo, imin_hi);
-    else { imin_lo = imax_lo; imin_hi = imax_hi; }
-    for (int u = rect_min_u; u < rect_max_u; ++u) {
-        float max_line = min_line + BLOCK_U;
-        if (max_line <= bmax_u) ellipse_cut(e, isY, max_line, imax_lo, imax_hi);
-        float ellipse_min, ellipse_max;
-        if (min_line <= argmin_v && argmin_v < max_line) ellipse_min = bmin_v;
-        else ellipse_min = fminf(imin_lo, imax_lo);
-        if (min_line <= argmax_v && argmax_v < max_line) ellipse_max = bmax_v;
-        else ellipse_max = fmaxf(imin_hi, imax_hi);
-        const int min_tile_v = max(rect_min_v, min(rect_max_v, lg_f2i(ellipse_min / BLOCK_V)));
-        const int max_tile_v = min(rect_max_v, max(rect_min_v, lg_f2i(ellipse_max / BLOCK_V + 1)));
-        count += max_tile_v - min_tile_v;
-        int key = (isY ? (u * gx + min_tile_v) : (min_tile_v * gx + u)) + 1;
-        for (int v = min_tile_v; v < max_tile_v && c < share; v++) {
-            kb[base + c] = (LdsKeyT)key;
-            ob[base + c] = (uint8_t)owner;
-            key += stride;
-            c++;
-        }
-        imin_lo = imax_lo; imin_hi = imax_hi;
-        min_line = max_line;
-    }
-    staged = c;
-    return count;
-}
-
 // fminf/fmaxf above drop a NaN operand (v_min_f32 / CUDA min()): a cut taken exactly on the ellipse's extreme line can have a
 // slightly negative discriminant (sqrt -> NaN) and the slice then uses the other line's intersection, as in the reference.
 

@@ -102,6 +102,21 @@ class Statistics:
             return
         N, _, Hp, Wp = last_contributor.shape
         ty, tx = Hp // th, Wp // tw
+        if last_contributor.is_cuda and N == 1 and last_contributor.dtype == torch.int16 and last_contributor.is_contiguous():
+            # the executor's own kernels (csrc/raster.hip): per-tile maximum of last_contributor by one wave per tile, heavy-first order by
+            # a counting sort on min(count, 1023) -- two launches instead of the reshape / permute / max / sort chain of torch kernels
+            # (a dozen launches per step of a statistics epoch, profiles/r05_training_state_timeline.md).  Ties, and tiles beyond 1023
+            # splats among themselves, come in tile order; torch.sort's order of equal counts is unspecified anyway.
+            from ._lib import check, lib
+            ntiles = ty * tx
+            work = torch.empty((1, ntiles + 1), dtype=torch.int32, device=last_contributor.device)
+            order = torch.empty((1, ntiles), dtype=torch.int32, device=last_contributor.device)
+            s = torch.cuda.current_stream().cuda_stream
+            check(lib().lg_tile_work_from_last(last_contributor.data_ptr(), 1, Hp, Wp, th, tw, work.data_ptr(), s), "tile_work_from_last")
+            check(lib().lg_tile_order(work.data_ptr(), 1, ntiles, order.data_ptr(), s), "tile_order")
+            self.tile_blend_count[self.current_frame] = work[0, 1:]
+            self.tile_schedule[self.current_frame] = order[0]
+            return
         per_tile = last_contributor.reshape(N, ty, th, tx, tw).permute(1, 3, 0, 2, 4).reshape(ty * tx, -1).max(dim=1).values
         self.tile_blend_count[self.current_frame] = per_tile
         self.tile_schedule[self.current_frame] = (per_tile.sort(descending=True)[1].int() + 1)

@@ -214,28 +214,26 @@ def test_degenerate_slices_keep_the_table_inside_each_splats_share(oracle):
     assert not any(v for k, v in counts.items() if k != "truncated_tables"), counts     # nothing had to be neutralised
 
 
-EMISSION_VARIANTS = {                       # lg_set_tuning(13, mode), (14, in-wave ceiling): csrc/binning.hip emit_wave_kernel
-    "workgroup_form": (0, 1024),            # round 2-5's dup_small + dup_big
-    "wave_form": (1, 1024),                 # the default
-    "wave_form_all_queued": (1, 32),        # every splat beyond the staged class goes to dup_big
-    "wave_form_nothing_queued": (1, 1 << 20),   # ... is emitted by the wave that owns its slot (2-D lane map), whatever its size
+EMISSION_VARIANTS = {                       # lg_set_tuning(10, ceiling): largest tile count the owning thread of dup_small walks itself (csrc/binning.hip)
+    "ceiling_256": 256,                     # the default
+    "ceiling_32": 32,                       # everything beyond 32 tiles goes to the cooperative kernel (dup_big)
+    "ceiling_128": 128,
 }
 
 
 @pytest.mark.parametrize("variant", list(EMISSION_VARIANTS))
 def test_emission_variants_build_one_table(oracle, variant):
-    """the three size classes of the key emission (staged in LDS by the owning lane / one lane per slice with the 2-D lane map / queued for
-    the cooperative kernel) are the same walk: whatever the ceilings, create_table returns the oracle's table bit for bit -- on the
-    degenerate splats (negative first slice), on near-camera giants (1 000..16 000 tiles, runs longer than 64 tiles) and on an exact and a
-    truncated table"""
+    """the two size classes of the key emission (walked by the owning thread into the workgroup's LDS buffer / queued for the cooperative
+    kernel, one lane per slice) are the same walk: wherever the ceiling between them sits, create_table returns the oracle's table bit for
+    bit -- on the degenerate splats (negative first slice), on near-camera giants (1 000..16 000 tiles) and on an exact and a truncated table"""
     from litegs_amd import fused as F
     from litegs_amd._lib import lib, check
     from litegs_amd.fast import FusedRenderer
-    mode, big = EMISSION_VARIANTS[variant]
+    ceiling = EMISSION_VARIANTS[variant]
     H, W = 1080, 1920
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     FusedRenderer.sanitised_counts(reset=True)
-    check(lib().lg_set_tuning(13, mode), "tuning"); check(lib().lg_set_tuning(14, big), "tuning")
+    check(lib().lg_set_tuning(10, ceiling), "tuning")
     try:
         for copies in (1, 40):
             ndc, inv, op, vz = degenerate_table_inputs(copies)
@@ -262,6 +260,6 @@ def test_emission_variants_build_one_table(oracle, variant):
         live = ks_r[0] > 0
         assert want < total and np.array_equal(ks.cpu().numpy(), ks_r) and np.array_equal(vs.cpu().numpy()[0][live], vs_r[0][live])
     finally:
-        check(lib().lg_set_tuning(13, 1), "tuning"); check(lib().lg_set_tuning(14, 1024), "tuning")
+        check(lib().lg_set_tuning(10, 256), "tuning")
     counts = FusedRenderer.sanitised_counts(reset=True)
     assert not any(v for k, v in counts.items() if k != "truncated_tables"), counts

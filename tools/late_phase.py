@@ -48,10 +48,7 @@ VARIANTS = {
     "emit_dynamic": (dict(_tuning={11: 2}), False),                        # key emission: groups handed out on demand after one static round (default: round robin)
     "emit_hi128": (dict(_tuning={10: 128}), False),                        # ... in-workgroup walk up to 128 tiles (default 256), larger splats cooperative
     "emit_hi64": (dict(_tuning={10: 64}), False),
-    "emit_wg": (dict(_tuning={13: 0}), False),                             # round 5's workgroup-form emission (dup_small)
     "sort_lb32": (dict(_tuning={15: 32}), False),                          # 32-wide look-back in the splat sort
-    "emit_big512": (dict(_tuning={14: 512}), False),                       # wave-form emission: in-wave ceiling 512 / 4096 tiles (default 1024)
-    "emit_big4096": (dict(_tuning={14: 4096}), False),
     "occ6": (dict(_tuning={19: 26, 20: 26}), False),                      # blend kernels capped at 6 / 5 / 4 / 3 waves per SIMD (unused dynamic LDS)
     "occ5": (dict(_tuning={19: 32, 20: 32}), False),
     "occ4": (dict(_tuning={19: 40, 20: 40}), False),
@@ -155,7 +152,7 @@ def configure(tr, attrs):
     base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
     base.update(attrs)
     from litegs_amd._lib import check, lib
-    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 13: 1, 14: 1024, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0}                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0}                          # lg_set_tuning keys a variant may change, at their defaults
     tuning.update(base.pop("_tuning", {}))
     for key, val in tuning.items():
         check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
