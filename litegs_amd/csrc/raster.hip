@@ -1100,28 +1100,48 @@ __global__ void __launch_bounds__(256) raster_backward_kernel(const int* __restr
 // Results: the same nine sums (the additions inside a lane associate differently: fp32 rounding only).
 // ---------------------------------------------------------------------------------------------
 
-// Nine totals; the adds behind the permlane32 swaps are packed (two totals per issue slot).  Input order chosen so that every packed
-// operand is a pair the producer leaves in adjacent registers: (v0, v2), (v1, v3), (v4, v6) and (v5, v7) -- v5 / v7 being the
-// two halves of one packed result.  Totals land as in reduce9: value k in the lane with wave_slot(lane) == k.
-__device__ __forceinline__ float reduce9_pk(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8)
+// The nine totals from SIX per-lane values (round 6).  Every moment with a dx in it is a column-weighted sum of a dx-free one --
+// Mx = sum_c dx_c S0_c, Mxx = sum_c dx_c^2 S0_c, Mxy = sum_c dx_c S1_c, with S0 / S1 the sums of m / m dy over the four lanes of a pixel
+// column (dx depends on the column only) -- so the two cross-ROW levels, the expensive ones (v_permlane*_swap issues at half rate), need
+// to carry S0, S1, S2 and the three colour sums only: five swaps instead of six, and no ninth value that has to cross the rows through
+// the LDS crossbar (ds_bpermute + ds_swizzle: two dependent ~100-cycle round trips per splat, and an lgkmcnt(0) wait in the middle of
+// the splat that also waits for the next record's scalar load).  After the row levels every row holds column totals of a different
+// quantity (A: S0 | S2 | S1 | Cr; C: Cg | Cg | Cb | Cb); the weights are applied per column (X1 = A dx, X2 = X1 dx: the three
+// per-lane multiplies in front of the old reduction become two behind the row levels) and the four registers go through the transposing
+// in-row butterfly together: 8 DPP adds.  Totals: lane 16 r + 4 g holds, for row r, g = 0: A, 1: X1, 2: C, 3: X2 -- wave_slot_cols().
+__device__ __forceinline__ float reduce9_cols(float s0, float s1, float s2, float cr, float cg, float cb, float dx)
 {
-    v8 += xor_32(v8);
-    swap32(v0, v1); swap32(v2, v3);
-    v2f a = { v0, v2 }, b = { v1, v3 };
-    a += b;                                           // {v0', v2'}
-    swap32(v4, v5); swap32(v6, v7);
-    v2f c = { v4, v6 }, d = { v5, v7 };
-    c += d;                                           // {v4', v6'}
-    v8 += xor_swz16(v8);
-    float a0 = a.x, a1 = a.y, c0 = c.x, c1 = c.y;
-    swap16(a0, a1); swap16(c0, c1);
-    a0 += a1; c0 += c1;
-    float r = bfly_mirror8(a0, c0);
-    v8 += mirror16(v8);
-    r = bfly_hmirror4(r, v8);
-    r += xor_dpp2(r);
-    r += xor_dpp1(r);
-    return r;
+    swap32(s0, s1); swap32(s2, cr); swap32(cg, cb);
+    v2f a = { s0, s2 }, b = { s1, cr };
+    a += b;                                           // a.x: rows 0-1 S0, rows 2-3 S1;  a.y: rows 0-1 S2, rows 2-3 Cr
+    float c = cg + cb;                                // rows 0-1 Cg, rows 2-3 Cb
+    float a0 = a.x, a1 = a.y;
+    swap16(a0, a1);
+    const float A = a0 + a1;                          // row 0 S0, row 1 S2, row 2 S1, row 3 Cr (column totals)
+    const float C = sum16(c);                         // rows 0-1 Cg, rows 2-3 Cb
+    const float X1 = A * dx, X2 = X1 * dx;
+    float P = bfly_mirror8(A, C);
+    const float Q = bfly_mirror8(X1, X2);
+    P = bfly_hmirror4(P, Q);
+    P += xor_dpp2(P);
+    P += xor_dpp1(P);
+    return P;
+}
+// record slot (Mx My Mxx Mxy Myy dr dg db M0 = 0..8) of the total lane `lane` holds after reduce9_cols (-1: none)
+__device__ __forceinline__ int wave_slot_cols(int lane)
+{
+    switch (lane) {
+    case 0: return 8;        // row 0, A: S0 = M0
+    case 4: return 0;        // row 0, X1: Mx
+    case 8: return 6;        // row 0, C: dg
+    case 12: return 2;       // row 0, X2: Mxx
+    case 16: return 4;       // row 1, A: S2 = Myy
+    case 32: return 1;       // row 2, A: S1 = My
+    case 36: return 3;       // row 2, X1: Mxy
+    case 40: return 7;       // row 2, C: db
+    case 48: return 5;       // row 3, A: dr
+    default: return -1;
+    }
 }
 
 struct BwdFast {
@@ -1179,9 +1199,7 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     const float s0 = m.x + m.y;
     const float s1 = my.x + my.y;
     const float s2 = __builtin_fmaf(my.x, dyv.x, my.y * dyv.y);
-    const float mx = dx * s0;
-    // order: (Mx My Mxx Mxy Myy dr DB DG M0) -- dg / db swapped against the record, see wave_slot_fast
-    float tot = reduce9_pk(mx, s1, dx * mx, dx * s1, s2, crg.x, v_b, crg.y, s0);
+    float tot = reduce9_cols(s0, s1, s2, crg.x, crg.y, v_b, dx);
     if constexpr (STAT == 2) {
         const float inv_o = __builtin_amdgcn_rcpf(rec[R_O]);
         const float vo0 = m.x * inv_o, vo1 = s0 * inv_o;
@@ -1216,7 +1234,7 @@ __device__ __forceinline__ int stat_lane_slot(int lane)
     return lane == 15 ? STAT_SLOT_COUNT : (lane == 31 ? STAT_SLOT_WEIGHT : (lane == 63 ? STAT_SLOT_ERRSQ : -1));
 }
 
-// map_mode: bits 0-7 workgroup -> tile map, 8-15 priority switch, 16-23 L2 warm-up block, 24 / 25 measurement hooks
+// map_mode: bits 0-7 workgroup -> tile map, 8-15 priority switch, 24 / 25 measurement hooks
 template <bool TRANS, int STAT>
 __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
                                                                    const float* __restrict__ packed, const int* __restrict__ tiles, int K,
@@ -1271,10 +1289,10 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     const int minlast = -rfl(wave_max_i(-min(st.lc0, st.lc1)));
     const int n = min(maxlast, end - start);        // list positions n-1 .. 0 are walked
     if (n <= 0) return;
-    int myslot = wave_slot(lane);
-    myslot = myslot == 6 ? 7 : (myslot == 7 ? 6 : myslot);       // reduce9_pk is fed (.., dr, db, dg, ..)
+    int myslot = wave_slot_cols(lane);
     if (STAT == 2 && stat_lane_slot(lane) >= 0) myslot = stat_lane_slot(lane);
     const unsigned long long writers = ((map_mode_in >> 24) & 1) ? 0ull : __ballot(myslot >= 0);      // (bit 24: measurement hook, no atomics)
+
     const unsigned idmask = ((map_mode_in >> 25) & 1) ? 0x3ffu : 0xffffffffu;                          // (bit 25: measurement hook, every tile reads the same 1024 records)
 #define rec_off(id_, N_) rec_off((int)((unsigned)(id_) & idmask), N_)
     const unsigned slot_off = (unsigned)max(myslot, 0) * 4u;
@@ -1297,27 +1315,11 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     rec_request(ra, pk, off_a);
     id_request(hot_a, hot, hot_on ? off_a >> 4 : 0u);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(hot_a));
-    // L2 warm-up one block down the list (PfState above); the walk descends, blocks end at positions = pfb - 1 (mod pfb)
-    const int pfb = (map_mode_in >> 16) & 0xff;
-    const bool pf_on = pfb > 0 && n >= 2 * pfb + 64;
-    PfState pf = { 0, 0u };
-    if (pf_on && lane < pfb) {
-        pf.g = pf_touch(pk, sp[max(pos - pfb - lane, 0)], N);
-        pf.ids = sp[max(pos - 2 * pfb - lane, 0)];
-    }
-#define PF_STEP()                                                                                             \
-    if (pf_on && (pos & (pfb - 1)) == pfb - 1) {                                                              \
-        pf_retire(pf.g);                                                                                      \
-        if (lane < pfb) {                                                                                     \
-            pf.g = pf_touch(pk, pf.ids, N);                                                                   \
-            pf.ids = sp[max(pos - 2 * pfb - lane, 0)];                                                        \
-        }                                                                                                     \
-    }
+    // (an L2 warm-up like the forward's -- PfState -- changes nothing here: 3.604 / 3.591 ms per step with, 3.596 / 3.592 without, profiles/r06_l2_warmup_ab.log)
     // phase 1: positions that some pixel of the tile had already stopped before (pos >= minlast): per-pixel last_contributor test
 #define HOT_TARGET(h, off) ((hot_on && (h) >= 0) ? (((unsigned)N + ((unsigned)(h) >> 6) + ((unsigned)tile & ((1u << ((h) & 63)) - 1u))) << 6) : (off))
 #define BWD_PAIR(CHK)                                                                                         \
     {                                                                                                         \
-        PF_STEP()                                                                                             \
         rec_request(rb, pk, off_b);                                                                           \
         id_request(hot_b, hot, hot_on ? off_b >> 4 : 0u);                                                     \
         id_request(id_a, sp, (unsigned)max(pos - 2, 0) << 2);                                                 \
@@ -1334,11 +1336,9 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     }
     for (; pos >= 1 && pos >= minlast; ) BWD_PAIR(true)
     for (; pos >= 1; ) BWD_PAIR(false)
-    pf_retire(pf.g);
     wclk_store(wclk, slot, wclk_t0, n, tile, lane);
 #undef rec_off
 #undef BWD_PAIR
-#undef PF_STEP
 #undef HOT_TARGET
 }
 
@@ -1559,7 +1559,7 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
     else if (TH == 8 && TW == 16 && g_bwd_fast && !(enable_stat && hot_of != nullptr)) {
 #define LAUNCH_RBF(T_, S_) hipLaunchKernelGGL((raster_backward_fast_kernel<T_, S_>), grid, block, (size_t)g_blend_lds_bwd << 10, s, sorted_points, start_index, packed, tiles, K, final_T, last, \
                                               d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots,                                                             \
-                                              g_bwd_map | (g_rank_prio << 8) | (g_pf_block << 16) | ((g_bwd_probe & 1) << 24) | (((g_bwd_probe >> 2) & 1) << 25), hot_of, g_wclk_bwd)
+                                              g_bwd_map | (g_rank_prio << 8) | ((g_bwd_probe & 1) << 24) | (((g_bwd_probe >> 2) & 1) << 25), hot_of, g_wclk_bwd)
         if (enable_stat && err_square_sum == nullptr) { if (d_trans) LAUNCH_RBF(true, 2); else LAUNCH_RBF(false, 2); }       // executor: statistics in the record
         else if (enable_stat) { if (d_trans) LAUNCH_RBF(true, 1); else LAUNCH_RBF(false, 1); }
         else { if (d_trans) LAUNCH_RBF(true, 0); else LAUNCH_RBF(false, 0); }
