@@ -156,6 +156,14 @@ struct TileMap {
 // The whole 64-byte record of splat `byte_off / 64` into 16 SGPRs: one scalar load, 32-bit scalar offset (records of one view span
 // < 4 GiB: N < 2^26, checked by the launchers).  Written as asm because the compiler neither forms the soffset addressing from a
 // 64-bit pointer sum nor keeps the request in flight across the loop body; the matching wait is rec_wait().
+// FRAGILE BY CONSTRUCTION, and checked by every parity test: the load completes asynchronously, somewhere before the matching wait, while
+// the compiler takes the output operand for defined at this statement.  That is sound as long as the register allocator never COPIES the
+// block between request and wait.  It does not while every record variable keeps one register block around the loops -- the shape all
+// kernels below have (two variables, ping-pong).  Round 6 tried to keep two more 64-bit masks alive across the requests of the lean
+// forward (last_contributor on the scalar unit): the allocator gave the four requests of a group four different blocks and moved words of
+// in-flight records with s_mov_b32 at the back edge -- a wrong image in every tile, caught by tests/test_gpu_ops.py.  Making the operand
+// read-write ("+s") did not pin the block either (and cost an occupancy step).  Reverted; anything that raises the scalar register
+// pressure of these loops has to be checked against the ISA (`grep s_load_dwordx16`: two destination blocks per loop).
 __device__ __forceinline__ void rec_request(f32x16& rec, const float* __restrict__ pk, unsigned byte_off)
 {
     asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(rec) : "s"(pk), "s"(byte_off));
