@@ -499,7 +499,9 @@ def main():
     # native executor: culled steps run speculatively (no gated repeat launches; a failed step is replayed by the trainer, exactly) --
     # tr.flush() inside every timed region makes the replays part of what is timed.  Across ranks (moment exchange only) the ranks agree
     # on the failed step through the gathered record headers and replay in lock-step (litegs_amd/dp.py "rank-consistent speculation")
-    tr.speculative = (not args.operator_path and os.environ.get("LITEGS_SPECULATIVE", "1") != "0")
+    # ... opt-in (LITEGS_DP_SPECULATIVE=1) until it has run on more than one GPU; the default across ranks is the gated repeat.
+    tr.speculative = (not args.operator_path and os.environ.get("LITEGS_SPECULATIVE", "1") != "0"
+                      and (world == 1 or os.environ.get("LITEGS_DP_SPECULATIVE", "0") == "1"))
     hook = None
     if world > 1:
         from litegs_amd import dp

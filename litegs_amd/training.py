@@ -192,8 +192,11 @@ def start(lp, op, pp, dp, test_epochs: Sequence[int] = (), save_ply: Sequence[in
         exchange = dp_mod.MomentExchange(trainer.params, world, n_slots=(len(frames) + world - 1) // world)
     trainer.exchange = exchange
     trainer.sched_ticks = world                           # the lr schedule counts frames, not optimizer steps (FrameTrainer.sched_ticks)
-    # speculative depth-bound culling (csrc/fused.hip; across ranks: litegs_amd/dp.py "rank-consistent speculation"); flushed at every epoch boundary
-    trainer.speculative = bool(fused)
+    # speculative depth-bound culling (csrc/fused.hip), flushed at every epoch boundary.  Across ranks (litegs_amd/dp.py "rank-consistent
+    # speculation": lock-step replay) it is OPT-IN -- LITEGS_DP_SPECULATIVE=1 -- until the protocol has run on more than one GPU: it has
+    # only ever seen two gloo ranks sharing a device, and a rank-local host exception would leave the peers blocked in a collective
+    # (VERDICT / ADVICE round 5).  The default across ranks is the gated repeat.
+    trainer.speculative = bool(fused) and (world == 1 or os.environ.get("LITEGS_DP_SPECULATIVE", "0") == "1")
     say(f"[litegs_amd] {len(frames)} training frames {W}x{H}, {len(test_frames_dev)} test frames, {init_points_num} initial points, "
         f"{total_epoch} epochs, world {world}, scene radius {norm_radius:.3f}")
 
