@@ -84,6 +84,12 @@ LG_API int lg_get_allocate_size(const float* ndc, const float* view_z, const flo
 //    slice counts into offsets, and the 64 lanes then write the splat's contiguous output range in
 //    256-byte coalesced stores.  Without this, one thread serialises a 16 200-tile splat and the launch
 //    waits for it (measured: 2.3 ms of a 4.9 ms training step at 3 M Gaussians).
+#ifndef LG_DUP_SMALL_WAVES
+#define LG_DUP_SMALL_WAVES __attribute__((amdgpu_waves_per_eu(5)))
+#endif
+#ifndef LG_DUP_BIG_WAVES
+#define LG_DUP_BIG_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+#endif
 #define DUP_SMALL 32
 #define DUP_SMALL_HI 256
 #define DUP_LDS_ENTRIES (TPB * DUP_SMALL)
@@ -191,7 +197,7 @@ __device__ __forceinline__ void dup_report_mismatch(int* __restrict__ dbg, int s
 // LdsKeyT: uint16_t when every tile id + 1 fits 16 bits (anything up to ~8 MPixel at 8x16 tiles) -- halves the staging buffer, one
 // more workgroup per CU for this latency-bound kernel.
 template <int TH, int TW, typename IdxT, bool PACKED, typename LdsKeyT>
-__global__ void __launch_bounds__(TPB) dup_small_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
+__global__ void __launch_bounds__(TPB) LG_DUP_SMALL_WAVES dup_small_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
                                                         const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                         long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
                                                         int* __restrict__ qcount /*[V][DUP_NQ], zero*/, uint32_t* __restrict__ qentries /*[V][DUP_NQ][cap]*/,
@@ -470,7 +476,7 @@ __device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src); 
 // output range in 256-byte coalesced stores.
 #define DUP_BATCH 16
 template <int TH, int TW, typename IdxT, bool PACKED>
-__global__ void __launch_bounds__(TPB) dup_big_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
+__global__ void __launch_bounds__(TPB) LG_DUP_BIG_WAVES dup_big_kernel(SplatSrc src, const int32_t* __restrict__ prefix,
                                                       const IdxT* __restrict__ sorted_id, int N, int H, int W, int gx, int gy,
                                                       long long table_len, int32_t* __restrict__ keys, int32_t* __restrict__ values,
                                                       const int* __restrict__ qcount, const uint32_t* __restrict__ qentries,
@@ -745,6 +751,7 @@ __global__ void __launch_bounds__(TPB) dup_queue_check_kernel(const int32_t* __r
 // count per key -- extent 250 and slice bounds ~100 per slice of ~3.5 keys -- not the barriers.  Removed; profiles/r06_binning_ab.log,
 // profiles/r06_emission_fresh_state_ab.log, git history of this file.)
 // launch variants of the key emission (lg_set_tuning keys 10 / 11: A/B hooks of tools/, plain ints as in raster.hip)
+static int g_depth_hist_blocks = 1024;        // workgroups of depth_keys_hist_kernel (lg_set_tuning(24, .))
 static int g_small_sort_lb = 8;                // look-back width of radix sorts with < 1024 key tiles (lg_set_tuning(15, 8 | 32); radix_onesweep_kernel).  32 measured SLOWER
                                                // (36-37 against 30 us per pass of the 2.2 M-key splat sort, profiles/r06_binning_ab.log): the passes are not bound by the look-back chain
 static int g_dup_small_hi = DUP_SMALL_HI;      // largest tile count the owning thread walks itself; larger splats go to dup_big
@@ -756,6 +763,7 @@ int lg_binning_set_tuning(int key, int value)
 {
     if (key == 10) { if (value < DUP_SMALL || value > DUP_SMALL_HI) return (int)hipErrorInvalidValue; g_dup_small_hi = value; return 0; }
     if (key == 11) { if (value < 0 || value > 2) return (int)hipErrorInvalidValue; g_dup_dynamic = value; return 0; }
+    if (key == 24) { if (value < 64 || value > 4096) return (int)hipErrorInvalidValue; g_depth_hist_blocks = value; return 0; }
     if (key == 15) { if (value != 8 && value != 32) return (int)hipErrorInvalidValue; g_small_sort_lb = value; return 0; }
     return (int)hipErrorInvalidValue;
 }
@@ -1514,7 +1522,7 @@ int lg_depth_keys_hist(const float* depth, long long n, uint32_t* keys, uint32_t
 {
     if (n <= 0) return 0;
     long long blocks = lg_cdiv(n, (long long)TPB * 16);         // >= 16 keys per thread: amortises the flush of the 1024-entry LDS table
-    if (blocks > 256) blocks = 256;
+    if (blocks > g_depth_hist_blocks) blocks = g_depth_hist_blocks;
     hipLaunchKernelGGL(depth_keys_hist_kernel, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)stream, depth, n, keys, vals, header);
     LG_RETURN_LAST();
 }

@@ -59,6 +59,7 @@ VARIANTS = {
     "probe_bwd_cached": (dict(_tuning={18: 5}), False),                   # backward: the same, and no atomics
     "probe_both_cached": (dict(_tuning={18: 7}), False),
                             # blend launches: one wave per tile, heaviest first (round 5) instead of the snake schedule
+    "dhist256": (dict(_tuning={24: 1024}), False),                         # depth_keys_hist_kernel: 256 workgroups (rounds 3-5; default 1024)
     "lean0": (dict(_tuning={17: 0}), False),                               # blend forward: the full kernel instead of the lean one
     "bwd_no_atomics": (dict(_tuning={18: 1}), False),                      # measurement hook: blend backward without its atomics (wrong gradients)
     "pf_off": (dict(_tuning={16: 0}), False),                              # blend kernels: L2 warm-up of the scalar record path off / block of 8, 32, 64 list positions (default 16)
@@ -152,7 +153,7 @@ def configure(tr, attrs):
     base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
     base.update(attrs)
     from litegs_amd._lib import check, lib
-    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0}                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0, 24: 1024}                          # lg_set_tuning keys a variant may change, at their defaults
     tuning.update(base.pop("_tuning", {}))
     for key, val in tuning.items():
         check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
