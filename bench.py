@@ -346,8 +346,11 @@ def _operator_path_ms(SyntheticTrainer, ops, n, W, H, focal, scene, frames, step
     for i in range(steps):
         tr.step(i % frames)
     torch.cuda.synchronize()
-    out = {"ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 4), "binding": ops.binding, "steps": steps,
-           "binning": "reference sequence (torch.sort, cumsum, create_table, tileRange)" if pattern == "reference" else "grouped (no full-length sorts)"}
+    from litegs_amd import binning as B
+    route = {"reference": "reference sequence (torch.sort, cumsum, create_table, tileRange)",
+             "grouped": "grouped (no full-length sorts)",
+             "sorted": "reference structure on this library's radix sort and scan (lists beyond 640 per tile)"}.get(B.last_route, str(B.last_route))
+    out = {"ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 4), "binding": ops.binding, "steps": steps, "binning": route}
     tr.close() if hasattr(tr, "close") else None
     return out
 

@@ -113,6 +113,7 @@ def reference_pattern_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, 
 LONG_LIST_PER_TILE = 640
 _MODE = os.environ.get("LITEGS_OPERATOR_BINNING", "grouped")
 _GROUPED = _MODE not in ("sorted", "reference")
+last_route = None             # which structure built the last table: "reference" | "grouped" | "sorted" (bench.py reports it)
 
 
 @torch.no_grad()
@@ -129,7 +130,9 @@ def binning(ndc, view_depth, inv_cov2d, opacity, valid_length, feedback_binning_
     b_visible = allocate_size != 0
     if on_visible is not None:
         on_visible(b_visible)
+    global last_route
     if _MODE == "reference":
+        last_route = "reference"
         tile_start_index, sorted_point = reference_pattern_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_binning_allocate_size,
                                                                  idx_tensor, H, W, th, tw, tiles_num)
         return tile_start_index, sorted_point, b_visible.sum(0)
@@ -140,9 +143,11 @@ def binning(ndc, view_depth, inv_cov2d, opacity, valid_length, feedback_binning_
     if _GROUPED and feedback_binning_allocate_size is not None and idx_tensor is not None:
         long_lists = int(feedback_binning_allocate_size[int(idx_tensor[0])]) > LONG_LIST_PER_TILE * tiles_num
     if _GROUPED and not long_lists and view_depth.shape[0] == 1 and view_depth.shape[1] < (1 << 24):
+        last_route = "grouped"
         tile_start_index, sorted_point = grouped_table(ndc, view_depth, inv_cov2d, opacity, allocate_size, feedback_binning_allocate_size,
                                                        idx_tensor, H, W, th, tw, tiles_num)
         return tile_start_index, sorted_point, b_visible.sum(0)
+    last_route = "sorted"
     depth_sorted_index, prefix_sum = depth_order_and_prefix(view_depth, allocate_size)
     sorted_tile, sorted_point = fused.create_table(ndc, inv_cov2d, opacity, prefix_sum, depth_sorted_index,
                                                    feedback_binning_allocate_size, idx_tensor, H, W, th, tw)

@@ -384,15 +384,18 @@ __device__ __forceinline__ bool fwd_splat_fast(FwdFast& st, const f32x16& rec, u
     return true;
 }
 
+#define RF_ARGS const int* __restrict__ sorted_points, const int* __restrict__ start_index,                                              \
+                const float* __restrict__ packed, const int* __restrict__ tiles, int K,                                                \
+                float* __restrict__ img, float* __restrict__ trans, short* __restrict__ last,                                          \
+                int* __restrict__ frag_count, float* __restrict__ frag_weight,                                                         \
+                const int* __restrict__ order, int* __restrict__ tile_work,                                                            \
+                const int* __restrict__ sched_in, int* __restrict__ sched_out, int zb_check,                                           \
+                int* __restrict__ fail_flag, int* __restrict__ fail_host, const int* __restrict__ gate,                                \
+                int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int fast
+#define RF_PASS sorted_points, start_index, packed, tiles, K, img, trans, last, frag_count, frag_weight, order, tile_work, sched_in, sched_out, zb_check, \
+                fail_flag, fail_host, gate, gx, ntiles, L, N, Hp, Wp, nslots, map_mode, fast
 template <int TH, int TW, bool STAT>
-__global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
-                                                             const float* __restrict__ packed, const int* __restrict__ tiles, int K,
-                                                             float* __restrict__ img, float* __restrict__ trans, short* __restrict__ last,
-                                                             int* __restrict__ frag_count, float* __restrict__ frag_weight,
-                                                             const int* __restrict__ order, int* __restrict__ tile_work,
-                                                             const int* __restrict__ sched_in, int* __restrict__ sched_out, int zb_check,
-                                                             int* __restrict__ fail_flag, int* __restrict__ fail_host, const int* __restrict__ gate,
-                                                             int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int fast)
+__device__ __forceinline__ void raster_forward_body(RF_ARGS)
 {
     if (gate != nullptr && *gate == 0) return;              // fallback launch of the depth-bound culling that is not needed
     // speculative executor (fused.hip): a failure raised earlier in this step (a truncated table) reaches the host mirror here
@@ -540,6 +543,11 @@ __global__ void __launch_bounds__(256) raster_forward_kernel(const int* __restri
     }
 }
 
+template <int TH, int TW, bool STAT>
+__global__ void __launch_bounds__(256) raster_forward_kernel(RF_ARGS) { raster_forward_body<TH, TW, STAT>(RF_PASS); }
+#undef RF_ARGS
+#undef RF_PASS
+
 // ---------------------------------------------------------------------------------------------
 // a13, lean form (round 6): the 8x16 blend forward without statistics, depth bounds or gates, with the SCALAR instruction count cut.
 //
@@ -584,12 +592,13 @@ __device__ __forceinline__ void fwd_splat_lean(FwdFast& st, const f32x16& rec, u
     st.T = st.T - w;
 }
 
-__global__ void __launch_bounds__(256) raster_forward_lean_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
-                                                                  const float* __restrict__ packed, const int* __restrict__ tiles, int K,
-                                                                  float* __restrict__ img, float* __restrict__ trans, short* __restrict__ last,
-                                                                  const int* __restrict__ order, int* __restrict__ tile_work,
-                                                                  int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int pfb,
-                                                                  long long* __restrict__ wclk)
+#define LEAN_ARGS const int* __restrict__ sorted_points, const int* __restrict__ start_index,                                             \
+                  const float* __restrict__ packed, const int* __restrict__ tiles, int K,                                               \
+                  float* __restrict__ img, float* __restrict__ trans, short* __restrict__ last,                                         \
+                  const int* __restrict__ order, int* __restrict__ tile_work,                                                           \
+                  int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int pfb, long long* __restrict__ wclk
+#define LEAN_PASS sorted_points, start_index, packed, tiles, K, img, trans, last, order, tile_work, gx, ntiles, L, N, Hp, Wp, nslots, map_mode, pfb, wclk
+__device__ __forceinline__ void raster_forward_lean_body(LEAN_ARGS)
 {
     const int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, gridDim.x, map_mode & 0xff) : (int)blockIdx.x;
     const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
@@ -691,6 +700,14 @@ __global__ void __launch_bounds__(256) raster_forward_lean_kernel(const int* __r
     wclk_store(wclk, slot, wclk_t0, n, tile, lane);
 }
 
+// Eight waves per SIMD need <= 80 scalar registers here, not the 96 the compiler's occupancy figure assumes: the runtime installs a trap
+// handler, which costs every wave 16 more (measured: with 90 registers the launch never holds more than 7 waves per SIMD,
+// profiles/r06_wave_clock_training_state_final.log).  The cap spills kernel arguments to lanes of one vector register outside the loop.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) raster_forward_lean_kernel(LEAN_ARGS) { raster_forward_lean_body(LEAN_PASS); }
+__global__ void __launch_bounds__(256) raster_forward_lean_s96_kernel(LEAN_ARGS) { raster_forward_lean_body(LEAN_PASS); }     // A/B: lg_set_tuning(17, 2)
+#undef LEAN_ARGS
+#undef LEAN_PASS
+
 LG_API int lg_raster_forward(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
                              int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
                              float* img, float* trans, short* last, int* frag_count, float* frag_weight,
@@ -721,7 +738,8 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
     hipStream_t s = (hipStream_t)stream;
     if (g_fwd_lean && g_fwd_fast && TH == 8 && TW == 16 && !enable_stat && sched_in == nullptr && sched_out == nullptr && fail_flag == nullptr &&
         fail_host == nullptr && gate == nullptr) {
-        hipLaunchKernelGGL(raster_forward_lean_kernel, grid, block, (size_t)g_blend_lds_fwd << 10, s, sorted_points, start_index, packed, tiles, K, img, trans, last, order,
+        hipLaunchKernelGGL(g_fwd_lean == 2 ? raster_forward_lean_s96_kernel : raster_forward_lean_kernel, grid, block, (size_t)g_blend_lds_fwd << 10, s,
+                           sorted_points, start_index, packed, tiles, K, img, trans, last, order,
                            tile_work, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map, g_pf_block | ((g_bwd_probe & 2) << 7), g_wclk_fwd);
         LG_RETURN_LAST();
     }
@@ -1501,7 +1519,7 @@ LG_API int lg_set_tuning(int key, int value)
     case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics; 2: the splat-parallel variant (A/B)
     case 16: if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return (int)hipErrorInvalidValue; g_pf_block = value; return 0;   // L2 warm-up block of the fast blend kernels
-    case 17: if (value < 0 || value > 1) return (int)hipErrorInvalidValue; g_fwd_lean = value; return 0;      // lean blend forward on / off
+    case 17: if (value < 0 || value > 2) return (int)hipErrorInvalidValue; g_fwd_lean = value; return 0;      // lean blend forward on / off
     case 19: if (value < 0 || value > 64) return (int)hipErrorInvalidValue; g_blend_lds_fwd = value; return 0;   // occupancy cap of the lean blend forward (KB of dynamic LDS per workgroup)
     case 20: if (value < 0 || value > 64) return (int)hipErrorInvalidValue; g_blend_lds_bwd = value; return 0;   // ... of the fast blend backward
     case 18: g_bwd_probe = value; return 0;                                      // measurement hook: blend backward without its atomics

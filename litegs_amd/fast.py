@@ -150,6 +150,9 @@ class FusedRenderer:
         # violated bounds per run (a frame is revisited after 150 steps of a moving cloud) eat what the culling saves, except in the last
         # 40 epochs (3.32 vs 3.49).  Depth-bound culling is a few-camera / converged-cloud feature: the reference's behaviour stays the default.
         self.stat_schedule_always = True
+        # The helper's list is re-made in statistics epochs only (statistic_helper.py:68-79): every 5th epoch.  True re-orders it after
+        # EVERY render from that render's own last_contributor (two small launches): the order is a hint, the set of tiles the same.
+        self.refresh_stat_schedule = False
         self.validate_tables = os.environ.get("LITEGS_VALIDATE_TABLES", "0") == "1"      # debugging aid (csrc/fused.hip "Table validators")
         self.tile_scatter = True           # per-tile mode: group by tile with counts + cursors (False: stable tile radix sort); same tables
         self.replicas_enabled = True       # gradient replicas (csrc/raster.hip) for renders whose records only the fused backward kernels consume
@@ -574,7 +577,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.replicas = replicas
         # the backward finds its lists where THIS frame's forward put them: same depth-order mode, same replica setting, no speculation
         ctx.cx = R.context(depth_order, replicas, F.margin, False)
-        if stat:
+        if stat or (tiles is not None and R.refresh_stat_schedule):
             STATS.update_tile_schedule(last, R.TH, R.TW)
         ctx.R, ctx.frame, ctx.meta = R, frame, (A, S, table_len, int(degree), chunks, sh_rest.shape[0], ws1_bytes, ws2_bytes, stat)
         ctx.tiles = tiles

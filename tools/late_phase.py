@@ -42,6 +42,9 @@ VARIANTS = {
     "own_schedule": (dict(stat_schedule_always=False), False),             # default list building, executor's schedule + depth-bound culling
     "own_schedule_tile": (dict(stat_schedule_always=False, long_list_global=0), False),
     "no_replicas": (dict(replicas_enabled=False), False),                  # gradient replicas off (blend backward contends, nothing to fold)
+    "sched_refresh": (dict(refresh_stat_schedule=True), False),
+    "lean_s96": (dict(_tuning={17: 2}), False),                            # lean blend forward without the 80-register cap (7 waves per SIMD under the trap handler)
+    "lean_s96_sched_refresh": (dict(refresh_stat_schedule=True, _tuning={17: 2}), False),            # the helper's tile list re-ordered after every render, not only in statistics epochs
     "prio": (dict(_tuning={8: 1}), False),                                 # issue priority by rank in the heavy-first schedule (csrc/raster.hip wave_rank_priority)
     "prio_stat_epoch": (dict(_tuning={8: 1}), True),
     "global_prio": (dict(depth_order=0, _tuning={8: 1}), False),
@@ -150,7 +153,8 @@ def stat_pass(tr, pick):
 
 def configure(tr, attrs):
     rd = tr.renderer
-    base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True)
+    base = dict(long_list_global=DEFAULTS["long_list_global"], depth_order=2, stat_schedule_always=DEFAULTS["stat_schedule_always"], replicas_enabled=True,
+                refresh_stat_schedule=False)
     base.update(attrs)
     from litegs_amd._lib import check, lib
     tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0, 24: 1024}                          # lg_set_tuning keys a variant may change, at their defaults

@@ -67,6 +67,24 @@ def analyse(name, rec):
         print(f"    chip-wide resident waves stay >= {int(frac * 100)} % of their peak ({int(peak)}) until {ev[below, 0] - begin:.1f} us ({100 * (ev[below, 0] - begin) / span:.0f} % of the span)")
 
 
+def by_rank(name, rec, walked_of_tile=None):
+    """Slots in schedule order, 16 equal groups: when they start, how long they live, what they walk -- is the order heavy-first in TIME,
+    and is a wave's lifetime proportional to its entries?"""
+    idx = np.nonzero(rec[:, 1] > 0)[0]
+    r = rec[idx]
+    begin = r[:, 0].min()
+    t0, t1 = (r[:, 0] - begin) * 1e-2, (r[:, 1] - begin) * 1e-2
+    tile = (r[:, 2] & 0xffffffff).astype(np.int64)
+    w = (r[:, 2] >> 32).astype(np.int64) if walked_of_tile is None else walked_of_tile[tile]
+    print(f"    {name}: slots in schedule order, 16 groups: entries walked (mean / max), start (mean), lifetime (mean / max), end (mean / max), ns per entry")
+    for g in np.array_split(np.arange(len(idx)), 16):
+        print(f"      slots {idx[g[0]]:6d}..{idx[g[-1]]:6d}: walked {w[g].mean():7.1f} / {w[g].max():5d}   start {t0[g].mean():7.1f}   life {(t1 - t0)[g].mean():6.1f} / {(t1 - t0)[g].max():6.1f}"
+              f"   end {t1[g].mean():7.1f} / {t1[g].max():7.1f}   {1e3 * (t1 - t0)[g].sum() / max(w[g].sum(), 1):6.1f}")
+    walked = np.zeros(int(tile.max()) + 1, dtype=np.int64)
+    walked[tile] = w
+    return walked
+
+
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     n, W, H, f = S.CONFIGS["3m_1080p"]
@@ -87,8 +105,11 @@ def main():
             tr.flush()
             torch.cuda.synchronize()
             print(f"--- step {i} (camera {i % 8})")
-            analyse("blend forward (lean)", fwd.cpu().numpy())
-            analyse("blend backward (fast)", bwd.cpu().numpy())
+            f_rec, b_rec = fwd.cpu().numpy(), bwd.cpu().numpy()
+            analyse("blend forward (lean)", f_rec)
+            analyse("blend backward (fast)", b_rec)
+            walked = by_rank("backward", b_rec)
+            by_rank("forward", f_rec, walked)
     finally:
         check(L.lg_debug_wave_clock(None, None), "wave clock off")
 
