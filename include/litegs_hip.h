@@ -212,7 +212,8 @@ int lg_unpack_gradient(const float* packed_grad, const float* packed /*[V,N,16] 
  * width of small radix sorts (8 | 32); key 16: L2
  * warm-up block of the blend kernels' scalar record path (0 | 8 | 16 | 32 | 64 list positions); key 17: lean blend forward on / off;
  * key 18: measurement hooks (wrong results: bit 0 blend backward without its atomics, bits 1 / 2 forward / backward read 1024 always-cached
- * records); keys 19 / 20: KB of unused dynamic LDS per workgroup of the lean forward / fast backward (caps their occupancy).  Out-of-range
+ * records); keys 19 / 20: KB of unused dynamic LDS per workgroup of the lean forward / fast backward (caps their occupancy); key 22: segmented blend
+ * backward of the executor on / off; key 23: log2 of its segment length (6 .. 12).  Out-of-range
  * values are refused.  Defaults are the
  * measured best; see DESIGN.md section 9. */
 int lg_set_tuning(int key, int value);
@@ -298,6 +299,7 @@ long long lg_fused_workspace2_bytes(long long L, long long N, int H, int W, int 
 long long lg_fused_total_offset(long long N);
 long long lg_fused_tile_start_offset(long long L, long long N, int H, int W, int TH, int TW);   /* int32[ntiles+2] tile ranges in workspace 2 (valid after stage 2) */
 long long lg_fused_sorted_points_offset(const LgFusedCtx* ctx, long long L, long long N, int H, int W, int TH, int TW); /* int32[L] tile-grouped, depth-ordered splat ids in workspace 2 (valid after stage 2) */
+long long lg_fused_unit_count_offset(long long L, long long N, int H, int W, int TH, int TW);   /* int32[17] in workspace 2: unit counts of the segmented blend backward -- full segments, then the 16 length classes of the remainders (valid after a stage 2 that rendered along a tile list) */
 long long lg_fused_alloc_offset(long long N);   /* int32[N] tile counts per compacted Gaussian (valid after stage 1) */
 long long lg_fused_packed_offset(long long N);  /* float[N,16] packed splat records (valid after stage 1) */
 int lg_fused_stage1(const LgFusedCtx* ctx, const float* aabb_origin, const float* aabb_ext, const float* planes_dev, int chunks,

@@ -506,6 +506,8 @@ struct Layout1 {      // sized by N = A*S (per-Gaussian buffers)
 };
 struct Layout2 {      // sized by the tile-instance table length L
     size_t tk_a, tv_a, tk_b, tv_b, tsort_table, tsort_table_words, tile_start, tile_work, dup_entries, tile_cursor, total;
+    size_t seg, seg_counts;                            // segmented blend backward (raster.hip LgSegments / LgSegLayout); behind everything else
+    int seg_shift;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -550,8 +552,18 @@ static Layout2 layout2(long long L, int ntiles, long long N)
     f.tile_work = take(sizeof(int) * ((size_t)ntiles + 1));
     f.dup_entries = take(4 * (size_t)lg_dup_queue_entries(N, L));
     f.tile_cursor = take(sizeof(int) * ((size_t)ntiles + 2));
+    // segmented blend backward: checkpoints of the lean forward (2 KB per segment boundary), the tiles' unclamped final colours, the units
+    f.seg_shift = lg_raster_segment_shift();
+    const LgSegLayout sl = lg_seg_layout(L, ntiles, f.seg_shift);
+    f.seg = take(sl.total);
+    f.seg_counts = f.seg + sl.counts;
     f.total = o;
     return f;
+}
+
+static LgSegments segments_of(char* w, const Layout2& f, long long L, int ntiles)
+{
+    return LgSegments{ w + f.seg, L, ntiles, f.seg_shift };
 }
 
 // where the blend kernels find the tile-grouped splat ids in workspace 2
@@ -582,6 +594,14 @@ LG_API long long lg_fused_tile_start_offset(long long L, long long N, int H, int
 {
     int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     return (long long)layout2(L > 0 ? L : 1, ntiles, N).tile_start;
+}
+
+// byte offset in workspace 2 of the unit count of the segmented blend backward (int32; valid after a stage 2 that rendered along a tile
+// list) -- tests: more units than non-empty tiles means the segments were really used
+LG_API long long lg_fused_unit_count_offset(long long L, long long N, int H, int W, int TH, int TW)
+{
+    int ntiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    return (long long)layout2(L > 0 ? L : 1, ntiles, N).seg_counts;
 }
 
 LG_API long long lg_fused_sorted_points_offset(const LgFusedCtx* ctx, long long L, long long N, int H, int W, int TH, int TW)
@@ -991,9 +1011,16 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     CRUMB("blend forward");
     // statistic epochs: the executor's blend backward accumulates the per-splat statistics inside the gradient record (raster.hip, STAT == 2);
     // the forward then is the plain one (frag_count == NULL).  A caller that wants the forward's own counters passes the two arrays.
-    return lg_raster_forward_bounds(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
-                                    (enable_stat && frag_count != nullptr && frag_weight != nullptr) ? 1 : 0, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order, tiles ? nullptr : tile_work,
-                                    tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, (zb_check & 1) | (x.margin_pct << 8), fail_flag, fail_host, gate, s);
+    // a render along a tile list leaves checkpoints and the unit list of the segmented blend backward (whether or not a backward follows:
+    // lg_fused_backward decides by the same rule and must find them)
+    const bool seg_on = K <= ntiles && ntiles < 65536 &&
+                        lg_raster_segments_apply(1, TH, TW, enable_stat, tiles, nullptr, fail_flag ? (const void*)fail_flag : (const void*)fail_host, gate, nullptr);
+    const LgSegments seg = segments_of(w, f, L, ntiles);
+    return lg_raster_forward_segments(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
+                                      (enable_stat && frag_count != nullptr && frag_weight != nullptr) ? 1 : 0, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order,
+                                      seg_on ? (int*)(w + f.tile_work) : (tiles ? nullptr : tile_work),
+                                      tiles ? nullptr : sched_in, tiles ? nullptr : sched_out, (zb_check & 1) | (x.margin_pct << 8), fail_flag, fail_host, gate,
+                                      seg_on ? &seg : nullptr, s);
 }
 
 static int culling_fallback(const Exec& x, char* w1, const Layout1& f1, char* w, const Layout2& f, long long N, long long L, int H, int W, int TH, int TW,
@@ -1104,9 +1131,12 @@ LG_API int lg_fused_backward(const LgFusedCtx* ctx, int A, int S, long long L, i
     const bool hot = x.replicas != 0;           // the context holds what this frame's lg_fused_stage1 ran with
     const int* hot_of = hot ? (const int*)(w1 + f1.hot_of) : nullptr;
     if (!packed_grad_is_zero) { rc = lg_memset_async(packed_grad, 0, (long long)sizeof(float) * GREC * (hot ? lg_fused_grad_lines(N) : N), stream); if (rc) return rc; }
-    rc = lg_raster_backward_hot(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, final_T, last, d_img, d_trans,
-                                1, L, (int)N, H, W, TH, TW, enable_stat, packed_grad, err_square_sum, nullptr, tiles ? nullptr : order,
-                                hot_of, hot ? hot_capacity(N) : 0, stream);
+    // the frame's forward (lg_fused_stage2 -> binning_and_blend) left checkpoints and work units under exactly this condition
+    const bool seg_on = K <= ntiles && ntiles < 65536 && lg_raster_segments_apply(1, TH, TW, enable_stat, tiles, nullptr, nullptr, nullptr, d_trans);
+    const LgSegments seg = segments_of(const_cast<char*>(w), f, L, ntiles);
+    rc = lg_raster_backward_segments(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, final_T, last, d_img, d_trans,
+                                     1, L, (int)N, H, W, TH, TW, enable_stat, packed_grad, err_square_sum, nullptr, tiles ? nullptr : order,
+                                     hot_of, hot ? hot_capacity(N) : 0, seg_on ? &seg : nullptr, stream);
     if (rc) return rc;
     if (d_pos == nullptr) return 0;
     Camera cam = make_camera(view_host, proj_host, H, W);

@@ -86,6 +86,38 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
                              const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag,
                              int* fail_host /*nullable pinned mirror: receives 1 when fail_flag is raised*/, const int* gate, void* stream);
 
+// Segmented blend backward (raster.hip): the buffers of one frame, one allocation.  ckpt: ((L >> shift) + 2) checkpoint records of 2 KB;
+// ckpt_fin: (tiles + 1) records; counts: 32 words (17 used: full segments, 16 length classes); units: cap_full + 16 * cap_class words
+// (tile | segment << 16: the full segments' region, then one region per length class of the remainders).
+struct LgSegLayout { size_t ckpt_fin, counts, units, total; int cap_full, cap_class; };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline LgSegLayout lg_seg_layout(long long L, int ntiles, int shift)
+{
+    LgSegLayout f;
+    f.cap_full = (int)((L >> shift) + 1);
+    f.cap_class = ntiles;
+    f.ckpt_fin = 2048 * ((size_t)(L >> shift) + 2);
+    f.counts = f.ckpt_fin + 2048 * ((size_t)ntiles + 1);
+    f.units = f.counts + 128;
+    f.total = f.units + 4 * ((size_t)f.cap_full + 16 * (size_t)f.cap_class);
+    return f;
+}
+struct LgSegments { char* base; long long L; int ntiles; int shift; };
+int lg_raster_segments_apply(int V, int TH, int TW, int enable_stat, const int* tiles, const void* sched, const void* fail, const void* gate, const void* d_trans);
+int lg_raster_segment_shift();
+int lg_raster_forward_segments(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
+                               int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
+                               float* img, float* trans, short* last, int* frag_count, float* frag_weight,
+                               const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check, int* fail_flag,
+                               int* fail_host, const int* gate, const LgSegments* seg, void* stream);
+int lg_raster_backward_segments(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
+                                const float* final_T, const short* last, const float* d_img, const float* d_trans,
+                                int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
+                                float* packed_grad, float* err_square_sum, int* tile_counters, const int* order,
+                                const int* hot_of, long long hot_lines, const LgSegments* seg, void* stream);
+
 // blend backward with gradient replicas for the splats that cover many tiles (raster.hip)
 int lg_raster_backward_hot(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
                            const float* final_T, const short* last, const float* d_img, const float* d_trans,

@@ -215,6 +215,14 @@ __device__ __forceinline__ void wclk_store(long long* __restrict__ w, int slot, 
     w[(size_t)slot * 4 + 0] = t0; w[(size_t)slot * 4 + 1] = t1;
     w[(size_t)slot * 4 + 2] = ((long long)n << 32) | (unsigned)tile; w[(size_t)slot * 4 + 3] = ((long long)xcc << 32) | hw;
 }
+// Segmented blend backward (round 6; VERDICT round 5 item 4, "transmittance checkpoints"): the lean forward leaves a checkpoint of every
+// pixel's {T, C} each 2^g_seg_shift list positions, the backward runs one wave per (tile, segment) -- see LG_UNIT_CLASSES.  Parity-green
+// (tests/test_gpu_trained_cloud.py) and OFF by default: the blend backward gets 4-6 % shorter (1170 -> 1102-1125 us in the training state;
+// the probe without checkpoint traffic promised 7-12 %), the forward pays 28 us for it (the counters' fill launch, stores and scalar
+// register pressure in the loop, one returning atomic per wave), the step gains 8-20 us of 3.4 ms (profiles/r06_bwd_segments_ab.log).
+// lg_set_tuning(22, 0 | 1) / (23, log2 of the segment length).
+static int g_bwd_segments = 0;
+static int g_seg_shift = 9;
 static int g_blend_lds_fwd = 0, g_blend_lds_bwd = 0;    // KB of (unused) dynamic LDS per workgroup: caps the resident workgroups per CU (160 KB / value); lg_set_tuning(19 / 20, KB)
 static int g_fwd_lean = 1;        // 1: renders without statistics / depth bounds / gates take the lean blend forward (lg_set_tuning(17, 0 | 1))
 static int g_bwd_probe = 0;       // measurement hook (wrong gradients!): 1 = the blend backward's atomics are issued with an empty lane mask (lg_set_tuning(18, .))
@@ -570,6 +578,25 @@ __device__ __forceinline__ void ids4_request(i32x4& q, const int* __restrict__ s
     asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(q) : "s"(sp), "s"(byte_off));
 }
 
+// Work units of the segmented blend backward: (tile | segment << 16) words, a segment = 2^shift list positions of a tile's walked range
+// (the deepest one shorter), dispatched LONGEST FIRST: all full segments, then the remainders by length class.  Why
+// (profiles/r06_bwd_segments_probe.log): the issue arbiter serves a SIMD's oldest wave first, so a launch ends with every SIMD's youngest
+// waves finishing alone at a third of the SIMD's rate; with whole tiles the last units dispatched are 150-300 entries long (a 1080p frame
+// of a trained cloud has no short tiles), with remainders sorted by length they are a few entries long and the drain goes away: 954 ->
+// 836 us and 1161 -> 1078 us on two frames with units of 512.  No sort: every forward wave appends its tile's units to the region of their
+// class with one returning atomic (unit_counts: [0] full segments, [1 + c] class c = remainders of (len - length) * 16 / len, zeroed before
+// the launch), and a backward wave finds its unit from its slot and the 17 counts (first a prefix over them, then one load).  A sorted list
+// built by a kernel of its own between the two launches cost 31 us (one workgroup: 16 000 tiles on one compute unit).
+#define LG_UNIT_CLASSES 16
+// checkpoint record: 64 lanes x {T.x T.y Cr.x Cr.y | Cg.x Cg.y Cb.x Cb.y}, 2 KB per (tile, boundary); slot (start >> shift) + boundary
+// index -- distinct for all boundaries of all tiles (a tile's boundaries lie inside its own list range, a range apart from each other)
+__device__ __forceinline__ void ckpt_store(float* __restrict__ ckpt, size_t slot, int lane, const FwdFast& f)
+{
+    float4* o = reinterpret_cast<float4*>(ckpt + (slot * 64 + lane) * 8);
+    o[0] = float4{ f.T.x, f.T.y, f.Cr.x, f.Cr.y };
+    o[1] = float4{ f.Cg.x, f.Cg.y, f.Cb.x, f.Cb.y };
+}
+
 __device__ __forceinline__ void fwd_splat_lean(FwdFast& st, const f32x16& rec, unsigned long long& act0, unsigned long long& act1)
 {
     act0 = __builtin_amdgcn_ballot_w64(st.T.x > 1.0f / 8192); act1 = __builtin_amdgcn_ballot_w64(st.T.y > 1.0f / 8192);
@@ -596,8 +623,9 @@ __device__ __forceinline__ void fwd_splat_lean(FwdFast& st, const f32x16& rec, u
                   const float* __restrict__ packed, const int* __restrict__ tiles, int K,                                               \
                   float* __restrict__ img, float* __restrict__ trans, short* __restrict__ last,                                         \
                   const int* __restrict__ order, int* __restrict__ tile_work,                                                           \
-                  int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int pfb, long long* __restrict__ wclk
-#define LEAN_PASS sorted_points, start_index, packed, tiles, K, img, trans, last, order, tile_work, gx, ntiles, L, N, Hp, Wp, nslots, map_mode, pfb, wclk
+                  int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode, int pfb, long long* __restrict__ wclk, \
+                  char* __restrict__ segbase /*nullable: the frame's segment buffers (LgSegLayout); their shift rides in bits 16-23 of pfb*/
+#define LEAN_PASS sorted_points, start_index, packed, tiles, K, img, trans, last, order, tile_work, gx, ntiles, L, N, Hp, Wp, nslots, map_mode, pfb, wclk, segbase
 __device__ __forceinline__ void raster_forward_lean_body(LEAN_ARGS)
 {
     const int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, gridDim.x, map_mode & 0xff) : (int)blockIdx.x;
@@ -627,11 +655,12 @@ __device__ __forceinline__ void raster_forward_lean_body(LEAN_ARGS)
     unsigned long long act0 = ~0ull, act1 = ~0ull;
     const int ng = n >> 2;                               // full groups of four list positions
     const unsigned idmask = (pfb & 0x100) ? 0x3ffu : 0xffffffffu;      // measurement hook (wrong image): every tile reads the same 1024 records (always cached)
+    const int seg_shift = (pfb >> 16) & 0xff;
     pfb &= 0xff;
 #define rec_off(id_, N_) rec_off((int)((unsigned)(id_) & idmask), N_)
+    f32x16 ra, rb;                                       // (one pair for the group loop and the tail: two destination blocks in all)
     if (ng > 0) {
         i32x4 qa, qb;                                    // ids of the current group / of the next one
-        f32x16 ra, rb;
         ids4_request(qa, sp, 0u);
         ids4_request(qb, sp, (unsigned)min(1, ng - 1) << 4);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qa), "+s"(qb));
@@ -664,10 +693,14 @@ __device__ __forceinline__ void raster_forward_lean_body(LEAN_ARGS)
             fwd_splat_lean(f, rb, act0, act1);                                                                              \
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(qcur));                                                    \
         }
+        const int seg_mask = (1 << seg_shift) - 1;
         for (int g = 0; g < ng; g += 2) {
             LEAN_GROUP(qa, qb, g)
             if ((act0 | act1) == 0ull || g + 1 >= ng) break;     // (masks of the group's last splat; activity is monotone)
             LEAN_GROUP(qb, qa, g + 1)
+            // checkpoint (segmented backward): the pixels' state after (g + 2) * 4 list positions, every 2^seg_shift of them (a multiple of 8)
+            if (segbase != nullptr && ((((g + 2) << 2) & seg_mask) == 0))
+                ckpt_store(reinterpret_cast<float*>(segbase), (size_t)(start >> seg_shift) + (size_t)(((g + 2) << 2) >> seg_shift), lane, f);
             if ((act0 | act1) == 0ull) break;
         }
 #undef LEAN_GROUP
@@ -676,12 +709,11 @@ __device__ __forceinline__ void raster_forward_lean_body(LEAN_ARGS)
     if ((act0 | act1) != 0ull) {
         for (int p = ng << 2; p < n; p++) {              // the last n % 4 positions, one at a time
             int id;
-            f32x16 r;
             id_request(id, sp, (unsigned)p << 2);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id));
-            rec_request(r, pk, rec_off(id, N));
-            rec_wait(r);
-            fwd_splat_lean(f, r, act0, act1);
+            rec_request(ra, pk, rec_off(id, N));
+            rec_wait(ra);
+            fwd_splat_lean(f, ra, act0, act1);
         }
     }
 #undef rec_off
@@ -689,6 +721,26 @@ __device__ __forceinline__ void raster_forward_lean_body(LEAN_ARGS)
     if (tile_work != nullptr) {
         const int visited = wave_max_i(max(f.lc0, f.lc1));
         if (lane == 0) tile_work[(size_t)view * (ntiles + 1) + tile] = visited;
+        const LgSegLayout sl = lg_seg_layout(L, ntiles, seg_shift);
+        if (segbase != nullptr && visited > (1 << seg_shift)) {           // more than one segment: their Bd needs the unclamped final colour
+            float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(segbase + sl.ckpt_fin) + ((size_t)tile * 64 + lane) * 8);
+            o[0] = float4{ f.Cr.x, f.Cr.y, f.Cg.x, f.Cg.y };
+            o[1] = float4{ f.Cb.x, f.Cb.y, 0.0f, 0.0f };
+        }
+        // the backward's work units of this tile (see the comment at LG_UNIT_CLASSES): its full segments into the first region, its
+        // deepest, shorter one into the region of its length class
+        if (segbase != nullptr && visited > 0 && lane == 0) {
+            int* __restrict__ unit_counts = reinterpret_cast<int*>(segbase + sl.counts);
+            int* __restrict__ units = reinterpret_cast<int*>(segbase + sl.units);
+            const int len = 1 << seg_shift, nseg = (visited + len - 1) >> seg_shift, rem = visited - ((nseg - 1) << seg_shift);
+            const int cls = ((len - rem) * LG_UNIT_CLASSES) >> seg_shift;
+            const int at = atomicAdd(&unit_counts[1 + cls], 1);
+            if (at < sl.cap_class) units[(size_t)sl.cap_full + (size_t)cls * sl.cap_class + at] = tile | ((nseg - 1) << 16);
+            if (nseg > 1) {
+                const int af = atomicAdd(&unit_counts[0], nseg - 1);
+                for (int j = 0; j < nseg - 1; j++) if (af + j < sl.cap_full) units[af + j] = tile | (j << 16);
+            }
+        }
     }
     const size_t plane = (size_t)Hp * Wp;
     const size_t o0 = (size_t)y0 * Wp + x, o1 = (size_t)(y0 + 2) * Wp + x;
@@ -727,6 +779,25 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
                              int zb_check /*bit 0 clear: nothing was culled, only produce new bounds; bits 8..: bound margin in percent (0 = 50)*/,
                              int* fail_flag, int* fail_host /*nullable pinned mirror of fail_flag*/, const int* gate, void* stream)
 {
+    return lg_raster_forward_segments(sorted_points, start_index, packed, tiles, K, V, L, N, H, W, TH, TW, enable_stat, img, trans, last, frag_count, frag_weight,
+                                      order, tile_work, sched_in, sched_out, zb_check, fail_flag, fail_host, gate, nullptr, stream);
+}
+
+// 1 if a render with these arguments takes the lean forward and may leave checkpoints for a segmented backward (the executor asks
+// before it hands over the buffers; the blend backward of the same frame asks again)
+int lg_raster_segments_apply(int V, int TH, int TW, int enable_stat, const int* tiles, const void* sched, const void* fail, const void* gate, const void* d_trans)
+{
+    return g_bwd_segments && g_fwd_lean && g_fwd_fast && g_bwd_fast == 1 && V == 1 && TH == 8 && TW == 16 && !enable_stat && tiles != nullptr && sched == nullptr &&
+           fail == nullptr && gate == nullptr && d_trans == nullptr;
+}
+int lg_raster_segment_shift() { return g_seg_shift; }
+
+int lg_raster_forward_segments(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
+                               int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
+                               float* img, float* trans, short* last, int* frag_count, float* frag_weight,
+                               const int* order, int* tile_work, const int* sched_in, int* sched_out, int zb_check,
+                               int* fail_flag, int* fail_host, const int* gate, const LgSegments* seg /*nullable*/, void* stream)
+{
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
     const int nslots = tiles ? K : ntiles;
@@ -736,11 +807,20 @@ int lg_raster_forward_bounds(const int* sorted_points, const int* start_index, c
     if (!g_use_order) order = nullptr;
     dim3 grid(lg_cdiv(nslots, 4), V), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (seg != nullptr && !(lg_raster_segments_apply(V, TH, TW, enable_stat, tiles, sched_in ? (const void*)sched_in : (const void*)sched_out,
+                                                     fail_flag ? (const void*)fail_flag : (const void*)fail_host, gate, nullptr) && tile_work != nullptr))
+        return (int)hipErrorInvalidValue;
     if (g_fwd_lean && g_fwd_fast && TH == 8 && TW == 16 && !enable_stat && sched_in == nullptr && sched_out == nullptr && fail_flag == nullptr &&
         fail_host == nullptr && gate == nullptr) {
+        if (seg != nullptr) {          // the unit counters the waves add to (one 128-byte fill)
+            if (seg->shift != g_seg_shift || seg->ntiles != ntiles || seg->L != L) return (int)hipErrorInvalidValue;
+            const int rcm = (int)hipMemsetAsync(seg->base + lg_seg_layout(L, ntiles, g_seg_shift).counts, 0, sizeof(int) * 32, s);
+            if (rcm) return rcm;
+        }
         hipLaunchKernelGGL(g_fwd_lean == 2 ? raster_forward_lean_s96_kernel : raster_forward_lean_kernel, grid, block, (size_t)g_blend_lds_fwd << 10, s,
                            sorted_points, start_index, packed, tiles, K, img, trans, last, order,
-                           tile_work, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map, g_pf_block | ((g_bwd_probe & 2) << 7), g_wclk_fwd);
+                           tile_work, gx, ntiles, L, N, Hp, Wp, nslots, g_fwd_map, g_pf_block | ((g_bwd_probe & 2) << 7) | (g_seg_shift << 16), g_wclk_fwd,
+                           seg ? seg->base : (char*)nullptr);
         LG_RETURN_LAST();
     }
 #define LAUNCH_RF(A_, B_, S_) hipLaunchKernelGGL((raster_forward_kernel<A_, B_, S_>), grid, block, 0, s, sorted_points, start_index, packed, \
@@ -1260,32 +1340,54 @@ __device__ __forceinline__ int stat_lane_slot(int lane)
     return lane == 15 ? STAT_SLOT_COUNT : (lane == 31 ? STAT_SLOT_WEIGHT : (lane == 63 ? STAT_SLOT_ERRSQ : -1));
 }
 
-// map_mode: bits 0-7 workgroup -> tile map, 8-15 priority switch, 24 / 25 measurement hooks
-template <bool TRANS, int STAT>
-__global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __restrict__ sorted_points, const int* __restrict__ start_index,
-                                                                   const float* __restrict__ packed, const int* __restrict__ tiles, int K,
-                                                                   const float* __restrict__ final_T, const short* __restrict__ last,
-                                                                   const float* __restrict__ d_img, const float* __restrict__ d_trans,
-                                                                   float* __restrict__ packed_grad, float* __restrict__ err_square_sum /*STAT*/,
-                                                                   const int* __restrict__ order,
-                                                                   int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode_in,
-                                                                   const int* __restrict__ hot_of, long long* __restrict__ wclk)
+#define RBF_ARGS const int* __restrict__ sorted_points, const int* __restrict__ start_index,                                             \
+                 const float* __restrict__ packed, const int* __restrict__ tiles, int K,                                               \
+                 const float* __restrict__ final_T, const short* __restrict__ last,                                                    \
+                 const float* __restrict__ d_img, const float* __restrict__ d_trans,                                                   \
+                 float* __restrict__ packed_grad, float* __restrict__ err_square_sum /*STAT*/,                                         \
+                 const int* __restrict__ order,                                                                                        \
+                 int gx, int ntiles, long long L, int N, int Hp, int Wp, int nslots, int map_mode_in,                                  \
+                 const int* __restrict__ hot_of, long long* __restrict__ wclk,                                                         \
+                 const char* __restrict__ segbase /*SEG: the frame's segment buffers (LgSegLayout)*/, int seg_shift
+#define RBF_PASS sorted_points, start_index, packed, tiles, K, final_T, last, d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, \
+                 nslots, map_mode_in, hot_of, wclk, segbase, seg_shift
+// -> true: `slot` lies beyond the last work unit (SEG: the caller's stride loop ends)
+template <bool TRANS, int STAT, bool SEG>
+__device__ __forceinline__ bool raster_backward_fast_body(int slot, RBF_ARGS)
 {
-    const int blk = (tiles == nullptr && order == nullptr) ? block_remap(blockIdx.x, gridDim.x, map_mode_in & 0xff) : (int)blockIdx.x;
-    const int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
-    if (slot >= nslots) return;
+    int unit = 0;                                             // tile | segment << 16
+    const LgSegLayout sl = lg_seg_layout(L, ntiles, SEG ? seg_shift : 0);
+    if (SEG) {
+        const int* __restrict__ unit_counts = reinterpret_cast<const int*>(segbase + sl.counts);
+        const int* __restrict__ units = reinterpret_cast<const int*>(segbase + sl.units);
+        const int cap_full = sl.cap_full, cap_class = sl.cap_class;
+        // slot -> unit: the regions in dispatch order (full segments, then the length classes, longest first), each as full as its count says
+        int rest = slot, region = -1;
+        size_t at = 0;
+#pragma unroll
+        for (int c = 0; c <= LG_UNIT_CLASSES; c++) {
+            const int cnt = min(rfl(unit_counts[c]), c == 0 ? cap_full : cap_class);
+            if (region < 0) {
+                if (rest < cnt) { region = c; at = (c == 0 ? (size_t)0 : (size_t)cap_full + (size_t)(c - 1) * cap_class) + rest; }
+                else rest -= cnt;
+            }
+        }
+        if (region < 0) return true;
+        unit = rfl(units[at]);
+    }
     wave_rank_priority((map_mode_in >> 8) & 0xff, slot, nslots, tiles != nullptr || order != nullptr);
     constexpr int TH = 8, TW = 16;
     const long long wclk_t0 = wclk != nullptr ? __builtin_amdgcn_s_memrealtime() : 0;
     const int lane = threadIdx.x & 63;
     const int view = blockIdx.y;
-    int tile = (tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1);
+    int tile = SEG ? (unit & 0xffff)
+                   : ((tiles != nullptr) ? tiles[(size_t)view * K + slot] : (order != nullptr ? order[(size_t)view * ntiles + slot] : slot + 1));
     tile = rfl(tile);
-    if (tile <= 0 || tile > ntiles) return;
+    if (tile <= 0 || tile > ntiles) return false;
     const int* __restrict__ si = start_index + (size_t)view * (ntiles + 2);
     const int start = rfl(si[tile]);
     const int end = rfl(si[tile + 1]);
-    if (start < 0 || start >= end) return;
+    if (start < 0 || start >= end) return false;
     const int* __restrict__ sp = sorted_points + (size_t)view * L + start;
     const float* __restrict__ pk = packed + (size_t)view * N * REC;
     float* __restrict__ pg = packed_grad + (size_t)view * N * GREC;
@@ -1313,8 +1415,27 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
     st.Bd = v2f{ 0.0f, 0.0f };
     const int maxlast = rfl(wave_max_i(max(st.lc0, st.lc1)));
     const int minlast = -rfl(wave_max_i(-min(st.lc0, st.lc1)));
-    const int n = min(maxlast, end - start);        // list positions n-1 .. 0 are walked
-    if (n <= 0) return;
+    int n = min(maxlast, end - start);              // list positions n-1 .. 0 are walked
+    int lo = 0;                                     // SEG: this wave walks positions hi-1 .. lo of the tile's n
+    if (SEG) {
+        const int seg = (int)((unsigned)unit >> 16);
+        lo = seg << seg_shift;
+        if (lo >= n) return false;
+        const int hi = min(lo + (1 << seg_shift), n);
+        if (hi < n) {
+            // not the tile's deepest segment: the state behind position hi-1 comes from the forward's checkpoint at hi -- T as the forward
+            // had it (exact, where the deepest segment's walk recovers it by divisions), and the colour blended behind, dotted with the
+            // pixel's gradient, from the colour accumulated by then: sum_{j >= hi} T_j alpha_j c_j = C_final - C_hi = T_hi * (behind colour)
+            const float4* c = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(segbase) + (((size_t)(start >> seg_shift) + seg + 1) * 64 + lane) * 8);
+            const float4* fc = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(segbase + sl.ckpt_fin) + ((size_t)tile * 64 + lane) * 8);
+            const float4 a = c[0], b = c[1], fa = fc[0], fb = fc[1];
+            st.T = v2f{ a.x, a.y };
+            const v2f num = v2f{ fa.x - a.z, fa.y - a.w } * st.gR + v2f{ fa.z - b.x, fa.w - b.y } * st.gG + v2f{ fb.x - b.z, fb.y - b.w } * st.gB;
+            st.Bd = v2f{ a.x > 0.0f ? num.x / a.x : 0.0f, a.y > 0.0f ? num.y / a.y : 0.0f };
+        }
+        n = hi;
+    }
+    if (n <= 0) return false;
     int myslot = wave_slot_cols(lane);
     if (STAT == 2 && stat_lane_slot(lane) >= 0) myslot = stat_lane_slot(lane);
     const unsigned long long writers = ((map_mode_in >> 24) & 1) ? 0ull : __ballot(myslot >= 0);      // (bit 24: measurement hook, no atomics)
@@ -1360,13 +1481,32 @@ __global__ void __launch_bounds__(256) raster_backward_fast_kernel(const int* __
         off_b = rec_off(id_b, N);                                                                          \
         pos -= 2;                                                                                             \
     }
-    for (; pos >= 1 && pos >= minlast; ) BWD_PAIR(true)
-    for (; pos >= 1; ) BWD_PAIR(false)
-    wclk_store(wclk, slot, wclk_t0, n, tile, lane);
+    for (; pos >= lo + 1 && pos >= minlast; ) BWD_PAIR(true)
+    for (; pos >= lo + 1; ) BWD_PAIR(false)
+    wclk_store(wclk, slot, wclk_t0, n - lo, tile, lane);
 #undef rec_off
 #undef BWD_PAIR
 #undef HOT_TARGET
+    return false;
 }
+
+// map_mode: bits 0-7 workgroup -> tile map, 8-15 priority switch, 24 / 25 measurement hooks.  SEG: one wave per (tile, segment) unit; the
+// grid covers an upper bound of the unit count (tiles + table length / segment length), waves beyond the count leave at once.
+template <bool TRANS, int STAT, bool SEG = false>
+__global__ void __launch_bounds__(256) raster_backward_fast_kernel(RBF_ARGS)
+{
+    const int blk = (SEG || tiles != nullptr || order != nullptr) ? (int)blockIdx.x : block_remap(blockIdx.x, gridDim.x, map_mode_in & 0xff);
+    int slot = rfl(blk * 4 + (int)(threadIdx.x >> 6));
+    if (!SEG) {
+        if (slot < nslots) raster_backward_fast_body<TRANS, STAT, false>(slot, RBF_PASS);
+        return;
+    }
+    // (a stride loop over the units -- a grid sized by an estimate -- was tried: 106 scalar / 71 vector registers, six waves per SIMD)
+    if (slot < nslots) raster_backward_fast_body<TRANS, STAT, true>(slot, RBF_PASS);
+}
+#undef RBF_ARGS
+#undef RBF_PASS
+
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1519,6 +1659,8 @@ LG_API int lg_set_tuning(int key, int value)
     case 7: g_fwd_fast = value; return 0;                                     // 0: the generic blend loop also for 8x16 tiles without statistics
     case 5: g_bwd_fast = value; return 0;                                     // 0: the generic blend backward also for 8x16 tiles without statistics; 2: the splat-parallel variant (A/B)
     case 16: if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return (int)hipErrorInvalidValue; g_pf_block = value; return 0;   // L2 warm-up block of the fast blend kernels
+    case 22: if (value < 0 || value > 1) return (int)hipErrorInvalidValue; g_bwd_segments = value; return 0;       // segmented blend backward on / off
+    case 23: if (value < 6 || value > 12) return (int)hipErrorInvalidValue; g_seg_shift = value; return 0;        // log2 of the segment length (64 .. 4096 list positions)
     case 17: if (value < 0 || value > 2) return (int)hipErrorInvalidValue; g_fwd_lean = value; return 0;      // lean blend forward on / off
     case 19: if (value < 0 || value > 64) return (int)hipErrorInvalidValue; g_blend_lds_fwd = value; return 0;   // occupancy cap of the lean blend forward (KB of dynamic LDS per workgroup)
     case 20: if (value < 0 || value > 64) return (int)hipErrorInvalidValue; g_blend_lds_bwd = value; return 0;   // ... of the fast blend backward
@@ -1553,6 +1695,16 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
                            float* packed_grad, float* err_square_sum, int* tile_counters, const int* order,
                            const int* hot_of, long long hot_lines, void* stream)
 {
+    return lg_raster_backward_segments(sorted_points, start_index, packed, tiles, K, final_T, last, d_img, d_trans, V, L, N, H, W, TH, TW, enable_stat,
+                                       packed_grad, err_square_sum, tile_counters, order, hot_of, hot_lines, nullptr, stream);
+}
+
+int lg_raster_backward_segments(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,
+                                const float* final_T, const short* last, const float* d_img, const float* d_trans,
+                                int V, long long L, int N, int H, int W, int TH, int TW, int enable_stat,
+                                float* packed_grad, float* err_square_sum, int* tile_counters, const int* order,
+                                const int* hot_of, long long hot_lines, const LgSegments* seg /*nullable: what the frame's forward filled*/, void* stream)
+{
     LG_REQUIRE(sorted_points, start_index, packed, final_T, last, d_img, packed_grad);
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const int ntiles = gx * gy, Hp = gy * TH, Wp = gx * TW;
@@ -1585,8 +1737,19 @@ int lg_raster_backward_hot(const int* sorted_points, const int* start_index, con
     else if (TH == 8 && TW == 16 && g_bwd_fast && !(enable_stat && hot_of != nullptr)) {
 #define LAUNCH_RBF(T_, S_) hipLaunchKernelGGL((raster_backward_fast_kernel<T_, S_>), grid, block, (size_t)g_blend_lds_bwd << 10, s, sorted_points, start_index, packed, tiles, K, final_T, last, \
                                               d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, nslots,                                                             \
-                                              g_bwd_map | (g_rank_prio << 8) | ((g_bwd_probe & 1) << 24) | (((g_bwd_probe >> 2) & 1) << 25), hot_of, g_wclk_bwd)
-        if (enable_stat && err_square_sum == nullptr) { if (d_trans) LAUNCH_RBF(true, 2); else LAUNCH_RBF(false, 2); }       // executor: statistics in the record
+                                              g_bwd_map | (g_rank_prio << 8) | ((g_bwd_probe & 1) << 24) | (((g_bwd_probe >> 2) & 1) << 25), hot_of, g_wclk_bwd, nullptr, 0)
+        if (seg != nullptr) {          // one wave per (tile, segment) unit of the list the forward's bwd_units_kernel left; the grid covers the bound
+            if (!lg_raster_segments_apply(V, TH, TW, enable_stat, tiles, nullptr, nullptr, nullptr, d_trans)) return (int)hipErrorInvalidValue;
+            if (seg->shift != g_seg_shift || seg->ntiles != ntiles || seg->L != L) return (int)hipErrorInvalidValue;
+            // units = tiles + full segments <= tiles + table length / segment length; the waves beyond the count cost nothing measurable
+            // (a grid of 2 x tiles instead of 5 x: 3.404 / 3.401 against 3.390 / 3.395 ms per step, profiles/r06_bwd_segments_ab.log)
+            const int est = nslots + (int)((L >> g_seg_shift) + 1);
+            dim3 ugrid(lg_cdiv(est, 4), 1);
+            hipLaunchKernelGGL((raster_backward_fast_kernel<false, 0, true>), ugrid, block, 0, s, sorted_points, start_index, packed, tiles, K, final_T, last,
+                               d_img, d_trans, packed_grad, err_square_sum, order, gx, ntiles, L, N, Hp, Wp, est,
+                               g_bwd_map | ((g_bwd_probe & 1) << 24), hot_of, g_wclk_bwd, (const char*)seg->base, g_seg_shift);
+        }
+        else if (enable_stat && err_square_sum == nullptr) { if (d_trans) LAUNCH_RBF(true, 2); else LAUNCH_RBF(false, 2); }       // executor: statistics in the record
         else if (enable_stat) { if (d_trans) LAUNCH_RBF(true, 1); else LAUNCH_RBF(false, 1); }
         else { if (d_trans) LAUNCH_RBF(true, 0); else LAUNCH_RBF(false, 0); }
 #undef LAUNCH_RBF

@@ -159,6 +159,68 @@ def test_image_and_all_gradients_on_the_trained_cloud_match_the_oracle(oracle, t
         p.grad = None
 
 
+@pytest.mark.parametrize("shift", [6, 9], ids=["segments_of_64", "segments_of_512"])
+def test_segmented_blend_backward_matches_the_oracle_and_the_plain_walk(oracle, trained, shift):
+    """lg_set_tuning(22, 1) (off by default: csrc/raster.hip g_bwd_segments): renders along a tile list take the lean blend forward, which then
+    leaves a checkpoint of every pixel's {T, C} each 2^shift list positions, and a blend backward of one wave per (tile, segment)
+    (csrc/raster.hip LG_UNIT_CLASSES, raster_backward_fast_kernel<.., SEG>).  Image and the six parameter gradients against the oracle
+    under the suite's rule, and against the same frame with the segments switched off."""
+    from litegs_amd import fast
+    from litegs_amd._lib import check, lib
+    from litegs_amd.statistics import STATS
+    from tests.util import compacted_grads, parity_image_and_gradients
+    tr, H, W = trained, HEIGHT, WIDTH
+    L = lib()
+    params_host = _host_params(tr)
+    degree = int(tr.degree)
+    origin, extend = _aabb(tr)
+    k = 1
+    fr, (view, proj, planes) = _frame(tr, k)
+    res = oracle.render_forward(params_host, view, proj, planes, H, W, degree)
+    rng = np.random.default_rng(23)
+    w_host = rng.standard_normal((1, 3, H, W)).astype(np.float32)
+    like = oracle.render_backward(res, params_host, view, proj, np.zeros_like(res.img), H, W, degree)[0]
+    grads = {}
+    try:
+        for segments in (1, 0):
+            check(L.lg_set_tuning(22, segments), "tuning 22"); check(L.lg_set_tuning(23, shift), "tuning 23")
+            rd = fast.FusedRenderer(1, H, W)
+            cam = fast.CameraFrame(fr.view, fr.proj, fr.planes, 0)
+            STATS.current_frame = 0
+            STATS.tile_schedule[0] = torch.randperm(rd.ntiles, generator=torch.Generator().manual_seed(5)).to(torch.int32).cuda() + 1
+            for p in tr.params:
+                p.grad = None
+            img, vis_id, vis_num = rd.render(cam, origin, extend, *tr.params, degree)
+            (img * torch.from_numpy(w_host).cuda()).sum().backward()
+            torch.cuda.synchronize()
+            ws2, tl, N = rd.last_ws2
+            if segments:
+                counts = ws2[L.lg_fused_unit_count_offset(tl, N, H, W, 8, 16):][:4 * 17].view(torch.int32).cpu().numpy()      # full segments, 16 length classes
+                units = int(counts.sum())
+                print(f"[segments] shift {shift}: {units} units for {rd.ntiles} tiles")
+                assert units > 0
+                if shift == 6:
+                    assert units > rd.ntiles, "lists of this cloud are longer than 64 entries: there must be more units than tiles"
+            grads[segments] = [g.copy() for g in compacted_grads(tr.params, res.nvis, like)]
+            if segments:
+                parity_image_and_gradients(oracle, res, img.detach().cpu().numpy(), grads[1], params_host, view, proj, w_host, H, W, degree,
+                                           tag=f" segments 2^{shift}", decided_max_img=600, decided_max_grad=200)
+            rd.close()
+    finally:
+        check(L.lg_set_tuning(22, 0), "tuning 22"); check(L.lg_set_tuning(23, 9), "tuning 23")      # the defaults
+        STATS.reset(1, 1, enabled_for_epoch=lambda e: False, device="cuda")
+        STATS.tile_schedule.clear(); STATS.tile_blend_count.clear()
+        for p in tr.params:
+            p.grad = None
+    # the two walks differ by rounding only (T from the checkpoint instead of by divisions, Bd from a colour difference) and by the order of
+    # the float atomics
+    for name, a, b in zip(("xyz", "scale", "rot", "sh_0", "sh_rest", "opacity"), grads[1], grads[0]):
+        scale = max(float(np.abs(b).max()), 1e-30)
+        err = float(np.abs(a - b).max()) / scale
+        print(f"[segments] {name}: max difference to the plain walk {err:.3e} of the largest element")
+        assert err <= 2e-5, (name, err)
+
+
 def test_statistics_in_the_gradient_record_match_the_oracle_on_the_trained_cloud(oracle, trained):
     """statistic epochs of the executor: fragment count, fragment weight sum and err_square travel in slots 9-11 of the blend backward's
     gradient record (csrc/raster.hip STAT == 2) and reach the statistics helper through lg_stat_accumulate -- against the oracle's

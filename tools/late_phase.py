@@ -43,6 +43,10 @@ VARIANTS = {
     "own_schedule_tile": (dict(stat_schedule_always=False, long_list_global=0), False),
     "no_replicas": (dict(replicas_enabled=False), False),                  # gradient replicas off (blend backward contends, nothing to fold)
     "sched_refresh": (dict(refresh_stat_schedule=True), False),
+    "seg": (dict(_tuning={22: 1}), False),                                 # segmented blend backward (checkpoints every 512 list positions)
+    "seg256": (dict(_tuning={22: 1, 23: 8}), False),                       # segments of 256 / 1024 / 128 list positions
+    "seg1024": (dict(_tuning={22: 1, 23: 10}), False),
+    "seg128": (dict(_tuning={22: 1, 23: 7}), False),
     "lean_s96": (dict(_tuning={17: 2}), False),                            # lean blend forward without the 80-register cap (7 waves per SIMD under the trap handler)
     "lean_s96_sched_refresh": (dict(refresh_stat_schedule=True, _tuning={17: 2}), False),            # the helper's tile list re-ordered after every render, not only in statistics epochs
     "prio": (dict(_tuning={8: 1}), False),                                 # issue priority by rank in the heavy-first schedule (csrc/raster.hip wave_rank_priority)
@@ -62,7 +66,7 @@ VARIANTS = {
     "probe_bwd_cached": (dict(_tuning={18: 5}), False),                   # backward: the same, and no atomics
     "probe_both_cached": (dict(_tuning={18: 7}), False),
                             # blend launches: one wave per tile, heaviest first (round 5) instead of the snake schedule
-    "dhist256": (dict(_tuning={24: 1024}), False),                         # depth_keys_hist_kernel: 256 workgroups (rounds 3-5; default 1024)
+    "dhist256": (dict(_tuning={24: 256}), False) ,                         # depth_keys_hist_kernel: 256 workgroups (rounds 3-5; default 1024)
     "lean0": (dict(_tuning={17: 0}), False),                               # blend forward: the full kernel instead of the lean one
     "bwd_no_atomics": (dict(_tuning={18: 1}), False),                      # measurement hook: blend backward without its atomics (wrong gradients)
     "pf_off": (dict(_tuning={16: 0}), False),                              # blend kernels: L2 warm-up of the scalar record path off / block of 8, 32, 64 list positions (default 16)
@@ -157,7 +161,7 @@ def configure(tr, attrs):
                 refresh_stat_schedule=False)
     base.update(attrs)
     from litegs_amd._lib import check, lib
-    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0, 24: 1024}                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0, 22: 0, 23: 9, 24: 1024}                          # lg_set_tuning keys a variant may change, at their defaults
     tuning.update(base.pop("_tuning", {}))
     for key, val in tuning.items():
         check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
