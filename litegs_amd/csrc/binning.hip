@@ -752,6 +752,7 @@ __global__ void __launch_bounds__(TPB) dup_queue_check_kernel(const int32_t* __r
 // profiles/r06_emission_fresh_state_ab.log, git history of this file.)
 // launch variants of the key emission (lg_set_tuning keys 10 / 11: A/B hooks of tools/, plain ints as in raster.hip)
 static int g_depth_hist_blocks = 1024;        // workgroups of depth_keys_hist_kernel (lg_set_tuning(24, .))
+static int g_sort_pack = 1;                   // two-pass tile sorts carry second digit + value in one word between the passes (lg_set_tuning(26, 0 | 1))
 static int g_small_sort_lb = 8;                // look-back width of radix sorts with < 1024 key tiles (lg_set_tuning(15, 8 | 32); radix_onesweep_kernel).  32 measured SLOWER
                                                // (36-37 against 30 us per pass of the 2.2 M-key splat sort, profiles/r06_binning_ab.log): the passes are not bound by the look-back chain
 static int g_dup_small_hi = DUP_SMALL_HI;      // largest tile count the owning thread walks itself; larger splats go to dup_big
@@ -764,6 +765,7 @@ int lg_binning_set_tuning(int key, int value)
     if (key == 10) { if (value < DUP_SMALL || value > DUP_SMALL_HI) return (int)hipErrorInvalidValue; g_dup_small_hi = value; return 0; }
     if (key == 11) { if (value < 0 || value > 2) return (int)hipErrorInvalidValue; g_dup_dynamic = value; return 0; }
     if (key == 24) { if (value < 64 || value > 4096) return (int)hipErrorInvalidValue; g_depth_hist_blocks = value; return 0; }
+    if (key == 26) { if (value < 0 || value > 1) return (int)hipErrorInvalidValue; g_sort_pack = value; return 0; }
     if (key == 15) { if (value != 8 && value != 32) return (int)hipErrorInvalidValue; g_small_sort_lb = value; return 0; }
     return (int)hipErrorInvalidValue;
 }
@@ -1060,13 +1062,19 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
 
 // TILES key tiles per workgroup (256 threads each, processed side by side) share ONE ticket: the ticket is a returning atomic on a
 // single address (~8 ns each, serialised in L2); at 2865 tiles per pass it delayed workgroup starts by ~16 us per pass.
-template <int TILES, bool BALLOT_RANK, int LB>
+// PACK (two-pass sorts of keys below 2^16 whose values fit beside the second digit: the tile sort -- 15 key bits at 1080p, 22 value bits
+// at 3 M Gaussians): the first pass (PACK == 1) writes ONE word per element, second digit << vbits | value; the second pass (PACK == 2)
+// reads that word alone and rebuilds the full key -- its first digit is the bucket of the first pass the element's position lies in,
+// found against the exclusive scan of the first pass's digit totals (`totals_prev`).  8 bytes per element less through HBM (28 instead
+// of 36 over the two passes and the range scan), same table bit for bit.
+template <int TILES, bool BALLOT_RANK, int LB, int PACK = 0>
 __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              const int* __restrict__ totals /*[RADIX] of this pass*/,
                                                              uint32_t* __restrict__ status /*[ntiles][RADIX], zero*/, int* __restrict__ ticket,
                                                              long long n, const int* __restrict__ n_dev, int shift, uint32_t mask,
-                                                             const int32_t* __restrict__ aux_in, int32_t* __restrict__ aux_out)
+                                                             const int32_t* __restrict__ aux_in, int32_t* __restrict__ aux_out,
+                                                             int vbits /*PACK*/, const int* __restrict__ totals_prev /*PACK == 2: [RADIX] of the first pass*/)
 {
     constexpr int NW = TPB / 64;
     constexpr int WAVE_KEYS = SORT_ITEMS * 64;       // each wave ranks a contiguous run of 1024 keys on its own (no block barriers)
@@ -1078,6 +1086,7 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
     __shared__ int wsum_[TILES][NW];
     __shared__ int wsum_g_[TILES][NW];
     __shared__ int bid_s;
+    __shared__ int low_base_[PACK == 2 ? TILES : 1][PACK == 2 ? RADIX + 1 : 1];      // PACK == 2: first position of every bucket of the first pass
     const int half = threadIdx.x / TPB;              // which of the workgroup's tiles this thread works on
     const int tid = threadIdx.x % TPB, lane = tid & 63, wave = tid >> 6;
     uint32_t* lds_k = lds_k_[half]; uint32_t* lds_v = lds_v_[half];
@@ -1102,7 +1111,42 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
         const int e = wave * WAVE_KEYS + j * 64 + lane;
         const bool ok = e < cnt_tile;
         key[j] = ok ? keys_in[base + e] : 0u;
-        val[j] = ok ? vals_in[base + e] : 0u;
+        if (PACK != 2) val[j] = ok ? vals_in[base + e] : 0u;
+    }
+    if constexpr (PACK == 2) {
+        // exclusive scan of the first pass's digit totals -> bucket boundaries; an element's first digit is the bucket its position is in
+        int* low_base = low_base_[half];
+        int tl = 0;
+#pragma unroll
+        for (int c = 0; c < LG_SORT_TOTALS_COPIES; c++) tl += totals_prev[c * LG_SORT_TOTALS_STRIDE + tid];
+        int inc = tl;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int wb = 0;
+        for (int w = 0; w < wave; w++) wb += wsum[w];
+        low_base[tid] = wb + inc - tl;
+        if (tid == TPB - 1) low_base[RADIX] = 0x7fffffff;
+        __syncthreads();
+        // a thread's elements lie 64 positions apart in ascending order: one binary search, then a walk
+        int lo = 0;
+        {
+            const long long p0 = base + wave * WAVE_KEYS + lane;
+            int a = 0, b = RADIX;                                           // largest d with low_base[d] <= p0
+            while (b - a > 1) { const int m = (a + b) >> 1; if ((long long)low_base[m] <= p0) a = m; else b = m; }
+            lo = a;
+        }
+        const uint32_t vmask = (1u << vbits) - 1u;
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; j++) {
+            const long long pj = base + wave * WAVE_KEYS + j * 64 + lane;
+            while ((long long)low_base[lo + 1] <= pj) lo++;
+            const uint32_t w = key[j];
+            val[j] = w & vmask;
+            key[j] = ((w >> vbits) << RADIX_BITS) | (uint32_t)lo;           // the full key again (shift == RADIX_BITS in this pass)
+        }
+        __syncthreads();                                                    // (wsum is reused below)
     }
     // Rank of a key among the wave's earlier keys with the same digit.
     // Fast path: the value a returning LDS add hands back -- rounds are sequential, and inside one ds_add_rtn instruction the LDS
@@ -1171,8 +1215,13 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
         if ((wave * WAVE_KEYS + j * 64 + lane) < cnt_tile) {
             const uint32_t d = (key[j] >> shift) & mask;
             const int pos = digit_base[d] + wave_cnt[wave][d] + lrank[j];
-            lds_k[pos] = key[j];
-            lds_v[pos] = val[j];
+            if constexpr (PACK == 1) {
+                lds_k[pos] = ((key[j] >> RADIX_BITS) << vbits) | (val[j] & ((1u << vbits) - 1u));    // second digit | value; the first digit is implied by the position
+                lds_v[pos] = d;
+            } else {
+                lds_k[pos] = key[j];
+                lds_v[pos] = val[j];
+            }
         }
     }
     if (act && bid != 0) {
@@ -1213,9 +1262,9 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
         const int p = j * TPB + tid;
         if (p < cnt_tile) {
             const uint32_t k = lds_k[p];
-            const uint32_t d = (k >> shift) & mask;
-            const int g = global_base[d] + (p - digit_base[d]);
             const uint32_t v = lds_v[p];
+            const uint32_t d = PACK == 1 ? v : ((k >> shift) & mask);
+            const int g = global_base[d] + (p - digit_base[d]);
             // g is built from the producer's digit totals and the predecessors' look-back words: if either is inconsistent with the keys
             // (a total that over-counts, a status word that was not zero on entry) g leaves [0, n) -- or lands on another key's slot,
             // which leaves a hole of stale memory elsewhere.  The first is caught here and counted; never a wild store.
@@ -1224,8 +1273,8 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
             bad_pos += in_range ? 0 : 1;
             if (in_range) {
                 keys_out[g] = k;
-                vals_out[g] = v;
-                if (aux_in) aux_out[g] = aux_in[v];      // last pass of the depth sort: tile counts gathered into depth order on the way out
+                if (PACK != 1) vals_out[g] = v;
+                if (PACK == 0 && aux_in) aux_out[g] = aux_in[v];      // last pass of the depth sort: tile counts gathered into depth order on the way out
             }
         }
     }
@@ -1304,12 +1353,15 @@ LG_API int lg_radix_set_rank_mode(int mode)          // test hook: 0 / 1 force a
 // workgroup so that every CU gets work.
 static void launch_onesweep(int ntiles, hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, const int* totals,
                             uint32_t* status, int* ticket, long long n, const int* n_dev, int shift, uint32_t mask, const int32_t* aux_in,
-                            int32_t* aux_out)
+                            int32_t* aux_out, int pack = 0, int vbits = 0, const int* totals_prev = nullptr)
 {
     const bool ballot = lg_radix_rank_mode() != 0;
-#define LAUNCH_OS(T_, B_, L_, G_) hipLaunchKernelGGL((radix_onesweep_kernel<T_, B_, L_>), dim3(G_), dim3(TPB * T_), 0, s, kin, vin, kout, vout, totals, status, \
-                                                 ticket, n, n_dev, shift, mask, aux_in, aux_out)
-    if (ntiles >= 1024) {                             // (4 tiles per workgroup measured slower: 97 vs 88 us per pass)
+#define LAUNCH_OSP(T_, B_, L_, G_, P_) hipLaunchKernelGGL((radix_onesweep_kernel<T_, B_, L_, P_>), dim3(G_), dim3(TPB * T_), 0, s, kin, vin, kout, vout, totals, status, \
+                                                      ticket, n, n_dev, shift, mask, aux_in, aux_out, vbits, totals_prev)
+#define LAUNCH_OS(T_, B_, L_, G_) LAUNCH_OSP(T_, B_, L_, G_, 0)
+    if (pack == 1) { if (ballot) LAUNCH_OSP(2, true, 8, (ntiles + 1) / 2, 1); else LAUNCH_OSP(2, false, 8, (ntiles + 1) / 2, 1); }
+    else if (pack == 2) { if (ballot) LAUNCH_OSP(2, true, 8, (ntiles + 1) / 2, 2); else LAUNCH_OSP(2, false, 8, (ntiles + 1) / 2, 2); }
+    else if (ntiles >= 1024) {                             // (4 tiles per workgroup measured slower: 97 vs 88 us per pass)
         if (ballot) LAUNCH_OS(2, true, 8, (ntiles + 1) / 2); else LAUNCH_OS(2, false, 8, (ntiles + 1) / 2);
     } else if (g_small_sort_lb == 8) {
         if (ballot) LAUNCH_OS(1, true, 8, ntiles); else LAUNCH_OS(1, false, 8, ntiles);
@@ -1317,6 +1369,7 @@ static void launch_onesweep(int ntiles, hipStream_t s, const uint32_t* kin, cons
         if (ballot) LAUNCH_OS(1, true, 32, ntiles); else LAUNCH_OS(1, false, 32, ntiles);
     }
 #undef LAUNCH_OS
+#undef LAUNCH_OSP
 }
 
 LG_API int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
@@ -1398,6 +1451,15 @@ long long lg_radix_table_words(long long n, int passes)
 int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                            int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted, void* stream)
 {
+    return lg_radix_sort_prepared_values(keys_a, vals_a, keys_b, vals_b, n, n_dev, begin_bit, end_bit, header, table, aux_in, aux_sorted, 0, stream);
+}
+
+// value_bits > 0: every value is below 2^value_bits (the caller's promise); a two-pass sort whose second digit fits beside such a value in
+// one word moves 8 bytes per element less (radix_onesweep_kernel PACK).  Same result in the same buffers.
+int lg_radix_sort_prepared_values(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
+                                  int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted,
+                                  int value_bits, void* stream)
+{
     int passes = lg_radix_sort_num_passes(begin_bit, end_bit);
     if (n <= 0 || passes == 0) return 0;
     if (passes > SORT_MAX_PASSES || n > 0x3fffffffLL) return (int)hipErrorInvalidValue;
@@ -1408,6 +1470,12 @@ int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
     int last_bits = (end_bit - begin_bit) - (passes - 1) * RADIX_BITS;
     uint32_t last_mask = (1u << last_bits) - 1u;
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
+    if (g_sort_pack && passes == 2 && begin_bit == 0 && value_bits > 0 && last_bits + value_bits <= 32 && aux_in == nullptr) {
+        launch_onesweep(ntiles, s, keys_a, vals_a, keys_b, vals_b, totals, table, ticket, n, n_dev, 0, (uint32_t)(RADIX - 1), nullptr, nullptr, 1, value_bits);
+        launch_onesweep(ntiles, s, keys_b, vals_b, keys_a, vals_a, totals + RADIX, table + (size_t)RADIX * ntiles, ticket + 1, n, n_dev, RADIX_BITS, last_mask,
+                        nullptr, nullptr, 2, value_bits, totals);
+        LG_RETURN_LAST();
+    }
     for (int p = 0; p < passes; p++) {
         int shift = begin_bit + p * RADIX_BITS;
         uint32_t mask = (p == passes - 1) ? last_mask : (uint32_t)(RADIX - 1);

@@ -989,8 +989,10 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     }
     // instance count on the device: only that many entries are sorted and range-scanned
     CRUMB("global route: tile radix sort");
-    rc = lg_radix_sort_prepared((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
-                                total_dev, 0, bits, tsort_hdr, (uint32_t*)(w + f.tsort_table), nullptr, nullptr, s);
+    int value_bits = 1;                                  // the values are compacted Gaussian indices below N; only total_dev entries exist (no padding)
+    while (value_bits < 32 && (1ll << value_bits) < N) value_bits++;
+    rc = lg_radix_sort_prepared_values((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
+                                       total_dev, 0, bits, tsort_hdr, (uint32_t*)(w + f.tsort_table), nullptr, nullptr, value_bits, s);
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));

@@ -20,6 +20,9 @@ int lg_depth_keys_hist(const float* depth, long long n, uint32_t* keys, uint32_t
 // aux_in/aux_sorted (nullable): the last pass also writes aux_sorted[g] = aux_in[sorted value at g] (a gather in sorted order)
 int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                            int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted, void* stream);
+int lg_radix_sort_prepared_values(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
+                                  int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted,
+                                  int value_bits /*0: unknown; else every value < 2^value_bits*/, void* stream);
 
 // big-splat queue: 64 sub-queue counters per view (zero on entry) and lg_dup_queue_entries(N, table_len) uint32 entries per view
 long long lg_dup_queue_entries(long long N, long long table_len);

@@ -1666,7 +1666,7 @@ LG_API int lg_set_tuning(int key, int value)
     case 20: if (value < 0 || value > 64) return (int)hipErrorInvalidValue; g_blend_lds_bwd = value; return 0;   // ... of the fast blend backward
     case 18: g_bwd_probe = value; return 0;                                      // measurement hook: blend backward without its atomics
     case 8: g_rank_prio = value ? 1 : 0; return 0;                            // 1: issue priority by rank in a heavy-first schedule (wave_rank_priority)
-    case 10: case 11: case 15: case 24: return lg_binning_set_tuning(key, value);   // binning.hip: key emission variants (10, 11), look-back width of small sorts (15)
+    case 10: case 11: case 15: case 24: case 26: return lg_binning_set_tuning(key, value);   // binning.hip: key emission variants (10, 11), look-back width of small sorts (15)
     case 12: return lg_fused_set_tuning(key, value);                           // fused projection (fused.hip): SH loads in front of the tile walk
     default: return (int)hipErrorInvalidValue;
     }
