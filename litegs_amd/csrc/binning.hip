@@ -752,7 +752,9 @@ __global__ void __launch_bounds__(TPB) dup_queue_check_kernel(const int32_t* __r
 // profiles/r06_emission_fresh_state_ab.log, git history of this file.)
 // launch variants of the key emission (lg_set_tuning keys 10 / 11: A/B hooks of tools/, plain ints as in raster.hip)
 static int g_depth_hist_blocks = 1024;        // workgroups of depth_keys_hist_kernel (lg_set_tuning(24, .))
-static int g_sort_pack = 1;                   // two-pass tile sorts carry second digit + value in one word between the passes (lg_set_tuning(26, 0 | 1))
+
+static int g_sort_pack = 2;                   // two-pass tile sorts: 1 = second digit + value in one word between the passes; 2 = ... and the second pass leaves the
+                                              // range table's starts instead of the sorted keys (lg_set_tuning(26, 0 | 1 | 2))
 static int g_small_sort_lb = 8;                // look-back width of radix sorts with < 1024 key tiles (lg_set_tuning(15, 8 | 32); radix_onesweep_kernel).  32 measured SLOWER
                                                // (36-37 against 30 us per pass of the 2.2 M-key splat sort, profiles/r06_binning_ab.log): the passes are not bound by the look-back chain
 static int g_dup_small_hi = DUP_SMALL_HI;      // largest tile count the owning thread walks itself; larger splats go to dup_big
@@ -765,7 +767,7 @@ int lg_binning_set_tuning(int key, int value)
     if (key == 10) { if (value < DUP_SMALL || value > DUP_SMALL_HI) return (int)hipErrorInvalidValue; g_dup_small_hi = value; return 0; }
     if (key == 11) { if (value < 0 || value > 2) return (int)hipErrorInvalidValue; g_dup_dynamic = value; return 0; }
     if (key == 24) { if (value < 64 || value > 4096) return (int)hipErrorInvalidValue; g_depth_hist_blocks = value; return 0; }
-    if (key == 26) { if (value < 0 || value > 1) return (int)hipErrorInvalidValue; g_sort_pack = value; return 0; }
+    if (key == 26) { if (value < 0 || value > 2) return (int)hipErrorInvalidValue; g_sort_pack = value; return 0; }
     if (key == 15) { if (value != 8 && value != 32) return (int)hipErrorInvalidValue; g_small_sort_lb = value; return 0; }
     return (int)hipErrorInvalidValue;
 }
@@ -1066,7 +1068,10 @@ __global__ void __launch_bounds__(TPB) radix_scatter_kernel(const uint32_t* __re
 // at 3 M Gaussians): the first pass (PACK == 1) writes ONE word per element, second digit << vbits | value; the second pass (PACK == 2)
 // reads that word alone and rebuilds the full key -- its first digit is the bucket of the first pass the element's position lies in,
 // found against the exclusive scan of the first pass's digit totals (`totals_prev`).  8 bytes per element less through HBM (28 instead
-// of 36 over the two passes and the range scan), same table bit for bit.
+// of 36 over the two passes and the range scan), same table bit for bit.  PACK == 3: the second pass does not write the keys at all but
+// the range table's starts -- the first element of a key inside a workgroup's tile proposes its output position with an unsigned
+// atomicMin on the table (pre-filled with -1 = the largest unsigned); tile_range_close_kernel then adds the words tile_range_kernel
+// derives from gaps and the table length.  20 bytes per instance, one 16 000-word kernel instead of a pass over the keys.
 template <int TILES, bool BALLOT_RANK, int LB, int PACK = 0>
 __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -1074,7 +1079,8 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
                                                              uint32_t* __restrict__ status /*[ntiles][RADIX], zero*/, int* __restrict__ ticket,
                                                              long long n, const int* __restrict__ n_dev, int shift, uint32_t mask,
                                                              const int32_t* __restrict__ aux_in, int32_t* __restrict__ aux_out,
-                                                             int vbits /*PACK*/, const int* __restrict__ totals_prev /*PACK == 2: [RADIX] of the first pass*/)
+                                                             int vbits /*PACK*/, const int* __restrict__ totals_prev /*PACK >= 2: [RADIX] of the first pass*/,
+                                                             int32_t* __restrict__ range_out /*PACK == 3: the tile range table, pre-filled with -1*/, int max_tile)
 {
     constexpr int NW = TPB / 64;
     constexpr int WAVE_KEYS = SORT_ITEMS * 64;       // each wave ranks a contiguous run of 1024 keys on its own (no block barriers)
@@ -1086,7 +1092,7 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
     __shared__ int wsum_[TILES][NW];
     __shared__ int wsum_g_[TILES][NW];
     __shared__ int bid_s;
-    __shared__ int low_base_[PACK == 2 ? TILES : 1][PACK == 2 ? RADIX + 1 : 1];      // PACK == 2: first position of every bucket of the first pass
+    __shared__ int low_base_[PACK >= 2 ? TILES : 1][PACK >= 2 ? RADIX + 1 : 1];      // PACK == 2: first position of every bucket of the first pass
     const int half = threadIdx.x / TPB;              // which of the workgroup's tiles this thread works on
     const int tid = threadIdx.x % TPB, lane = tid & 63, wave = tid >> 6;
     uint32_t* lds_k = lds_k_[half]; uint32_t* lds_v = lds_v_[half];
@@ -1111,9 +1117,9 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
         const int e = wave * WAVE_KEYS + j * 64 + lane;
         const bool ok = e < cnt_tile;
         key[j] = ok ? keys_in[base + e] : 0u;
-        if (PACK != 2) val[j] = ok ? vals_in[base + e] : 0u;
+        if (PACK < 2) val[j] = ok ? vals_in[base + e] : 0u;
     }
-    if constexpr (PACK == 2) {
+    if constexpr (PACK >= 2) {
         // exclusive scan of the first pass's digit totals -> bucket boundaries; an element's first digit is the bucket its position is in
         int* low_base = low_base_[half];
         int tl = 0;
@@ -1272,7 +1278,13 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
             const bool in_range = (unsigned long long)(long long)g < (unsigned long long)n;
             bad_pos += in_range ? 0 : 1;
             if (in_range) {
-                keys_out[g] = k;
+                if constexpr (PACK == 3) {
+                    // equal keys are adjacent inside a digit's run of the tile (the input is ordered by the first digit, the ranking is stable)
+                    if (p == digit_base[d] || lds_k[p - 1] != k) {
+                        if ((unsigned)k <= (unsigned)max_tile) atomicMin(reinterpret_cast<unsigned int*>(range_out) + k, (unsigned int)g);
+                        else bad_pos++;
+                    }
+                } else keys_out[g] = k;
                 if (PACK != 1) vals_out[g] = v;
                 if (PACK == 0 && aux_in) aux_out[g] = aux_in[v];      // last pass of the depth sort: tile counts gathered into depth order on the way out
             }
@@ -1353,14 +1365,15 @@ LG_API int lg_radix_set_rank_mode(int mode)          // test hook: 0 / 1 force a
 // workgroup so that every CU gets work.
 static void launch_onesweep(int ntiles, hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, const int* totals,
                             uint32_t* status, int* ticket, long long n, const int* n_dev, int shift, uint32_t mask, const int32_t* aux_in,
-                            int32_t* aux_out, int pack = 0, int vbits = 0, const int* totals_prev = nullptr)
+                            int32_t* aux_out, int pack = 0, int vbits = 0, const int* totals_prev = nullptr, int32_t* range_out = nullptr, int max_tile = 0)
 {
     const bool ballot = lg_radix_rank_mode() != 0;
 #define LAUNCH_OSP(T_, B_, L_, G_, P_) hipLaunchKernelGGL((radix_onesweep_kernel<T_, B_, L_, P_>), dim3(G_), dim3(TPB * T_), 0, s, kin, vin, kout, vout, totals, status, \
-                                                      ticket, n, n_dev, shift, mask, aux_in, aux_out, vbits, totals_prev)
+                                                      ticket, n, n_dev, shift, mask, aux_in, aux_out, vbits, totals_prev, range_out, max_tile)
 #define LAUNCH_OS(T_, B_, L_, G_) LAUNCH_OSP(T_, B_, L_, G_, 0)
     if (pack == 1) { if (ballot) LAUNCH_OSP(2, true, 8, (ntiles + 1) / 2, 1); else LAUNCH_OSP(2, false, 8, (ntiles + 1) / 2, 1); }
     else if (pack == 2) { if (ballot) LAUNCH_OSP(2, true, 8, (ntiles + 1) / 2, 2); else LAUNCH_OSP(2, false, 8, (ntiles + 1) / 2, 2); }
+    else if (pack == 3) { if (ballot) LAUNCH_OSP(2, true, 8, (ntiles + 1) / 2, 3); else LAUNCH_OSP(2, false, 8, (ntiles + 1) / 2, 3); }
     else if (ntiles >= 1024) {                             // (4 tiles per workgroup measured slower: 97 vs 88 us per pass)
         if (ballot) LAUNCH_OS(2, true, 8, (ntiles + 1) / 2); else LAUNCH_OS(2, false, 8, (ntiles + 1) / 2);
     } else if (g_small_sort_lb == 8) {
@@ -1451,15 +1464,60 @@ long long lg_radix_table_words(long long n, int passes)
 int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                            int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted, void* stream)
 {
-    return lg_radix_sort_prepared_values(keys_a, vals_a, keys_b, vals_b, n, n_dev, begin_bit, end_bit, header, table, aux_in, aux_sorted, 0, stream);
+    return lg_radix_sort_prepared_values(keys_a, vals_a, keys_b, vals_b, n, n_dev, begin_bit, end_bit, header, table, aux_in, aux_sorted, 0, nullptr, 0, nullptr, stream);
+}
+
+// The words tile_range_kernel writes besides the starts (which the sort's last pass left by atomicMin): a tile without entries behind one
+// with entries gets the end of that one's run (= the start of the next tile that has entries), the table's last word its length.
+__global__ void __launch_bounds__(1024) tile_range_close_kernel(int32_t* __restrict__ out, int max_tile, long long L, const int* __restrict__ n_dev)
+{
+    constexpr int PER = 16;
+    __shared__ unsigned int wmin[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nb = max_tile + 1;                       // bins 0 .. max_tile
+    const long long total = bounded_n(L, n_dev);
+    if (total <= 0) return;                            // nothing was sorted (a gated fallback pass that is not needed): the table is not this launch's
+    unsigned int carry = 0xffffffffu;                  // smallest start among the bins behind the current chunk
+    for (int top = ((nb + 1024 * PER - 1) / (1024 * PER)) * (1024 * PER); top > 0; top -= 1024 * PER) {
+        const int b0 = top - 1024 * PER + t * PER;     // this thread's bins b0 .. b0 + PER - 1
+        unsigned int v[PER + 1];
+#pragma unroll
+        for (int k = 0; k < PER; k++) v[k + 1] = (b0 + k < nb) ? (unsigned int)out[b0 + k] : 0xffffffffu;
+        v[0] = (b0 - 1 >= 0 && b0 - 1 < nb) ? (unsigned int)out[b0 - 1] : 0xffffffffu;
+        unsigned int m = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < PER; k++) m = min(m, v[k + 1]);
+        // suffix minimum over the threads behind this one (higher t)
+        unsigned int suf = m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_down(suf, o); if (lane + o < 64) suf = min(suf, u); }
+        if (lane == 0) wmin[wave] = suf;
+        __syncthreads();
+        unsigned int behind = carry;
+        for (int w = wave + 1; w < 16; w++) behind = min(behind, wmin[w]);
+        const unsigned int nxt = __shfl_down(suf, 1);
+        unsigned int after = (lane < 63) ? min(behind, nxt) : behind;          // smallest start in the bins behind this thread's
+        unsigned int chunk_min = carry;
+        for (int w = 0; w < 16; w++) chunk_min = min(chunk_min, wmin[w]);
+        __syncthreads();
+#pragma unroll
+        for (int k = PER - 1; k >= 0; k--) {
+            if (b0 + k < nb && v[k + 1] == 0xffffffffu && v[k] != 0xffffffffu && after != 0xffffffffu) out[b0 + k] = (int32_t)after;
+            after = min(after, v[k + 1]);
+        }
+        carry = chunk_min;
+    }
+    if (t == 0) out[max_tile + 1] = (int32_t)total;
 }
 
 // value_bits > 0: every value is below 2^value_bits (the caller's promise); a two-pass sort whose second digit fits beside such a value in
 // one word moves 8 bytes per element less (radix_onesweep_kernel PACK).  Same result in the same buffers.
 int lg_radix_sort_prepared_values(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                                   int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted,
-                                  int value_bits, void* stream)
+                                  int value_bits, int32_t* range_out /*nullable: tile range table pre-filled with -1*/, int max_tile,
+                                  int* ranges_done /*nullable: set to 1 when the sort wrote range_out itself (the sorted KEYS then do not exist)*/, void* stream)
 {
+    if (ranges_done) *ranges_done = 0;
     int passes = lg_radix_sort_num_passes(begin_bit, end_bit);
     if (n <= 0 || passes == 0) return 0;
     if (passes > SORT_MAX_PASSES || n > 0x3fffffffLL) return (int)hipErrorInvalidValue;
@@ -1472,8 +1530,13 @@ int lg_radix_sort_prepared_values(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
     if (g_sort_pack && passes == 2 && begin_bit == 0 && value_bits > 0 && last_bits + value_bits <= 32 && aux_in == nullptr) {
         launch_onesweep(ntiles, s, keys_a, vals_a, keys_b, vals_b, totals, table, ticket, n, n_dev, 0, (uint32_t)(RADIX - 1), nullptr, nullptr, 1, value_bits);
+        const bool ranges = g_sort_pack == 2 && range_out != nullptr && ranges_done != nullptr && max_tile < (1 << (RADIX_BITS + last_bits));
         launch_onesweep(ntiles, s, keys_b, vals_b, keys_a, vals_a, totals + RADIX, table + (size_t)RADIX * ntiles, ticket + 1, n, n_dev, RADIX_BITS, last_mask,
-                        nullptr, nullptr, 2, value_bits, totals);
+                        nullptr, nullptr, ranges ? 3 : 2, value_bits, totals, range_out, max_tile);
+        if (ranges) {
+            hipLaunchKernelGGL(tile_range_close_kernel, dim3(1), dim3(1024), 0, s, range_out, max_tile, n, n_dev);
+            *ranges_done = 1;
+        }
         LG_RETURN_LAST();
     }
     for (int p = 0; p < passes; p++) {

@@ -991,8 +991,10 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     CRUMB("global route: tile radix sort");
     int value_bits = 1;                                  // the values are compacted Gaussian indices below N; only total_dev entries exist (no padding)
     while (value_bits < 32 && (1ll << value_bits) < N) value_bits++;
+    int ranges_done = 0;                                 // (the validators read the sorted keys: they keep the range scan)
     rc = lg_radix_sort_prepared_values((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
-                                       total_dev, 0, bits, tsort_hdr, (uint32_t*)(w + f.tsort_table), nullptr, nullptr, value_bits, s);
+                                       total_dev, 0, bits, tsort_hdr, (uint32_t*)(w + f.tsort_table), nullptr, nullptr, value_bits,
+                                       x.validate ? (int32_t*)nullptr : (int32_t*)(w + f.tile_start), ntiles, x.validate ? (int*)nullptr : &ranges_done, s);
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
@@ -1001,7 +1003,7 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
         if (rc) return rc;
     }
     CRUMB("global route: tile ranges");
-    rc = lg_tile_range_prefilled(sorted_keys, 1, Ls, total_dev, ntiles, (int32_t*)(w + f.tile_start), s); if (rc) return rc;
+    if (!ranges_done) { rc = lg_tile_range_prefilled(sorted_keys, 1, Ls, total_dev, ntiles, (int32_t*)(w + f.tile_start), s); if (rc) return rc; }
     CRUMB("global route: validators / per-tile sort");
     if (x.validate) { rc = validate_table(x, (int32_t*)(w + (odd ? f.tv_b : f.tv_a)), (int32_t*)(w + f.tile_start), Ls, total_dev, ntiles, (int)N, (int*)(w1 + f1.flags) + LG_VALIDATE_LOCK_WORD, gate, s); if (rc) return rc; }
     if (tile_mode) {      // depth order inside every tile; scratch for lists beyond 2048: the key buffer the tile sort did not end in

@@ -22,7 +22,8 @@ int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
                            int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted, void* stream);
 int lg_radix_sort_prepared_values(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                                   int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted,
-                                  int value_bits /*0: unknown; else every value < 2^value_bits*/, void* stream);
+                                  int value_bits /*0: unknown; else every value < 2^value_bits*/, int32_t* range_out /*nullable*/, int max_tile,
+                                  int* ranges_done /*nullable*/, void* stream);
 
 // big-splat queue: 64 sub-queue counters per view (zero on entry) and lg_dup_queue_entries(N, table_len) uint32 entries per view
 long long lg_dup_queue_entries(long long N, long long table_len);

@@ -43,6 +43,7 @@ VARIANTS = {
     "own_schedule_tile": (dict(stat_schedule_always=False, long_list_global=0), False),
     "no_replicas": (dict(replicas_enabled=False), False),                  # gradient replicas off (blend backward contends, nothing to fold)
     "sched_refresh": (dict(refresh_stat_schedule=True), False),
+    "sort_packed_keys": (dict(_tuning={26: 1}), False),                    # packed between the passes, keys written by the second pass + tile_range (first packed form)
     "sort_unpacked": (dict(_tuning={26: 0}), False),                       # tile radix sort with separate key / value arrays between its two passes (rounds 2-5)
     "seg": (dict(_tuning={22: 1}), False),                                 # segmented blend backward (checkpoints every 512 list positions)
     "seg256": (dict(_tuning={22: 1, 23: 8}), False),                       # segments of 256 / 1024 / 128 list positions
@@ -162,7 +163,7 @@ def configure(tr, attrs):
                 refresh_stat_schedule=False)
     base.update(attrs)
     from litegs_amd._lib import check, lib
-    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0, 22: 0, 23: 9, 24: 1024, 26: 1}                          # lg_set_tuning keys a variant may change, at their defaults
+    tuning = {5: 1, 8: 0, 10: 256, 11: 0, 12: 0, 15: 8, 16: 16, 17: 1, 18: 0, 19: 0, 20: 0, 22: 0, 23: 9, 24: 1024, 26: 2}                          # lg_set_tuning keys a variant may change, at their defaults
     tuning.update(base.pop("_tuning", {}))
     for key, val in tuning.items():
         check(lib().lg_set_tuning(int(key), int(val)), "lg_set_tuning")
