@@ -1464,13 +1464,15 @@ long long lg_radix_table_words(long long n, int passes)
 int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                            int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted, void* stream)
 {
-    return lg_radix_sort_prepared_values(keys_a, vals_a, keys_b, vals_b, n, n_dev, begin_bit, end_bit, header, table, aux_in, aux_sorted, 0, nullptr, 0, nullptr, stream);
+    return lg_radix_sort_prepared_values(keys_a, vals_a, keys_b, vals_b, n, n_dev, begin_bit, end_bit, header, table, aux_in, aux_sorted, 0, nullptr, 0, nullptr, nullptr, stream);
 }
 
 // The words tile_range_kernel writes besides the starts (which the sort's last pass left by atomicMin): a tile without entries behind one
 // with entries gets the end of that one's run (= the start of the next tile that has entries), the table's last word its length.
-__global__ void __launch_bounds__(1024) tile_range_close_kernel(int32_t* __restrict__ out, int max_tile, long long L, const int* __restrict__ n_dev)
+__global__ void __launch_bounds__(1024) tile_range_close_kernel(int32_t* __restrict__ out, int max_tile, long long L, const int* __restrict__ n_dev,
+                                                                int* __restrict__ zero32 /*nullable: 32 words cleared on the side (the blend's unit counters)*/)
 {
+    if (zero32 != nullptr && threadIdx.x < 32) zero32[threadIdx.x] = 0;
     constexpr int PER = 16;
     __shared__ unsigned int wmin[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1515,7 +1517,8 @@ __global__ void __launch_bounds__(1024) tile_range_close_kernel(int32_t* __restr
 int lg_radix_sort_prepared_values(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                                   int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted,
                                   int value_bits, int32_t* range_out /*nullable: tile range table pre-filled with -1*/, int max_tile,
-                                  int* ranges_done /*nullable: set to 1 when the sort wrote range_out itself (the sorted KEYS then do not exist)*/, void* stream)
+                                  int* ranges_done /*nullable: set to 1 when the sort wrote range_out itself (the sorted KEYS then do not exist)*/,
+                                  int* zero32 /*nullable: 32 words the range kernel clears on the side when ranges_done*/, void* stream)
 {
     if (ranges_done) *ranges_done = 0;
     int passes = lg_radix_sort_num_passes(begin_bit, end_bit);
@@ -1534,7 +1537,7 @@ int lg_radix_sort_prepared_values(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
         launch_onesweep(ntiles, s, keys_b, vals_b, keys_a, vals_a, totals + RADIX, table + (size_t)RADIX * ntiles, ticket + 1, n, n_dev, RADIX_BITS, last_mask,
                         nullptr, nullptr, ranges ? 3 : 2, value_bits, totals, range_out, max_tile);
         if (ranges) {
-            hipLaunchKernelGGL(tile_range_close_kernel, dim3(1), dim3(1024), 0, s, range_out, max_tile, n, n_dev);
+            hipLaunchKernelGGL(tile_range_close_kernel, dim3(1), dim3(1024), 0, s, range_out, max_tile, n, n_dev, zero32);
             *ranges_done = 1;
         }
         LG_RETURN_LAST();

@@ -563,7 +563,7 @@ static Layout2 layout2(long long L, int ntiles, long long N)
 
 static LgSegments segments_of(char* w, const Layout2& f, long long L, int ntiles)
 {
-    return LgSegments{ w + f.seg, L, ntiles, f.seg_shift };
+    return LgSegments{ w + f.seg, L, ntiles, f.seg_shift, 0 };
 }
 
 // where the blend kernels find the tile-grouped splat ids in workspace 2
@@ -938,6 +938,7 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     const bool tile_mode = use_tile_order(x, N);
     const void* depth_order = tile_mode ? (const void*)nullptr : (odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));     // nullptr: emission in splat-id order
     const int bits = tile_key_bits(ntiles);
+    bool seg_counts_zeroed = false;                      // the range kernel of the global route clears the segmented backward's unit counters on the side
     const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(x, f, N, ntiles));
     int rc;
     if (crumbs_on())
@@ -994,7 +995,9 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     int ranges_done = 0;                                 // (the validators read the sorted keys: they keep the range scan)
     rc = lg_radix_sort_prepared_values((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
                                        total_dev, 0, bits, tsort_hdr, (uint32_t*)(w + f.tsort_table), nullptr, nullptr, value_bits,
-                                       x.validate ? (int32_t*)nullptr : (int32_t*)(w + f.tile_start), ntiles, x.validate ? (int*)nullptr : &ranges_done, s);
+                                       x.validate ? (int32_t*)nullptr : (int32_t*)(w + f.tile_start), ntiles, x.validate ? (int*)nullptr : &ranges_done,
+                                       (int*)(w + f.seg_counts), s);
+    seg_counts_zeroed = ranges_done != 0;
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
@@ -1019,7 +1022,8 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     // lg_fused_backward decides by the same rule and must find them)
     const bool seg_on = K <= ntiles && ntiles < 65536 &&
                         lg_raster_segments_apply(1, TH, TW, enable_stat, tiles, nullptr, fail_flag ? (const void*)fail_flag : (const void*)fail_host, gate, nullptr);
-    const LgSegments seg = segments_of(w, f, L, ntiles);
+    LgSegments seg = segments_of(w, f, L, ntiles);
+    seg.counts_zeroed = seg_counts_zeroed ? 1 : 0;
     return lg_raster_forward_segments(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
                                       (enable_stat && frag_count != nullptr && frag_weight != nullptr) ? 1 : 0, img, trans, last, frag_count, frag_weight, tiles ? nullptr : order,
                                       seg_on ? (int*)(w + f.tile_work) : (tiles ? nullptr : tile_work),

@@ -23,7 +23,7 @@ int lg_radix_sort_prepared(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
 int lg_radix_sort_prepared_values(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                                   int begin_bit, int end_bit, int* header, uint32_t* table, const int32_t* aux_in, int32_t* aux_sorted,
                                   int value_bits /*0: unknown; else every value < 2^value_bits*/, int32_t* range_out /*nullable*/, int max_tile,
-                                  int* ranges_done /*nullable*/, void* stream);
+                                  int* ranges_done /*nullable*/, int* zero32 /*nullable*/, void* stream);
 
 // big-splat queue: 64 sub-queue counters per view (zero on entry) and lg_dup_queue_entries(N, table_len) uint32 entries per view
 long long lg_dup_queue_entries(long long N, long long table_len);
@@ -108,7 +108,7 @@ inline LgSegLayout lg_seg_layout(long long L, int ntiles, int shift)
     f.total = f.units + 4 * ((size_t)f.cap_full + 16 * (size_t)f.cap_class);
     return f;
 }
-struct LgSegments { char* base; long long L; int ntiles; int shift; };
+struct LgSegments { char* base; long long L; int ntiles; int shift; int counts_zeroed /*1: an earlier kernel of the stream cleared the unit counters*/; };
 int lg_raster_segments_apply(int V, int TH, int TW, int enable_stat, const int* tiles, const void* sched, const void* fail, const void* gate, const void* d_trans);
 int lg_raster_segment_shift();
 int lg_raster_forward_segments(const int* sorted_points, const int* start_index, const float* packed, const int* tiles, int K,

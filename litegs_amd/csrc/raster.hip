@@ -218,8 +218,9 @@ __device__ __forceinline__ void wclk_store(long long* __restrict__ w, int slot, 
 // Segmented blend backward (round 6; VERDICT round 5 item 4, "transmittance checkpoints"): the lean forward leaves a checkpoint of every
 // pixel's {T, C} each 2^g_seg_shift list positions, the backward runs one wave per (tile, segment) -- see LG_UNIT_CLASSES.  Parity-green
 // (tests/test_gpu_trained_cloud.py) and OFF by default: the blend backward gets 4-6 % shorter (1170 -> 1102-1125 us in the training state;
-// the probe without checkpoint traffic promised 7-12 %), the forward pays 28 us for it (the counters' fill launch, stores and scalar
-// register pressure in the loop, one returning atomic per wave), the step gains 8-20 us of 3.4 ms (profiles/r06_bwd_segments_ab.log).
+// the probe without checkpoint traffic promised 7-12 %), the forward pays 21-28 us for it (stores and scalar register pressure in the
+// loop, one returning atomic per wave, the counters' fill launch outside the global route), the step gains 2-20 us of 3.3 ms
+// (profiles/r06_bwd_segments_ab.log).
 // lg_set_tuning(22, 0 | 1) / (23, log2 of the segment length).
 static int g_bwd_segments = 0;
 static int g_seg_shift = 9;
@@ -814,8 +815,10 @@ int lg_raster_forward_segments(const int* sorted_points, const int* start_index,
         fail_host == nullptr && gate == nullptr) {
         if (seg != nullptr) {          // the unit counters the waves add to (one 128-byte fill)
             if (seg->shift != g_seg_shift || seg->ntiles != ntiles || seg->L != L) return (int)hipErrorInvalidValue;
-            const int rcm = (int)hipMemsetAsync(seg->base + lg_seg_layout(L, ntiles, g_seg_shift).counts, 0, sizeof(int) * 32, s);
-            if (rcm) return rcm;
+            if (!seg->counts_zeroed) {
+                const int rcm = (int)hipMemsetAsync(seg->base + lg_seg_layout(L, ntiles, g_seg_shift).counts, 0, sizeof(int) * 32, s);
+                if (rcm) return rcm;
+            }
         }
         hipLaunchKernelGGL(g_fwd_lean == 2 ? raster_forward_lean_s96_kernel : raster_forward_lean_kernel, grid, block, (size_t)g_blend_lds_fwd << 10, s,
                            sorted_points, start_index, packed, tiles, K, img, trans, last, order,
