@@ -213,7 +213,9 @@ int lg_unpack_gradient(const float* packed_grad, const float* packed /*[V,N,16] 
  * warm-up block of the blend kernels' scalar record path (0 | 8 | 16 | 32 | 64 list positions); key 17: lean blend forward on / off;
  * key 18: measurement hooks (wrong results: bit 0 blend backward without its atomics, bits 1 / 2 forward / backward read 1024 always-cached
  * records); keys 19 / 20: KB of unused dynamic LDS per workgroup of the lean forward / fast backward (caps their occupancy); key 22: segmented blend
- * backward of the executor on / off; key 23: log2 of its segment length (6 .. 12).  Out-of-range
+ * backward of the executor on / off (default off); key 23: log2 of its segment length (6 .. 12); key 26: the executor's two-pass tile sort
+ * with separate key / value arrays (0), second digit + value in one word between the passes (1), ... and the range table's starts left by
+ * the second pass instead of the sorted keys (2, default).  Out-of-range
  * values are refused.  Defaults are the
  * measured best; see DESIGN.md section 9. */
 int lg_set_tuning(int key, int value);

@@ -1085,7 +1085,8 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
     constexpr int NW = TPB / 64;
     constexpr int WAVE_KEYS = SORT_ITEMS * 64;       // each wave ranks a contiguous run of 1024 keys on its own (no block barriers)
     __shared__ uint32_t lds_k_[TILES][SORT_TILE];
-    __shared__ uint32_t lds_v_[TILES][SORT_TILE];
+    __shared__ uint32_t lds_v_[PACK ? 1 : TILES][PACK ? 1 : SORT_TILE];
+    __shared__ unsigned char lds_b_[PACK ? TILES : 1][PACK ? SORT_TILE : 1];      // PACK: the first digit of the element (its value rides in the packed word)
     __shared__ int wave_cnt_[TILES][NW][RADIX];      // running per-wave digit counts, then exclusive offset of the wave inside the digit
     __shared__ int digit_base_[TILES][RADIX];        // exclusive local base of the digit in the sorted tile
     __shared__ int global_base_[TILES][RADIX];
@@ -1095,7 +1096,8 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
     __shared__ int low_base_[PACK >= 2 ? TILES : 1][PACK >= 2 ? RADIX + 1 : 1];      // PACK == 2: first position of every bucket of the first pass
     const int half = threadIdx.x / TPB;              // which of the workgroup's tiles this thread works on
     const int tid = threadIdx.x % TPB, lane = tid & 63, wave = tid >> 6;
-    uint32_t* lds_k = lds_k_[half]; uint32_t* lds_v = lds_v_[half];
+    uint32_t* lds_k = lds_k_[half]; uint32_t* lds_v = lds_v_[PACK ? 0 : half];
+    unsigned char* lds_b = lds_b_[PACK ? half : 0];
     int (*wave_cnt)[RADIX] = wave_cnt_[half];
     int* digit_base = digit_base_[half]; int* global_base = global_base_[half];
     int* wsum = wsum_[half]; int* wsum_g = wsum_g_[half];
@@ -1148,10 +1150,9 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
         for (int j = 0; j < SORT_ITEMS; j++) {
             const long long pj = base + wave * WAVE_KEYS + j * 64 + lane;
             while ((long long)low_base[lo + 1] <= pj) lo++;
-            const uint32_t w = key[j];
-            val[j] = w & vmask;
-            key[j] = ((w >> vbits) << RADIX_BITS) | (uint32_t)lo;           // the full key again (shift == RADIX_BITS in this pass)
+            val[j] = (uint32_t)lo;                                          // (the packed word stays in key[j]: second digit << vbits | value)
         }
+        (void)vmask;
         __syncthreads();                                                    // (wsum is reused below)
     }
     // Rank of a key among the wave's earlier keys with the same digit.
@@ -1166,7 +1167,7 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
         const bool ok = (wave * WAVE_KEYS + j * 64 + lane) < cnt_tile;
-        const uint32_t d = (key[j] >> shift) & mask;
+        const uint32_t d = PACK >= 2 ? ((key[j] >> vbits) & mask) : ((key[j] >> shift) & mask);
         if constexpr (!BALLOT_RANK) {
             lrank[j] = ok ? atomicAdd(&my_cnt[d], 1) : 0;
         } else {
@@ -1219,11 +1220,14 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
         if ((wave * WAVE_KEYS + j * 64 + lane) < cnt_tile) {
-            const uint32_t d = (key[j] >> shift) & mask;
+            const uint32_t d = PACK >= 2 ? ((key[j] >> vbits) & mask) : ((key[j] >> shift) & mask);
             const int pos = digit_base[d] + wave_cnt[wave][d] + lrank[j];
             if constexpr (PACK == 1) {
                 lds_k[pos] = ((key[j] >> RADIX_BITS) << vbits) | (val[j] & ((1u << vbits) - 1u));    // second digit | value; the first digit is implied by the position
-                lds_v[pos] = d;
+                lds_b[pos] = (unsigned char)d;
+            } else if constexpr (PACK >= 2) {
+                lds_k[pos] = key[j];                                        // the packed word
+                lds_b[pos] = (unsigned char)val[j];                         // the first digit, rebuilt from the element's position
             } else {
                 lds_k[pos] = key[j];
                 lds_v[pos] = val[j];
@@ -1267,9 +1271,11 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
     for (int j = 0; j < SORT_ITEMS; j++) {
         const int p = j * TPB + tid;
         if (p < cnt_tile) {
-            const uint32_t k = lds_k[p];
-            const uint32_t v = lds_v[p];
-            const uint32_t d = PACK == 1 ? v : ((k >> shift) & mask);
+            const uint32_t kw = lds_k[p];
+            const uint32_t lb = PACK ? (uint32_t)lds_b[p] : 0u;
+            const uint32_t d = PACK == 1 ? lb : (PACK >= 2 ? ((kw >> vbits) & mask) : ((kw >> shift) & mask));
+            const uint32_t k = PACK >= 2 ? ((d << RADIX_BITS) | lb) : kw;                       // PACK >= 2: the full key again
+            const uint32_t v = PACK >= 2 ? (kw & ((1u << vbits) - 1u)) : (PACK == 1 ? 0u : lds_v[p]);
             const int g = global_base[d] + (p - digit_base[d]);
             // g is built from the producer's digit totals and the predecessors' look-back words: if either is inconsistent with the keys
             // (a total that over-counts, a status word that was not zero on entry) g leaves [0, n) -- or lands on another key's slot,
@@ -1280,7 +1286,7 @@ __global__ void __launch_bounds__(TPB * TILES) radix_onesweep_kernel(const uint3
             if (in_range) {
                 if constexpr (PACK == 3) {
                     // equal keys are adjacent inside a digit's run of the tile (the input is ordered by the first digit, the ranking is stable)
-                    if (p == digit_base[d] || lds_k[p - 1] != k) {
+                    if (p == digit_base[d] || (lds_k[p - 1] >> vbits) != (kw >> vbits) || lds_b[p - 1] != (unsigned char)lb) {
                         if ((unsigned)k <= (unsigned)max_tile) atomicMin(reinterpret_cast<unsigned int*>(range_out) + k, (unsigned int)g);
                         else bad_pos++;
                     }
@@ -1371,6 +1377,7 @@ static void launch_onesweep(int ntiles, hipStream_t s, const uint32_t* kin, cons
 #define LAUNCH_OSP(T_, B_, L_, G_, P_) hipLaunchKernelGGL((radix_onesweep_kernel<T_, B_, L_, P_>), dim3(G_), dim3(TPB * T_), 0, s, kin, vin, kout, vout, totals, status, \
                                                       ticket, n, n_dev, shift, mask, aux_in, aux_out, vbits, totals_prev, range_out, max_tile)
 #define LAUNCH_OS(T_, B_, L_, G_) LAUNCH_OSP(T_, B_, L_, G_, 0)
+    // (one key tile per workgroup for the packed passes -- 27 KB of LDS, five workgroups per CU instead of two: +20 us per step, profiles/r06_packed_tile_sort_ab.log)
     if (pack == 1) { if (ballot) LAUNCH_OSP(2, true, 8, (ntiles + 1) / 2, 1); else LAUNCH_OSP(2, false, 8, (ntiles + 1) / 2, 1); }
     else if (pack == 2) { if (ballot) LAUNCH_OSP(2, true, 8, (ntiles + 1) / 2, 2); else LAUNCH_OSP(2, false, 8, (ntiles + 1) / 2, 2); }
     else if (pack == 3) { if (ballot) LAUNCH_OSP(2, true, 8, (ntiles + 1) / 2, 3); else LAUNCH_OSP(2, false, 8, (ntiles + 1) / 2, 3); }
