@@ -1236,6 +1236,31 @@ __device__ __forceinline__ float reduce9_cols(float s0, float s1, float s2, floa
     P += xor_dpp1(P);
     return P;
 }
+// The same with two more per-lane values (statistic epochs: the splat's fragment weight and err_square partials).  After the row levels
+// the colour register of reduce9_cols holds Cg in rows 0 AND 1, Cb in rows 2 AND 3: half of it is redundant.  One more swap32 pairs the two
+// extra values, and the swap16 that sum16() spends on duplicating the colour rows transposes them in instead: row 1 carries the weight
+// sum, row 3 err_square; their totals come out in lanes 24 and 56 (the C column of rows 1 and 3).  Two instructions more than
+// reduce9_cols, where a reduction of their own cost nine.
+__device__ __forceinline__ float reduce11_cols(float s0, float s1, float s2, float cr, float cg, float cb, float b, float e, float dx)
+{
+    swap32(s0, s1); swap32(s2, cr); swap32(cg, cb); swap32(b, e);
+    v2f a = { s0, s2 }, bb = { s1, cr };
+    a += bb;                                          // a.x: rows 0-1 S0, rows 2-3 S1;  a.y: rows 0-1 S2, rows 2-3 Cr
+    float c = cg + cb;                                // rows 0-1 Cg, rows 2-3 Cb
+    float be = b + e;                                 // rows 0-1 weight, rows 2-3 err_square
+    float a0 = a.x, a1 = a.y;
+    swap16(a0, a1);
+    const float A = a0 + a1;                          // row 0 S0, row 1 S2, row 2 S1, row 3 Cr (column totals)
+    swap16(c, be);
+    const float C = c + be;                           // row 0 Cg, row 1 weight, row 2 Cb, row 3 err_square
+    const float X1 = A * dx, X2 = X1 * dx;
+    float P = bfly_mirror8(A, C);
+    const float Q = bfly_mirror8(X1, X2);
+    P = bfly_hmirror4(P, Q);
+    P += xor_dpp2(P);
+    P += xor_dpp1(P);
+    return P;
+}
 // record slot (Mx My Mxx Mxy Myy dr dg db M0 = 0..8) of the total lane `lane` holds after reduce9_cols (-1: none)
 __device__ __forceinline__ int wave_slot_cols(int lane)
 {
@@ -1308,22 +1333,18 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     const float s0 = m.x + m.y;
     const float s1 = my.x + my.y;
     const float s2 = __builtin_fmaf(my.x, dyv.x, my.y * dyv.y);
-    float tot = reduce9_cols(s0, s1, s2, crg.x, crg.y, v_b, dx);
+    float tot;
     if constexpr (STAT == 2) {
         const float inv_o = __builtin_amdgcn_rcpf(rec[R_O]);
         const float vo0 = m.x * inv_o, vo1 = s0 * inv_o;
-        float b = w.x + w.y;                                                                     // blend weights of this lane's fragments
-        float c = __builtin_fmaf(vo0, vo0, __any(val1) ? vo1 * vo1 : 0.0f);
-        // the fragment COUNT is the popcount of the two validity masks: scalar unit, no reduction.  Weight and err_square: one
-        // permlane32 swap puts the b partials into lanes 0-31 and the c partials into lanes 32-63, four row_shr adds leave every row's
-        // total in its lane 15, one row_bcast:15 adds rows 0 / 2 into rows 1 / 3: lane 31 holds the weight sum, lane 63 err_square
+        const float b = w.x + w.y;                                                               // blend weights of this lane's fragments
+        const float c = __builtin_fmaf(vo0, vo0, __any(val1) ? vo1 * vo1 : 0.0f);
+        // the fragment COUNT is the popcount of the two validity masks: scalar unit, no reduction.  Weight and err_square ride in the
+        // redundant half of the colour register of the moment reduction (reduce11_cols): totals in lanes 24 and 56
         const float fcount = (float)(__popcll(__ballot(val0)) + __popcll(__ballot(val1)));
-        swap32(b, c);
-        b += c;
-        b = DPP_ADD(b, 0x111, 0xF, 0xF); b = DPP_ADD(b, 0x112, 0xF, 0xF); b = DPP_ADD(b, 0x114, 0xF, 0xF); b = DPP_ADD(b, 0x118, 0xF, 0xF);
-        b = DPP_ADD(b, 0x142, 0xA, 0xF);
-        tot = (lane == 15) ? fcount : (((lane & 31) == 31) ? b : tot);
-    }
+        tot = reduce11_cols(s0, s1, s2, crg.x, crg.y, v_b, b, c, dx);
+        tot = (lane == 15) ? fcount : tot;
+    } else tot = reduce9_cols(s0, s1, s2, crg.x, crg.y, v_b, dx);
     // ONE atomic instruction from the lanes that hold a total: scalar base = the splat's gradient record
     const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pg) + pid_off);
     asm volatile("s_mov_b64 exec, %2\n\t"
@@ -1337,10 +1358,10 @@ __device__ __forceinline__ void bwd_splat_fast(BwdFast& st, const f32x16& rec, i
     }
 }
 
-// record slot of the statistics total that lane 15 / 31 / 63 holds at the end of bwd_splat_fast<.., 2> (-1: none)
+// record slot of the statistics total that lane 15 / 24 / 56 holds at the end of bwd_splat_fast<.., 2> (-1: none)
 __device__ __forceinline__ int stat_lane_slot(int lane)
 {
-    return lane == 15 ? STAT_SLOT_COUNT : (lane == 31 ? STAT_SLOT_WEIGHT : (lane == 63 ? STAT_SLOT_ERRSQ : -1));
+    return lane == 15 ? STAT_SLOT_COUNT : (lane == 24 ? STAT_SLOT_WEIGHT : (lane == 56 ? STAT_SLOT_ERRSQ : -1));
 }
 
 #define RBF_ARGS const int* __restrict__ sorted_points, const int* __restrict__ start_index,                                             \
