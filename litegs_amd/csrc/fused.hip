@@ -939,6 +939,10 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     const void* depth_order = tile_mode ? (const void*)nullptr : (odd32 ? (w1 + f1.dv_b) : (w1 + f1.dv_a));     // nullptr: emission in splat-id order
     const int bits = tile_key_bits(ntiles);
     bool seg_counts_zeroed = false;                      // the range kernel of the global route clears the segmented backward's unit counters on the side
+    // a render along a tile list leaves checkpoints and the unit list of the segmented blend backward (whether or not a backward follows:
+    // lg_fused_backward decides by the same rule and must find them)
+    const bool seg_on = K <= ntiles && ntiles < 65536 &&
+                        lg_raster_segments_apply(1, TH, TW, enable_stat, tiles, nullptr, fail_flag ? (const void*)fail_flag : (const void*)fail_host, gate, nullptr);
     const int32_t* sorted_pts = (const int32_t*)(w + sorted_points_offset(x, f, N, ntiles));
     int rc;
     if (crumbs_on())
@@ -996,8 +1000,8 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     rc = lg_radix_sort_prepared_values((uint32_t*)(w + f.tk_a), (uint32_t*)(w + f.tv_a), (uint32_t*)(w + f.tk_b), (uint32_t*)(w + f.tv_b), Ls,
                                        total_dev, 0, bits, tsort_hdr, (uint32_t*)(w + f.tsort_table), nullptr, nullptr, value_bits,
                                        x.validate ? (int32_t*)nullptr : (int32_t*)(w + f.tile_start), ntiles, x.validate ? (int*)nullptr : &ranges_done,
-                                       (int*)(w + f.seg_counts), s);
-    seg_counts_zeroed = ranges_done != 0;
+                                       seg_on ? (int*)(w + f.seg_counts) : (int*)nullptr, s);
+    seg_counts_zeroed = seg_on && ranges_done != 0;
     if (rc) return rc;
     const bool odd = lg_radix_sort_num_passes(0, bits) % 2 == 1;
     const int32_t* sorted_keys = (const int32_t*)(w + (odd ? f.tk_b : f.tk_a));
@@ -1018,10 +1022,6 @@ static int binning_and_blend(const Exec& x, char* w1, const Layout1& f1, char* w
     CRUMB("blend forward");
     // statistic epochs: the executor's blend backward accumulates the per-splat statistics inside the gradient record (raster.hip, STAT == 2);
     // the forward then is the plain one (frag_count == NULL).  A caller that wants the forward's own counters passes the two arrays.
-    // a render along a tile list leaves checkpoints and the unit list of the segmented blend backward (whether or not a backward follows:
-    // lg_fused_backward decides by the same rule and must find them)
-    const bool seg_on = K <= ntiles && ntiles < 65536 &&
-                        lg_raster_segments_apply(1, TH, TW, enable_stat, tiles, nullptr, fail_flag ? (const void*)fail_flag : (const void*)fail_host, gate, nullptr);
     LgSegments seg = segments_of(w, f, L, ntiles);
     seg.counts_zeroed = seg_counts_zeroed ? 1 : 0;
     return lg_raster_forward_segments(sorted_pts, (const int*)(w + f.tile_start), (const float*)(w1 + f1.packed), tiles, K, 1, L, (int)N, H, W, TH, TW,
