@@ -155,6 +155,12 @@ int lg_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, ui
 int lg_radix_sort_pairs_bounded(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev,
                                 int begin_bit, int end_bit, void* temp, long long temp_bytes, void* stream);
 int lg_tile_range_bounded(const int32_t* sorted_keys, int V, long long L, const int* n_dev, int max_tile, int32_t* out, void* stream);
+/* the executor's tile sort as one call (tests): (key, value) pairs, keys in 0..max_tile, values below 2^value_bits (0: unknown) -> the values
+ * grouped by key in input order (in vals_a for an even number of 8-bit passes over the key bits, else vals_b) and tileRange's table in
+ * range_out[max_tile + 2].  temp: lg_radix_sort_temp_bytes(n).  *ranges_from_sort (host int) = 1 when the packed passes ran and the last one
+ * left the ranges itself (binning.hip radix_onesweep_kernel PACK; the sorted keys then do not exist), 0 for key / value passes + range scan. */
+int lg_tile_sort_ranges(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev, int max_tile,
+                        int value_bits, void* temp, long long temp_bytes, int32_t* range_out, int* ranges_from_sort, void* stream);
 /* depth sort keys + gathered inclusive scan: the torch.sort / gather / cumsum glue of wrapper.py:739-745 */
 int lg_depth_sort_keys(const float* depth, long long n, uint32_t* keys, uint32_t* vals, void* stream);
 long long lg_scan_temp_bytes(long long n);

@@ -1562,6 +1562,40 @@ int lg_radix_sort_prepared_values(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
     LG_RETURN_LAST();
 }
 
+// The executor's tile sort as an operator of its own (tests; what lg_fused_stage2 runs between the key emission and the blend): (key,
+// value) pairs with keys in 0..max_tile and values below 2^value_bits -> values grouped by key in their input order (vals_a when the
+// number of passes is even, else vals_b) and the tile range table of tileRange (GR/binning.cu:228-287) in range_out[max_tile + 2].  With two
+// passes and a second digit that fits beside the value the passes are packed and the last one leaves the ranges itself (radix_onesweep_kernel
+// PACK); *ranges_from_sort says which route ran.  The sorted KEYS exist only when it is 0.
+LG_API int lg_tile_sort_ranges(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, long long n, const int* n_dev, int max_tile,
+                               int value_bits, void* temp, long long temp_bytes, int32_t* range_out, int* ranges_from_sort, void* stream)
+{
+    LG_REQUIRE(range_out, ranges_from_sort);
+    *ranges_from_sort = 0;
+    if (max_tile < 0) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t err = hipMemsetAsync(range_out, 0xFF, sizeof(int32_t) * ((size_t)max_tile + 2), s);
+    if (err != hipSuccess) return (int)err;
+    if (n <= 0) return 0;
+    LG_REQUIRE(keys_a, vals_a, keys_b, vals_b, temp);
+    int end_bit = 1;
+    while ((1ll << end_bit) <= (long long)max_tile) end_bit++;
+    const int passes = lg_radix_sort_num_passes(0, end_bit);
+    if (passes > SORT_MAX_PASSES || n > 0x3fffffffLL || temp_bytes < lg_radix_sort_temp_bytes(n)) return (int)hipErrorInvalidValue;
+    const int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
+    int* totals = (int*)temp;
+    err = hipMemsetAsync(totals, 0, sizeof(int) * (SORT_HEADER_INTS + (size_t)passes * RADIX * ntiles), s);
+    if (err != hipSuccess) return (int)err;
+    const int last_bits = end_bit - (passes - 1) * RADIX_BITS;
+    hipLaunchKernelGGL(radix_totals_kernel, dim3(ntiles < 512 ? ntiles : 512), dim3(TPB), 0, s, keys_a, n, n_dev, 0, passes, (1u << last_bits) - 1u, totals);
+    int rc = lg_radix_sort_prepared_values(keys_a, vals_a, keys_b, vals_b, n, n_dev, 0, end_bit, totals, (uint32_t*)(totals + SORT_HEADER_INTS), nullptr, nullptr,
+                                           value_bits, range_out, max_tile, ranges_from_sort, nullptr, stream);
+    if (rc) return rc;
+    if (!*ranges_from_sort)
+        rc = lg_tile_range_prefilled((const int32_t*)(passes % 2 == 1 ? keys_b : keys_a), 1, n, n_dev, max_tile, range_out, stream);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // create_table (GR/binning.cu:123-226) as one entry point for a single view: key/value emission that also counts the sort's digits,
 // zero padding of an over-allocated table, then the prepared radix sort -- no counting pass over the keys, no pre-cleared key table.

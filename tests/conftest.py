@@ -18,7 +18,7 @@ def pytest_configure(config):
 # in the order of SURVEY.md section 8's rows, then the executor-level parity files, then everything whose assertion is a bound on a
 # noisy training trajectory, diagnostics (test_zz_*) last.  A wobble in a noise-bounded test can then never hide a parity row.
 _FILE_RANK = {name: i for i, name in enumerate((
-    "test_gpu_ops.py", "test_gpu_reference_call_pattern.py", "test_gpu_fullsize.py", "test_gpu_pipeline.py", "test_gpu_fused.py", "test_gpu_tilesort.py", "test_gpu_trained_cloud.py",
+    "test_gpu_ops.py", "test_gpu_reference_call_pattern.py", "test_gpu_fullsize.py", "test_gpu_pipeline.py", "test_gpu_fused.py", "test_gpu_tilesort.py", "test_gpu_tile_sort.py", "test_gpu_trained_cloud.py",
     "test_gpu_tilesizes.py", "test_gpu_edge.py", "test_gpu_stats.py", "test_gpu_schedule.py", "test_gpu_loss.py", "test_gpu_knn.py",
     "test_gpu_refine.py", "test_gpu_lifetime.py", "test_gpu_cull.py", "test_gpu_adam_skip.py", "test_gpu_dp.py", "test_gpu_training.py",
     "test_gpu_convergence.py", "test_bench_contract.py"))}
