@@ -61,3 +61,14 @@ def pytest_terminal_summary(terminalreporter):
     for rep in terminalreporter.stats.get("xfailed", []):
         reason = getattr(rep, "wasxfail", "") or ""
         terminalreporter.write_line(f"XFAIL {rep.nodeid}: {reason[:3500]}")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _env_tuning():
+    """LITEGS_TUNING=key=value[,...] (measurement / A-B aid): the launch variants of lg_set_tuning for the whole test process, so that a
+    non-default kernel variant can be held to the same suite (`LITEGS_TUNING=28=1 pytest -m gpu`); operator tests do not import fast.py"""
+    import os
+    if os.environ.get("LITEGS_TUNING"):
+        from litegs_amd import fast
+        fast._apply_env_tuning()
+    yield
